@@ -1,0 +1,145 @@
+"""ctypes binding of oracle/libgml_oracle.so (gml_oracle.c) plus the host-side glue of the
+reference that involves no arithmetic (histogram splitting, multi-body symmetrisation).
+
+TEST INFRASTRUCTURE ONLY -- see gml_oracle.c header.  Reference citations are relative to
+/root/reference/src/GraphicalModelLearning.jl.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FORMS = {"RISE": 0, "logRISE": 1, "RPLE": 2}
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libgml_oracle.so")
+    src = os.path.join(_HERE, "gml_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libgml_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        i64, dbl, p = C.c_int64, C.c_double, C.c_void_p
+        L.gml_oracle_lambda.restype = dbl
+        L.gml_oracle_lambda.argtypes = [dbl, i64, dbl]
+        L.gml_oracle_multi_nparams.restype = i64
+        L.gml_oracle_multi_nparams.argtypes = [i64, C.c_int]
+        L.gml_oracle_multi_keys.restype = None
+        L.gml_oracle_multi_keys.argtypes = [i64, C.c_int, i64, p]
+        L.gml_oracle_objgrad_pair.restype = None
+        L.gml_oracle_objgrad_pair.argtypes = [C.c_int, i64, i64, p, p, i64, p, p, p]
+        L.gml_oracle_objgrad_rise_nodes.restype = None
+        L.gml_oracle_objgrad_rise_nodes.argtypes = [i64, i64, p, p, p, i64, p, p, p]
+        L.gml_oracle_learn_pair.restype = dbl
+        L.gml_oracle_learn_pair.argtypes = [C.c_int, i64, i64, p, p, dbl, C.c_int, dbl, p, p, p]
+        L.gml_oracle_objgrad_multi.restype = None
+        L.gml_oracle_objgrad_multi.argtypes = [i64, i64, C.c_int, p, p, i64, p, p, p]
+        L.gml_oracle_learn_multi.restype = dbl
+        L.gml_oracle_learn_multi.argtypes = [i64, i64, C.c_int, p, p, dbl, dbl, p, p]
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def split_histogram(samples):
+    """samples: K x (1+n) histogram, column 0 = counts, columns 1.. = +-1 spins
+    (format produced by sampling.jl:52-54, consumed at :76-81).  Returns (counts f64, spins i8)."""
+    s = np.asarray(samples)
+    counts = np.ascontiguousarray(s[:, 0], dtype=np.float64)
+    spins = np.ascontiguousarray(s[:, 1:], dtype=np.int8)
+    return counts, spins
+
+
+def lam(c, n, M):
+    return lib().gml_oracle_lambda(float(c), int(n), float(M))
+
+
+def objgrad_pair(samples, form, u, theta):
+    counts, spins = split_histogram(samples)
+    K, n = spins.shape
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    f = C.c_double()
+    g = np.zeros(n)
+    lib().gml_oracle_objgrad_pair(FORMS[form], K, n, _ptr(counts), _ptr(spins), int(u), _ptr(theta),
+                                  C.byref(f), _ptr(g))
+    return f.value, g
+
+
+def objgrad_rise_nodes(counts, spins, nodes, theta):
+    """fast RISE objgrad for the cpu_baseline timing; theta is len(nodes) x n."""
+    K, n = spins.shape
+    nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    f = np.zeros(len(nodes))
+    g = np.zeros((len(nodes), n))
+    lib().gml_oracle_objgrad_rise_nodes(K, n, _ptr(counts), _ptr(spins), _ptr(nodes), len(nodes),
+                                        _ptr(theta), _ptr(f), _ptr(g))
+    return f, g
+
+
+def learn_pair(samples, form="RISE", c=None, symmetrize=True, tol=1e-12):
+    """learn(samples, RISE/logRISE/RPLE(c, symmetrize)) restated (:154-189, :263-298, :301-336).
+    Returns (n x n matrix, per-node KKT residuals, per-node Newton iterations)."""
+    defaults = {"RISE": 0.4, "logRISE": 0.8, "RPLE": 0.2}  # :35, :49, :56
+    if c is None:
+        c = defaults[form]
+    counts, spins = split_histogram(samples)
+    K, n = spins.shape
+    out = np.zeros((n, n))
+    kkt = np.zeros(n)
+    iters = np.zeros(n, dtype=np.int32)
+    lib().gml_oracle_learn_pair(FORMS[form], K, n, _ptr(counts), _ptr(spins), float(c), int(bool(symmetrize)),
+                                float(tol), _ptr(out), _ptr(kkt), _ptr(iters))
+    return out, kkt, iters
+
+
+def multi_keys(n, order, u):
+    """keys of node u in the reference's construction order (:94-104, models.jl:228-246), 0-based."""
+    P = lib().gml_oracle_multi_nparams(n, order)
+    keys = np.zeros((P, order), dtype=np.int32)
+    lib().gml_oracle_multi_keys(n, order, int(u), _ptr(keys))
+    return [tuple(int(v) for v in row if v >= 0) for row in keys]
+
+
+def objgrad_multi(samples, order, u, theta):
+    counts, spins = split_histogram(samples)
+    K, n = spins.shape
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    f = C.c_double()
+    g = np.zeros(len(theta))
+    lib().gml_oracle_objgrad_multi(K, n, int(order), _ptr(counts), _ptr(spins), int(u), _ptr(theta),
+                                   C.byref(f), _ptr(g))
+    return f.value, g
+
+
+def learn_multi(samples, c=0.4, symmetrize=True, order=2, tol=1e-12):
+    """learn(samples, multiRISE(c, symmetrize, order)) restated (:83-152).
+    Returns (dict {1-based key tuple: value}, per-node KKT).  Keys are 1-based like the reference's."""
+    counts, spins = split_histogram(samples)
+    K, n = spins.shape
+    P = lib().gml_oracle_multi_nparams(n, order)
+    out = np.zeros((n, P))
+    kkt = np.zeros(n)
+    lib().gml_oracle_learn_multi(K, n, int(order), _ptr(counts), _ptr(spins), float(c), float(tol), _ptr(out), _ptr(kkt))
+    rec = {}
+    for u in range(n):
+        for key, v in zip(multi_keys(n, order, u), out[u]):
+            rec[tuple(i + 1 for i in key)] = float(v)  # :129-132, key = (u, ascending others)
+    if symmetrize:  # :135-149  group by sorted key, mean
+        groups = {}
+        for k, v in rec.items():
+            groups.setdefault(tuple(sorted(k)), []).append(v)
+        rec = {k: float(np.mean(v)) for k, v in groups.items()}
+    return rec, kkt
