@@ -1,0 +1,187 @@
+"""ctypes binding of libgml_hip.so (C ABI: include/gml.h).
+
+The library is the only compute path: if it is missing, or no HIP device is present, every
+call fails loudly -- there is no CPU fallback in the product.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgml_hip.so")
+
+GML_OK, GML_EINVAL, GML_ENOTCONV, GML_EHIP, GML_ENOMEM, GML_EUNSUPPORTED = range(6)
+FORMULATION_IDS = {"RISE": 0, "RISEA": 0, "multiRISE": 0, "logRISE": 1, "RPLE": 2}
+DTYPES = {np.dtype(np.int8): 0, np.dtype(np.int32): 1, np.dtype(np.int64): 2, np.dtype(np.float64): 3}
+PRECISIONS = {"f64": 0, "i8x": 1}
+
+
+class GMLError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libgml_hip error {code}: {msg}")
+        self.code = code
+
+
+class GMLConvergenceError(AssertionError):
+    """Mirrors the reference's `@assert termination_status == LOCALLY_SOLVED`
+    (GraphicalModelLearning.jl:127,180,251,289,327)."""
+
+
+class Opts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("precision", C.c_int32),
+                ("max_working", C.c_int32), ("max_add", C.c_int32), ("verbose", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("passes", C.c_int32), ("forward_passes", C.c_int32),
+                ("hessian_passes", C.c_int32), ("node_evals", C.c_int64), ("max_kkt", C.c_double),
+                ("lambda_", C.c_double), ("t_pack", C.c_double), ("t_pass", C.c_double),
+                ("t_hess", C.c_double), ("t_host", C.c_double), ("t_total", C.c_double),
+                ("not_converged", C.c_int32), ("reserved", C.c_int32)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+_lib = None
+
+
+def lib():
+    """Load libgml_hip.so.  torch (if installed) is imported first so that both share one HIP
+    runtime (same libamdhip64 SONAME)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GMLError(GML_EHIP, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                 "(make -C graphicalmodellearning.jl_amd/csrc)")
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64.so first)
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    i64, dbl, p, i32 = C.c_int64, C.c_double, C.c_void_p, C.c_int
+    L.gml_last_error.restype = C.c_char_p
+    L.gml_default_opts.argtypes = [C.POINTER(Opts)]
+    L.gml_default_opts.restype = None
+    L.gml_lambda.restype = dbl
+    L.gml_lambda.argtypes = [dbl, i64, dbl]
+    L.gml_problem_create.argtypes = [p, i32, i64, i64, i64, i32, i32, i64, i64, i32, C.POINTER(p)]
+    L.gml_problem_create_spins.argtypes = [p, p, i64, i64, i32, i64, i64, i32, C.POINTER(p)]
+    L.gml_problem_destroy.argtypes = [p]
+    L.gml_problem_destroy.restype = None
+    L.gml_problem_info.argtypes = [p] + [p] * 6
+    L.gml_multi_keys.argtypes = [p, i64, p]
+    L.gml_objgrad_batch.argtypes = [p, i32, i32, i64, p, p, i64, p, p]
+    L.gml_learn.argtypes = [p, i32, dbl, C.POINTER(Opts), p, p, C.POINTER(Stats)]
+    L.gml_bench_pass.argtypes = [p, i32, i32, p, i32, i32, p]
+    _lib = L
+    return L
+
+
+def check(rc, allow=()):
+    if rc != GML_OK and rc not in allow:
+        raise GMLError(rc, lib().gml_last_error().decode())
+    return rc
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Problem:
+    """RAII wrapper of a gml_problem handle (packed spins + weights resident in HBM)."""
+
+    def __init__(self, samples=None, *, counts=None, spins=None, order=2, node_range=None, device=0):
+        L = lib()
+        h = C.c_void_p()
+        if samples is not None:
+            s = np.asarray(samples)
+            if s.ndim != 2 or s.shape[1] < 2:
+                raise GMLError(GML_EINVAL, "samples must be a K x (1+n) histogram matrix")
+            if s.dtype not in DTYPES:
+                s = s.astype(np.float64)
+            col_major = bool(s.flags.f_contiguous and not s.flags.c_contiguous)
+            if not (s.flags.c_contiguous or s.flags.f_contiguous):
+                s = np.ascontiguousarray(s)
+            K, n = s.shape[0], s.shape[1] - 1
+            ld = K if col_major else n + 1
+            n0, n1 = node_range if node_range is not None else (0, n)
+            check(L.gml_problem_create(_ptr(s), DTYPES[s.dtype], K, n, ld, int(col_major), int(order), n0, n1,
+                                       int(device), C.byref(h)))
+        else:
+            spins = np.ascontiguousarray(spins, dtype=np.int8)
+            K, n = spins.shape
+            if counts is not None:
+                counts = np.ascontiguousarray(counts, dtype=np.float64)
+            n0, n1 = node_range if node_range is not None else (0, n)
+            check(L.gml_problem_create_spins(_ptr(counts), _ptr(spins), K, n, int(order), n0, n1, int(device),
+                                             C.byref(h)))
+        self._h = h
+        nn, KK, PP, a, b = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        M = C.c_double()
+        check(L.gml_problem_info(h, C.byref(nn), C.byref(KK), C.byref(M), C.byref(PP), C.byref(a), C.byref(b)))
+        self.n, self.K, self.M, self.P, self.node0, self.node1 = nn.value, KK.value, M.value, PP.value, a.value, b.value
+        self.order = int(order)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gml_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def multi_keys(self, u):
+        keys = np.zeros((self.P, self.order), dtype=np.int32)
+        check(lib().gml_multi_keys(self._h, int(u), _ptr(keys)))
+        return [tuple(int(v) for v in row if v >= 0) for row in keys]
+
+    def objgrad(self, formulation, nodes, theta, precision="f64", want_grad=True):
+        nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(len(nodes), -1)
+        f = np.zeros(len(nodes))
+        g = np.zeros_like(theta) if want_grad else None
+        check(lib().gml_objgrad_batch(self._h, FORMULATION_IDS[formulation], PRECISIONS[precision], len(nodes),
+                                      _ptr(nodes), _ptr(theta), theta.shape[1], _ptr(f), _ptr(g)))
+        return f, g
+
+    def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="f64", max_working=256, max_add=32,
+              verbose=0, out_ptr=None, raise_on_fail=True):
+        L = lib()
+        o = Opts()
+        L.gml_default_opts(C.byref(o))
+        o.tol, o.max_iter, o.precision = float(tol), int(max_iter), PRECISIONS[precision]
+        o.max_working, o.max_add, o.verbose = int(max_working), int(max_add), int(verbose)
+        R = self.node1 - self.node0
+        out = None
+        if out_ptr is None:
+            out = np.zeros((R, self.P))
+            out_ptr = _ptr(out)
+        kkt = np.zeros(R)
+        st = Stats()
+        rc = L.gml_learn(self._h, FORMULATION_IDS[formulation], float(c), C.byref(o), out_ptr, _ptr(kkt), C.byref(st))
+        if rc == GML_ENOTCONV:
+            if raise_on_fail:
+                raise GMLConvergenceError(L.gml_last_error().decode())
+        else:
+            check(rc)
+        return out, kkt, st.asdict()
+
+    def bench_pass(self, formulation, theta=None, steps=5, warmup=1, precision="f64"):
+        ms = np.zeros(3)
+        th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
+        check(lib().gml_bench_pass(self._h, FORMULATION_IDS[formulation], PRECISIONS[precision], _ptr(th), int(steps),
+                                   int(warmup), _ptr(ms)))
+        return {"fwd_ms": ms[0], "bwd_ms": ms[1], "pass_ms": ms[2]}

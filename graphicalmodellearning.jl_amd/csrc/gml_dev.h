@@ -1,0 +1,44 @@
+// Internal device-side interface of libgml_hip (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gml {
+
+// Device-resident problem data.  Layout (all padded, padding is zero):
+//   Xs [Kp][Qp] int8   sample-major design matrix: Xs[k][c] = prod_{i in key_c} s_i^k
+//   Xt [Qp][Kp] int8   the same matrix feature-major
+//   w  [Kp]     f64    c_k / M   (samples[k,1]/num_samples, GraphicalModelLearning.jl:170)
+// Column 0 is the empty key (constant 1: the node's field), columns 1..n the single spins,
+// then pairs (i<j) in lexicographic order, ... (multi-body, :94-108).  Node u's sign
+// s_u^k is row 1+u of Xt.  Column Qp-1 is always a zero (padding) column.
+struct DevProblem {
+    int64_t K, Kp, n, Q, Qp;
+    int8_t *Xs, *Xt;
+    double *w;
+};
+
+// ---- packing -----------------------------------------------------------------------------
+void launch_transpose_i8(const int8_t *src, int64_t rows, int64_t cols, int64_t ld_src,
+                         int8_t *dst, int64_t ld_dst, hipStream_t st);
+void launch_expand_features(const int8_t *St, int64_t n, int64_t K, int64_t Kp,
+                            const int32_t *keys, int order, int64_t Q, int8_t *Xt,
+                            hipStream_t st);
+
+// ---- FP64 path -----------------------------------------------------------------------------
+// Theta [Rp][Qp] (internal column layout, masked slots zero), rowcol[r] = 1+u (row of Xt
+// holding node u's sign) or -1 for padding rows.  Rp multiple of 32.
+// V [Rp][Kp]: V[r][k] = d f_r / d E_rk * s_rk = -w_k exp(-E) s (RISE: `partial_obj` of :204 times s)
+// fsum [Rp]: sum_k w_k phi(E_rk)  (must be zeroed by the caller)
+// groups: ids of the 32-row groups to evaluate (padded with -1 to a multiple of 4).
+void launch_fwd_f64(const DevProblem &P, const double *Theta, const int *rowcol, const int *groups,
+                    int ngroups4, int form, double *V, double *fsum, hipStream_t st);
+// G [Rp][Qp] += sum_k V[r][k] * Xt[c][k] = the gradient (:205-207); must be zeroed by the caller
+void launch_bwd_f64(const DevProblem &P, const double *V, const int *groups, int ngroups, double *G,
+                    hipStream_t st);
+// H [Rp][cap][cap] += sum_k h_rk Xt[F_ri][k] Xt[F_rj][k], lower-triangular 32x32 tiles only.
+// F [Rp][cap] column ids (padding = Qp-1), mt[r] = number of 32-tiles used by row r.
+void launch_hess_f64(const DevProblem &P, const double *V, const int *rowcol, const int *F,
+                     const int *mt, int R, int cap, int form, double *H, hipStream_t st);
+
+} // namespace gml

@@ -1,0 +1,973 @@
+// libgml_hip: C ABI (include/gml.h) + host side of the MI355X learn() hot path.
+//
+// What lives here: histogram validation/packing, the per-node parameter layout of the
+// reference (pairwise :162, multi-body :94-104), the batched working-set Newton solver that
+// replaces the reference's per-node Ipopt solve (:164-181), and the orchestration of the
+// device passes.  All arithmetic over the K configurations happens in HIP kernels
+// (gml_kernels_f64.hip, gml_kernels_i8.hip); there is no CPU fallback for it.
+#include "../../include/gml.h"
+#include "gml_dev.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace gml;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? GML_ENOMEM : GML_EHIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                       \
+    } while (0)
+
+extern "C" const char *gml_last_error(void) { return g_err.c_str(); }
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static void parallel_for(int64_t n, const std::function<void(int64_t)> &fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 32) nt = 32;
+    if ((int64_t)nt > n) nt = (unsigned)n;
+    if (nt <= 1) {
+        for (int64_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<int64_t> next(0);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&] {
+            for (;;) {
+                int64_t i = next.fetch_add(1);
+                if (i >= n) break;
+                fn(i);
+            }
+        });
+    for (auto &t : th) t.join();
+}
+
+static int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// ------------------------------------------------------------------------------------------
+// problem handle
+// ------------------------------------------------------------------------------------------
+struct gml_problem {
+    int device = 0;
+    hipStream_t st = nullptr;
+    int64_t n = 0, K = 0, P = 0, node0 = 0, node1 = 0;
+    int order = 2;
+    double M = 0;
+    DevProblem d{};
+    std::vector<int32_t> gkeys; // [Q][ko] subsets of spins (feature keys), -1 padded
+    int ko = 1;
+    std::vector<int64_t> qoff; // qoff[q] = first column of the size-q subsets
+    // workspace (sized for ws_rows rows)
+    int64_t ws_rows = 0;
+    double *dTheta = nullptr, *dV = nullptr, *dG = nullptr, *dF = nullptr;
+    int *dRowcol = nullptr, *dGroups = nullptr;
+    // hessian workspace
+    int64_t hs_rows = 0, hs_cap = 0;
+    int *dFidx = nullptr, *dMt = nullptr;
+    double *dH = nullptr;
+    // i8 path workspace lives in gml_i8 (allocated lazily)
+    void *i8ws = nullptr;
+};
+
+static int64_t binom(int64_t n, int64_t k) {
+    if (k < 0 || k > n) return 0;
+    int64_t r = 1;
+    for (int64_t i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+    return r;
+}
+
+extern "C" double gml_lambda(double c, int64_t n, double M) {
+    // lambda = regularizer*sqrt(log((num_spins^2)/0.05)/num_samples)   (:157)
+    return c * std::sqrt(std::log(((double)n * (double)n) / 0.05) / M);
+}
+
+extern "C" void gml_default_opts(gml_opts *o) {
+    std::memset(o, 0, sizeof *o);
+    o->tol = 1e-9;
+    o->max_iter = 100;
+    o->precision = GML_PREC_F64;
+    o->max_working = 256;
+    o->max_add = 32;
+    o->verbose = 0;
+}
+
+// next q-subset of {0..n-1} in lexicographic order; returns false after the last one
+static bool next_comb(std::vector<int> &idx, int64_t n) {
+    const int q = (int)idx.size();
+    int t = q - 1;
+    while (t >= 0 && idx[t] == (int)n - q + t) --t;
+    if (t < 0) return false;
+    ++idx[t];
+    for (int s = t + 1; s < q; ++s) idx[s] = idx[s - 1] + 1;
+    return true;
+}
+
+// Parameter j of node u (reference order, :94-104: (u), then (u,S) with S the ascending
+// subsets of the other spins, by size then lexicographically) -> internal column.
+static void node_cols(const gml_problem *p, int64_t u, std::vector<int32_t> &cols) {
+    cols.clear();
+    cols.reserve((size_t)p->P);
+    cols.push_back(0);
+    const int fo = p->order - 1;
+    if (fo >= 1) {
+        for (int64_t i = 0; i < p->n; ++i)
+            if (i != u) cols.push_back((int32_t)(1 + i));
+    }
+    for (int q = 2; q <= fo; ++q) {
+        if (q > p->n) break;
+        std::vector<int> idx(q);
+        for (int t = 0; t < q; ++t) idx[t] = t;
+        int64_t c = p->qoff[q];
+        do {
+            bool has = false;
+            for (int t = 0; t < q; ++t) has |= (idx[t] == (int)u);
+            if (!has) cols.push_back((int32_t)c);
+            ++c;
+        } while (next_comb(idx, p->n));
+    }
+}
+
+static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /*K x n row-major*/) {
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamCreate(&p->st));
+    DevProblem &d = p->d;
+    const int fo = p->order - 1;
+    p->ko = fo > 0 ? fo : 1;
+    p->qoff.assign(fo + 2, 0);
+    int64_t Q = 1;
+    for (int q = 1; q <= fo; ++q) {
+        p->qoff[q] = Q;
+        Q += binom(p->n, q);
+    }
+    p->qoff[fo + 1] = Q;
+    p->P = 0;
+    for (int q = 0; q <= fo; ++q) p->P += binom(p->n - 1, q);
+    d.K = p->K;
+    d.n = p->n;
+    d.Q = Q;
+    d.Kp = round_up(p->K, 256);
+    d.Qp = round_up(Q + 1, 64);
+    if ((double)d.Kp * (double)d.Qp * 2.0 > 200e9)
+        return fail(GML_ENOMEM, "design matrix %lld x %lld does not fit (on-the-fly monomials are not implemented yet)",
+                    (long long)d.Kp, (long long)d.Qp);
+    // feature keys
+    p->gkeys.assign((size_t)Q * p->ko, -1);
+    {
+        int64_t c = 1;
+        for (int q = 1; q <= fo && q <= p->n; ++q) {
+            std::vector<int> idx(q);
+            for (int t = 0; t < q; ++t) idx[t] = t;
+            do {
+                for (int t = 0; t < q; ++t) p->gkeys[(size_t)c * p->ko + t] = idx[t];
+                ++c;
+            } while (next_comb(idx, p->n));
+        }
+    }
+    HIPCHK(hipMalloc(&d.Xs, (size_t)d.Kp * d.Qp));
+    HIPCHK(hipMalloc(&d.Xt, (size_t)d.Kp * d.Qp));
+    HIPCHK(hipMalloc(&d.w, sizeof(double) * d.Kp));
+    HIPCHK(hipMemsetAsync(d.Xs, 0, (size_t)d.Kp * d.Qp, p->st));
+    HIPCHK(hipMemsetAsync(d.Xt, 0, (size_t)d.Kp * d.Qp, p->st));
+    HIPCHK(hipMemsetAsync(d.w, 0, sizeof(double) * d.Kp, p->st));
+    // weights w_k = counts[k]/M  (:170)
+    std::vector<double> w((size_t)p->K);
+    for (int64_t k = 0; k < p->K; ++k) w[k] = (counts ? counts[k] : 1.0) / p->M;
+    HIPCHK(hipMemcpyAsync(d.w, w.data(), sizeof(double) * p->K, hipMemcpyHostToDevice, p->st));
+    // spins: upload sample-major, transpose to spin-major St [n][Kp], expand, transpose back
+    int8_t *dS = nullptr, *dSt = nullptr;
+    int32_t *dkeys = nullptr;
+    HIPCHK(hipMalloc(&dS, (size_t)p->K * p->n));
+    HIPCHK(hipMalloc(&dSt, (size_t)p->n * d.Kp));
+    HIPCHK(hipMalloc(&dkeys, sizeof(int32_t) * p->gkeys.size()));
+    HIPCHK(hipMemcpyAsync(dS, spins, (size_t)p->K * p->n, hipMemcpyHostToDevice, p->st));
+    HIPCHK(hipMemcpyAsync(dkeys, p->gkeys.data(), sizeof(int32_t) * p->gkeys.size(), hipMemcpyHostToDevice, p->st));
+    HIPCHK(hipMemsetAsync(dSt, 0, (size_t)p->n * d.Kp, p->st));
+    launch_transpose_i8(dS, p->K, p->n, p->n, dSt, d.Kp, p->st);
+    launch_expand_features(dSt, p->n, p->K, d.Kp, dkeys, p->ko, Q, d.Xt, p->st);
+    launch_transpose_i8(d.Xt, Q, p->K, d.Kp, d.Xs, d.Qp, p->st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(p->st));
+    HIPCHK(hipFree(dS));
+    HIPCHK(hipFree(dSt));
+    HIPCHK(hipFree(dkeys));
+    return GML_OK;
+}
+
+static int create_common(const double *counts, const int8_t *spins, int64_t K, int64_t n, int order,
+                         int64_t node0, int64_t node1, int device, gml_problem **out) {
+    if (!out) return fail(GML_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (K <= 0 || n <= 0) return fail(GML_EINVAL, "empty histogram (K=%lld, n=%lld)", (long long)K, (long long)n);
+    if (order < 1 || order > 8) return fail(GML_EINVAL, "interaction order %d out of range [1,8]", order);
+    if (node0 < 0 || node1 > n || node0 >= node1)
+        return fail(GML_EINVAL, "bad node range [%lld,%lld) for n=%lld", (long long)node0, (long long)node1, (long long)n);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GML_EHIP, "no HIP device available (libgml_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(GML_EINVAL, "device %d out of range (%d devices)", device, ndev);
+    double M = 0;
+    for (int64_t k = 0; k < K; ++k) {
+        double c = counts ? counts[k] : 1.0;
+        if (!(c >= 0) || !std::isfinite(c)) return fail(GML_EINVAL, "count of configuration %lld is negative or not finite", (long long)k);
+        M += c;
+    }
+    if (!(M > 0)) return fail(GML_EINVAL, "sum of counts is zero");
+    gml_problem *p = new gml_problem();
+    p->device = device;
+    p->n = n;
+    p->K = K;
+    p->M = M;
+    p->order = order;
+    p->node0 = node0;
+    p->node1 = node1;
+    int rc = alloc_dev(p, counts, spins);
+    if (rc != GML_OK) {
+        std::string keep = g_err;
+        gml_problem_destroy(p);
+        g_err = keep;
+        return rc;
+    }
+    *out = p;
+    return GML_OK;
+}
+
+extern "C" int gml_problem_create_spins(const double *counts, const int8_t *spins, int64_t K, int64_t n,
+                                        int order, int64_t node0, int64_t node1, int device,
+                                        gml_problem **out) {
+    if (!spins) return fail(GML_EINVAL, "spins is NULL");
+    std::atomic<int64_t> bad(-1);
+    parallel_for((K + 65535) / 65536, [&](int64_t b) {
+        const int64_t k1 = std::min(K, (b + 1) * 65536);
+        for (int64_t k = b * 65536; k < k1; ++k)
+            for (int64_t i = 0; i < n; ++i) {
+                int8_t v = spins[k * n + i];
+                if (v != 1 && v != -1) bad = k;
+            }
+    });
+    if (bad >= 0) return fail(GML_EINVAL, "configuration %lld holds a spin that is not +-1", (long long)bad.load());
+    return create_common(counts, spins, K, n, order, node0, node1, device, out);
+}
+
+extern "C" int gml_problem_create(const void *samples, int dtype, int64_t K, int64_t n, int64_t ld,
+                                  int col_major, int order, int64_t node0, int64_t node1, int device,
+                                  gml_problem **out) {
+    if (!samples) return fail(GML_EINVAL, "samples is NULL");
+    if (K <= 0 || n <= 0) return fail(GML_EINVAL, "empty histogram (K=%lld, n=%lld)", (long long)K, (long long)n);
+    if (dtype != GML_I8 && dtype != GML_I32 && dtype != GML_I64 && dtype != GML_F64)
+        return fail(GML_EINVAL, "unknown dtype %d", dtype);
+    if (ld < (col_major ? K : n + 1)) return fail(GML_EINVAL, "leading dimension %lld too small", (long long)ld);
+    auto at = [&](int64_t k, int64_t j) -> double {
+        const int64_t off = col_major ? k + j * ld : k * ld + j;
+        switch (dtype) {
+        case GML_I8: return (double)((const int8_t *)samples)[off];
+        case GML_I32: return (double)((const int32_t *)samples)[off];
+        case GML_I64: return (double)((const int64_t *)samples)[off];
+        default: return ((const double *)samples)[off];
+        }
+    };
+    // data_info (:76-81): column 1 = counts, the rest = spins
+    std::vector<double> counts((size_t)K);
+    std::vector<int8_t> spins((size_t)K * n);
+    std::atomic<int64_t> bad(-1);
+    parallel_for((K + 4095) / 4096, [&](int64_t b) {
+        const int64_t k1 = std::min(K, (b + 1) * 4096);
+        for (int64_t k = b * 4096; k < k1; ++k) {
+            counts[k] = at(k, 0);
+            for (int64_t i = 0; i < n; ++i) {
+                double v = at(k, 1 + i);
+                if (v == 1.0) spins[k * n + i] = 1;
+                else if (v == -1.0) spins[k * n + i] = -1;
+                else bad = k;
+            }
+        }
+    });
+    if (bad >= 0) return fail(GML_EINVAL, "configuration %lld holds a spin that is not +-1", (long long)bad.load());
+    return create_common(counts.data(), spins.data(), K, n, order, node0, node1, device, out);
+}
+
+namespace gml { void i8_free(void *ws); }
+
+extern "C" void gml_problem_destroy(gml_problem *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->st) (void)hipStreamSynchronize(p->st);
+    void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dGroups, p->dFidx, p->dMt, p->dH};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    if (p->i8ws) gml::i8_free(p->i8ws);
+    if (p->st) (void)hipStreamDestroy(p->st);
+    delete p;
+}
+
+extern "C" int gml_problem_info(const gml_problem *p, int64_t *n, int64_t *K, double *M, int64_t *P,
+                                int64_t *node0, int64_t *node1) {
+    if (!p) return fail(GML_EINVAL, "problem is NULL");
+    if (n) *n = p->n;
+    if (K) *K = p->K;
+    if (M) *M = p->M;
+    if (P) *P = p->P;
+    if (node0) *node0 = p->node0;
+    if (node1) *node1 = p->node1;
+    return GML_OK;
+}
+
+extern "C" int gml_multi_keys(const gml_problem *p, int64_t u, int32_t *keys) {
+    if (!p || !keys) return fail(GML_EINVAL, "NULL argument");
+    if (u < 0 || u >= p->n) return fail(GML_EINVAL, "node %lld out of range", (long long)u);
+    std::vector<int32_t> cols;
+    node_cols(p, u, cols);
+    const int order = p->order;
+    for (int64_t j = 0; j < p->P; ++j) {
+        int32_t *k = keys + j * order;
+        for (int t = 0; t < order; ++t) k[t] = -1;
+        k[0] = (int32_t)u;
+        const int32_t c = cols[j];
+        for (int t = 0; t < p->ko && t + 1 < order; ++t) k[1 + t] = p->gkeys[(size_t)c * p->ko + t];
+    }
+    return GML_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// device pass orchestration
+// ------------------------------------------------------------------------------------------
+namespace gml {
+// implemented in gml_kernels_i8.hip: the exact int8-limb pass (same contract as the f64 one)
+int i8_pass(void **ws, const DevProblem &d, const double *dTheta, const int *dRowcol, const int *hRowcol,
+            const int *hGroups, int ngroups, int Rp, int form, bool want_grad, double *dF, double *dG,
+            hipStream_t st, hipEvent_t *ev /* [3] or NULL */, std::string *err);
+}
+
+static int ensure_ws(gml_problem *p, int64_t rows) {
+    const int64_t Rp = round_up(rows, 32);
+    if (Rp <= p->ws_rows) return GML_OK;
+    void *ptrs[] = {p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dGroups};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    p->dTheta = p->dV = p->dG = p->dF = nullptr;
+    p->dRowcol = p->dGroups = nullptr;
+    p->ws_rows = 0;
+    size_t freeb = 0, totalb = 0;
+    HIPCHK(hipMemGetInfo(&freeb, &totalb));
+    const double need = (double)Rp * p->d.Kp * 8.0 + 2.0 * Rp * p->d.Qp * 8.0;
+    if (need > 0.9 * (double)freeb)
+        return fail(GML_ENOMEM, "workspace of %.1f GB for %lld rows does not fit in %.1f GB free HBM", need / 1e9,
+                    (long long)Rp, freeb / 1e9);
+    HIPCHK(hipMalloc(&p->dTheta, sizeof(double) * Rp * p->d.Qp));
+    HIPCHK(hipMalloc(&p->dG, sizeof(double) * Rp * p->d.Qp));
+    HIPCHK(hipMalloc(&p->dV, sizeof(double) * Rp * p->d.Kp));
+    HIPCHK(hipMalloc(&p->dF, sizeof(double) * Rp));
+    HIPCHK(hipMalloc(&p->dRowcol, sizeof(int) * Rp));
+    HIPCHK(hipMalloc(&p->dGroups, sizeof(int) * (Rp / 32 + 4)));
+    HIPCHK(hipMemsetAsync(p->dV, 0, sizeof(double) * Rp * p->d.Kp, p->st));
+    HIPCHK(hipMemsetAsync(p->dTheta, 0, sizeof(double) * Rp * p->d.Qp, p->st));
+    p->ws_rows = Rp;
+    return GML_OK;
+}
+
+struct RowSet {
+    int64_t R = 0;
+    std::vector<int64_t> node; // node id per row
+};
+
+// One device pass over the rows flagged in `act` (size R).  theta: R x Qp host, internal
+// layout.  Writes f[r], and g (R x Qp) when want_grad, for the active rows only.
+static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8_t> &act, const double *theta,
+                       int form, int precision, bool want_grad, double *f, double *g, gml_stats *stats,
+                       float *ms /* [2]: fwd, bwd or NULL */ = nullptr) {
+    const int64_t R = rs.R, Qp = p->d.Qp;
+    const int64_t Rp = round_up(R, 32);
+    int rc = ensure_ws(p, R);
+    if (rc) return rc;
+    std::vector<int> rowcol((size_t)Rp, -1), groups;
+    int64_t nact = 0;
+    for (int64_t r = 0; r < R; ++r)
+        if (act[r]) {
+            rowcol[r] = (int)(1 + rs.node[r]);
+            ++nact;
+        }
+    if (nact == 0) return GML_OK;
+    for (int64_t gidx = 0; gidx < Rp / 32; ++gidx) {
+        bool any = false;
+        for (int64_t r = gidx * 32; r < std::min(R, (gidx + 1) * 32); ++r) any |= (act[r] != 0);
+        if (any) groups.push_back((int)gidx);
+    }
+    const double t0 = now_s();
+    hipStream_t st = p->st;
+    for (int gi : groups) {
+        const int64_t r0 = (int64_t)gi * 32, r1 = std::min(R, r0 + 32);
+        HIPCHK(hipMemcpyAsync(p->dTheta + r0 * Qp, theta + r0 * Qp, sizeof(double) * (r1 - r0) * Qp,
+                              hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipMemcpyAsync(p->dRowcol, rowcol.data(), sizeof(int) * Rp, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(p->dF, 0, sizeof(double) * Rp, st));
+    if (want_grad) HIPCHK(hipMemsetAsync(p->dG, 0, sizeof(double) * Rp * Qp, st));
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    if (ms)
+        for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    std::vector<int> gpad = groups;
+    while (gpad.size() % 4) gpad.push_back(-1);
+    HIPCHK(hipMemcpyAsync(p->dGroups, gpad.data(), sizeof(int) * gpad.size(), hipMemcpyHostToDevice, st));
+    if (precision == GML_PREC_I8X) {
+        std::string err;
+        rc = gml::i8_pass(&p->i8ws, p->d, p->dTheta, p->dRowcol, rowcol.data(), groups.data(), (int)groups.size(),
+                          (int)Rp, form, want_grad, p->dF, p->dG, st, ms ? ev : nullptr, &err);
+        if (rc) return fail(rc, "%s", err.c_str());
+    } else {
+        if (ms) HIPCHK(hipEventRecord(ev[0], st));
+        launch_fwd_f64(p->d, p->dTheta, p->dRowcol, p->dGroups, (int)gpad.size(), form, p->dV, p->dF, st);
+        if (ms) HIPCHK(hipEventRecord(ev[1], st));
+        if (want_grad) launch_bwd_f64(p->d, p->dV, p->dGroups, (int)groups.size(), p->dG, st);
+        if (ms) HIPCHK(hipEventRecord(ev[2], st));
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<double> fh((size_t)Rp);
+    HIPCHK(hipMemcpyAsync(fh.data(), p->dF, sizeof(double) * Rp, hipMemcpyDeviceToHost, st));
+    std::vector<double> gh;
+    if (want_grad) {
+        gh.resize(groups.size() * 32 * (size_t)Qp);
+        for (size_t a = 0; a < groups.size(); ++a)
+            HIPCHK(hipMemcpyAsync(gh.data() + a * 32 * Qp, p->dG + (int64_t)groups[a] * 32 * Qp,
+                                  sizeof(double) * 32 * Qp, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    if (ms) {
+        HIPCHK(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
+        HIPCHK(hipEventElapsedTime(&ms[1], ev[1], ev[2]));
+        for (auto &e : ev) (void)hipEventDestroy(e);
+    }
+    for (int64_t r = 0; r < R; ++r)
+        if (act[r]) f[r] = fh[r];
+    if (want_grad)
+        for (size_t a = 0; a < groups.size(); ++a)
+            for (int i = 0; i < 32; ++i) {
+                const int64_t r = (int64_t)groups[a] * 32 + i;
+                if (r < R && act[r]) std::memcpy(g + r * Qp, gh.data() + (a * 32 + i) * Qp, sizeof(double) * Qp);
+            }
+    if (stats) {
+        stats->t_pass += now_s() - t0;
+        stats->node_evals += nact;
+        if (want_grad) ++stats->passes;
+        else ++stats->forward_passes;
+    }
+    return GML_OK;
+}
+
+// Working-set Hessians of the active rows (FP64 MFMA kernel over the V of the last full pass).
+// Fidx: R x cap column ids (padding = Qp-1), m[r] = working-set size (0 = skip).
+// Hout: R x cap x cap host, lower 32x32 tiles filled.
+static int device_hessian(gml_problem *p, const RowSet &rs, const std::vector<int> &Fidx, const std::vector<int> &m,
+                          int cap, int form, std::vector<double> &Hout, gml_stats *stats) {
+    const int64_t R = rs.R;
+    const double t0 = now_s();
+    if (R > p->hs_rows || cap > p->hs_cap) {
+        void *ptrs[] = {p->dFidx, p->dMt, p->dH};
+        for (void *q : ptrs)
+            if (q) (void)hipFree(q);
+        p->dFidx = p->dMt = nullptr;
+        p->dH = nullptr;
+        p->hs_rows = std::max(R, p->hs_rows);
+        p->hs_cap = std::max<int64_t>(cap, p->hs_cap);
+        HIPCHK(hipMalloc(&p->dFidx, sizeof(int) * p->hs_rows * p->hs_cap));
+        HIPCHK(hipMalloc(&p->dMt, sizeof(int) * 2 * p->hs_rows));
+        HIPCHK(hipMalloc(&p->dH, sizeof(double) * p->hs_rows * p->hs_cap * p->hs_cap));
+    }
+    std::vector<int> mt2((size_t)2 * R);
+    for (int64_t r = 0; r < R; ++r) {
+        mt2[r] = (m[r] + 31) / 32;
+        mt2[R + r] = (int)(1 + rs.node[r]);
+    }
+    hipStream_t st = p->st;
+    HIPCHK(hipMemcpyAsync(p->dFidx, Fidx.data(), sizeof(int) * R * cap, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->dMt, mt2.data(), sizeof(int) * 2 * R, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(p->dH, 0, sizeof(double) * R * cap * cap, st));
+    launch_hess_f64(p->d, p->dV, p->dMt + R, p->dFidx, p->dMt, (int)R, cap, form, p->dH, st);
+    HIPCHK(hipGetLastError());
+    Hout.resize((size_t)R * cap * cap);
+    HIPCHK(hipMemcpyAsync(Hout.data(), p->dH, sizeof(double) * R * cap * cap, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (stats) {
+        stats->t_hess += now_s() - t0;
+        ++stats->hessian_passes;
+    }
+    return GML_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// layouts: reference parameter vector <-> internal column layout
+// ------------------------------------------------------------------------------------------
+struct NodeLayout {
+    std::vector<int32_t> cols; // reference slot j -> internal column
+};
+
+static void build_layout(const gml_problem *p, int64_t u, NodeLayout &L) {
+    if (p->order == 2) { // slot i <-> spin i, slot u = field (:162)
+        L.cols.resize((size_t)p->n);
+        for (int64_t i = 0; i < p->n; ++i) L.cols[i] = (int32_t)(i == u ? 0 : 1 + i);
+    } else {
+        node_cols(p, u, L.cols);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// dense Cholesky solve (host, small systems)
+// ------------------------------------------------------------------------------------------
+static bool chol_solve(std::vector<double> &A, std::vector<double> &b, int m) {
+    for (int j = 0; j < m; ++j) {
+        double d = A[(size_t)j * m + j];
+        for (int k = 0; k < j; ++k) d -= A[(size_t)j * m + k] * A[(size_t)j * m + k];
+        if (!(d > 0) || !std::isfinite(d)) return false;
+        d = std::sqrt(d);
+        A[(size_t)j * m + j] = d;
+        for (int i = j + 1; i < m; ++i) {
+            double s = A[(size_t)i * m + j];
+            for (int k = 0; k < j; ++k) s -= A[(size_t)i * m + k] * A[(size_t)j * m + k];
+            A[(size_t)i * m + j] = s / d;
+        }
+    }
+    for (int i = 0; i < m; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= A[(size_t)i * m + k] * b[k];
+        b[i] = s / A[(size_t)i * m + i];
+    }
+    for (int i = m - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < m; ++k) s -= A[(size_t)k * m + i] * b[k];
+        b[i] = s / A[(size_t)i * m + i];
+    }
+    return true;
+}
+
+static inline double pseudo_grad(double x, double g, double lam) {
+    if (lam == 0.0) return g;
+    if (x > 0) return g + lam;
+    if (x < 0) return g - lam;
+    if (g + lam < 0) return g + lam;
+    if (g - lam > 0) return g - lam;
+    return 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// gml_learn: batched working-set orthant-wise Newton.
+//
+// Every local node u solves   min_x f_u(x) + lambda * sum_{j penalised} |x_j|   -- the problem
+// the reference builds for Ipopt with the z >= |x| epigraph (:166-177) -- in lock-step:
+//   1. one device pass gives f and the full gradient of every active node;
+//   2. pseudo-gradient / KKT residual per node; converged nodes drop out;
+//   3. working set = non-zeros + the largest violators; its Hessian comes from one device
+//      kernel over the same K configurations; Newton step by Cholesky on the host;
+//   4. projected (orthant) backtracking line search: first trial is a full pass (it usually
+//      succeeds), further trials are objective-only passes over the rows that need them.
+// ------------------------------------------------------------------------------------------
+extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, const gml_opts *opts_in,
+                         double *out, double *kkt_out, gml_stats *stats_out) {
+    if (!p || !out) return fail(GML_EINVAL, "NULL argument");
+    if (formulation < 0 || formulation > 2) return fail(GML_EINVAL, "unknown formulation %d", formulation);
+    if (formulation != GML_RISE && p->order != 2)
+        return fail(GML_EUNSUPPORTED, "multi-body statistics are defined for RISE only (multiRISE, :83-152)");
+    if (!(regularizer_c >= 0)) return fail(GML_EINVAL, "regularizer must be >= 0");
+    gml_opts o;
+    if (opts_in) o = *opts_in;
+    else gml_default_opts(&o);
+    if (!(o.tol > 0)) o.tol = 1e-9;
+    if (o.max_iter <= 0) o.max_iter = 100;
+    if (o.max_working < 32) o.max_working = 256;
+    o.max_working = (int)round_up(o.max_working, 32);
+    if (o.max_add <= 0) o.max_add = 32;
+    HIPCHK(hipSetDevice(p->device));
+    gml_stats stl;
+    std::memset(&stl, 0, sizeof stl);
+    gml_stats *stats = &stl;
+    const double t_start = now_s();
+
+    const int64_t R = p->node1 - p->node0, Qp = p->d.Qp, Q = p->d.Q, P = p->P;
+    const double lambda = gml_lambda(regularizer_c, p->n, p->M);
+    stats->lambda = lambda;
+    const double noise = (o.precision == GML_PREC_I8X) ? 1e-11 : 1e-13;
+
+    RowSet rs;
+    rs.R = R;
+    rs.node.resize((size_t)R);
+    for (int64_t r = 0; r < R; ++r) rs.node[r] = p->node0 + r;
+
+    // kind[r][c]: 0 = structurally absent (key contains u), 1 = free, 2 = l1-penalised
+    std::vector<uint8_t> kind((size_t)R * Qp, 0);
+    std::vector<NodeLayout> lay((size_t)R);
+    parallel_for(R, [&](int64_t r) {
+        build_layout(p, rs.node[r], lay[r]);
+        uint8_t *kr = kind.data() + r * Qp;
+        for (int32_t c : lay[r].cols) kr[c] = (c == 0) ? 1 : 2; // length(inter) > 1 is penalised (:118,:171)
+    });
+
+    std::vector<double> X((size_t)R * Qp, 0.0), G((size_t)R * Qp, 0.0), Xt((size_t)R * Qp, 0.0),
+        Gt((size_t)R * Qp, 0.0), Xbest((size_t)R * Qp, 0.0);
+    std::vector<double> f((size_t)R, 0.0), ft((size_t)R, 0.0), Fobj((size_t)R, 0.0), kkt((size_t)R, INFINITY),
+        best((size_t)R, INFINITY), Z((size_t)R, 1.0), Zt((size_t)R, 1.0), alpha((size_t)R, 1.0), dd((size_t)R, 0.0);
+    std::vector<uint8_t> done((size_t)R, 0), act((size_t)R, 1), need((size_t)R, 0), vstale((size_t)R, 0);
+    std::vector<int> stall((size_t)R, 0), msz((size_t)R, 0);
+    std::vector<std::vector<int>> Fset((size_t)R);
+    std::vector<std::vector<double>> Dset((size_t)R), PGset((size_t)R);
+
+    // logRISE post-processing of a pass: f = log Z, g = grad Z / Z   (:279)
+    auto post = [&](const std::vector<uint8_t> &a, std::vector<double> &fv, std::vector<double> &gv,
+                    std::vector<double> &zv, bool grad) {
+        if (formulation != GML_LOGRISE) return;
+        parallel_for(R, [&](int64_t r) {
+            if (!a[r]) return;
+            const double z = fv[r];
+            zv[r] = z;
+            fv[r] = std::log(z);
+            if (grad) {
+                double *gr = gv.data() + r * Qp;
+                for (int64_t c = 0; c < Q; ++c) gr[c] /= z;
+            }
+        });
+    };
+
+    int rc = device_pass(p, rs, act, X.data(), formulation, o.precision, true, f.data(), G.data(), stats);
+    if (rc) return rc;
+    post(act, f, G, Z, true);
+
+    int it = 0;
+    for (it = 0; it < o.max_iter; ++it) {
+        const double th0 = now_s();
+        // ---- KKT residuals, working sets ----------------------------------------------
+        parallel_for(R, [&](int64_t r) {
+            if (done[r]) return;
+            const double *x = X.data() + r * Qp, *g = G.data() + r * Qp;
+            const uint8_t *kr = kind.data() + r * Qp;
+            double F = f[r], worst = 0;
+            std::vector<std::pair<double, int>> viol;
+            std::vector<int> &Fs = Fset[r];
+            Fs.clear();
+            for (int64_t c = 0; c < Q; ++c) {
+                if (!kr[c]) continue;
+                const double l = kr[c] == 2 ? lambda : 0.0;
+                F += l * std::fabs(x[c]);
+                const double pg = pseudo_grad(x[c], g[c], l);
+                if (std::fabs(pg) > worst) worst = std::fabs(pg);
+                if (x[c] != 0.0 || kr[c] == 1) Fs.push_back((int)c);
+                else if (pg != 0.0) viol.emplace_back(-std::fabs(pg), (int)c);
+            }
+            if (!std::isfinite(worst)) worst = INFINITY;
+            Fobj[r] = F;
+            kkt[r] = worst;
+            if (worst < best[r]) {
+                best[r] = worst;
+                std::memcpy(Xbest.data() + r * Qp, x, sizeof(double) * Qp);
+                stall[r] = 0;
+            } else {
+                ++stall[r];
+            }
+            if (worst <= o.tol || stall[r] >= 4) {
+                done[r] = 1;
+                return;
+            }
+            int room = std::min<int>(o.max_add, o.max_working - (int)Fs.size());
+            if (room < 0) room = 0;
+            if ((int)viol.size() > room) {
+                std::nth_element(viol.begin(), viol.begin() + room, viol.end());
+                viol.resize(room);
+            }
+            for (auto &v : viol) Fs.push_back(v.second);
+            std::sort(Fs.begin(), Fs.end());
+            if ((int)Fs.size() > o.max_working) Fs.resize(o.max_working); // |support| above the cap: block Newton
+        });
+        int64_t nactive = 0;
+        double worst_all = 0;
+        int maxm = 0;
+        for (int64_t r = 0; r < R; ++r) {
+            if (!done[r]) {
+                ++nactive;
+                maxm = std::max<int>(maxm, (int)Fset[r].size());
+            }
+            worst_all = std::max(worst_all, std::min(kkt[r], best[r]));
+        }
+        if (o.verbose)
+            fprintf(stderr, "[gml] it %3d active %6lld  max-kkt %.3e  max|F| %d  passes %d fwd %d\n", it,
+                    (long long)nactive, worst_all, maxm, stats->passes, stats->forward_passes);
+        if (nactive == 0) break;
+
+        // rows whose V was overwritten by a rejected trial need a fresh pass before the Hessian
+        bool anystale = false;
+        for (int64_t r = 0; r < R; ++r) {
+            need[r] = (!done[r] && vstale[r]);
+            anystale |= need[r] != 0;
+        }
+        stats->t_host += now_s() - th0;
+        if (anystale) {
+            rc = device_pass(p, rs, need, X.data(), formulation, o.precision, true, f.data(), G.data(), stats);
+            if (rc) return rc;
+            post(need, f, G, Z, true);
+            for (int64_t r = 0; r < R; ++r)
+                if (need[r]) vstale[r] = 0;
+        }
+
+        // ---- Hessians on the working sets -----------------------------------------------
+        const int cap = (int)round_up(std::max(maxm, 1), 32);
+        std::vector<int> Fidx((size_t)R * cap, (int)(Qp - 1));
+        for (int64_t r = 0; r < R; ++r) {
+            msz[r] = done[r] ? 0 : (int)Fset[r].size();
+            for (int a = 0; a < msz[r]; ++a) Fidx[(size_t)r * cap + a] = Fset[r][a];
+        }
+        std::vector<double> H;
+        rc = device_hessian(p, rs, Fidx, msz, cap, formulation, H, stats);
+        if (rc) return rc;
+
+        // ---- Newton directions -------------------------------------------------------------
+        const double th1 = now_s();
+        parallel_for(R, [&](int64_t r) {
+            if (done[r]) return;
+            const int m = msz[r];
+            const std::vector<int> &Fs = Fset[r];
+            const double *x = X.data() + r * Qp, *g = G.data() + r * Qp;
+            const uint8_t *kr = kind.data() + r * Qp;
+            std::vector<double> A((size_t)m * m), b((size_t)m), pgv((size_t)m), gF((size_t)m);
+            const double *Hr = H.data() + (size_t)r * cap * cap;
+            for (int a = 0; a < m; ++a) {
+                const int c = Fs[a];
+                const double l = kr[c] == 2 ? lambda : 0.0;
+                pgv[a] = pseudo_grad(x[c], g[c], l);
+                gF[a] = g[c];
+            }
+            for (int a = 0; a < m; ++a)
+                for (int bb = 0; bb <= a; ++bb) {
+                    // tile (a/32, bb/32) with a/32 >= bb/32 is stored; inside a diagonal tile both halves are
+                    double h = Hr[(size_t)a * cap + bb];
+                    if (formulation == GML_LOGRISE) h = h / Z[r] - gF[a] * gF[bb]; // Hess log Z
+                    A[(size_t)a * m + bb] = h;
+                    A[(size_t)bb * m + a] = h;
+                }
+            double ridge = 0.0;
+            std::vector<double> Aw, bw;
+            for (int tries = 0; tries < 12; ++tries) {
+                Aw = A;
+                bw.assign(m, 0.0);
+                for (int a = 0; a < m; ++a) {
+                    Aw[(size_t)a * m + a] += ridge;
+                    bw[a] = -pgv[a];
+                }
+                if (chol_solve(Aw, bw, m)) break;
+                ridge = ridge == 0.0 ? 1e-12 : ridge * 100.0;
+                bw.assign(m, 0.0);
+            }
+            Dset[r] = bw;
+            PGset[r] = pgv;
+        });
+        stats->t_host += now_s() - th1;
+
+        // ---- projected backtracking line search ----------------------------------------
+        for (int64_t r = 0; r < R; ++r) {
+            need[r] = !done[r];
+            alpha[r] = 1.0;
+        }
+        std::vector<uint8_t> accepted_fwd((size_t)R, 0);
+        for (int ls = 0; ls < 40; ++ls) {
+            const double th2 = now_s();
+            bool any = false;
+            parallel_for(R, [&](int64_t r) {
+                if (!need[r]) return;
+                const double *x = X.data() + r * Qp;
+                double *xt = Xt.data() + r * Qp;
+                const uint8_t *kr = kind.data() + r * Qp;
+                std::memcpy(xt, x, sizeof(double) * Qp);
+                const std::vector<int> &Fs = Fset[r];
+                double d_ = 0;
+                for (int a = 0; a < msz[r]; ++a) {
+                    const int c = Fs[a];
+                    double v = x[c] + alpha[r] * Dset[r][a];
+                    if (kr[c] == 2 && lambda > 0) {
+                        const double pg = PGset[r][a];
+                        const double xi = x[c] != 0.0 ? (x[c] > 0 ? 1.0 : -1.0) : (pg < 0 ? 1.0 : -1.0);
+                        if (v * xi < 0) v = 0.0; // crossed zero: clip to the orthant face
+                    }
+                    xt[c] = v;
+                    d_ += PGset[r][a] * (v - x[c]);
+                }
+                dd[r] = d_;
+            });
+            for (int64_t r = 0; r < R; ++r) any |= need[r] != 0;
+            stats->t_host += now_s() - th2;
+            if (!any) break;
+            const bool full = (ls == 0);
+            rc = device_pass(p, rs, need, Xt.data(), formulation, o.precision, full, ft.data(), Gt.data(), stats);
+            if (rc) return rc;
+            post(need, ft, Gt, Zt, full);
+            const double th3 = now_s();
+            parallel_for(R, [&](int64_t r) {
+                if (!need[r]) return;
+                vstale[r] = 1;
+                const double *xt = Xt.data() + r * Qp;
+                const uint8_t *kr = kind.data() + r * Qp;
+                double Fn = ft[r];
+                for (int a = 0; a < msz[r]; ++a) {
+                    const int c = Fset[r][a];
+                    if (kr[c] == 2) Fn += lambda * std::fabs(xt[c]);
+                }
+                // Armijo with an allowance for the summation noise of f (a Newton step whose predicted
+                // decrease is below that noise cannot be certified by function values)
+                const bool ok = std::isfinite(Fn) && Fn <= Fobj[r] + 1e-4 * dd[r] + noise * std::max(1.0, std::fabs(Fobj[r]));
+                if (ok) {
+                    std::memcpy(X.data() + r * Qp, xt, sizeof(double) * Qp);
+                    f[r] = ft[r];
+                    Z[r] = Zt[r];
+                    if (full) {
+                        std::memcpy(G.data() + r * Qp, Gt.data() + r * Qp, sizeof(double) * Qp);
+                        vstale[r] = 0;
+                    } else {
+                        accepted_fwd[r] = 1;
+                    }
+                    need[r] = 0;
+                } else {
+                    alpha[r] *= 0.5;
+                }
+            });
+            stats->t_host += now_s() - th3;
+        }
+        // rows accepted on an objective-only trial still need their gradient (and V)
+        bool anyf = false;
+        for (int64_t r = 0; r < R; ++r) anyf |= accepted_fwd[r] != 0;
+        if (anyf) {
+            rc = device_pass(p, rs, accepted_fwd, X.data(), formulation, o.precision, true, f.data(), G.data(), stats);
+            if (rc) return rc;
+            post(accepted_fwd, f, G, Z, true);
+            for (int64_t r = 0; r < R; ++r)
+                if (accepted_fwd[r]) vstale[r] = 0;
+        }
+        // rows whose line search failed entirely: they stay where they are; the stall counter ends them
+    }
+
+    // ---- results in the reference layout --------------------------------------------------
+    int notconv = 0;
+    double maxk = 0;
+    for (int64_t r = 0; r < R; ++r) {
+        const double k = std::min(best[r], kkt[r]);
+        if (!(k <= o.tol)) ++notconv;
+        maxk = std::max(maxk, k);
+        if (kkt_out) kkt_out[r] = k;
+    }
+    std::vector<double> res((size_t)R * P);
+    parallel_for(R, [&](int64_t r) {
+        const double *x = (best[r] <= kkt[r] ? Xbest.data() : X.data()) + r * Qp;
+        for (int64_t j = 0; j < P; ++j) res[(size_t)r * P + j] = x[lay[r].cols[j]];
+    });
+    hipPointerAttribute_t attr;
+    bool dev_out = false;
+    if (hipPointerGetAttributes(&attr, out) == hipSuccess) dev_out = (attr.type == hipMemoryTypeDevice);
+    else (void)hipGetLastError();
+    if (dev_out) {
+        HIPCHK(hipMemcpy(out, res.data(), sizeof(double) * R * P, hipMemcpyHostToDevice));
+    } else {
+        std::memcpy(out, res.data(), sizeof(double) * R * P);
+    }
+    stats->iterations = it;
+    stats->max_kkt = maxk;
+    stats->not_converged = notconv;
+    stats->t_total = now_s() - t_start;
+    if (stats_out) *stats_out = *stats;
+    if (notconv)
+        return fail(GML_ENOTCONV, "%d of %lld nodes did not reach the KKT tolerance %.1e (worst %.3e)", notconv,
+                    (long long)R, o.tol, maxk);
+    return GML_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// gml_objgrad_batch: the operator (:191-208, :221-233)
+// ------------------------------------------------------------------------------------------
+extern "C" int gml_objgrad_batch(gml_problem *p, int formulation, int precision, int64_t nrows,
+                                 const int64_t *nodes, const double *theta, int64_t ld, double *f, double *g) {
+    if (!p || !nodes || !theta || !f) return fail(GML_EINVAL, "NULL argument");
+    if (formulation < 0 || formulation > 2) return fail(GML_EINVAL, "unknown formulation %d", formulation);
+    if (nrows <= 0) return fail(GML_EINVAL, "nrows must be positive");
+    if (ld < p->P) return fail(GML_EINVAL, "ld %lld smaller than the %lld parameters per node", (long long)ld, (long long)p->P);
+    for (int64_t r = 0; r < nrows; ++r)
+        if (nodes[r] < 0 || nodes[r] >= p->n) return fail(GML_EINVAL, "node id %lld out of range", (long long)nodes[r]);
+    HIPCHK(hipSetDevice(p->device));
+    const int64_t Qp = p->d.Qp, P = p->P;
+    RowSet rs;
+    rs.R = nrows;
+    rs.node.assign(nodes, nodes + nrows);
+    std::vector<NodeLayout> lay((size_t)nrows);
+    std::vector<double> Th((size_t)nrows * Qp, 0.0), Gi(g ? (size_t)nrows * Qp : 0);
+    parallel_for(nrows, [&](int64_t r) {
+        build_layout(p, nodes[r], lay[r]);
+        for (int64_t j = 0; j < P; ++j) Th[(size_t)r * Qp + lay[r].cols[j]] = theta[r * ld + j];
+    });
+    std::vector<uint8_t> act((size_t)nrows, 1);
+    std::vector<double> fv((size_t)nrows);
+    int rc = device_pass(p, rs, act, Th.data(), formulation, precision, g != nullptr, fv.data(), Gi.data(), nullptr);
+    if (rc) return rc;
+    parallel_for(nrows, [&](int64_t r) {
+        double z = fv[r];
+        if (formulation == GML_LOGRISE) f[r] = std::log(z);
+        else f[r] = z;
+        if (g)
+            for (int64_t j = 0; j < P; ++j) {
+                double v = Gi[(size_t)r * Qp + lay[r].cols[j]];
+                if (formulation == GML_LOGRISE) v /= z;
+                g[r * ld + j] = v;
+            }
+    });
+    return GML_OK;
+}
+
+extern "C" int gml_bench_pass(gml_problem *p, int formulation, int precision, const double *theta, int steps,
+                              int warmup, double kernel_ms[3]) {
+    if (!p || !kernel_ms) return fail(GML_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(p->device));
+    const int64_t R = p->node1 - p->node0, Qp = p->d.Qp, P = p->P;
+    RowSet rs;
+    rs.R = R;
+    rs.node.resize((size_t)R);
+    std::vector<double> Th((size_t)R * Qp, 0.0), Gi((size_t)R * Qp), fv((size_t)R);
+    for (int64_t r = 0; r < R; ++r) rs.node[r] = p->node0 + r;
+    if (theta)
+        parallel_for(R, [&](int64_t r) {
+            NodeLayout L;
+            build_layout(p, rs.node[r], L);
+            for (int64_t j = 0; j < P; ++j) Th[(size_t)r * Qp + L.cols[j]] = theta[r * P + j];
+        });
+    std::vector<uint8_t> act((size_t)R, 1);
+    double sum[2] = {0, 0};
+    for (int s = 0; s < warmup + steps; ++s) {
+        float ms[2] = {0, 0};
+        int rc = device_pass(p, rs, act, Th.data(), formulation, precision, true, fv.data(), Gi.data(), nullptr, ms);
+        if (rc) return rc;
+        if (s >= warmup) {
+            sum[0] += ms[0];
+            sum[1] += ms[1];
+        }
+    }
+    kernel_ms[0] = sum[0] / steps;
+    kernel_ms[1] = sum[1] / steps;
+    kernel_ms[2] = kernel_ms[0] + kernel_ms[1];
+    return GML_OK;
+}

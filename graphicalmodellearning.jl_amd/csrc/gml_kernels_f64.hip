@@ -1,0 +1,353 @@
+// FP64 device path of the learn() hot path: packing kernels + the three FP64-MFMA kernels
+// (energies+pointwise, gradient, working-set Hessian).  gfx950 only.
+//
+// Math restated from /root/reference/src/GraphicalModelLearning.jl:
+//   energy   E_rk = s_u^k * sum_c Theta[r][c] * X[k][c]          (:162 + :170 inner sum)
+//   RISE     f = sum_k w_k exp(-E)          partial_k = -w_k exp(-E)            (:196, :204)
+//   logRISE  Z = sum_k w_k exp(-E) (f = log Z, done on the host side)           (:279)
+//   RPLE     f = sum_k w_k log(1+exp(-2E))                                      (:317)
+//   gradient g[c] = sum_k stat[k,c] * partial_k                                 (:205-207)
+// All three kernels are "NT" products C[i][j] = sum_t A[i][t] * B[j][t] on
+// v_mfma_f64_16x16x4_f64 with the +-1 operand converted from int8 in registers; operands go
+// straight from global memory / L2 to VGPRs (one f64 MFMA takes 64 cycles per SIMD, which
+// leaves ample time for the few loads per step), no LDS.
+#include "gml_dev.h"
+
+namespace gml {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------
+// packing
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose_i8(const int8_t *__restrict__ src, int64_t rows,
+                                                      int64_t cols, int64_t ld_src,
+                                                      int8_t *__restrict__ dst, int64_t ld_dst) {
+    __shared__ int8_t tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        int64_t r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[r * ld_src + c] : (int8_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        int64_t c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) dst[c * ld_dst + r] = tile[tx][i];
+    }
+}
+
+void launch_transpose_i8(const int8_t *src, int64_t rows, int64_t cols, int64_t ld_src, int8_t *dst,
+                         int64_t ld_dst, hipStream_t st) {
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+    hipLaunchKernelGGL(k_transpose_i8, grid, dim3(256), 0, st, src, rows, cols, ld_src, dst, ld_dst);
+}
+
+// Xt[c][k] = prod_{i in key_c} St[i][k]   (multi-body statistic, :107; the node's own spin is
+// applied later as the sign s_u).  key = -1 slots are unused; the empty key is the constant 1.
+__global__ __launch_bounds__(256) void k_expand_features(const int8_t *__restrict__ St, int64_t K,
+                                                         int64_t Kp, const int32_t *__restrict__ keys,
+                                                         int order, int64_t Q, int8_t *__restrict__ Xt) {
+    const int64_t c = blockIdx.y;
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= Q || k >= K) return;
+    int v = 1;
+    for (int t = 0; t < order; ++t) {
+        int i = keys[c * order + t];
+        if (i >= 0) v *= (int)St[(int64_t)i * Kp + k];
+    }
+    Xt[c * Kp + k] = (int8_t)v;
+}
+
+void launch_expand_features(const int8_t *St, int64_t n, int64_t K, int64_t Kp, const int32_t *keys,
+                            int order, int64_t Q, int8_t *Xt, hipStream_t st) {
+    (void)n;
+    dim3 grid((unsigned)((K + 255) / 256), (unsigned)Q);
+    hipLaunchKernelGGL(k_expand_features, grid, dim3(256), 0, st, St, K, Kp, keys, order, Q, Xt);
+}
+
+// ------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load8d(const double *p, double (&d)[8]) {
+    const double4 *q = reinterpret_cast<const double4 *>(p);
+    double4 a = q[0], b = q[1];
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
+    d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+}
+__device__ __forceinline__ void load8b(const int8_t *p, double (&d)[8]) {
+    // 8 consecutive int8 -> 8 doubles
+    uint2 u = *reinterpret_cast<const uint2 *>(p);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        d[s] = (double)(int)(int8_t)((u.x >> (8 * s)) & 0xff);
+        d[4 + s] = (double)(int)(int8_t)((u.y >> (8 * s)) & 0xff);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: energies + pointwise.  Wave tile: 32 rows (nodes) x 64 samples.
+// grid.x = Kp/64, grid.y = ceil(Rp/128); 4 waves = 4 x 32 rows on the same 64 samples.
+// Lane (li = lane&15, q = lane>>4) feeds MFMA step s of a 32-deep block with the element at
+// contraction index 8q+s for both operands (a fixed permutation of the contraction order).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_f64(const double *__restrict__ Theta,
+                                                 const int8_t *__restrict__ Xs,
+                                                 const int8_t *__restrict__ Xt,
+                                                 const int *__restrict__ rowcol,
+                                                 const int *__restrict__ groups,
+                                                 const double *__restrict__ w, int64_t Qp,
+                                                 int64_t Kp, int form, double *__restrict__ V,
+                                                 double *__restrict__ fsum) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, q = lane >> 4;
+    const int grp = groups[blockIdx.y * 4 + wave]; // 32-row group handled by this wave (-1: none)
+    if (grp < 0) return;
+    const int r0 = grp * 32;
+    const int64_t k0 = (int64_t)blockIdx.x * 64;
+
+    v4d acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (v4d){0, 0, 0, 0};
+
+    const double *arow[2];
+    const int8_t *brow[4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) arow[mi] = Theta + (int64_t)(r0 + 16 * mi + li) * Qp + 8 * q;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) brow[ni] = Xs + (k0 + 16 * ni + li) * Qp + 8 * q;
+
+    for (int64_t t0 = 0; t0 < Qp; t0 += 32) {
+        double a[2][8], b[4][8];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) load8d(arow[mi] + t0, a[mi]);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) load8b(brow[ni] + t0, b[ni]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MFMA_F64(a[mi][s], b[ni][s], acc[mi][ni]);
+    }
+
+    // epilogue: lane holds C[r = r0+16mi+q+4j][k = k0+16ni+li]
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + 16 * mi + q + 4 * j;
+            const int rc = rowcol[r];
+            double fpart = 0.0;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int64_t k = k0 + 16 * ni + li;
+                double val = 0.0;
+                if (rc >= 0) {
+                    const double wk = w[k];
+                    const double s = (double)(int)Xt[(int64_t)rc * Kp + k];
+                    const double E = s * acc[mi][ni][j];
+                    if (form == 2) { // RPLE (:317)
+                        const double t = -2.0 * E;
+                        const double sp = t > 0 ? t + log1p(exp(-t)) : log1p(exp(t));
+                        const double sg = 1.0 / (1.0 + exp(2.0 * E));
+                        fpart += wk * sp;
+                        val = -2.0 * wk * sg * s; // d/dE of w log(1+exp(-2E)), times s
+                    } else { // RISE (:196) / logRISE Z (:279)
+                        const double e = wk * exp(-E);
+                        fpart += e;
+                        val = -e * s; // partial_obj (:204) times the node's sign
+                    }
+                }
+                if (rc >= 0) V[(int64_t)r * Kp + k] = val; // inactive rows keep their previous V
+            }
+            // reduce over the 16 lanes sharing this row (li = 0..15)
+            fpart += __shfl_xor(fpart, 1);
+            fpart += __shfl_xor(fpart, 2);
+            fpart += __shfl_xor(fpart, 4);
+            fpart += __shfl_xor(fpart, 8);
+            if (li == 0 && rc >= 0) unsafeAtomicAdd(&fsum[r], fpart);
+        }
+    }
+}
+
+void launch_fwd_f64(const DevProblem &P, const double *Theta, const int *rowcol, const int *groups,
+                    int ngroups4, int form, double *V, double *fsum, hipStream_t st) {
+    dim3 grid((unsigned)(P.Kp / 64), (unsigned)(ngroups4 / 4));
+    hipLaunchKernelGGL(k_fwd_f64, grid, dim3(256), 0, st, Theta, P.Xs, P.Xt, rowcol, groups, P.w, P.Qp, P.Kp,
+                       form, V, fsum);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: G[r][c] += sum_k V[r][k] * Xt[c][k].  Wave tile 32 rows x 64 columns; the 4 waves
+// of a workgroup share the 32 rows (V is fetched once per workgroup, the other waves hit L1/L2)
+// and take 4 adjacent 64-column tiles.  grid = (ceil(Qp/256), Rp/32, nsplit); split-K partial
+// sums are combined with f64 atomics.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bwd_f64(const double *__restrict__ V,
+                                                 const int8_t *__restrict__ Xt,
+                                                 const int *__restrict__ groups, int64_t Qp,
+                                                 int64_t Kp, int64_t kchunk, double *__restrict__ G) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, q = lane >> 4;
+    const int r0 = groups[blockIdx.y] * 32;
+    const int64_t c0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    if (c0 >= Qp) return;
+    const int64_t kb = (int64_t)blockIdx.z * kchunk;
+    const int64_t ke = (kb + kchunk < Kp) ? kb + kchunk : Kp;
+
+    v4d acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (v4d){0, 0, 0, 0};
+    const double *arow[2];
+    const int8_t *brow[4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) arow[mi] = V + (int64_t)(r0 + 16 * mi + li) * Kp + 8 * q;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) brow[ni] = Xt + (c0 + 16 * ni + li) * Kp + 8 * q;
+
+    for (int64_t t0 = kb; t0 < ke; t0 += 32) {
+        double a[2][8], b[4][8];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) load8d(arow[mi] + t0, a[mi]);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) load8b(brow[ni] + t0, b[ni]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MFMA_F64(a[mi][s], b[ni][s], acc[mi][ni]);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = r0 + 16 * mi + q + 4 * j;
+                const int64_t c = c0 + 16 * ni + li;
+                unsafeAtomicAdd(&G[(int64_t)r * Qp + c], acc[mi][ni][j]);
+            }
+}
+
+void launch_bwd_f64(const DevProblem &P, const double *V, const int *groups, int ngroups, double *G,
+                    hipStream_t st) {
+    const unsigned gx = (unsigned)((P.Qp + 255) / 256), gy = (unsigned)ngroups;
+    int64_t nsplit = (4096 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
+    const int64_t maxsplit = P.Kp / 1024 > 0 ? P.Kp / 1024 : 1;
+    if (nsplit > maxsplit) nsplit = maxsplit;
+    if (nsplit < 1) nsplit = 1;
+    int64_t kchunk = (P.Kp + nsplit - 1) / nsplit;
+    kchunk = (kchunk + 31) / 32 * 32;
+    nsplit = (P.Kp + kchunk - 1) / kchunk;
+    dim3 grid(gx, gy, (unsigned)nsplit);
+    hipLaunchKernelGGL(k_bwd_f64, grid, dim3(256), 0, st, V, P.Xt, groups, P.Qp, P.Kp, kchunk, G);
+}
+
+// ------------------------------------------------------------------------------------------
+// working-set Hessian: H_r[i][j] += sum_k h_rk * Xt[F_ri][k] * Xt[F_rj][k]  for the lower
+// triangular 32x32 tiles of row r's working set.  h_rk is the second-derivative weight:
+//   RISE / logRISE(Z): h = w_k exp(-E) = V*s ;   RPLE: h = 4 w sg (1-sg), sg = (V*s)/(2w).
+// One wave per (row, tile pair, k-split); grid = (ceil(nsplit/4), maxpairs, R).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
+                                                  const int8_t *__restrict__ Xt,
+                                                  const double *__restrict__ w,
+                                                  const int *__restrict__ rowcol,
+                                                  const int *__restrict__ F, const int *__restrict__ mt,
+                                                  int cap, int64_t Kp, int64_t kchunk, int nsplit,
+                                                  int form, double *__restrict__ H) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, q = lane >> 4;
+    const int r = blockIdx.z;
+    const int m = mt[r];
+    const int pair = blockIdx.y;
+    if (pair >= m * (m + 1) / 2) return;
+    const int ks = blockIdx.x * 4 + wave;
+    if (ks >= nsplit) return;
+    int ti = (int)((sqrtf(8.0f * pair + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= pair) ++ti;
+    while (ti * (ti + 1) / 2 > pair) --ti;
+    const int tj = pair - ti * (ti + 1) / 2;
+    const int64_t kb = (int64_t)ks * kchunk;
+    const int64_t ke = (kb + kchunk < Kp) ? kb + kchunk : Kp;
+    const int rc = rowcol[r];
+    if (rc < 0) return;
+
+    const int *Fr = F + (int64_t)r * cap;
+    const int8_t *arow[2], *brow[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) arow[mi] = Xt + (int64_t)Fr[ti * 32 + 16 * mi + li] * Kp + 8 * q;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) brow[ni] = Xt + (int64_t)Fr[tj * 32 + 16 * ni + li] * Kp + 8 * q;
+    const double *vrow = V + (int64_t)r * Kp + 8 * q;
+    const int8_t *srow = Xt + (int64_t)rc * Kp + 8 * q;
+    const double *wrow = w + 8 * q;
+
+    v4d acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (v4d){0, 0, 0, 0};
+
+    for (int64_t t0 = kb; t0 < ke; t0 += 32) {
+        double h[8], sg[8], a[2][8], b[2][8];
+        load8d(vrow + t0, h);
+        load8b(srow + t0, sg);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) h[s] *= -sg[s]; // |V| = w |phi'|
+        if (form == 2) {
+            double wk[8];
+            load8d(wrow + t0, wk);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) h[s] = wk[s] > 0 ? 2.0 * h[s] * (1.0 - h[s] / (2.0 * wk[s])) : 0.0;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) load8b(arow[mi] + t0, a[mi]);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) load8b(brow[ni] + t0, b[ni]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = MFMA_F64(a[mi][s] * h[s], b[ni][s], acc[mi][ni]);
+    }
+    double *Hr = H + (int64_t)r * cap * cap;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = ti * 32 + 16 * mi + q + 4 * j;
+                const int jj = tj * 32 + 16 * ni + li;
+                unsafeAtomicAdd(&Hr[(int64_t)i * cap + jj], acc[mi][ni][j]);
+            }
+}
+
+void launch_hess_f64(const DevProblem &P, const double *V, const int *rowcol, const int *F,
+                     const int *mt, int R, int cap, int form, double *H, hipStream_t st) {
+    const int tiles = cap / 32;
+    const int maxpairs = tiles * (tiles + 1) / 2;
+    int64_t nsplit = (8192 + (int64_t)R * maxpairs - 1) / ((int64_t)R * maxpairs);
+    const int64_t maxsplit = P.Kp / 512 > 0 ? P.Kp / 512 : 1;
+    if (nsplit > maxsplit) nsplit = maxsplit;
+    if (nsplit < 1) nsplit = 1;
+    int64_t kchunk = (P.Kp + nsplit - 1) / nsplit;
+    kchunk = (kchunk + 31) / 32 * 32;
+    nsplit = (P.Kp + kchunk - 1) / kchunk;
+    dim3 grid((unsigned)((nsplit + 3) / 4), (unsigned)maxpairs, (unsigned)R);
+    hipLaunchKernelGGL(k_hess_f64, grid, dim3(256), 0, st, V, P.Xt, P.w, rowcol, F, mt, cap, P.Kp, kchunk,
+                       (int)nsplit, form, H);
+}
+
+} // namespace gml

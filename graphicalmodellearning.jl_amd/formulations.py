@@ -1,0 +1,76 @@
+"""The reference's formulation / method types (GraphicalModelLearning.jl:20-65), same names,
+same field order, same defaults -- plus the one new GMLMethod subtype, HIP."""
+from dataclasses import dataclass, field
+from typing import Any, Optional, Tuple
+
+
+class GMLFormulation:  # :20
+    pass
+
+
+@dataclass
+class multiRISE(GMLFormulation):  # :22-28
+    regularizer: float = 0.4
+    symmetrization: bool = True
+    interaction_order: int = 2
+
+
+# BASELINE.json calls the multi-body estimator "ISODUS"; the reference's name is multiRISE.
+ISODUS = multiRISE
+
+
+@dataclass
+class RISE(GMLFormulation):  # :30-35
+    regularizer: float = 0.4
+    symmetrization: bool = True
+
+
+@dataclass
+class RISEA(GMLFormulation):  # :37-42 (same objective as RISE, hand-written obj/grad :191-208)
+    regularizer: float = 0.4
+    symmetrization: bool = True
+
+
+@dataclass
+class logRISE(GMLFormulation):  # :44-49
+    regularizer: float = 0.8
+    symmetrization: bool = True
+
+
+@dataclass
+class RPLE(GMLFormulation):  # :51-56
+    regularizer: float = 0.2
+    symmetrization: bool = True
+
+
+class GMLMethod:  # :59
+    pass
+
+
+@dataclass
+class HIP(GMLMethod):
+    """Solve every node-wise problem on MI355X through libgml_hip (include/gml.h).
+
+    tol        KKT tolerance (max |pseudo-gradient| per node)
+    precision  "f64" (FP64 MFMA) or "i8x" (exact int8-limb fixed point on the i8 MFMA)
+    device     HIP device ordinal; with distributed=True the local rank's device
+    distributed  shard the nodes over torch.distributed ranks and gather the rows (RCCL)
+    """
+    tol: float = 1e-9
+    precision: str = "f64"
+    device: Optional[int] = None
+    max_iter: int = 100
+    max_working: int = 256
+    max_add: int = 32
+    verbose: int = 0
+    distributed: bool = False
+    node_range: Optional[Tuple[int, int]] = None
+    stats: dict = field(default_factory=dict, repr=False, compare=False)
+
+
+@dataclass
+class NLP(GMLMethod):  # :61-65
+    """The reference's method type: `solver` is a JuMP optimizer factory there.  Neither Julia
+    nor Ipopt exists on this platform, so NLP(...) is accepted for source compatibility and
+    dispatches to the same device solver as HIP() with default options."""
+    solver: Any = None

@@ -1,0 +1,162 @@
+/*
+ * gml.h -- C ABI of the MI355X-native learn() hot path of GraphicalModelLearning.jl.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / C++ types.  Every
+ * entry point names the reference interface it replaces (paths relative to
+ * /root/reference/src/GraphicalModelLearning.jl).  The reference-side binding (Julia
+ * `ccall`) is shown in INTEGRATION.md and graphicalmodellearning.jl_amd/julia/.
+ *
+ * All functions return 0 on success or a GML_E* code; gml_last_error() returns a
+ * thread-local message for the last failure.  The library never falls back to a CPU
+ * implementation: without a usable HIP device every compute entry point fails with
+ * GML_EHIP.
+ */
+#ifndef GML_H
+#define GML_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------- */
+#define GML_OK 0
+#define GML_EINVAL 1     /* bad argument: shape, dtype, non +-1 spin, negative count, ...   */
+#define GML_ENOTCONV 2   /* a node did not reach the KKT tolerance (reference: the
+                            `@assert termination_status == LOCALLY_SOLVED` at :127,180,251,289,327) */
+#define GML_EHIP 3       /* HIP runtime error / no device                                   */
+#define GML_ENOMEM 4     /* the problem does not fit the device                             */
+#define GML_EUNSUPPORTED 5
+
+/* ---- formulations: the GMLFormulation subtypes (:20-56) ----------------------------- */
+#define GML_RISE 0       /* RISE    (:30-35), objective :169-172; RISEA (:37-42, :191-260) is the same math */
+#define GML_LOGRISE 1    /* logRISE (:44-49), objective :278-281                            */
+#define GML_RPLE 2       /* RPLE    (:51-56), objective :316-319                            */
+
+/* ---- element types of the sample histogram ------------------------------------------ */
+#define GML_I8 0
+#define GML_I32 1
+#define GML_I64 2        /* what `sample()` returns (sampling.jl:52-54)                     */
+#define GML_F64 3        /* what `readdlm` returns (test/runtests.jl:71)                    */
+
+/* ---- arithmetic of the device objective/gradient pass ------------------------------- */
+#define GML_PREC_F64 0   /* FP64 MFMA (v_mfma_f64_16x16x4_f64)                             */
+#define GML_PREC_I8X 1   /* exact fixed-point: int8 limbs on v_mfma_i32_*_i8                */
+
+typedef struct gml_problem gml_problem; /* opaque: packed spins + weights resident in HBM  */
+
+typedef struct gml_opts {
+    double tol;          /* KKT tolerance: max |pseudo-gradient| per node (default 1e-9)    */
+    int32_t max_iter;    /* outer (Newton) iterations (default 100)                         */
+    int32_t precision;   /* GML_PREC_*                                                      */
+    int32_t max_working; /* cap on a node's working set (default 256, multiple of 32)       */
+    int32_t max_add;     /* new coordinates admitted per node per iteration (default 32)    */
+    int32_t verbose;     /* 0 silent, 1 per-iteration line on stderr                        */
+    int32_t reserved[3];
+} gml_opts;
+
+typedef struct gml_stats {
+    int32_t iterations;      /* outer iterations                                            */
+    int32_t passes;          /* full objective+gradient passes (all local nodes)            */
+    int32_t forward_passes;  /* objective-only passes (line-search trials)                  */
+    int32_t hessian_passes;
+    int64_t node_evals;      /* sum over passes of the number of nodes evaluated            */
+    double max_kkt;          /* worst final KKT residual over local nodes                   */
+    double lambda;           /* the regulariser actually used (:157)                        */
+    double t_pack, t_pass, t_hess, t_host, t_total; /* seconds                              */
+    int32_t not_converged;   /* number of local nodes above tol                             */
+    int32_t reserved;
+} gml_stats;
+
+const char *gml_last_error(void);
+void gml_default_opts(gml_opts *o);
+
+/*
+ * gml_problem_create -- replaces what every `learn` method does first: `data_info(samples)`
+ * (:76-81) and the per-node `nodal_stat` comprehension (:162, :218, :271, :309; multi-body
+ * :94-108), which it never materialises.
+ *
+ *   samples   K x (1+n) histogram, column 0 = counts, columns 1..n = spins in {-1,+1}
+ *             (the `Array{T,2}` produced by sampling.jl:52-54).  ld = leading dimension;
+ *             col_major != 0 for a Julia matrix (element (k,j) at samples[k + j*ld]),
+ *             0 for a C/numpy matrix (samples[k*ld + j]).
+ *   order     interaction order of the statistics: 2 = pairwise (RISE/logRISE/RPLE),
+ *             p >= 2 = multiRISE(..., p) (:22-28).  order 1 = fields only.
+ *   node0,node1  this handle solves nodes [node0, node1) (0-based); node-wise sharding for
+ *             one-process-per-GPU runs (the `for current_spin = 1:num_spins` loop, :161).
+ *   device    HIP device ordinal.
+ * The caller keeps ownership of `samples`; it is not referenced after return.
+ */
+int gml_problem_create(const void *samples, int dtype, int64_t K, int64_t n, int64_t ld,
+                       int col_major, int order, int64_t node0, int64_t node1, int device,
+                       gml_problem **out);
+
+/* Same, from split inputs: counts (K doubles, NULL = all ones) and spins (K x n int8,
+ * row-major).  Used by the synthetic benchmark so that no 8-byte histogram is built. */
+int gml_problem_create_spins(const double *counts, const int8_t *spins, int64_t K, int64_t n,
+                             int order, int64_t node0, int64_t node1, int device,
+                             gml_problem **out);
+
+void gml_problem_destroy(gml_problem *p);
+
+/* sizes: n, K (rows given), M = sum(counts) (:79), P = parameters per node
+ * (n for order 2; sum_{p<=order} C(n-1,p-1) in general), local node range */
+int gml_problem_info(const gml_problem *p, int64_t *n, int64_t *K, double *M, int64_t *P,
+                     int64_t *node0, int64_t *node1);
+
+/* lambda = c*sqrt(log(n^2/0.05)/M)  (:157; identical at :86, :213, :266, :304) */
+double gml_lambda(double c, int64_t n, double M);
+
+/* Multi-body keys of node u in the reference's construction order (:94-104 with
+ * models.jl:228-246): P rows of `order` int32 (0-based spin ids, -1 = unused slot). */
+int gml_multi_keys(const gml_problem *p, int64_t u, int32_t *keys);
+
+/*
+ * gml_objgrad_batch -- the operator boundary.  Replaces the pair the reference registers
+ * with JuMP, `obj(x...)` / `grad(g, x...)` = risea_obj / grad_risea_obj (:191-208, :221-233),
+ * for many nodes at once, and the @NLobjective smooth parts of logRISE (:278-281) and
+ * RPLE (:316-319).
+ *
+ *   nodes[r]        node id (0-based, any node, repeats allowed), r < nrows
+ *   theta[r*ld + j] parameter j of row r in the REFERENCE's layout: pairwise -> j = spin
+ *                   index, slot j == nodes[r] is the field (the u-th column of nodal_stat
+ *                   is s_u, :162); multi-body -> j indexes gml_multi_keys(nodes[r]).
+ *   f[r]            smooth objective (no l1 term)
+ *   g[r*ld + j]     its gradient, same layout as theta
+ * One "node evaluation" = one row.
+ */
+int gml_objgrad_batch(gml_problem *p, int formulation, int precision, int64_t nrows,
+                      const int64_t *nodes, const double *theta, int64_t ld, double *f,
+                      double *g);
+
+/*
+ * gml_learn -- replaces learn(samples, formulation, method) for the handle's node range
+ * (:154-189 RISE, :263-298 logRISE, :301-336 RPLE, :210-260 RISEA, :83-133 multiRISE up to
+ * the per-node solve).  For every local node it minimises
+ *     f_u(x) + lambda * sum_{j penalised} |x_j|
+ * (the problem the reference hands to Ipopt through the z >= |x| epigraph, :166-181).
+ *
+ *   out   (node1-node0) x P, row-major: row r = solution of node node0+r in the reference's
+ *         layout (pairwise: reconstruction[u, 1:n] of :181, diagonal slot = field).
+ *         May be a host pointer or a device pointer (detected).
+ *   kkt   optional (node1-node0) host array: final max|pseudo-gradient| per node.
+ * Symmetrisation (:184-186, :135-149) needs all rows and is done by the caller after the
+ * gather (see the Python / Julia host layer).
+ * Returns GML_ENOTCONV if some node stayed above opts->tol (out is still filled).
+ */
+int gml_learn(gml_problem *p, int formulation, double regularizer_c, const gml_opts *opts,
+              double *out, double *kkt, gml_stats *stats);
+
+/* Timing hook for the benchmark: runs `steps` full objective+gradient passes over the local
+ * nodes at the given theta ((node1-node0) x P, reference layout, host) on the handle's
+ * stream and returns the average device time of the dominant kernels measured with HIP
+ * events.  kernel_ms[0] = forward (energies + pointwise), [1] = backward (gradient),
+ * [2] = whole pass. */
+int gml_bench_pass(gml_problem *p, int formulation, int precision, const double *theta,
+                   int steps, int warmup, double kernel_ms[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GML_H */
