@@ -27,7 +27,11 @@ def _local_solve_hip(samples, formulation, method, order, node_range, device):
                                   max_working=method.max_working, max_add=method.max_add, verbose=method.verbose)
         keys = None
         if isinstance(formulation, multiRISE):
-            keys = [prob.multi_keys(u) for u in range(node_range[0], node_range[1])]
+            if order == 2:  # the C ABI keeps the pairwise slot layout for order 2 (slot u = field)
+                n = prob.n
+                keys = [[(u,) if i == u else (u, i) for i in range(n)] for u in range(node_range[0], node_range[1])]
+            else:
+                keys = [prob.multi_keys(u) for u in range(node_range[0], node_range[1])]
     return out, kkt, st, keys
 
 
@@ -96,7 +100,7 @@ def learn(samples, formulation=None, method=None, *, _local_solve=None):
 
     if isinstance(formulation, multiRISE):
         if keys is None or method.distributed and world > 1:
-            keys = _all_multi_keys(n, order, node_range)
+            keys = _all_multi_keys(n, order, node_range, pairwise_slots=(order == 2 and _local_solve is None))
         rec = {}
         for r, u in enumerate(range(node_range[0], node_range[1])):
             for key, v in zip(keys[r], out[r]):
@@ -114,10 +118,13 @@ def learn(samples, formulation=None, method=None, *, _local_solve=None):
     return R
 
 
-def _all_multi_keys(n, order, node_range):
-    """(u), (u,i)..., (u,i,j)... in the reference's order (:94-104, models.jl:228-246); 0-based."""
+def _all_multi_keys(n, order, node_range, pairwise_slots=False):
+    """(u), (u,i)..., (u,i,j)... in the reference's order (:94-104, models.jl:228-246); 0-based.
+    pairwise_slots: the order-2 slot layout of the C ABI (slot i <-> spin i, slot u = field)."""
     from itertools import combinations
     keys = []
+    if pairwise_slots:
+        return [[(u,) if i == u else (u, i) for i in range(n)] for u in range(node_range[0], node_range[1])]
     for u in range(node_range[0], node_range[1]):
         others = [i for i in range(n) if i != u]
         ku = []

@@ -25,7 +25,7 @@ def block_ising(n, K, block=16, seed=0, p_edge=0.3, jmin=0.2, jmax=0.6, hmax=0.1
         A[iu] = np.where(on, vals, 0.0)
         A = A + A.T
         h = rng.uniform(-hmax, hmax, size=block)
-        en = 0.5 * np.einsum("si,ij,sj->s", sf, A, sf) + sf @ h  # weigh_proba (sampling.jl:26-30)
+        en = 0.5 * ((sf @ A) * sf).sum(1) + sf @ h  # weigh_proba (sampling.jl:26-30)
         pr = np.exp(en - en.max())
         cdf = np.cumsum(pr / pr.sum())
         idx = np.minimum(np.searchsorted(cdf, rng.random(K)), 2 ** block - 1)
@@ -78,7 +78,7 @@ def enumerate_sample(J, N, seed=0):
     states = ((np.arange(2 ** n)[:, None] >> np.arange(n)) & 1) * 2 - 1  # int_to_spin (sampling.jl:11-14)
     sf = states.astype(float)
     A = J - np.diag(np.diag(J))
-    en = 0.5 * np.einsum("si,ij,sj->s", sf, A, sf) + sf @ np.diag(J)
+    en = 0.5 * ((sf @ A) * sf).sum(1) + sf @ np.diag(J)
     pr = np.exp(en - en.max())
     pr /= pr.sum()
     counts = rng.multinomial(N, pr)
