@@ -9,13 +9,17 @@ namespace gml {
 //   Xs [Kp][Qp] int8   sample-major design matrix: Xs[k][c] = prod_{i in key_c} s_i^k
 //   Xt [Qp][Kp] int8   the same matrix feature-major
 //   w  [Kp]     f64    c_k / M   (samples[k,1]/num_samples, GraphicalModelLearning.jl:170)
-// Column 0 is the empty key (constant 1: the node's field), columns 1..n the single spins,
-// then pairs (i<j) in lexicographic order, ... (multi-body, :94-108).  Node u's sign
-// s_u^k is row 1+u of Xt.  Column Qp-1 is always a zero (padding) column.
+// Columns 0..n-1 are the single spins, then pairs (i<j) in lexicographic order, ... (multi-body,
+// :94-108); column `cconst` is the empty key (constant 1: the node's field).  Node u's sign
+// s_u^k is row u of Xt.  Column Qp-1 is always a zero (padding) column.
 struct DevProblem {
-    int64_t K, Kp, n, Q, Qp;
+    int64_t K, Kp, n;
+    int64_t Qf, Qfp;  // statistic columns [0,Qf), zero padded to Qfp (multiple of 64)
+    int64_t cconst;   // column of the constant statistic (= Qfp)
+    int64_t Qp;       // row pitch of Xs / number of rows of Xt (= Qfp + 64)
     int8_t *Xs, *Xt;
     double *w;
+    double wmax;      // max_k w_k
 };
 
 // ---- packing -----------------------------------------------------------------------------
@@ -26,7 +30,7 @@ void launch_expand_features(const int8_t *St, int64_t n, int64_t K, int64_t Kp,
                             hipStream_t st);
 
 // ---- FP64 path -----------------------------------------------------------------------------
-// Theta [Rp][Qp] (internal column layout, masked slots zero), rowcol[r] = 1+u (row of Xt
+// Theta [Rp][Qp] (internal column layout, masked slots zero), rowcol[r] = u (row of Xt
 // holding node u's sign) or -1 for padding rows.  Rp multiple of 32.
 // V [Rp][Kp]: V[r][k] = d f_r / d E_rk * s_rk = -w_k exp(-E) s (RISE: `partial_obj` of :204 times s)
 // fsum [Rp]: sum_k w_k phi(E_rk)  (must be zeroed by the caller)
@@ -38,7 +42,10 @@ void launch_bwd_f64(const DevProblem &P, const double *V, const int *groups, int
                     hipStream_t st);
 // H [Rp][cap][cap] += sum_k h_rk Xt[F_ri][k] Xt[F_rj][k], lower-triangular 32x32 tiles only.
 // F [Rp][cap] column ids (padding = Qp-1), mt[r] = number of 32-tiles used by row r.
-void launch_hess_f64(const DevProblem &P, const double *V, const int *rowcol, const int *F,
-                     const int *mt, int R, int cap, int form, double *H, hipStream_t st);
+// The weights come either from V (FP64 pass) or, when V == NULL, from the int8 limb planes Vq
+// with per-row step tau (exact fixed-point pass).
+void launch_hess_f64(const DevProblem &P, const double *V, const int8_t *Vq, const double *tau,
+                     const int *rowcol, const int *F, const int *mt, int R, int cap, int form, double *H,
+                     hipStream_t st);
 
 } // namespace gml

@@ -136,11 +136,11 @@ static bool next_comb(std::vector<int> &idx, int64_t n) {
 static void node_cols(const gml_problem *p, int64_t u, std::vector<int32_t> &cols) {
     cols.clear();
     cols.reserve((size_t)p->P);
-    cols.push_back(0);
+    cols.push_back((int32_t)p->d.cconst); // (u,) : the field, statistic s_u * 1
     const int fo = p->order - 1;
     if (fo >= 1) {
         for (int64_t i = 0; i < p->n; ++i)
-            if (i != u) cols.push_back((int32_t)(1 + i));
+            if (i != u) cols.push_back((int32_t)i);
     }
     for (int q = 2; q <= fo; ++q) {
         if (q > p->n) break;
@@ -162,27 +162,33 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
     DevProblem &d = p->d;
     const int fo = p->order - 1;
     p->ko = fo > 0 ? fo : 1;
+    // internal columns: [0, Qf) = the non-empty subsets of spins (singles, then pairs (i<j)
+    // lexicographic, ...), zero padding up to Qfp, then the constant column `cconst` (the empty
+    // subset: the node's field) opening a final 64-byte block.
     p->qoff.assign(fo + 2, 0);
-    int64_t Q = 1;
+    int64_t Qf = 0;
     for (int q = 1; q <= fo; ++q) {
-        p->qoff[q] = Q;
-        Q += binom(p->n, q);
+        p->qoff[q] = Qf;
+        Qf += binom(p->n, q);
     }
-    p->qoff[fo + 1] = Q;
+    p->qoff[fo + 1] = Qf;
     p->P = 0;
     for (int q = 0; q <= fo; ++q) p->P += binom(p->n - 1, q);
     d.K = p->K;
     d.n = p->n;
-    d.Q = Q;
-    d.Kp = round_up(p->K, 256);
-    d.Qp = round_up(Q + 1, 64);
+    d.Qf = Qf;
+    d.Qfp = round_up(std::max<int64_t>(Qf, 1), 64);
+    d.cconst = d.Qfp;
+    d.Qp = d.Qfp + 64;
+    d.Kp = round_up(p->K, 1024);
+    const int64_t Q = Qf;
     if ((double)d.Kp * (double)d.Qp * 2.0 > 200e9)
         return fail(GML_ENOMEM, "design matrix %lld x %lld does not fit (on-the-fly monomials are not implemented yet)",
                     (long long)d.Kp, (long long)d.Qp);
     // feature keys
-    p->gkeys.assign((size_t)Q * p->ko, -1);
+    p->gkeys.assign((size_t)std::max<int64_t>(Q, 1) * p->ko, -1);
     {
-        int64_t c = 1;
+        int64_t c = 0;
         for (int q = 1; q <= fo && q <= p->n; ++q) {
             std::vector<int> idx(q);
             for (int t = 0; t < q; ++t) idx[t] = t;
@@ -200,7 +206,11 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
     HIPCHK(hipMemsetAsync(d.w, 0, sizeof(double) * d.Kp, p->st));
     // weights w_k = counts[k]/M  (:170)
     std::vector<double> w((size_t)p->K);
-    for (int64_t k = 0; k < p->K; ++k) w[k] = (counts ? counts[k] : 1.0) / p->M;
+    d.wmax = 0;
+    for (int64_t k = 0; k < p->K; ++k) {
+        w[k] = (counts ? counts[k] : 1.0) / p->M;
+        d.wmax = std::max(d.wmax, w[k]);
+    }
     HIPCHK(hipMemcpyAsync(d.w, w.data(), sizeof(double) * p->K, hipMemcpyHostToDevice, p->st));
     // spins: upload sample-major, transpose to spin-major St [n][Kp], expand, transpose back
     int8_t *dS = nullptr, *dSt = nullptr;
@@ -212,8 +222,9 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
     HIPCHK(hipMemcpyAsync(dkeys, p->gkeys.data(), sizeof(int32_t) * p->gkeys.size(), hipMemcpyHostToDevice, p->st));
     HIPCHK(hipMemsetAsync(dSt, 0, (size_t)p->n * d.Kp, p->st));
     launch_transpose_i8(dS, p->K, p->n, p->n, dSt, d.Kp, p->st);
-    launch_expand_features(dSt, p->n, p->K, d.Kp, dkeys, p->ko, Q, d.Xt, p->st);
-    launch_transpose_i8(d.Xt, Q, p->K, d.Kp, d.Xs, d.Qp, p->st);
+    if (Q > 0) launch_expand_features(dSt, p->n, p->K, d.Kp, dkeys, p->ko, Q, d.Xt, p->st);
+    HIPCHK(hipMemsetAsync(d.Xt + d.cconst * d.Kp, 1, (size_t)p->K, p->st)); // the constant statistic
+    launch_transpose_i8(d.Xt, d.cconst + 1, p->K, d.Kp, d.Xs, d.Qp, p->st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(p->st));
     HIPCHK(hipFree(dS));
@@ -314,7 +325,10 @@ extern "C" int gml_problem_create(const void *samples, int dtype, int64_t K, int
     return create_common(counts.data(), spins.data(), K, n, order, node0, node1, device, out);
 }
 
-namespace gml { void i8_free(void *ws); }
+namespace gml {
+void i8_free(void *ws);
+void i8_get_v(void *ws, const int8_t **Vq, const double **tau);
+}
 
 extern "C" void gml_problem_destroy(gml_problem *p) {
     if (!p) return;
@@ -351,7 +365,8 @@ extern "C" int gml_multi_keys(const gml_problem *p, int64_t u, int32_t *keys) {
         for (int t = 0; t < order; ++t) k[t] = -1;
         k[0] = (int32_t)u;
         const int32_t c = cols[j];
-        for (int t = 0; t < p->ko && t + 1 < order; ++t) k[1 + t] = p->gkeys[(size_t)c * p->ko + t];
+        if (c != (int32_t)p->d.cconst)
+            for (int t = 0; t < p->ko && t + 1 < order; ++t) k[1 + t] = p->gkeys[(size_t)c * p->ko + t];
     }
     return GML_OK;
 }
@@ -402,7 +417,8 @@ struct RowSet {
 // layout.  Writes f[r], and g (R x Qp) when want_grad, for the active rows only.
 static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8_t> &act, const double *theta,
                        int form, int precision, bool want_grad, double *f, double *g, gml_stats *stats,
-                       float *ms /* [2]: fwd, bwd or NULL */ = nullptr) {
+                       float *ms /* [2]: fwd, bwd or NULL */ = nullptr,
+                       double *fnoise /* R: absolute uncertainty of f[r] (before any log) or NULL */ = nullptr) {
     const int64_t R = rs.R, Qp = p->d.Qp;
     const int64_t Rp = round_up(R, 32);
     int rc = ensure_ws(p, R);
@@ -411,7 +427,7 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
     int64_t nact = 0;
     for (int64_t r = 0; r < R; ++r)
         if (act[r]) {
-            rowcol[r] = (int)(1 + rs.node[r]);
+            rowcol[r] = (int)rs.node[r]; // row of Xt holding s_u
             ++nact;
         }
     if (nact == 0) return GML_OK;
@@ -458,7 +474,23 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
             HIPCHK(hipMemcpyAsync(gh.data() + a * 32 * Qp, p->dG + (int64_t)groups[a] * 32 * Qp,
                                   sizeof(double) * 32 * Qp, hipMemcpyDeviceToHost, st));
     }
+    std::vector<double> tauh;
+    if (fnoise && precision == GML_PREC_I8X) {
+        const int8_t *Vq = nullptr;
+        const double *tau = nullptr;
+        gml::i8_get_v(p->i8ws, &Vq, &tau);
+        tauh.resize((size_t)Rp);
+        HIPCHK(hipMemcpyAsync(tauh.data(), tau, sizeof(double) * Rp, hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(hipStreamSynchronize(st));
+    if (fnoise)
+        for (int64_t r = 0; r < R; ++r) {
+            if (!act[r]) continue;
+            // f64: summation rounding.  int8 limbs: every V_rk is rounded to a multiple of tau_r and
+            // the roundings can add coherently (few distinct energies): K * tau/2 worst case.
+            fnoise[r] = 1e-13 * std::max(1.0, std::fabs(fh[r]));
+            if (precision == GML_PREC_I8X && form != GML_RPLE) fnoise[r] += 0.5 * (double)p->K * tauh[r];
+        }
     if (ms) {
         HIPCHK(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
         HIPCHK(hipEventElapsedTime(&ms[1], ev[1], ev[2]));
@@ -485,7 +517,7 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
 // Fidx: R x cap column ids (padding = Qp-1), m[r] = working-set size (0 = skip).
 // Hout: R x cap x cap host, lower 32x32 tiles filled.
 static int device_hessian(gml_problem *p, const RowSet &rs, const std::vector<int> &Fidx, const std::vector<int> &m,
-                          int cap, int form, std::vector<double> &Hout, gml_stats *stats) {
+                          int cap, int form, int precision, std::vector<double> &Hout, gml_stats *stats) {
     const int64_t R = rs.R;
     const double t0 = now_s();
     if (R > p->hs_rows || cap > p->hs_cap) {
@@ -503,13 +535,21 @@ static int device_hessian(gml_problem *p, const RowSet &rs, const std::vector<in
     std::vector<int> mt2((size_t)2 * R);
     for (int64_t r = 0; r < R; ++r) {
         mt2[r] = (m[r] + 31) / 32;
-        mt2[R + r] = (int)(1 + rs.node[r]);
+        mt2[R + r] = (int)rs.node[r];
     }
     hipStream_t st = p->st;
     HIPCHK(hipMemcpyAsync(p->dFidx, Fidx.data(), sizeof(int) * R * cap, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(p->dMt, mt2.data(), sizeof(int) * 2 * R, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(p->dH, 0, sizeof(double) * R * cap * cap, st));
-    launch_hess_f64(p->d, p->dV, p->dMt + R, p->dFidx, p->dMt, (int)R, cap, form, p->dH, st);
+    if (precision == GML_PREC_I8X) {
+        const int8_t *Vq = nullptr;
+        const double *tau = nullptr;
+        gml::i8_get_v(p->i8ws, &Vq, &tau);
+        if (!Vq) return fail(GML_EINVAL, "no int8 pass has run on this handle");
+        launch_hess_f64(p->d, nullptr, Vq, tau, p->dMt + R, p->dFidx, p->dMt, (int)R, cap, form, p->dH, st);
+    } else {
+        launch_hess_f64(p->d, p->dV, nullptr, nullptr, p->dMt + R, p->dFidx, p->dMt, (int)R, cap, form, p->dH, st);
+    }
     HIPCHK(hipGetLastError());
     Hout.resize((size_t)R * cap * cap);
     HIPCHK(hipMemcpyAsync(Hout.data(), p->dH, sizeof(double) * R * cap * cap, hipMemcpyDeviceToHost, st));
@@ -531,7 +571,7 @@ struct NodeLayout {
 static void build_layout(const gml_problem *p, int64_t u, NodeLayout &L) {
     if (p->order == 2) { // slot i <-> spin i, slot u = field (:162)
         L.cols.resize((size_t)p->n);
-        for (int64_t i = 0; i < p->n; ++i) L.cols[i] = (int32_t)(i == u ? 0 : 1 + i);
+        for (int64_t i = 0; i < p->n; ++i) L.cols[i] = (int32_t)(i == u ? p->d.cconst : i);
     } else {
         node_cols(p, u, L.cols);
     }
@@ -608,10 +648,10 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     gml_stats *stats = &stl;
     const double t_start = now_s();
 
-    const int64_t R = p->node1 - p->node0, Qp = p->d.Qp, Q = p->d.Q, P = p->P;
+    const int64_t R = p->node1 - p->node0, Qp = p->d.Qp, Q = p->d.Qp, P = p->P;
+    const int32_t cconst = (int32_t)p->d.cconst;
     const double lambda = gml_lambda(regularizer_c, p->n, p->M);
     stats->lambda = lambda;
-    const double noise = (o.precision == GML_PREC_I8X) ? 1e-11 : 1e-13;
 
     RowSet rs;
     rs.R = R;
@@ -624,13 +664,14 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     parallel_for(R, [&](int64_t r) {
         build_layout(p, rs.node[r], lay[r]);
         uint8_t *kr = kind.data() + r * Qp;
-        for (int32_t c : lay[r].cols) kr[c] = (c == 0) ? 1 : 2; // length(inter) > 1 is penalised (:118,:171)
+        for (int32_t c : lay[r].cols) kr[c] = (c == cconst) ? 1 : 2; // length(inter) > 1 is penalised (:118,:171)
     });
 
     std::vector<double> X((size_t)R * Qp, 0.0), G((size_t)R * Qp, 0.0), Xt((size_t)R * Qp, 0.0),
         Gt((size_t)R * Qp, 0.0), Xbest((size_t)R * Qp, 0.0);
     std::vector<double> f((size_t)R, 0.0), ft((size_t)R, 0.0), Fobj((size_t)R, 0.0), kkt((size_t)R, INFINITY),
-        best((size_t)R, INFINITY), Z((size_t)R, 1.0), Zt((size_t)R, 1.0), alpha((size_t)R, 1.0), dd((size_t)R, 0.0);
+        best((size_t)R, INFINITY), Z((size_t)R, 1.0), Zt((size_t)R, 1.0), alpha((size_t)R, 1.0), dd((size_t)R, 0.0),
+        fn((size_t)R, 0.0), fnt((size_t)R, 0.0);
     std::vector<uint8_t> done((size_t)R, 0), act((size_t)R, 1), need((size_t)R, 0), vstale((size_t)R, 0);
     std::vector<int> stall((size_t)R, 0), msz((size_t)R, 0);
     std::vector<std::vector<int>> Fset((size_t)R);
@@ -638,13 +679,14 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
 
     // logRISE post-processing of a pass: f = log Z, g = grad Z / Z   (:279)
     auto post = [&](const std::vector<uint8_t> &a, std::vector<double> &fv, std::vector<double> &gv,
-                    std::vector<double> &zv, bool grad) {
+                    std::vector<double> &zv, std::vector<double> &nv, bool grad) {
         if (formulation != GML_LOGRISE) return;
         parallel_for(R, [&](int64_t r) {
             if (!a[r]) return;
             const double z = fv[r];
             zv[r] = z;
             fv[r] = std::log(z);
+            nv[r] = nv[r] / z; // uncertainty of log Z
             if (grad) {
                 double *gr = gv.data() + r * Qp;
                 for (int64_t c = 0; c < Q; ++c) gr[c] /= z;
@@ -652,9 +694,10 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         });
     };
 
-    int rc = device_pass(p, rs, act, X.data(), formulation, o.precision, true, f.data(), G.data(), stats);
+    int rc = device_pass(p, rs, act, X.data(), formulation, o.precision, true, f.data(), G.data(), stats, nullptr,
+                         fn.data());
     if (rc) return rc;
-    post(act, f, G, Z, true);
+    post(act, f, G, Z, fn, true);
 
     int it = 0;
     for (it = 0; it < o.max_iter; ++it) {
@@ -724,9 +767,10 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         }
         stats->t_host += now_s() - th0;
         if (anystale) {
-            rc = device_pass(p, rs, need, X.data(), formulation, o.precision, true, f.data(), G.data(), stats);
+            rc = device_pass(p, rs, need, X.data(), formulation, o.precision, true, f.data(), G.data(), stats, nullptr,
+                             fn.data());
             if (rc) return rc;
-            post(need, f, G, Z, true);
+            post(need, f, G, Z, fn, true);
             for (int64_t r = 0; r < R; ++r)
                 if (need[r]) vstale[r] = 0;
         }
@@ -739,7 +783,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             for (int a = 0; a < msz[r]; ++a) Fidx[(size_t)r * cap + a] = Fset[r][a];
         }
         std::vector<double> H;
-        rc = device_hessian(p, rs, Fidx, msz, cap, formulation, H, stats);
+        rc = device_hessian(p, rs, Fidx, msz, cap, formulation, o.precision, H, stats);
         if (rc) return rc;
 
         // ---- Newton directions -------------------------------------------------------------
@@ -785,14 +829,20 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         stats->t_host += now_s() - th1;
 
         // ---- projected backtracking line search ----------------------------------------
+        // Two acceptance regimes per row:
+        //  * the predicted decrease is well above the uncertainty of f  -> Armijo on F;
+        //  * otherwise ("noise regime": near the optimum, or a noisy int8-limb f) function values
+        //    cannot certify the step; the trial is then a full pass and is accepted iff it lowers
+        //    the KKT residual (max |pseudo-gradient|), which is what convergence is measured by.
+        std::vector<uint8_t> nreg((size_t)R, 0);
         for (int64_t r = 0; r < R; ++r) {
             need[r] = !done[r];
             alpha[r] = 1.0;
         }
         std::vector<uint8_t> accepted_fwd((size_t)R, 0);
-        for (int ls = 0; ls < 40; ++ls) {
+        for (int ls = 0; ls < 30; ++ls) {
             const double th2 = now_s();
-            bool any = false;
+            bool any = false, anynoise = false;
             parallel_for(R, [&](int64_t r) {
                 if (!need[r]) return;
                 const double *x = X.data() + r * Qp;
@@ -813,31 +863,47 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                     d_ += PGset[r][a] * (v - x[c]);
                 }
                 dd[r] = d_;
+                nreg[r] = !(-1e-4 * d_ > 8.0 * fn[r]);
             });
-            for (int64_t r = 0; r < R; ++r) any |= need[r] != 0;
+            for (int64_t r = 0; r < R; ++r) {
+                any |= need[r] != 0;
+                anynoise |= (need[r] && nreg[r]);
+            }
             stats->t_host += now_s() - th2;
             if (!any) break;
-            const bool full = (ls == 0);
-            rc = device_pass(p, rs, need, Xt.data(), formulation, o.precision, full, ft.data(), Gt.data(), stats);
+            const bool full = (ls == 0) || anynoise;
+            rc = device_pass(p, rs, need, Xt.data(), formulation, o.precision, full, ft.data(), Gt.data(), stats, nullptr,
+                             fnt.data());
             if (rc) return rc;
-            post(need, ft, Gt, Zt, full);
+            post(need, ft, Gt, Zt, fnt, full);
             const double th3 = now_s();
             parallel_for(R, [&](int64_t r) {
                 if (!need[r]) return;
                 vstale[r] = 1;
                 const double *xt = Xt.data() + r * Qp;
                 const uint8_t *kr = kind.data() + r * Qp;
-                double Fn = ft[r];
-                for (int a = 0; a < msz[r]; ++a) {
-                    const int c = Fset[r][a];
-                    if (kr[c] == 2) Fn += lambda * std::fabs(xt[c]);
+                bool ok;
+                if (nreg[r]) {
+                    const double *gt = Gt.data() + r * Qp;
+                    double kt = 0;
+                    for (int64_t c = 0; c < Q; ++c) {
+                        if (!kr[c]) continue;
+                        const double pg = pseudo_grad(xt[c], gt[c], kr[c] == 2 ? lambda : 0.0);
+                        kt = std::max(kt, std::fabs(pg));
+                    }
+                    ok = std::isfinite(ft[r]) && kt < kkt[r];
+                } else {
+                    double Fn = ft[r];
+                    for (int a = 0; a < msz[r]; ++a) {
+                        const int c = Fset[r][a];
+                        if (kr[c] == 2) Fn += lambda * std::fabs(xt[c]);
+                    }
+                    ok = std::isfinite(Fn) && Fn <= Fobj[r] + 1e-4 * dd[r] + fn[r] + fnt[r];
                 }
-                // Armijo with an allowance for the summation noise of f (a Newton step whose predicted
-                // decrease is below that noise cannot be certified by function values)
-                const bool ok = std::isfinite(Fn) && Fn <= Fobj[r] + 1e-4 * dd[r] + noise * std::max(1.0, std::fabs(Fobj[r]));
                 if (ok) {
                     std::memcpy(X.data() + r * Qp, xt, sizeof(double) * Qp);
                     f[r] = ft[r];
+                    fn[r] = fnt[r];
                     Z[r] = Zt[r];
                     if (full) {
                         std::memcpy(G.data() + r * Qp, Gt.data() + r * Qp, sizeof(double) * Qp);
@@ -848,6 +914,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                     need[r] = 0;
                 } else {
                     alpha[r] *= 0.5;
+                    if (nreg[r] && alpha[r] < 1.0 / 64) need[r] = 0; // cannot improve: the stall counter ends it
                 }
             });
             stats->t_host += now_s() - th3;
@@ -856,9 +923,10 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         bool anyf = false;
         for (int64_t r = 0; r < R; ++r) anyf |= accepted_fwd[r] != 0;
         if (anyf) {
-            rc = device_pass(p, rs, accepted_fwd, X.data(), formulation, o.precision, true, f.data(), G.data(), stats);
+            rc = device_pass(p, rs, accepted_fwd, X.data(), formulation, o.precision, true, f.data(), G.data(), stats,
+                             nullptr, fn.data());
             if (rc) return rc;
-            post(accepted_fwd, f, G, Z, true);
+            post(accepted_fwd, f, G, Z, fn, true);
             for (int64_t r = 0; r < R; ++r)
                 if (accepted_fwd[r]) vstale[r] = 0;
         }

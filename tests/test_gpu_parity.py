@@ -14,7 +14,13 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 synthetic = __import__("importlib").import_module("gml_amd.synthetic")
 FORMS = ["RISE", "logRISE", "RPLE"]
-PRECS = ["f64"]
+PRECS = ["f64", "i8x"]
+# objective/gradient tolerances: FP64 path = rounding only; int8-limb path = 30-bit quantisation of
+# V relative to the per-node bound (worst case K * 2^-31 * bound; ~1e-7 on the tiny, very
+# non-uniform mvt histogram, ~1e-10 on benchmark-like inputs)
+FTOL = {"f64": 1e-12, "i8x": 2e-6}
+GTOL = {"f64": 1e-12, "i8x": 2e-6}
+SOLTOL = {"f64": 1e-9, "i8x": 2e-7}
 
 
 def hist_from_spins(spins):
@@ -35,8 +41,8 @@ def test_objgrad_matches_oracle(name, form, prec):
         f, g = p.objgrad(form, np.arange(n), theta, precision=prec)
     for u in range(n):
         f0, g0 = O.objgrad_pair(s, form, u, theta[u])
-        assert f[u] == pytest.approx(f0, rel=1e-12, abs=1e-13)
-        np.testing.assert_allclose(g[u], g0, rtol=1e-10, atol=1e-12)
+        assert f[u] == pytest.approx(f0, rel=FTOL[prec], abs=FTOL[prec])
+        np.testing.assert_allclose(g[u], g0, rtol=1e-10, atol=GTOL[prec])
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -50,8 +56,8 @@ def test_objgrad_repeated_and_permuted_nodes(prec):
         f, g = p.objgrad("RISE", nodes, theta, precision=prec)
     for r, u in enumerate(nodes):
         f0, g0 = O.objgrad_pair(s, "RISE", int(u), theta[r])
-        assert f[r] == pytest.approx(f0, rel=1e-12)
-        np.testing.assert_allclose(g[r], g0, rtol=1e-10, atol=1e-12)
+        assert f[r] == pytest.approx(f0, rel=FTOL[prec])
+        np.testing.assert_allclose(g[r], g0, rtol=1e-10, atol=GTOL[prec])
 
 
 def test_objgrad_multibody_matches_oracle():
@@ -76,14 +82,15 @@ def test_objgrad_multibody_matches_oracle():
 def test_learn_abc_goldens(name, form, prec):
     # runtests.jl:68-80 -- default regularisers, symmetrised
     s = load_csv(f"{name}_samples.csv")
-    m = gml.HIP(tol=1e-11, precision=prec)
+    tol = 1e-11 if prec == "f64" else 1e-7
+    m = gml.HIP(tol=tol, precision=prec)
     R = gml.learn(s, getattr(gml, form)(), m)
     G = load_csv(f"{name}_{form}_learned.csv")
-    assert np.abs(R - G).max() <= 5e-8
+    assert np.abs(R - G).max() <= (5e-8 if prec == "f64" else 3e-7)
     assert np.linalg.norm(R - G) / np.linalg.norm(G) <= 1e-6
     R0, _, _ = O.learn_pair(s, form, c=DEFAULT_C[form], symmetrize=True)
-    assert np.abs(R - R0).max() <= 1e-9
-    assert m.stats["max_kkt"] <= 1e-11
+    assert np.abs(R - R0).max() <= SOLTOL[prec]
+    assert m.stats["max_kkt"] <= tol
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -91,14 +98,15 @@ def test_learn_abc_goldens(name, form, prec):
 def test_learn_mvt_goldens(form, prec):
     # runtests.jl:83-101 -- X(0.2, false); goldens carry Ipopt's barrier residual (~1e-4)
     s = load_csv("mvt_samples.csv")
-    m = gml.HIP(tol=1e-11, precision=prec)
+    m = gml.HIP(tol=1e-11 if prec == "f64" else 1e-6, precision=prec)
     R = gml.learn(s, getattr(gml, form)(0.2, False), m)
     G = load_csv(f"mvt_{form}_learned.csv")
     assert np.abs(R - G).max() <= 3e-4
     R0, _, _ = O.learn_pair(s, form, c=0.2, symmetrize=False)
-    assert np.abs(R - R0).max() <= 1e-9
-    assert np.linalg.norm(R - R0) / np.linalg.norm(R0) <= 1e-6
-    assert ((R == 0) == (R0 == 0)).all()  # same exact-zero pattern
+    assert np.abs(R - R0).max() <= (1e-9 if prec == "f64" else 2e-5)  # lambda = 5e-5: H^-1 amplifies the 1e-7 noise
+    assert np.linalg.norm(R - R0) / np.linalg.norm(R0) <= (1e-6 if prec == "f64" else 3e-5)
+    if prec == "f64":
+        assert ((R == 0) == (R0 == 0)).all()  # same exact-zero pattern
 
 
 def test_multirise_order2_equals_rise_on_device():
@@ -140,7 +148,7 @@ def test_learn_synthetic_block_ising_vs_oracle(prec):
     hist = hist_from_spins(spins)
     R0, kkt0, _ = O.learn_pair(hist, "RISE", c=0.4, symmetrize=False, tol=1e-13)
     with gml.Problem(spins=spins) as p:
-        out, kkt, st = p.learn("RISE", 0.4, tol=1e-12, precision=prec)
+        out, kkt, st = p.learn("RISE", 0.4, tol=1e-12 if prec == "f64" else 2e-9, precision=prec)
     assert st["not_converged"] == 0
     assert np.linalg.norm(out - R0) / np.linalg.norm(R0) <= 1e-6
     assert np.abs(out - R0).max() / np.abs(R0).max() <= 1e-6
@@ -169,8 +177,9 @@ def test_c2_config_kkt_certificate(prec):
     n, K = 256, 100000
     spins, J = synthetic.block_ising(n, K, block=16, seed=0)
     with gml.Problem(spins=spins) as p:
-        out, kkt, st = p.learn("RISE", 0.4, tol=1e-10, precision=prec)
-    assert st["not_converged"] == 0 and kkt.max() <= 1e-10
+        tol = 1e-10 if prec == "f64" else 1e-9
+        out, kkt, st = p.learn("RISE", 0.4, tol=tol, precision=prec)
+    assert st["not_converged"] == 0 and kkt.max() <= tol
     lam = O.lam(0.4, n, K)
     counts = np.ones(K)
     nodes = np.array([0, 17, 100, 255])
@@ -180,7 +189,7 @@ def test_c2_config_kkt_certificate(prec):
         pen = np.arange(n) != u
         pg = np.where(x > 0, g[a] + lam, np.where(x < 0, g[a] - lam, np.sign(g[a]) * np.maximum(np.abs(g[a]) - lam, 0)))
         pg[~pen] = g[a][~pen]
-        assert np.abs(pg).max() <= 1e-9
+        assert np.abs(pg).max() <= (1e-9 if prec == "f64" else 5e-9)
     sym = 0.5 * (out + out.T)
     assert np.abs(sym - J).max() <= 0.1  # ground truth recovered
 
@@ -216,3 +225,47 @@ def test_ragged_and_tiny_inputs():
         out, _, _ = p.learn("logRISE", 0.8, tol=1e-11)
     R0, _, _ = O.learn_pair(hist_from_spins(spins), "logRISE", c=0.8, symmetrize=False)
     assert np.abs(out - R0).max() <= 1e-8
+
+
+def _quantise_like_device(theta, LF=5):
+    # gml_kernels_i8.hip k_quant_theta: sigma = 2^(ex-(8LF-2)), max|theta_r| < 2^ex
+    mx = np.abs(theta).max(1)
+    ex = np.where(mx > 0, np.frexp(mx)[1], 0)
+    sg = np.ldexp(1.0, ex - (8 * LF - 2))
+    return np.rint(theta / sg[:, None]) * sg[:, None]
+
+
+def test_i8x_is_exact_for_the_quantised_theta_and_deterministic():
+    # the int8-limb pass evaluates f and grad EXACTLY (integer GEMMs) at the quantised theta, up to
+    # the 30-bit rounding of V; two runs are bitwise identical (integer atomics)
+    n, K = 64, 20000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=4)
+    rng = np.random.default_rng(0)
+    theta = J + rng.normal(scale=0.01, size=J.shape) * (rng.random(J.shape) < 0.2)
+    thq = _quantise_like_device(theta)
+    with gml.Problem(spins=spins) as p:
+        f1, g1 = p.objgrad("RISE", np.arange(n), theta, precision="i8x")
+        f2, g2 = p.objgrad("RISE", np.arange(n), theta, precision="i8x")
+        f64, g64 = p.objgrad("RISE", np.arange(n), thq, precision="f64")
+    assert np.array_equal(f1, f2) and np.array_equal(g1, g2)
+    assert np.abs(f1 / f64 - 1).max() <= 5e-9
+    assert np.abs(g1 - g64).max() <= 5e-9
+
+
+def test_i8x_linearity_in_counts_full_size_property():
+    # size-independent property: duplicating every configuration (counts x2, same M-normalised
+    # weights) leaves f and grad unchanged; halving K changes them -- checked at a size the oracle
+    # cannot reach (n=512, 2e5 samples) on both device paths against each other
+    n, K = 512, 200000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=5)
+    theta = J.copy()
+    with gml.Problem(spins=spins) as p:
+        fa, ga = p.objgrad("RISE", np.arange(n), theta, precision="f64")
+        fb, gb = p.objgrad("RISE", np.arange(n), theta, precision="i8x")
+    # a sparse theta row yields only a few distinct energies, so the V roundings add up coherently:
+    # the bound is K * tau/2 ~ 1e-8, not the sqrt(K) of independent roundings
+    assert np.abs(fb / fa - 1).max() <= 3e-8
+    assert np.abs(gb - ga).max() <= 3e-8
+    with gml.Problem(counts=2 * np.ones(K), spins=spins) as p:
+        fc, gc = p.objgrad("RISE", np.arange(n), theta, precision="i8x")
+    assert np.array_equal(fc, fb) and np.array_equal(gc, gb)  # exact integer arithmetic: bitwise equal
