@@ -31,7 +31,7 @@ class GMLConvergenceError(AssertionError):
 class Opts(C.Structure):
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("precision", C.c_int32),
                 ("max_working", C.c_int32), ("max_add", C.c_int32), ("verbose", C.c_int32),
-                ("reserved", C.c_int32 * 3)]
+                ("hess_samples", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Stats(C.Structure):
@@ -158,12 +158,13 @@ class Problem:
         return f, g
 
     def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="f64", max_working=256, max_add=32,
-              verbose=0, out_ptr=None, raise_on_fail=True):
+              verbose=0, hess_samples=0, out_ptr=None, raise_on_fail=True):
         L = lib()
         o = Opts()
         L.gml_default_opts(C.byref(o))
         o.tol, o.max_iter, o.precision = float(tol), int(max_iter), PRECISIONS[precision]
         o.max_working, o.max_add, o.verbose = int(max_working), int(max_add), int(verbose)
+        o.hess_samples = int(hess_samples)
         R = self.node1 - self.node0
         out = None
         if out_ptr is None:

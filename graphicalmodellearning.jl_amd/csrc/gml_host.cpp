@@ -86,6 +86,7 @@ struct gml_problem {
     std::vector<int32_t> gkeys; // [Q][ko] subsets of spins (feature keys), -1 padded
     int ko = 1;
     std::vector<int64_t> qoff; // qoff[q] = first column of the size-q subsets
+    std::vector<double> wprefix; // wprefix[j] = sum of w over the first 1024*j configurations
     // workspace (sized for ws_rows rows)
     int64_t ws_rows = 0;
     double *dTheta = nullptr, *dV = nullptr, *dG = nullptr, *dF = nullptr;
@@ -210,6 +211,15 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
     for (int64_t k = 0; k < p->K; ++k) {
         w[k] = (counts ? counts[k] : 1.0) / p->M;
         d.wmax = std::max(d.wmax, w[k]);
+    }
+    p->wprefix.assign((size_t)(d.Kp / 1024) + 1, 0.0);
+    {
+        double acc = 0;
+        for (int64_t k = 0; k < d.Kp; ++k) {
+            if ((k & 1023) == 0) p->wprefix[(size_t)(k >> 10)] = acc;
+            if (k < p->K) acc += w[k];
+        }
+        p->wprefix[(size_t)(d.Kp >> 10)] = acc;
     }
     HIPCHK(hipMemcpyAsync(d.w, w.data(), sizeof(double) * p->K, hipMemcpyHostToDevice, p->st));
     // spins: upload sample-major, transpose to spin-major St [n][Kp], expand, transpose back
@@ -517,7 +527,7 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
 // Fidx: R x cap column ids (padding = Qp-1), m[r] = working-set size (0 = skip).
 // Hout: R x cap x cap host, lower 32x32 tiles filled.
 static int device_hessian(gml_problem *p, const RowSet &rs, const std::vector<int> &Fidx, const std::vector<int> &m,
-                          int cap, int form, int precision, std::vector<double> &Hout, gml_stats *stats) {
+                          int cap, int form, int precision, int64_t Kh, std::vector<double> &Hout, gml_stats *stats) {
     const int64_t R = rs.R;
     const double t0 = now_s();
     if (R > p->hs_rows || cap > p->hs_cap) {
@@ -546,9 +556,9 @@ static int device_hessian(gml_problem *p, const RowSet &rs, const std::vector<in
         const double *tau = nullptr;
         gml::i8_get_v(p->i8ws, &Vq, &tau);
         if (!Vq) return fail(GML_EINVAL, "no int8 pass has run on this handle");
-        launch_hess_f64(p->d, nullptr, Vq, tau, p->dMt + R, p->dFidx, p->dMt, (int)R, cap, form, p->dH, st);
+        launch_hess_f64(p->d, nullptr, Vq, tau, p->dMt + R, p->dFidx, p->dMt, (int)R, cap, form, Kh, p->dH, st);
     } else {
-        launch_hess_f64(p->d, p->dV, nullptr, nullptr, p->dMt + R, p->dFidx, p->dMt, (int)R, cap, form, p->dH, st);
+        launch_hess_f64(p->d, p->dV, nullptr, nullptr, p->dMt + R, p->dFidx, p->dMt, (int)R, cap, form, Kh, p->dH, st);
     }
     HIPCHK(hipGetLastError());
     Hout.resize((size_t)R * cap * cap);
@@ -652,6 +662,17 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     const int32_t cconst = (int32_t)p->d.cconst;
     const double lambda = gml_lambda(regularizer_c, p->n, p->M);
     stats->lambda = lambda;
+    // sub-sampled Newton: Hessians over the first Kh configurations, rescaled by M / M_h
+    int64_t Kh = p->d.Kp;
+    double hscale = 1.0;
+    {
+        int64_t want = o.hess_samples == 0 ? 131072 : (o.hess_samples < 0 ? p->d.Kp : (int64_t)o.hess_samples);
+        want = round_up(std::max<int64_t>(want, 1024), 1024);
+        if (want < p->K) {
+            Kh = want;
+            hscale = 1.0 / p->wprefix[(size_t)(Kh / 1024)];
+        }
+    }
 
     RowSet rs;
     rs.R = R;
@@ -783,7 +804,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             for (int a = 0; a < msz[r]; ++a) Fidx[(size_t)r * cap + a] = Fset[r][a];
         }
         std::vector<double> H;
-        rc = device_hessian(p, rs, Fidx, msz, cap, formulation, o.precision, H, stats);
+        rc = device_hessian(p, rs, Fidx, msz, cap, formulation, o.precision, Kh, H, stats);
         if (rc) return rc;
 
         // ---- Newton directions -------------------------------------------------------------
@@ -805,7 +826,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             for (int a = 0; a < m; ++a)
                 for (int bb = 0; bb <= a; ++bb) {
                     // tile (a/32, bb/32) with a/32 >= bb/32 is stored; inside a diagonal tile both halves are
-                    double h = Hr[(size_t)a * cap + bb];
+                    double h = hscale * Hr[(size_t)a * cap + bb];
                     if (formulation == GML_LOGRISE) h = h / Z[r] - gF[a] * gF[bb]; // Hess log Z
                     A[(size_t)a * m + bb] = h;
                     A[(size_t)bb * m + a] = h;

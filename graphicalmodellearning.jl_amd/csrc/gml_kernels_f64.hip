@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
                                                   const double *__restrict__ w,
                                                   const int *__restrict__ rowcol,
                                                   const int *__restrict__ F, const int *__restrict__ mt,
-                                                  int cap, int64_t Kp, int64_t kchunk, int nsplit,
+                                                  int cap, int64_t Kp, int64_t Kh, int64_t kchunk, int nsplit,
                                                   int form, double *__restrict__ H) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, q = lane >> 4;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
     while (ti * (ti + 1) / 2 > pair) --ti;
     const int tj = pair - ti * (ti + 1) / 2;
     const int64_t kb = (int64_t)ks * kchunk;
-    const int64_t ke = (kb + kchunk < Kp) ? kb + kchunk : Kp;
+    const int64_t ke = (kb + kchunk < Kh) ? kb + kchunk : Kh; // only the first Kh configurations
     const int rc = rowcol[r];
     if (rc < 0) return;
 
@@ -350,19 +350,19 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
 }
 
 void launch_hess_f64(const DevProblem &P, const double *V, const int8_t *Vq, const double *tau,
-                     const int *rowcol, const int *F, const int *mt, int R, int cap, int form, double *H,
-                     hipStream_t st) {
+                     const int *rowcol, const int *F, const int *mt, int R, int cap, int form, int64_t Kh,
+                     double *H, hipStream_t st) {
     const int tiles = cap / 32;
     const int maxpairs = tiles * (tiles + 1) / 2;
     int64_t nsplit = (8192 + (int64_t)R * maxpairs - 1) / ((int64_t)R * maxpairs);
-    const int64_t maxsplit = P.Kp / 512 > 0 ? P.Kp / 512 : 1;
+    const int64_t maxsplit = Kh / 512 > 0 ? Kh / 512 : 1;
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
-    int64_t kchunk = (P.Kp + nsplit - 1) / nsplit;
+    int64_t kchunk = (Kh + nsplit - 1) / nsplit;
     kchunk = (kchunk + 31) / 32 * 32;
-    nsplit = (P.Kp + kchunk - 1) / kchunk;
+    nsplit = (Kh + kchunk - 1) / kchunk;
     dim3 grid((unsigned)((nsplit + 3) / 4), (unsigned)maxpairs, (unsigned)R);
-    hipLaunchKernelGGL(k_hess_f64, grid, dim3(256), 0, st, V, Vq, tau, P.Xt, P.w, rowcol, F, mt, cap, P.Kp, kchunk,
+    hipLaunchKernelGGL(k_hess_f64, grid, dim3(256), 0, st, V, Vq, tau, P.Xt, P.w, rowcol, F, mt, cap, P.Kp, Kh, kchunk,
                        (int)nsplit, form, H);
 }
 

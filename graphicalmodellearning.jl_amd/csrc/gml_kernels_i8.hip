@@ -138,7 +138,7 @@ __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ t
 // Workgroup = 4 waves (2 along samples x 2 node tiles): 64*WM samples x 2 node tiles x LF limbs.
 // ------------------------------------------------------------------------------------------
 template <int WM, int LF>
-__global__ __launch_bounds__(256) void k_fwd_i8(
+__global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const int8_t *__restrict__ Xs, const int8_t *__restrict__ Xt, const int8_t *__restrict__ Tq,
     const int *__restrict__ rowcol, const int *__restrict__ pairs, int npairs, const double *__restrict__ w,
     const double *__restrict__ sigma, const long long *__restrict__ qconst, const double *__restrict__ invtau,
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_fwd_i8(
 // backward: Gacc[m][c] += sum_k Vq[m][k] * Xt[c][k]  (i32, split-K with integer atomics).
 // Workgroup tile: 128 rows (one node tile x 4 limbs) x 256 columns; waves 2 x 2, each 64 x 128.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bwd_i8(const int8_t *__restrict__ Vq, const int8_t *__restrict__ Xt,
+__global__ __launch_bounds__(256, 2) void k_bwd_i8(const int8_t *__restrict__ Vq, const int8_t *__restrict__ Xt,
                                                 const int *__restrict__ groups, int ngroups, int nNt,
                                                 int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit,
                                                 int32_t *__restrict__ Gacc) {

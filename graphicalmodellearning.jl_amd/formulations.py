@@ -62,6 +62,7 @@ class HIP(GMLMethod):
     max_iter: int = 100
     max_working: int = 256
     max_add: int = 32
+    hess_samples: int = 0  # Newton Hessians use the first hess_samples configurations (0 = 131072, <0 = all)
     verbose: int = 0
     distributed: bool = False
     node_range: Optional[Tuple[int, int]] = None

@@ -24,7 +24,8 @@ def _local_solve_hip(samples, formulation, method, order, node_range, device):
     with _lib.Problem(samples, order=order, node_range=node_range, device=device) as prob:
         out, kkt, st = prob.learn(_form_name(formulation), formulation.regularizer, tol=method.tol,
                                   max_iter=method.max_iter, precision=method.precision,
-                                  max_working=method.max_working, max_add=method.max_add, verbose=method.verbose)
+                                  max_working=method.max_working, max_add=method.max_add, verbose=method.verbose,
+                                  hess_samples=method.hess_samples)
         keys = None
         if isinstance(formulation, multiRISE):
             if order == 2:  # the C ABI keeps the pairwise slot layout for order 2 (slot u = field)

@@ -53,7 +53,9 @@ typedef struct gml_opts {
     int32_t max_working; /* cap on a node's working set (default 256, multiple of 32)       */
     int32_t max_add;     /* new coordinates admitted per node per iteration (default 32)    */
     int32_t verbose;     /* 0 silent, 1 per-iteration line on stderr                        */
-    int32_t reserved[3];
+    int32_t hess_samples; /* Newton Hessians use the first hess_samples configurations (0 = default
+                            131072, < 0 = all); the gradient always uses all of them           */
+    int32_t reserved[2];
 } gml_opts;
 
 typedef struct gml_stats {
