@@ -15,7 +15,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -49,27 +51,91 @@ static double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static void parallel_for(int64_t n, const std::function<void(int64_t)> &fn) {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 1;
-    if (nt > 32) nt = 32;
-    if ((int64_t)nt > n) nt = (unsigned)n;
-    if (nt <= 1) {
-        for (int64_t i = 0; i < n; ++i) fn(i);
-        return;
+// persistent worker pool for the host-side per-node loops (thread creation per call would cost
+// more than most of these loops)
+namespace {
+class Pool {
+  public:
+    Pool() {
+        unsigned nt = std::thread::hardware_concurrency();
+        if (nt == 0) nt = 1;
+        if (nt > 16) nt = 16;
+        nworkers_ = nt > 1 ? nt - 1 : 0;
+        for (unsigned t = 0; t < nworkers_; ++t) threads_.emplace_back([this] { loop(); });
     }
-    std::atomic<int64_t> next(0);
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; ++t)
-        th.emplace_back([&] {
-            for (;;) {
-                int64_t i = next.fetch_add(1);
-                if (i >= n) break;
-                fn(i);
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    void run(int64_t n, const std::function<void(int64_t)> &fn) {
+        if (n <= 0) return;
+        if (nworkers_ == 0 || n == 1) {
+            for (int64_t i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        std::lock_guard<std::mutex> serial(run_m_); // one job at a time
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn;
+            n_ = n;
+            next_.store(0);
+            pending_ = nworkers_;
+            ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m_);
+        done_cv_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void work() {
+        for (;;) {
+            const int64_t i = next_.fetch_add(1);
+            if (i >= n_) break;
+            (*fn_)(i);
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
             }
-        });
-    for (auto &t : th) t.join();
+            work();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) done_cv_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    unsigned nworkers_ = 0;
+    std::mutex m_, run_m_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(int64_t)> *fn_ = nullptr;
+    int64_t n_ = 0;
+    std::atomic<int64_t> next_{0};
+    unsigned pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+Pool &pool() {
+    static Pool *p = new Pool(); // intentionally leaked: no destructor races at process exit
+    return *p;
 }
+} // namespace
+
+static void parallel_for(int64_t n, const std::function<void(int64_t)> &fn) { pool().run(n, fn); }
 
 static int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
@@ -91,6 +157,7 @@ struct gml_problem {
     int64_t ws_rows = 0;
     double *dTheta = nullptr, *dV = nullptr, *dG = nullptr, *dF = nullptr;
     int *dRowcol = nullptr, *dGroups = nullptr;
+    double *hTh = nullptr, *hG = nullptr, *hF = nullptr; // pinned staging (ws_rows x Qp, ws_rows)
     // hessian workspace
     int64_t hs_rows = 0, hs_cap = 0;
     int *dFidx = nullptr, *dMt = nullptr;
@@ -347,6 +414,9 @@ extern "C" void gml_problem_destroy(gml_problem *p) {
     void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dGroups, p->dFidx, p->dMt, p->dH};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    void *hptrs[] = {p->hTh, p->hG, p->hF};
+    for (void *q : hptrs)
+        if (q) (void)hipHostFree(q);
     if (p->i8ws) gml::i8_free(p->i8ws);
     if (p->st) (void)hipStreamDestroy(p->st);
     delete p;
@@ -397,6 +467,10 @@ static int ensure_ws(gml_problem *p, int64_t rows) {
     void *ptrs[] = {p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dGroups};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    void *hptrs[] = {p->hTh, p->hG, p->hF};
+    for (void *q : hptrs)
+        if (q) (void)hipHostFree(q);
+    p->hTh = p->hG = p->hF = nullptr;
     p->dTheta = p->dV = p->dG = p->dF = nullptr;
     p->dRowcol = p->dGroups = nullptr;
     p->ws_rows = 0;
@@ -412,6 +486,9 @@ static int ensure_ws(gml_problem *p, int64_t rows) {
     HIPCHK(hipMalloc(&p->dF, sizeof(double) * Rp));
     HIPCHK(hipMalloc(&p->dRowcol, sizeof(int) * Rp));
     HIPCHK(hipMalloc(&p->dGroups, sizeof(int) * (Rp / 32 + 4)));
+    HIPCHK(hipHostMalloc(&p->hTh, sizeof(double) * Rp * p->d.Qp));
+    HIPCHK(hipHostMalloc(&p->hG, sizeof(double) * Rp * p->d.Qp));
+    HIPCHK(hipHostMalloc(&p->hF, sizeof(double) * Rp));
     HIPCHK(hipMemsetAsync(p->dV, 0, sizeof(double) * Rp * p->d.Kp, p->st));
     HIPCHK(hipMemsetAsync(p->dTheta, 0, sizeof(double) * Rp * p->d.Qp, p->st));
     p->ws_rows = Rp;
@@ -448,11 +525,13 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
     }
     const double t0 = now_s();
     hipStream_t st = p->st;
-    for (int gi : groups) {
-        const int64_t r0 = (int64_t)gi * 32, r1 = std::min(R, r0 + 32);
-        HIPCHK(hipMemcpyAsync(p->dTheta + r0 * Qp, theta + r0 * Qp, sizeof(double) * (r1 - r0) * Qp,
-                              hipMemcpyHostToDevice, st));
-    }
+    // one contiguous upload covering the active groups, through the pinned staging buffer
+    const int64_t ra = (int64_t)groups.front() * 32, rb = std::min(R, (int64_t)groups.back() * 32 + 32);
+    parallel_for((rb - ra + 31) / 32, [&](int64_t b) {
+        const int64_t r0 = ra + b * 32, r1 = std::min(rb, r0 + 32);
+        std::memcpy(p->hTh + r0 * Qp, theta + r0 * Qp, sizeof(double) * (r1 - r0) * Qp);
+    });
+    HIPCHK(hipMemcpyAsync(p->dTheta + ra * Qp, p->hTh + ra * Qp, sizeof(double) * (rb - ra) * Qp, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(p->dRowcol, rowcol.data(), sizeof(int) * Rp, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(p->dF, 0, sizeof(double) * Rp, st));
     if (want_grad) HIPCHK(hipMemsetAsync(p->dG, 0, sizeof(double) * Rp * Qp, st));
@@ -475,15 +554,10 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
         if (ms) HIPCHK(hipEventRecord(ev[2], st));
     }
     HIPCHK(hipGetLastError());
-    std::vector<double> fh((size_t)Rp);
-    HIPCHK(hipMemcpyAsync(fh.data(), p->dF, sizeof(double) * Rp, hipMemcpyDeviceToHost, st));
-    std::vector<double> gh;
-    if (want_grad) {
-        gh.resize(groups.size() * 32 * (size_t)Qp);
-        for (size_t a = 0; a < groups.size(); ++a)
-            HIPCHK(hipMemcpyAsync(gh.data() + a * 32 * Qp, p->dG + (int64_t)groups[a] * 32 * Qp,
-                                  sizeof(double) * 32 * Qp, hipMemcpyDeviceToHost, st));
-    }
+    double *fh = p->hF;
+    HIPCHK(hipMemcpyAsync(fh, p->dF, sizeof(double) * Rp, hipMemcpyDeviceToHost, st));
+    if (want_grad)
+        HIPCHK(hipMemcpyAsync(p->hG + ra * Qp, p->dG + ra * Qp, sizeof(double) * (rb - ra) * Qp, hipMemcpyDeviceToHost, st));
     std::vector<double> tauh;
     if (fnoise && precision == GML_PREC_I8X) {
         const int8_t *Vq = nullptr;
@@ -509,11 +583,12 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
     for (int64_t r = 0; r < R; ++r)
         if (act[r]) f[r] = fh[r];
     if (want_grad)
-        for (size_t a = 0; a < groups.size(); ++a)
+        parallel_for((int64_t)groups.size(), [&](int64_t a) {
             for (int i = 0; i < 32; ++i) {
                 const int64_t r = (int64_t)groups[a] * 32 + i;
-                if (r < R && act[r]) std::memcpy(g + r * Qp, gh.data() + (a * 32 + i) * Qp, sizeof(double) * Qp);
+                if (r < R && act[r]) std::memcpy(g + r * Qp, p->hG + r * Qp, sizeof(double) * Qp);
             }
+        });
     if (stats) {
         stats->t_pass += now_s() - t0;
         stats->node_evals += nact;
