@@ -36,7 +36,8 @@ def main():
     ap.add_argument("--n", type=int, default=1024)
     ap.add_argument("--samples", type=int, default=1000000)
     ap.add_argument("--block", type=int, default=16)
-    ap.add_argument("--precision", default=os.environ.get("GML_BENCH_PRECISION", "f64"), choices=["f64", "i8x"])
+    ap.add_argument("--precision", default=os.environ.get("GML_BENCH_PRECISION", "i8x"), choices=["f64", "i8x"],
+                    help="i8x: exact int8-limb MFMA pass (default, fastest); f64: FP64 MFMA pass")
     ap.add_argument("--no-learn", action="store_true", help="skip the full learn() wall-clock leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -105,6 +106,14 @@ def main():
                 "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": None, "fwd_ms": km["fwd_ms"], "bwd_ms": km["bwd_ms"],
                 "pass_tflops": 2 * flops_kernel / (km["pass_ms"] * 1e-3) / 1e12}
+    if args.precision == "i8x":
+        # the int8-limb pass issues LF forward + 4 backward digit-plane products per algorithmic one
+        LF = int(os.environ.get("GML_I8_LF", "5"))
+        limbs = {"fwd": LF, "bwd": 4}[dom]
+        roofline["limb_products"] = limbs
+        roofline["mfma_issue_frac"] = limbs * achieved / peak
+        roofline["note"] = ("achieved counts algorithmic flops once; the kernel issues limb_products int8 MFMA products per "
+                            "algorithmic product (exact fixed point), so frac <= 1/limb_products")
 
     extra = {}
     if not args.no_learn:

@@ -1,0 +1,139 @@
+# GraphicalModelLearningHIP.jl -- the reference-side binding of libgml_hip (include/gml.h).
+#
+# Drop this file next to the reference package (or `include` it after `using
+# GraphicalModelLearning`) and point ENV["LIBGML_HIP"] at libgml_hip.so.  It adds ONE new
+# GMLMethod subtype, `HIP`, and the `learn(samples, formulation, ::HIP)` methods; every type,
+# constructor and default of GraphicalModelLearning.jl:20-65 is reused unchanged, so
+#
+#     learn(samples, RISE(), HIP())          # instead of learn(samples, RISE(), NLP())
+#
+# is the whole migration.  The file only marshals arguments: all arithmetic is in the library.
+# NOTE: there is no Julia in the build/test image of this repository, so this file is kept 1:1
+# with the Python ctypes binding (graphicalmodellearning.jl_amd/_lib.py), which IS exercised by
+# the test-suite on MI355X.
+module GraphicalModelLearningHIP
+
+using GraphicalModelLearning
+import GraphicalModelLearning: learn, GMLMethod, GMLFormulation, RISE, RISEA, logRISE, RPLE, multiRISE, FactorGraph
+import LinearAlgebra
+import Statistics: mean
+
+export HIP
+
+const libgml = get(ENV, "LIBGML_HIP", "libgml_hip.so")
+
+# gml.h constants
+const GML_OK, GML_ENOTCONV = Cint(0), Cint(2)
+const GML_RISE, GML_LOGRISE, GML_RPLE = Cint(0), Cint(1), Cint(2)
+const GML_I64, GML_F64 = Cint(2), Cint(3)
+const GML_PREC_F64, GML_PREC_I8X = Cint(0), Cint(1)
+
+struct GmlOpts                      # struct gml_opts
+    tol::Cdouble; max_iter::Int32; precision::Int32; max_working::Int32; max_add::Int32
+    verbose::Int32; hess_samples::Int32; reserved1::Int32; reserved2::Int32
+end
+
+struct GmlStats                     # struct gml_stats
+    iterations::Int32; passes::Int32; forward_passes::Int32; hessian_passes::Int32
+    node_evals::Int64; max_kkt::Cdouble; lambda::Cdouble
+    t_pack::Cdouble; t_pass::Cdouble; t_hess::Cdouble; t_host::Cdouble; t_total::Cdouble
+    not_converged::Int32; reserved::Int32
+end
+
+"""
+    HIP(; tol=1e-9, precision=:f64, device=0, max_iter=100, node_range=nothing)
+
+GMLMethod that solves every node-wise problem on an MI355X through libgml_hip.
+`precision = :i8x` selects the exact int8-limb fixed-point pass.
+"""
+mutable struct HIP <: GMLMethod
+    tol::Float64
+    precision::Symbol
+    device::Int
+    max_iter::Int
+    node_range::Union{Nothing,Tuple{Int,Int}}   # 1-based inclusive, for one-process-per-GPU sharding
+end
+HIP(; tol=1e-9, precision=:f64, device=0, max_iter=100, node_range=nothing) = HIP(tol, precision, device, max_iter, node_range)
+
+lasterr() = unsafe_string(ccall((:gml_last_error, libgml), Cstring, ()))
+
+formulation_id(::Union{RISE,RISEA,multiRISE}) = GML_RISE
+formulation_id(::logRISE) = GML_LOGRISE
+formulation_id(::RPLE) = GML_RPLE
+
+# rows node0+1 .. node1 of the reconstruction (un-symmetrised), P columns
+function solve_rows(samples::Array{T,2}, formulation, method::HIP, order::Int) where T <: Real
+    s = T <: AbstractFloat ? convert(Array{Float64,2}, samples) : convert(Array{Int64,2}, samples)
+    dtype = eltype(s) == Float64 ? GML_F64 : GML_I64
+    K, n = size(s, 1), size(s, 2) - 1
+    n0, n1 = method.node_range === nothing ? (0, n) : (method.node_range[1] - 1, method.node_range[2])
+    handle = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:gml_problem_create, libgml), Cint,
+               (Ptr{Cvoid}, Cint, Int64, Int64, Int64, Cint, Cint, Int64, Int64, Cint, Ref{Ptr{Cvoid}}),
+               s, dtype, K, n, K, 1 #= column-major =#, order, n0, n1, method.device, handle)
+    rc == GML_OK || error("gml_problem_create: $(lasterr())")
+    try
+        P = Ref{Int64}(0)
+        ccall((:gml_problem_info, libgml), Cint,
+              (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}, Ptr{Int64}, Ptr{Int64}),
+              handle[], C_NULL, C_NULL, C_NULL, P, C_NULL, C_NULL)
+        R = n1 - n0
+        out = Array{Float64}(undef, P[], R)          # C row-major (R x P) == Julia (P x R)
+        opts = Ref(GmlOpts(method.tol, method.max_iter, method.precision == :i8x ? GML_PREC_I8X : GML_PREC_F64,
+                           256, 32, 0, 0, 0, 0))
+        stats = Ref{GmlStats}()
+        rc = ccall((:gml_learn, libgml), Cint,
+                   (Ptr{Cvoid}, Cint, Cdouble, Ref{GmlOpts}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{GmlStats}),
+                   handle[], formulation_id(formulation), Float64(formulation.regularizer), opts, out, C_NULL, stats)
+        # the reference: @assert JuMP.termination_status(model) == JuMP.MOI.LOCALLY_SOLVED  (:180)
+        rc == GML_ENOTCONV && throw(AssertionError(lasterr()))
+        rc == GML_OK || error("gml_learn: $(lasterr())")
+        keys = nothing
+        if order != 2
+            keys = Vector{Matrix{Int32}}()
+            for u in n0:(n1 - 1)
+                k = Array{Int32}(undef, order, P[])
+                ccall((:gml_multi_keys, libgml), Cint, (Ptr{Cvoid}, Int64, Ptr{Int32}), handle[], u, k)
+                push!(keys, k)
+            end
+        end
+        return permutedims(out), keys, n0                # R x P
+    finally
+        ccall((:gml_problem_destroy, libgml), Cvoid, (Ptr{Cvoid},), handle[])
+    end
+end
+
+# RISE / logRISE / RPLE / RISEA: n x n matrix, diagonal = fields  (:154-189, :263-298, :301-336, :210-260)
+function learn(samples::Array{T,2}, formulation::Union{RISE,RISEA,logRISE,RPLE}, method::HIP) where T <: Real
+    reconstruction, _, _ = solve_rows(samples, formulation, method, 2)
+    if formulation.symmetrization && size(reconstruction, 1) == size(reconstruction, 2)
+        reconstruction = 0.5 * (reconstruction + transpose(reconstruction))      # :184-186
+    end
+    return reconstruction
+end
+
+# multiRISE: FactorGraph keyed by (u, ascending others), optionally symmetrised  (:83-152)
+function learn(samples::Array{T,2}, formulation::multiRISE, method::HIP) where T <: Real
+    order = formulation.interaction_order
+    rows, keys, n0 = solve_rows(samples, formulation, method, order)
+    n = size(samples, 2) - 1
+    reconstruction = Dict{Tuple,Real}()
+    for r in 1:size(rows, 1)
+        u = n0 + r
+        for j in 1:size(rows, 2)
+            key = order == 2 ? (j == u ? (u,) : (u, j)) :                      # order 2 keeps the pairwise slots
+                               tuple((Int(k) + 1 for k in keys[r][:, j] if k >= 0)...)
+            reconstruction[key] = rows[r, j]                                      # :129-132
+        end
+    end
+    if formulation.symmetrization                                                 # :135-149
+        groups = Dict{Tuple,Vector{Real}}()
+        for (k, v) in reconstruction
+            push!(get!(groups, tuple(sort(collect(k))...), Vector{Real}()), v)
+        end
+        reconstruction = Dict{Tuple,Real}(k => mean(v) for (k, v) in groups)
+    end
+    return FactorGraph(order, n, :spin, reconstruction)                           # :151
+end
+
+end # module
