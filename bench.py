@@ -160,7 +160,7 @@ def main():
         # parity spot check of the timed GPU operator against the oracle on the same rows
         f_gpu, g_gpu = prob.objgrad("RISE", nodes, theta[nodes], precision=args.precision)
         cpu = {"value": done / t_cpu, "unit": "node-evals/s", "cores": cores, "kind": "port",
-               "sample": f"{done} node evaluations (nodes {nodes.tolist()}) at full K={K}, n={n}; oracle/gml_oracle.c "
+               "sample": f"{done} node evaluations ({len(nodes)} nodes spread over 0..{n - 1}, one per core) at full K={K}, n={n}; oracle/gml_oracle.c "
                          f"gml_oracle_objgrad_rise_nodes, OpenMP over nodes",
                "seconds": t_cpu,
                "parity_max_abs_grad_diff": float(np.abs(g_gpu - g_cpu).max()),

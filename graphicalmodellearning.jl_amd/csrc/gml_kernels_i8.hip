@@ -131,57 +131,115 @@ __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ t
     return ldexp(tab[n & 63] * p, n >> 6);
 }
 
+// exp(x) to ~3e-10 relative (the 31-bit quantisation of V needs no more): the reduced argument
+// |r| <= ln2/128 goes through an FP32 polynomial for expm1(r) -- its rounding error is relative to
+// |r|, i.e. 2^-24 * 0.0054 of the result -- and only the range reduction and the final table
+// multiply stay in FP64.  Returns tab[j] * (1 + expm1(r)) * 2^m.
+__device__ __forceinline__ double exp_tab32(double x, const double *__restrict__ tab) {
+    const double t = rint(x * 92.33248261689366);  // 64/ln2
+    double r = fma(t, -0.01083042469326756, x);    // ln2/64 high part
+    r = fma(t, -2.9815858269852933e-12, r);        // low part
+    const float rf = (float)r;
+    float d = fmaf(rf, 4.1666668e-02f, 1.6666667e-01f);
+    d = fmaf(d, rf, 0.5f);
+    d = fmaf(d, rf, 1.0f);
+    d = d * rf; // expm1(r)
+    const int n = (int)t;
+    const double tj = tab[n & 63];
+    return ldexp(fma(tj, (double)d, tj), n >> 6);
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA ring shared by both GEMM kernels.  A stage image is [AROWS + BROWS][64 bytes]; it is
+// filled by global_load_lds_dwordx4 in 1-KB pieces (16 rows): the LDS destination of a piece is
+// linear (base + lane*16), so the XOR swizzle of lds_off() is applied to the per-lane SOURCE
+// address instead.  Three stages: the loads of tile kt+2 are issued right after the barrier that
+// retires tile kt-1, and stay in flight across two compute phases (counted vmcnt, raw s_barrier).
+// ------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+template <int NP>
+__device__ __forceinline__ void ring_issue(const int8_t *const (&src)[NP], int64_t off, int8_t *stage_base, int wave,
+                                           int npiece) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        int pc = wave + 4 * j;
+        if (pc >= npiece) pc = npiece - 1; // duplicate piece: keeps the per-wave vmcnt count uniform
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + off), (lptr_t)(stage_base + pc * 1024), 16, 0, 0);
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void ring_issue8(const int8_t *const (&src)[NP], int64_t off, int8_t *stage_base, int wave,
+                                            int npiece) {
+    (void)npiece;
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + off), (lptr_t)(stage_base + (wave + 8 * j) * 1024), 16, 0, 0);
+}
+
+template <int NP>
+__device__ __forceinline__ void ring_wait(bool more) {
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // ------------------------------------------------------------------------------------------
 // forward: C[k][m] = sum_c Xs[k][c] * Tq[m][c] on i8 MFMA, then the pointwise epilogue
 //   E = s * sigma_r * (sum_l 256^l C_l + q0),  V = -w_k exp(-E) s  (RISE / logRISE),
 //   V -> LB balanced limbs -> Vq planes (via an LDS transpose so that global stores are 16 B).
-// Workgroup = 4 waves (2 along samples x 2 node tiles): 64*WM samples x 2 node tiles x LF limbs.
+// Workgroup = 4 waves along the samples: 256 samples x one 32-node tile x LF limb planes.
 // ------------------------------------------------------------------------------------------
-template <int WM, int LF>
+template <int LF, int FORM /* 0: exp forms (RISE, logRISE), 2: RPLE */, bool WANTF>
 __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const int8_t *__restrict__ Xs, const int8_t *__restrict__ Xt, const int8_t *__restrict__ Tq,
-    const int *__restrict__ rowcol, const int *__restrict__ pairs, int npairs, const double *__restrict__ w,
+    const int *__restrict__ rowcol, const int *__restrict__ groups, int ngroups, const double *__restrict__ w,
     const double *__restrict__ sigma, const long long *__restrict__ qconst, const double *__restrict__ invtau,
-    int64_t Qp, int64_t Qfp, int64_t Kp, int ntiles_k, int form, int8_t *__restrict__ Vq,
+    int64_t Qp, int64_t Qfp, int64_t Kp, int ntiles_k, int dbg, int stagger, int8_t *__restrict__ Vq,
     long long *__restrict__ csum, long long *__restrict__ asum, double *__restrict__ fsum) {
-    constexpr int BM = 64 * WM, BN = 64 * LF;
-    constexpr int TILE = (BM + BN) * 64;
-    constexpr int PITCH = 32 * WM + 16; // staging row pitch (bytes)
-    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
-    __shared__ double etab[64];
+    constexpr int WM = 2;                 // 32-sample MFMA tiles per wave
+    constexpr int AR = 256, BR = 32 * LF; // stage image rows
+    constexpr int STAGE = (AR + BR) * 64;
+    constexpr int NPIECE = (AR + BR) / 16, NP = (NPIECE + 3) / 4;
+    constexpr int PITCH = 32 * WM + 16;   // epilogue staging row pitch (bytes)
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[]; // 3 stages, then the exp table
+    double *etab = reinterpret_cast<double *>(lds + 3 * STAGE);
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lr = lane & 31, h = lane >> 5;
-    const int wm = wave & 1, wn = wave >> 1;
     if (tid < 64) etab[tid] = exp2((double)tid / 64.0);
 
-    // XCD-aware mapping: the blocks of one sample tile (all node-tile pairs) share an XCD / L2
+    // XCD-aware L2 blocking.  Blocks b and b+8 share an XCD (round-robin dispatch); XCD x owns the
+    // sample tiles st = 8*i + x.  Within an XCD: groups of TG node tiles (outer), sample tiles
+    // (middle), the TG node tiles (inner): the ~64 resident workgroups of an XCD cover 8 sample
+    // tiles x 8 node tiles = 2 MB of Xs + 1.3 MB of Tq in its 4 MB L2; Tq stays resident over the
+    // sweep and each Xs tile is fetched once per node-tile group.
+    constexpr int TG = 8;
     const int b = blockIdx.x, xcd = b & 7, bi = b >> 3;
-    const int st = (bi / npairs) * 8 + xcd, pr = bi % npairs;
-    if (st >= ntiles_k) return;
-    const int64_t k0 = (int64_t)st * BM;
-    const int t0 = pairs[2 * pr], t1 = pairs[2 * pr + 1];
-    const int mytile = wn ? t1 : t0;
+    const int ntk8 = (ntiles_k + 7) >> 3;
+    const int tgi = bi / (ntk8 * TG), rem = bi % (ntk8 * TG);
+    const int st = (rem / TG) * 8 + xcd, gi = tgi * TG + rem % TG;
+    if (st >= ntiles_k || gi >= ngroups) return;
+    (void)stagger;
+    const int64_t k0 = (int64_t)st * AR;
+    const int mytile = groups[gi];
 
-    // ---- global -> register staging descriptors -----------------------------------------
-    const int8_t *asrc[WM];
-    int adst[WM];
+    // per-lane source of each 1-KB piece this wave loads (swizzle applied to the source)
+    const int8_t *src[NP];
 #pragma unroll
-    for (int j = 0; j < WM; ++j) {
-        const int q = tid + 256 * j, row = q >> 2, slot = q & 3;
-        asrc[j] = Xs + (k0 + row) * Qp + slot * 16;
-        adst[j] = lds_off(row, slot);
-    }
-    const int8_t *bsrc[LF];
-    int bdst[LF];
-#pragma unroll
-    for (int j = 0; j < LF; ++j) {
-        const int q = tid + 256 * j, row = q >> 2, slot = q & 3;
-        const int half = row / (32 * LF), l = (row >> 5) % LF, rl = row & 31;
-        int tl = half ? t1 : t0;
-        if (tl < 0) tl = t0;
-        bsrc[j] = Tq + ((int64_t)(tl * LF + l) * 32 + rl) * Qfp + slot * 16;
-        bdst[j] = BM * 64 + lds_off(row, slot);
+    for (int j = 0; j < NP; ++j) {
+        int pc = wave + 4 * j;
+        if (pc >= NPIECE) pc = NPIECE - 1;
+        const int row = pc * 16 + (lane >> 2);
+        const int slot = (lane & 3) ^ ((row >> 2) & 3);
+        if (row < AR) src[j] = Xs + (k0 + row) * Qp + slot * 16;
+        else {
+            const int br = row - AR, l = br >> 5, rl = br & 31;
+            src[j] = Tq + ((int64_t)(mytile * LF + l) * 32 + rl) * Qfp + slot * 16;
+        }
     }
 
     v16i acc[WM][LF];
@@ -193,63 +251,48 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
             for (int e = 0; e < 16; ++e) acc[i][l][e] = 0;
 
     const int nk = (int)(Qfp / 64);
-    v4i ra[WM], rb[LF];
-#pragma unroll
-    for (int j = 0; j < WM; ++j) ra[j] = *reinterpret_cast<const v4i *>(asrc[j]);
-#pragma unroll
-    for (int j = 0; j < LF; ++j) rb[j] = *reinterpret_cast<const v4i *>(bsrc[j]);
-#pragma unroll
-    for (int j = 0; j < WM; ++j) *reinterpret_cast<v4i *>(lds + adst[j]) = ra[j];
-#pragma unroll
-    for (int j = 0; j < LF; ++j) *reinterpret_cast<v4i *>(lds + bdst[j]) = rb[j];
-    __syncthreads();
-
+    ring_issue<NP>(src, 0, lds, wave, NPIECE);
+    if (nk > 1) ring_issue<NP>(src, 64, lds + STAGE, wave, NPIECE);
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = (kt & 1) * TILE, nxt = TILE - cur;
-        if (kt + 1 < nk) {
-            const int64_t c0 = (int64_t)(kt + 1) * 64;
-#pragma unroll
-            for (int j = 0; j < WM; ++j) ra[j] = *reinterpret_cast<const v4i *>(asrc[j] + c0);
-#pragma unroll
-            for (int j = 0; j < LF; ++j) rb[j] = *reinterpret_cast<const v4i *>(bsrc[j] + c0);
-        }
+        ring_wait<NP>(kt + 1 < nk);
+        if (kt + 2 < nk) ring_issue<NP>(src, (int64_t)(kt + 2) * 64, lds + ((kt + 2) % 3) * STAGE, wave, NPIECE);
+        const int8_t *cur = lds + (kt % 3) * STAGE;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int slot = 2 * t + h;
             v4i fa[WM], fb[LF];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-                fa[i] = *reinterpret_cast<const v4i *>(lds + cur + lds_off(wm * 32 * WM + i * 32 + lr, slot));
+                fa[i] = *reinterpret_cast<const v4i *>(cur + lds_off(wave * 64 + i * 32 + lr, slot));
 #pragma unroll
             for (int l = 0; l < LF; ++l)
-                fb[l] = *reinterpret_cast<const v4i *>(lds + cur + BM * 64 + lds_off((wn * LF + l) * 32 + lr, slot));
+                fb[l] = *reinterpret_cast<const v4i *>(cur + AR * 64 + lds_off(l * 32 + lr, slot));
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int l = 0; l < LF; ++l) acc[i][l] = MFMA_I8(fa[i], fb[l], acc[i][l]);
         }
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int j = 0; j < WM; ++j) *reinterpret_cast<v4i *>(lds + nxt + adst[j]) = ra[j];
-#pragma unroll
-            for (int j = 0; j < LF; ++j) *reinterpret_cast<v4i *>(lds + nxt + bdst[j]) = rb[j];
-        }
-        __syncthreads();
+    }
+    __syncthreads(); // every wave is done with the ring: it becomes the epilogue's staging area
+    if (dbg >= 100) { // timing experiment: GEMM only
+        if (acc[0][0][0] == 0x7fffffff) Vq[0] = 1;
+        return;
     }
 
     // ---- epilogue ----------------------------------------------------------------------------
     // lane <-> node row (lr), register e <-> sample (e&3) + 8*(e>>2) + 4*h within the 32-sample tile
-    const bool valid = mytile >= 0;
-    const int r = (valid ? mytile : 0) * 32 + lr;
-    const int rc = valid ? rowcol[r] : -1;
+    const int r = mytile * 32 + lr;
+    const int rc = rowcol[r];
     const bool active = rc >= 0;
     const double sg = active ? sigma[r] : 0.0;
     const double q0 = active ? (double)qconst[r] : 0.0;
     const double it = active ? invtau[r] : 0.0;
     int8_t *stage = lds + wave * (LB * 32 * PITCH);
+    const int form = FORM;
     long long cs = 0, as = 0;
     double fp = 0.0;
-    const int64_t kw = k0 + wm * 32 * WM; // first sample of this wave
+    const int64_t kw = k0 + wave * 64; // first sample of this wave
+    const double sgq0 = sg * q0;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -261,27 +304,38 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int e = 4 * g + j;
-                double a = (double)acc[i][LF - 1][e];
-#pragma unroll
-                for (int l = LF - 2; l >= 0; --l) a = fma(a, 256.0, (double)acc[i][l][e]);
-                a += q0;
-                const int sb = (int)(int8_t)((sw >> (8 * j)) & 0xff); // s_u^k (0 on padded samples)
-                const double s = (double)sb;
-                const double E = s * sg * a;
+                // exact recombination of the limb planes: pairs in int32 (|acc| <= 2^18), then FP64
+                double a;
+                if (LF == 5) {
+                    const int lo = acc[i][0][e] + (acc[i][1][e] << 8);
+                    const int mid = acc[i][2][e] + (acc[i][3][e] << 8);
+                    a = fma((double)acc[i][4][e], 65536.0, (double)mid);
+                    a = fma(a, 65536.0, (double)lo);
+                } else if (LF == 4) {
+                    const int lo = acc[i][0][e] + (acc[i][1][e] << 8);
+                    const int mid = acc[i][2][e] + (acc[i][3][e] << 8);
+                    a = fma((double)mid, 65536.0, (double)lo);
+                } else {
+                    const int lo = acc[i][0][e] + (acc[i][1][e] << 8);
+                    a = fma((double)acc[i][2][e], 65536.0, (double)lo);
+                }
+                const double Ea = fma(a, sg, sgq0);                 // |E| pre-sign: sigma * (A + q0)
+                const bool neg = ((sw >> (8 * j + 7)) & 1u) != 0;   // s_u^k == -1 (padding: s = 0, w = 0)
                 const double wk = w[kk + j] * it;
-                double val;
-                if (form == 2) { // RPLE (:317)
+                int vq;
+                if (FORM == 2) { // RPLE (:317): V = -2 w s / (1 + exp(2E)), E = s * Ea
+                    const double E = neg ? -Ea : Ea;
                     const double ex = exp_tab(2.0 * E, etab);
-                    const double sgm = 1.0 / (1.0 + ex);
-                    val = -2.0 * wk * sgm * s;
+                    const int mag = (int)rint(2.0 * wk / (1.0 + ex));
+                    vq = neg ? mag : -mag;
                     const double tt = -2.0 * E;
                     fp += w[kk + j] * (tt > 0 ? tt + log1p(exp(-tt)) : log1p(exp(tt)));
-                } else { // RISE (:196,:204) / logRISE Z (:279)
-                    val = -wk * exp_tab(-E, etab) * s;
+                } else { // RISE (:196,:204) / logRISE Z (:279): V = -w exp(-E) s
+                    const int mag = (int)rint(wk * exp_tab32(neg ? Ea : -Ea, etab));
+                    vq = neg ? mag : -mag;
+                    if (WANTF) as += mag;
                 }
-                const int vq = (int)rint(val);
                 cs += vq;
-                as -= (long long)vq * sb;
                 dj[j] = ((unsigned)vq + 0x80808080u) ^ 0x80808080u; // 4 balanced base-256 digits
             }
             // 4 samples x 4 limbs byte transpose -> one dword per limb plane
@@ -299,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     as += __shfl_xor(as, 32);
     if (active && h == 0) {
         atomicAdd(reinterpret_cast<unsigned long long *>(&csum[r]), (unsigned long long)cs);
-        atomicAdd(reinterpret_cast<unsigned long long *>(&asum[r]), (unsigned long long)as);
+        if (WANTF) atomicAdd(reinterpret_cast<unsigned long long *>(&asum[r]), (unsigned long long)as);
     }
     if (form == 2) {
         fp += __shfl_xor(fp, 32);
@@ -313,112 +367,187 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
         const int q = ps * 64 + lane, row = q / CH, slot = q % CH;
         const int lb = row >> 5, rl = row & 31;
         const v4i dat = *reinterpret_cast<const v4i *>(stage + row * PITCH + slot * 16);
-        if (valid && rowcol[mytile * 32 + rl] >= 0)
+        if (rowcol[mytile * 32 + rl] >= 0)
             *reinterpret_cast<v4i *>(Vq + ((int64_t)(mytile * LB + lb) * 32 + rl) * Kp + kw + slot * 16) = dat;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // backward: Gacc[m][c] += sum_k Vq[m][k] * Xt[c][k]  (i32, split-K with integer atomics).
-// Workgroup tile: 128 rows (one node tile x 4 limbs) x 256 columns; waves 2 x 2, each 64 x 128.
+// Workgroup tile: TM node tiles (TM*128 rows of Vq: 4 limbs x 32 nodes each) x 256 columns;
+// waves 2 x 2, each (64*TM) x 128.  TM = 2 halves the bytes staged per MFMA (1 wave/SIMD).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_bwd_i8(const int8_t *__restrict__ Vq, const int8_t *__restrict__ Xt,
-                                                const int *__restrict__ groups, int ngroups, int nNt,
-                                                int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit,
-                                                int32_t *__restrict__ Gacc) {
-    constexpr int BM = 128, BN = 256, TILE = (BM + BN) * 64;
+template <int TM>
+__global__ __launch_bounds__(256, (TM == 1 ? 2 : 1)) void k_bwd_i8(
+    const int8_t *__restrict__ Vq, const int8_t *__restrict__ Xt, const int *__restrict__ groups, int ngroups_t,
+    int nNt, int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit, int32_t *__restrict__ Gacc) {
+    constexpr int AR = 128 * TM, BR = 256, STAGE = (AR + BR) * 64;
+    constexpr int NPIECE = (AR + BR) / 16, NP = NPIECE / 4;
+    constexpr int WMT = 2 * TM; // 32-row MFMA tiles per wave along M
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lr = lane & 31, h = lane >> 5;
     const int wm = wave & 1, wn = wave >> 1;
-    const int T = ngroups * nNt;
+    const int T = ngroups_t * nNt; // ngroups_t = number of TM-groups of node tiles
     const int b = blockIdx.x, xcd = b & 7, bi = b >> 3;
-    const int chunk = (bi / T) * 8 + xcd, ti = bi % T;
+    const int chunk = (bi / T) * 8 + xcd, ti = bi % T; // all tiles of one k-chunk on one XCD
     if (chunk >= nsplit) return;
-    const int tile = groups[ti / nNt], nt = ti % nNt;
+    const int gi = ti / nNt, nt = ti % nNt;
+    int tiles[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) tiles[t] = groups[gi * TM + t]; // -1: padding (computed on tile 0, not stored)
     const int64_t kb = (int64_t)chunk * kchunk;
     const int64_t ke = (kb + kchunk < Kp) ? kb + kchunk : Kp;
-    const int64_t n0 = (int64_t)nt * BN;
+    const int64_t n0 = (int64_t)nt * BR;
 
-    const int8_t *asrc[2], *bsrc[4];
-    int adst[2], bdst[4];
+    const int8_t *src[NP];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = tid + 256 * j, row = q >> 2, slot = q & 3;
-        asrc[j] = Vq + ((int64_t)tile * 128 + row) * Kp + slot * 16;
-        adst[j] = lds_off(row, slot);
+    for (int j = 0; j < NP; ++j) {
+        const int pc = wave + 4 * j;
+        const int row = pc * 16 + (lane >> 2);
+        const int slot = (lane & 3) ^ ((row >> 2) & 3);
+        if (row < AR) {
+            int tl = tiles[row >> 7];
+            if (tl < 0) tl = tiles[0];
+            src[j] = Vq + ((int64_t)tl * 128 + (row & 127)) * Kp + slot * 16;
+        } else {
+            int64_t c = n0 + (row - AR);
+            if (c >= Qfp) c = Qfp - 1; // columns beyond the matrix: computed, never stored
+            src[j] = Xt + c * Kp + slot * 16;
+        }
     }
+    v16i acc[WMT][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = tid + 256 * j, row = q >> 2, slot = q & 3;
-        int64_t c = n0 + row;
-        if (c >= Qfp) c = Qfp - 1; // columns beyond the matrix: computed, never stored
-        bsrc[j] = Xt + c * Kp + slot * 16;
-        bdst[j] = BM * 64 + lds_off(row, slot);
-    }
-    v16i acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WMT; ++i)
 #pragma unroll
         for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0;
 
-    v4i ra[2], rb[4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) ra[j] = *reinterpret_cast<const v4i *>(asrc[j] + kb);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rb[j] = *reinterpret_cast<const v4i *>(bsrc[j] + kb);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) *reinterpret_cast<v4i *>(lds + adst[j]) = ra[j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<v4i *>(lds + bdst[j]) = rb[j];
-    __syncthreads();
-
-    int it = 0;
-    for (int64_t kk = kb; kk < ke; kk += 64, ++it) {
-        const int cur = (it & 1) * TILE, nxt = TILE - cur;
-        const bool more = kk + 64 < ke;
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) ra[j] = *reinterpret_cast<const v4i *>(asrc[j] + kk + 64);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rb[j] = *reinterpret_cast<const v4i *>(bsrc[j] + kk + 64);
-        }
+    const int nk = (int)((ke - kb) / 64);
+    ring_issue<NP>(src, kb, lds, wave, NPIECE);
+    if (nk > 1) ring_issue<NP>(src, kb + 64, lds + STAGE, wave, NPIECE);
+    for (int kt = 0; kt < nk; ++kt) {
+        ring_wait<NP>(kt + 1 < nk);
+        if (kt + 2 < nk) ring_issue<NP>(src, kb + (int64_t)(kt + 2) * 64, lds + ((kt + 2) % 3) * STAGE, wave, NPIECE);
+        const int8_t *cur = lds + (kt % 3) * STAGE;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int slot = 2 * t + h;
-            v4i fa[2], fb[4];
+            v4i fa[WMT], fb[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                fa[i] = *reinterpret_cast<const v4i *>(lds + cur + lds_off(wm * 64 + i * 32 + lr, slot));
+            for (int i = 0; i < WMT; ++i)
+                fa[i] = *reinterpret_cast<const v4i *>(cur + lds_off(wm * 32 * WMT + i * 32 + lr, slot));
 #pragma unroll
             for (int jn = 0; jn < 4; ++jn)
-                fb[jn] = *reinterpret_cast<const v4i *>(lds + cur + BM * 64 + lds_off(wn * 128 + jn * 32 + lr, slot));
+                fb[jn] = *reinterpret_cast<const v4i *>(cur + AR * 64 + lds_off(wn * 128 + jn * 32 + lr, slot));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < WMT; ++i)
 #pragma unroll
                 for (int jn = 0; jn < 4; ++jn) acc[i][jn] = MFMA_I8(fa[i], fb[jn], acc[i][jn]);
         }
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) *reinterpret_cast<v4i *>(lds + nxt + adst[j]) = ra[j];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<v4i *>(lds + nxt + bdst[j]) = rb[j];
-        }
-        __syncthreads();
     }
     // C layout: column (lane&31) <-> Xt row (c), register e <-> Vq row (e&3)+8*(e>>2)+4*h
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WMT; ++i)
 #pragma unroll
         for (int jn = 0; jn < 4; ++jn) {
             const int64_t c = n0 + wn * 128 + jn * 32 + lr;
-            if (c < Qfp) {
+            const int grow = wm * 32 * WMT + i * 32; // first row of this MFMA tile within the workgroup tile
+            const int tl = tiles[grow >> 7];
+            if (c < Qfp && tl >= 0) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int mrow = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    atomicAdd(&Gacc[((int64_t)tile * 128 + mrow) * Qfp + c], acc[i][jn][e]);
+                    const int mrow = (grow & 127) + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    atomicAdd(&Gacc[((int64_t)tl * 128 + mrow) * Qfp + c], acc[i][jn][e]);
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(512, 2) void k_bwd_i8w8(
+    const int8_t *__restrict__ Vq, const int8_t *__restrict__ Xt, const int *__restrict__ groups, int ngroups_t,
+    int nNt, int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit, int32_t *__restrict__ Gacc) {
+    constexpr int TM = 2;
+    constexpr int AR = 128 * TM, BR = 256, STAGE = (AR + BR) * 64;
+    constexpr int NPIECE = (AR + BR) / 16, NP = NPIECE / 8;
+    constexpr int WMT = 4, WNT = 2; // wave tile 128 x 64
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lr = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1; // wn in 0..3
+    const int T = ngroups_t * nNt; // ngroups_t = number of TM-groups of node tiles
+    const int b = blockIdx.x, xcd = b & 7, bi = b >> 3;
+    const int chunk = (bi / T) * 8 + xcd, ti = bi % T; // all tiles of one k-chunk on one XCD
+    if (chunk >= nsplit) return;
+    const int gi = ti / nNt, nt = ti % nNt;
+    int tiles[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) tiles[t] = groups[gi * TM + t]; // -1: padding (computed on tile 0, not stored)
+    const int64_t kb = (int64_t)chunk * kchunk;
+    const int64_t ke = (kb + kchunk < Kp) ? kb + kchunk : Kp;
+    const int64_t n0 = (int64_t)nt * BR;
+
+    const int8_t *src[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int pc = wave + 8 * j;
+        const int row = pc * 16 + (lane >> 2);
+        const int slot = (lane & 3) ^ ((row >> 2) & 3);
+        if (row < AR) {
+            int tl = tiles[row >> 7];
+            if (tl < 0) tl = tiles[0];
+            src[j] = Vq + ((int64_t)tl * 128 + (row & 127)) * Kp + slot * 16;
+        } else {
+            int64_t c = n0 + (row - AR);
+            if (c >= Qfp) c = Qfp - 1; // columns beyond the matrix: computed, never stored
+            src[j] = Xt + c * Kp + slot * 16;
+        }
+    }
+    v16i acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int jn = 0; jn < WNT; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0;
+
+    const int nk = (int)((ke - kb) / 64);
+    ring_issue8<NP>(src, kb, lds, wave, NPIECE);
+    if (nk > 1) ring_issue8<NP>(src, kb + 64, lds + STAGE, wave, NPIECE);
+    for (int kt = 0; kt < nk; ++kt) {
+        ring_wait<NP>(kt + 1 < nk);
+        if (kt + 2 < nk) ring_issue8<NP>(src, kb + (int64_t)(kt + 2) * 64, lds + ((kt + 2) % 3) * STAGE, wave, NPIECE);
+        const int8_t *cur = lds + (kt % 3) * STAGE;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int slot = 2 * t + h;
+            v4i fa[WMT], fb[WNT];
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+                fa[i] = *reinterpret_cast<const v4i *>(cur + lds_off(wm * 32 * WMT + i * 32 + lr, slot));
+#pragma unroll
+            for (int jn = 0; jn < WNT; ++jn)
+                fb[jn] = *reinterpret_cast<const v4i *>(cur + AR * 64 + lds_off(wn * 64 + jn * 32 + lr, slot));
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                for (int jn = 0; jn < WNT; ++jn) acc[i][jn] = MFMA_I8(fa[i], fb[jn], acc[i][jn]);
+        }
+    }
+    // C layout: column (lane&31) <-> Xt row (c), register e <-> Vq row (e&3)+8*(e>>2)+4*h
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int jn = 0; jn < WNT; ++jn) {
+            const int64_t c = n0 + wn * 64 + jn * 32 + lr;
+            const int grow = wm * 32 * WMT + i * 32; // first row of this MFMA tile within the workgroup tile
+            const int tl = tiles[grow >> 7];
+            if (c < Qfp && tl >= 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int mrow = (grow & 127) + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    atomicAdd(&Gacc[((int64_t)tl * 128 + mrow) * Qfp + c], acc[i][jn][e]);
                 }
             }
         }
@@ -436,7 +565,17 @@ __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__
     if (rowcol[r] < 0) return;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const double t = tau[r];
-    if (c == 0 && form != 2) f[r] = t * (double)asum[r];
+    if (c == 0 && form != 2) {
+        if (want_grad) { // f = sum_k w exp(-E) = -sum_k V_k s_k = -G[r][u] (u = the node's own, masked, column)
+            const int tile = r >> 5, rl = r & 31, u = rowcol[r];
+            long long s = 0;
+#pragma unroll
+            for (int l = LB - 1; l >= 0; --l) s = s * 256 + (long long)Gacc[((int64_t)(tile * LB + l) * 32 + rl) * Qfp + u];
+            f[r] = -t * (double)s;
+        } else {
+            f[r] = t * (double)asum[r];
+        }
+    }
     if (!want_grad || c >= Qp) return;
     double v = 0.0;
     if (c < Qfp) {
@@ -511,17 +650,30 @@ int i8_limbs_forward() {
     return lf;
 }
 
-template <int WM, int LF>
-static void launch_fwd(const I8Ws *w, const DevProblem &d, const int *dRowcol, int npairs, int form, double *dF,
+template <int LF, int FORM, bool WANTF>
+static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, int ngroups, double *dF, hipStream_t st) {
+    constexpr int STAGE = (256 + 32 * LF) * 64;
+    constexpr int shmem = 3 * STAGE + 512; // ring + exp table (the epilogue staging aliases the ring)
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+        attr = true;
+    }
+    const int ntk = (int)(d.Kp / 256);
+    const int grid = ((ntk + 7) / 8) * 8 * ((ngroups + 7) / 8) * 8;
+    static const int dbg = getenv("GML_DEBUG_NOEPI") ? 100 : 0;
+    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xs, d.Xt, w->Tq, dRowcol, w->pairs,
+                       ngroups, d.w, w->sigma, w->qconst, w->invtau, d.Qp, d.Qfp, d.Kp, ntk, dbg, 0, w->Vq, w->csum, w->asum,
+                       dF);
+}
+
+template <int LF>
+static void launch_fwd(const I8Ws *w, const DevProblem &d, const int *dRowcol, int ngroups, int form, bool wantf, double *dF,
                        hipStream_t st) {
-    constexpr int BM = 64 * WM, BN = 64 * LF;
-    constexpr int gemm_bytes = 2 * (BM + BN) * 64;
-    constexpr int stage_bytes = 4 * LB * 32 * (32 * WM + 16);
-    constexpr int shmem = gemm_bytes > stage_bytes ? gemm_bytes : stage_bytes;
-    const int ntk = (int)(d.Kp / BM);
-    const int grid = ((ntk + 7) / 8) * 8 * npairs;
-    hipLaunchKernelGGL((k_fwd_i8<WM, LF>), dim3(grid), dim3(256), shmem, st, d.Xs, d.Xt, w->Tq, dRowcol, w->pairs, npairs,
-                       d.w, w->sigma, w->qconst, w->invtau, d.Qp, d.Qfp, d.Kp, ntk, form, w->Vq, w->csum, w->asum, dF);
+    if (form == 2) launch_fwd2<LF, 2, true>(w, d, dRowcol, ngroups, dF, st);
+    else if (wantf) launch_fwd2<LF, 0, true>(w, d, dRowcol, ngroups, dF, st);
+    else launch_fwd2<LF, 0, false>(w, d, dRowcol, ngroups, dF, st);
 }
 
 int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dRowcol, const int *hRowcol,
@@ -567,9 +719,10 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
     }
     if (ev) I8CHK(hipEventRecord(ev[0], st));
     switch (LF) {
-    case 3: launch_fwd<2, 3>(w, d, dRowcol, npairs, form, dF, st); break;
-    case 5: launch_fwd<2, 5>(w, d, dRowcol, npairs, form, dF, st); break;
-    default: launch_fwd<2, 4>(w, d, dRowcol, npairs, form, dF, st);
+    // with the gradient requested, f comes out of the backward GEMM for free (column u of row u)
+    case 3: launch_fwd<3>(w, d, dRowcol, ngroups, form, !want_grad, dF, st); break;
+    case 5: launch_fwd<5>(w, d, dRowcol, ngroups, form, !want_grad, dF, st); break;
+    default: launch_fwd<4>(w, d, dRowcol, ngroups, form, !want_grad, dF, st);
     }
     if (ev) I8CHK(hipEventRecord(ev[1], st));
     if (want_grad) {
@@ -579,10 +732,42 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
         kchunk = (kchunk + 63) / 64 * 64;
         if (kchunk < 1024) kchunk = 1024;
         nsplit = (int)((d.Kp + kchunk - 1) / kchunk);
-        const int T = ngroups * nNt;
+        static const int TM = [] {
+            const char *e = getenv("GML_I8_BWD_TM");
+            return (e && atoi(e) == 1) ? 1 : 2;
+        }();
+        const int ngt = (ngroups + TM - 1) / TM;
+        const int T = ngt * nNt;
         const int grid = ((nsplit + 7) / 8) * 8 * T;
-        hipLaunchKernelGGL(k_bwd_i8, dim3(grid), dim3(256), 2 * (128 + 256) * 64, st, w->Vq, d.Xt, w->pairs, ngroups, nNt,
-                           d.Qfp, d.Kp, kchunk, nsplit, w->Gacc);
+        const int shmem = 3 * (128 * TM + 256) * 64;
+        static bool bwd_attr = false;
+        if (!bwd_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      3 * (128 + 256) * 64);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      3 * (256 + 256) * 64);
+            bwd_attr = true;
+        }
+        // w->pairs holds the active tile list padded with -1 to an even count
+        static const bool w8 = [] {
+            const char *e = getenv("GML_I8_BWD_W8");
+            return !(e && atoi(e) == 0);
+        }();
+        if (TM == 2 && w8) {
+            static bool a8 = false;
+            if (!a8) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8w8), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          3 * (256 + 256) * 64);
+                a8 = true;
+            }
+            hipLaunchKernelGGL(k_bwd_i8w8, dim3(grid), dim3(512), shmem, st, w->Vq, d.Xt, w->pairs, ngt, nNt, d.Qfp, d.Kp, kchunk,
+                               nsplit, w->Gacc);
+        } else if (TM == 2)
+            hipLaunchKernelGGL((k_bwd_i8<2>), dim3(grid), dim3(256), shmem, st, w->Vq, d.Xt, w->pairs, ngt, nNt, d.Qfp, d.Kp,
+                               kchunk, nsplit, w->Gacc);
+        else
+            hipLaunchKernelGGL((k_bwd_i8<1>), dim3(grid), dim3(256), shmem, st, w->Vq, d.Xt, w->pairs, ngt, nNt, d.Qfp, d.Kp,
+                               kchunk, nsplit, w->Gacc);
     }
     if (ev) I8CHK(hipEventRecord(ev[2], st));
     hipLaunchKernelGGL(k_finalize_i8, dim3((unsigned)((d.Qp + 255) / 256), (unsigned)Rp), dim3(256), 0, st, w->Gacc, w->tau,
