@@ -45,8 +45,9 @@ void launch_bwd_f64(const DevProblem &P, const double *V, const int *groups, int
 // The weights come either from V (FP64 pass) or, when V == NULL, from the int8 limb planes Vq
 // with per-row step tau (exact fixed-point pass).
 void launch_hess_f64(const DevProblem &P, const double *V, const int8_t *Vq, const double *tau,
-                     const int *rowcol, const int *F, const int *mt, int R, int cap, int form, int64_t Kh,
-                     double *H, hipStream_t st);
+                     const int *rowcol, const int *F, const int *mt, const long long *hoff, int R, int cap, int form,
+                     int64_t Kh, double *H, hipStream_t st);
+// H is ragged: row r's block starts at hoff[r] and is (32 mt[r]) x (32 mt[r]) with that pitch.
 // Kh (multiple of 32, <= Kp): the Hessian is accumulated over the first Kh configurations only
 // (sub-sampled Newton: the gradient stays exact, so only the convergence rate is affected).
 

@@ -159,9 +159,10 @@ struct gml_problem {
     int *dRowcol = nullptr, *dGroups = nullptr;
     double *hTh = nullptr, *hG = nullptr, *hF = nullptr; // pinned staging (ws_rows x Qp, ws_rows)
     // hessian workspace
-    int64_t hs_rows = 0, hs_cap = 0;
+    int64_t hs_rows = 0, hs_cap = 0, hs_elems = 0;
     int *dFidx = nullptr, *dMt = nullptr;
-    double *dH = nullptr;
+    long long *dHoff = nullptr;
+    double *dH = nullptr, *hH = nullptr;
     // i8 path workspace lives in gml_i8 (allocated lazily)
     void *i8ws = nullptr;
 };
@@ -405,6 +406,9 @@ extern "C" int gml_problem_create(const void *samples, int dtype, int64_t K, int
 namespace gml {
 void i8_free(void *ws);
 void i8_get_v(void *ws, const int8_t **Vq, const double **tau);
+int i8_hessian(void *ws, const DevProblem &d, const int *dRowcol, const int *dF, const int *dMt, const int *hMt,
+               const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh, double *dH, hipStream_t st,
+               std::string *err);
 }
 
 extern "C" void gml_problem_destroy(gml_problem *p) {
@@ -414,9 +418,10 @@ extern "C" void gml_problem_destroy(gml_problem *p) {
     void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dGroups, p->dFidx, p->dMt, p->dH};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    void *hptrs[] = {p->hTh, p->hG, p->hF};
+    void *hptrs[] = {p->hTh, p->hG, p->hF, p->hH};
     for (void *q : hptrs)
         if (q) (void)hipHostFree(q);
+    if (p->dHoff) (void)hipFree(p->dHoff);
     if (p->i8ws) gml::i8_free(p->i8ws);
     if (p->st) (void)hipStreamDestroy(p->st);
     delete p;
@@ -598,47 +603,68 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
     return GML_OK;
 }
 
-// Working-set Hessians of the active rows (FP64 MFMA kernel over the V of the last full pass).
-// Fidx: R x cap column ids (padding = Qp-1), m[r] = working-set size (0 = skip).
-// Hout: R x cap x cap host, lower 32x32 tiles filled.
+// Working-set Hessians of the active rows (int8 kernel over the limb planes of the last pass, or the
+// FP64 MFMA kernel over V).  Fidx: R x cap column ids (padding = Qp-1), m[r] = working-set size
+// (0 = skip).  The result is ragged: row r's block starts at hoff[r] in Hout and is mp x mp with
+// mp = 32*ceil(m[r]/32) (lower 32x32 tiles filled).
 static int device_hessian(gml_problem *p, const RowSet &rs, const std::vector<int> &Fidx, const std::vector<int> &m,
-                          int cap, int form, int precision, int64_t Kh, std::vector<double> &Hout, gml_stats *stats) {
+                          int cap, int form, int precision, int64_t Kh, std::vector<long long> &hoff, double **Hout,
+                          gml_stats *stats) {
     const int64_t R = rs.R;
     const double t0 = now_s();
-    if (R > p->hs_rows || cap > p->hs_cap) {
-        void *ptrs[] = {p->dFidx, p->dMt, p->dH};
-        for (void *q : ptrs)
-            if (q) (void)hipFree(q);
-        p->dFidx = p->dMt = nullptr;
-        p->dH = nullptr;
-        p->hs_rows = std::max(R, p->hs_rows);
-        p->hs_cap = std::max<int64_t>(cap, p->hs_cap);
-        HIPCHK(hipMalloc(&p->dFidx, sizeof(int) * p->hs_rows * p->hs_cap));
-        HIPCHK(hipMalloc(&p->dMt, sizeof(int) * 2 * p->hs_rows));
-        HIPCHK(hipMalloc(&p->dH, sizeof(double) * p->hs_rows * p->hs_cap * p->hs_cap));
-    }
     std::vector<int> mt2((size_t)2 * R);
+    hoff.assign((size_t)R + 1, 0);
     for (int64_t r = 0; r < R; ++r) {
         mt2[r] = (m[r] + 31) / 32;
         mt2[R + r] = (int)rs.node[r];
+        hoff[r + 1] = hoff[r] + (long long)mt2[r] * 32 * mt2[r] * 32;
+    }
+    const int64_t htotal = std::max<long long>(hoff[R], 1);
+    if (R > p->hs_rows || (int64_t)R * cap > p->hs_cap || htotal > p->hs_elems) {
+        void *ptrs[] = {p->dFidx, p->dMt, p->dH, p->dHoff};
+        for (void *q : ptrs)
+            if (q) (void)hipFree(q);
+        if (p->hH) (void)hipHostFree(p->hH);
+        p->dFidx = p->dMt = nullptr;
+        p->dH = nullptr;
+        p->dHoff = nullptr;
+        p->hH = nullptr;
+        p->hs_rows = std::max(R, p->hs_rows);
+        p->hs_cap = std::max<int64_t>((int64_t)R * cap, p->hs_cap);
+        p->hs_elems = std::max<int64_t>(htotal + htotal / 4, p->hs_elems);
+        HIPCHK(hipMalloc(&p->dFidx, sizeof(int) * p->hs_cap));
+        HIPCHK(hipMalloc(&p->dMt, sizeof(int) * 2 * p->hs_rows));
+        HIPCHK(hipMalloc(&p->dHoff, sizeof(long long) * (p->hs_rows + 1)));
+        HIPCHK(hipMalloc(&p->dH, sizeof(double) * p->hs_elems));
+        HIPCHK(hipHostMalloc(&p->hH, sizeof(double) * p->hs_elems));
     }
     hipStream_t st = p->st;
     HIPCHK(hipMemcpyAsync(p->dFidx, Fidx.data(), sizeof(int) * R * cap, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(p->dMt, mt2.data(), sizeof(int) * 2 * R, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(p->dH, 0, sizeof(double) * R * cap * cap, st));
+    HIPCHK(hipMemcpyAsync(p->dHoff, hoff.data(), sizeof(long long) * (R + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(p->dH, 0, sizeof(double) * htotal, st));
+    bool done = false;
     if (precision == GML_PREC_I8X) {
+        std::string err;
+        int hrc = gml::i8_hessian(p->i8ws, p->d, p->dMt + R, p->dFidx, p->dMt, mt2.data(), p->dHoff, htotal, (int)R, cap, form,
+                                  Kh, p->dH, st, &err);
+        if (hrc == GML_OK) done = true;
+        else if (hrc != GML_EUNSUPPORTED) return fail(hrc, "%s", err.c_str());
+    }
+    if (!done) {
         const int8_t *Vq = nullptr;
         const double *tau = nullptr;
-        gml::i8_get_v(p->i8ws, &Vq, &tau);
-        if (!Vq) return fail(GML_EINVAL, "no int8 pass has run on this handle");
-        launch_hess_f64(p->d, nullptr, Vq, tau, p->dMt + R, p->dFidx, p->dMt, (int)R, cap, form, Kh, p->dH, st);
-    } else {
-        launch_hess_f64(p->d, p->dV, nullptr, nullptr, p->dMt + R, p->dFidx, p->dMt, (int)R, cap, form, Kh, p->dH, st);
+        if (precision == GML_PREC_I8X) { // a working set above 128 entries: FP64 kernel on the limb planes
+            gml::i8_get_v(p->i8ws, &Vq, &tau);
+            if (!Vq) return fail(GML_EINVAL, "no int8 pass has run on this handle");
+        }
+        launch_hess_f64(p->d, Vq ? nullptr : p->dV, Vq, tau, p->dMt + R, p->dFidx, p->dMt, p->dHoff, (int)R, cap, form, Kh,
+                        p->dH, st);
     }
     HIPCHK(hipGetLastError());
-    Hout.resize((size_t)R * cap * cap);
-    HIPCHK(hipMemcpyAsync(Hout.data(), p->dH, sizeof(double) * R * cap * cap, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(p->hH, p->dH, sizeof(double) * htotal, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    *Hout = p->hH;
     if (stats) {
         stats->t_hess += now_s() - t0;
         ++stats->hessian_passes;
@@ -878,8 +904,9 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             msz[r] = done[r] ? 0 : (int)Fset[r].size();
             for (int a = 0; a < msz[r]; ++a) Fidx[(size_t)r * cap + a] = Fset[r][a];
         }
-        std::vector<double> H;
-        rc = device_hessian(p, rs, Fidx, msz, cap, formulation, o.precision, Kh, H, stats);
+        std::vector<long long> hoff;
+        double *H = nullptr;
+        rc = device_hessian(p, rs, Fidx, msz, cap, formulation, o.precision, Kh, hoff, &H, stats);
         if (rc) return rc;
 
         // ---- Newton directions -------------------------------------------------------------
@@ -891,7 +918,8 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             const double *x = X.data() + r * Qp, *g = G.data() + r * Qp;
             const uint8_t *kr = kind.data() + r * Qp;
             std::vector<double> A((size_t)m * m), b((size_t)m), pgv((size_t)m), gF((size_t)m);
-            const double *Hr = H.data() + (size_t)r * cap * cap;
+            const double *Hr = H + hoff[r];
+            const int hp = ((m + 31) / 32) * 32;
             for (int a = 0; a < m; ++a) {
                 const int c = Fs[a];
                 const double l = kr[c] == 2 ? lambda : 0.0;
@@ -901,7 +929,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             for (int a = 0; a < m; ++a)
                 for (int bb = 0; bb <= a; ++bb) {
                     // tile (a/32, bb/32) with a/32 >= bb/32 is stored; inside a diagonal tile both halves are
-                    double h = hscale * Hr[(size_t)a * cap + bb];
+                    double h = hscale * Hr[(size_t)a * hp + bb];
                     if (formulation == GML_LOGRISE) h = h / Z[r] - gF[a] * gF[bb]; // Hess log Z
                     A[(size_t)a * m + bb] = h;
                     A[(size_t)bb * m + a] = h;

@@ -264,8 +264,9 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
                                                   const double *__restrict__ w,
                                                   const int *__restrict__ rowcol,
                                                   const int *__restrict__ F, const int *__restrict__ mt,
-                                                  int cap, int64_t Kp, int64_t Kh, int64_t kchunk, int nsplit,
-                                                  int form, double *__restrict__ H) {
+                                                  const long long *__restrict__ hoff, int cap, int64_t Kp,
+                                                  int64_t Kh, int64_t kchunk, int nsplit, int form,
+                                                  double *__restrict__ H) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, q = lane >> 4;
     const int r = blockIdx.z;
@@ -336,7 +337,8 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = MFMA_F64(a[mi][s] * h[s], b[ni][s], acc[mi][ni]);
     }
-    double *Hr = H + (int64_t)r * cap * cap;
+    double *Hr = H + hoff[r]; // row r's block: (32 m) x (32 m), pitch 32 m
+    const int hp = 32 * m;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -345,13 +347,13 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
             for (int j = 0; j < 4; ++j) {
                 const int i = ti * 32 + 16 * mi + q + 4 * j;
                 const int jj = tj * 32 + 16 * ni + li;
-                unsafeAtomicAdd(&Hr[(int64_t)i * cap + jj], acc[mi][ni][j]);
+                unsafeAtomicAdd(&Hr[(int64_t)i * hp + jj], acc[mi][ni][j]);
             }
 }
 
 void launch_hess_f64(const DevProblem &P, const double *V, const int8_t *Vq, const double *tau,
-                     const int *rowcol, const int *F, const int *mt, int R, int cap, int form, int64_t Kh,
-                     double *H, hipStream_t st) {
+                     const int *rowcol, const int *F, const int *mt, const long long *hoff, int R, int cap, int form,
+                     int64_t Kh, double *H, hipStream_t st) {
     const int tiles = cap / 32;
     const int maxpairs = tiles * (tiles + 1) / 2;
     int64_t nsplit = (8192 + (int64_t)R * maxpairs - 1) / ((int64_t)R * maxpairs);
@@ -362,7 +364,7 @@ void launch_hess_f64(const DevProblem &P, const double *V, const int8_t *Vq, con
     kchunk = (kchunk + 31) / 32 * 32;
     nsplit = (Kh + kchunk - 1) / kchunk;
     dim3 grid((unsigned)((nsplit + 3) / 4), (unsigned)maxpairs, (unsigned)R);
-    hipLaunchKernelGGL(k_hess_f64, grid, dim3(256), 0, st, V, Vq, tau, P.Xt, P.w, rowcol, F, mt, cap, P.Kp, Kh, kchunk,
+    hipLaunchKernelGGL(k_hess_f64, grid, dim3(256), 0, st, V, Vq, tau, P.Xt, P.w, rowcol, F, mt, hoff, cap, P.Kp, Kh, kchunk,
                        (int)nsplit, form, H);
 }
 

@@ -37,6 +37,10 @@ struct I8Ws {
     double *sigma = nullptr, *tau = nullptr, *invtau = nullptr;
     long long *qconst = nullptr, *csum = nullptr, *asum = nullptr;
     int *pairs = nullptr;
+    // working-set Hessian on the int8 cores
+    int64_t hKh = 0, hcap_elems = 0;
+    int8_t *Mt = nullptr, *Hq = nullptr; // bit masks of Xt (0x00 / 0xFF) and limb planes of the Hessian weights
+    long long *hS = nullptr, *H64 = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -590,6 +594,165 @@ __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__
     G[(int64_t)r * Qp + c] = v;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Working-set Hessian on the int8 matrix cores.
+//   H_r[i][j] = sum_k h_rk x_ki x_kj,  x = +-1 = 1 - 2b  (b = 1 where x = -1)
+//             = S - 2 T_ii - 2 T_jj + 4 T_ij,   T_ij = sum_k h_rk b_ki b_kj,  S = sum_k h_rk.
+// With the masks m = -b (bytes 0x00 / 0xFF) the products become (h_l & m_i) * m_j = -h_l b_i b_j
+// for each base-256 digit plane h_l of the (non-negative, 31-bit) weight: exact integer GEMMs.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_make_masks(const int8_t *__restrict__ Xt, int64_t Kp, int64_t Kh,
+                                                    int8_t *__restrict__ Mt) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (k < Kh) Mt[c * Kh + k] = Xt[c * Kp + k] < 0 ? (int8_t)-1 : (int8_t)0;
+}
+
+// Hessian weights of the active rows as limb planes: RISE / logRISE h = |V|; RPLE h = 2a(1 - a/(2w)), a = |V|
+__global__ __launch_bounds__(256) void k_make_hw(const int8_t *__restrict__ Vq, const int8_t *__restrict__ Xt,
+                                                 const double *__restrict__ w, const double *__restrict__ tau,
+                                                 const int *__restrict__ rowcol, const int *__restrict__ mt, int64_t Kp,
+                                                 int64_t Kh, int form, int8_t *__restrict__ Hq,
+                                                 long long *__restrict__ hS) {
+    const int r = blockIdx.y;
+    if (mt[r] == 0) return;
+    const int u = rowcol[r];
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int tile = r >> 5, rl = r & 31;
+    const int8_t *vq = Vq + ((int64_t)tile * 128 + rl) * Kp + k;
+    const int q = (int)vq[0] + 256 * ((int)vq[32 * Kp] + 256 * ((int)vq[64 * Kp] + 256 * (int)vq[96 * Kp]));
+    const int s = (int)Xt[(int64_t)u * Kp + k];
+    int mag = -q * s; // >= 0
+    if (form == 2) {
+        const double t = tau[r], a = (double)mag * t, wk = w[k];
+        mag = wk > 0 ? (int)rint(2.0 * a * (1.0 - a / (2.0 * wk)) / t) : 0;
+    }
+    const unsigned dg = ((unsigned)mag + 0x80808080u) ^ 0x80808080u;
+    int8_t *hq = Hq + ((int64_t)tile * 128 + rl) * Kh + k;
+    hq[0] = (int8_t)(dg & 0xff);
+    hq[32 * Kh] = (int8_t)((dg >> 8) & 0xff);
+    hq[64 * Kh] = (int8_t)((dg >> 16) & 0xff);
+    hq[96 * Kh] = (int8_t)((dg >> 24) & 0xff);
+    // S = sum of the weights
+    long long sm = mag;
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+    __shared__ long long red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sm;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&hS[r]), (unsigned long long)(red[0] + red[1] + red[2] + red[3]));
+}
+
+// One workgroup per (row, k-chunk); wave l handles digit plane l for ALL lower-triangular 32x32 tile
+// pairs of the row's working set (MT tiles per side).  LDS double buffer, register staged.
+template <int MT>
+__global__ __launch_bounds__(256) void k_hess_i8(const int8_t *__restrict__ Mt, const int8_t *__restrict__ Hq,
+                                                 const int *__restrict__ F, const int *__restrict__ mt,
+                                                 const long long *__restrict__ hoff, int cap, int64_t Kh,
+                                                 int64_t kchunk, long long *__restrict__ H64) {
+    constexpr int ROWS = MT * 32 + 4; // mask rows + the four weight planes
+    constexpr int NCH = (ROWS * 4 + 255) / 256;
+    constexpr int NPAIR = MT * (MT + 1) / 2;
+    __shared__ __attribute__((aligned(16))) int8_t lds[2][(MT * 32 + 16) * 64];
+    const int r = blockIdx.y;
+    const int m = mt[r];
+    if (m != MT) return; // one launch per working-set size class
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, h = lane >> 5;
+    const int64_t kb = (int64_t)blockIdx.x * kchunk;
+    if (kb >= Kh) return;
+    const int64_t ke = (kb + kchunk < Kh) ? kb + kchunk : Kh;
+    const int tile = r >> 5, rl = r & 31;
+    const int *Fr = F + (int64_t)r * cap;
+
+    const int8_t *src[NCH];
+    int dst[NCH];
+    bool have[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int q = tid + 256 * j, row = q >> 2, slot = q & 3;
+        have[j] = row < ROWS;
+        if (row < MT * 32) src[j] = Mt + (int64_t)Fr[row < m * 32 ? row : 0] * Kh + slot * 16;
+        else src[j] = Hq + ((int64_t)tile * 128 + (row - MT * 32 < 4 ? row - MT * 32 : 0) * 32 + rl) * Kh + slot * 16;
+        dst[j] = lds_off(row, slot);
+    }
+    v16i acc[NPAIR];
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[p][e] = 0;
+
+    v4i rg[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+        if (have[j]) rg[j] = *reinterpret_cast<const v4i *>(src[j] + kb);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+        if (have[j]) *reinterpret_cast<v4i *>(&lds[0][dst[j]]) = rg[j];
+    __syncthreads();
+    int it = 0;
+    for (int64_t kk = kb; kk < ke; kk += 64, ++it) {
+        const int cur = it & 1;
+        const bool more = kk + 64 < ke;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+                if (have[j]) rg[j] = *reinterpret_cast<const v4i *>(src[j] + kk + 64);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int slot = 2 * t + h;
+            const v4i mg = *reinterpret_cast<const v4i *>(&lds[cur][lds_off(MT * 32 + wave, slot)]);
+            v4i mi[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) mi[i] = *reinterpret_cast<const v4i *>(&lds[cur][lds_off(i * 32 + lr, slot)]);
+            int p = 0;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const v4i a = mi[i] & mg;
+#pragma unroll
+                for (int j = 0; j <= i; ++j, ++p) acc[p] = MFMA_I8(a, mi[j], acc[p]);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+                if (have[j]) *reinterpret_cast<v4i *>(&lds[cur ^ 1][dst[j]]) = rg[j];
+        }
+        __syncthreads();
+    }
+    // acc = -sum_k h_l b_i b_j : accumulate 256^l * acc into the int64 tile (integer atomics: deterministic)
+    long long *Hr = H64 + hoff[r];
+    constexpr int hp = 32 * MT;
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j, ++p) {
+            if (i < m) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ii = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, jj = j * 32 + lr;
+                    const long long v = -((long long)acc[p][e]) * (1ll << (8 * wave));
+                    if (v != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&Hr[(int64_t)ii * hp + jj]), (unsigned long long)v);
+                }
+            }
+        }
+}
+
+// H[i][j] = tau * (S - 2 T_ii - 2 T_jj + 4 T_ij) on the lower-triangular tiles
+__global__ __launch_bounds__(256) void k_hess_i8_fin(const long long *__restrict__ H64, const long long *__restrict__ hS,
+                                                     const double *__restrict__ tau, const int *__restrict__ mt,
+                                                     const long long *__restrict__ hoff, double *__restrict__ H) {
+    const int r = blockIdx.y;
+    const int m = mt[r] * 32;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= m * m) return;
+    const int i = idx / m, j = idx % m;
+    if ((j >> 5) > (i >> 5)) return;
+    const long long *Hr = H64 + hoff[r];
+    const long long T = Hr[(int64_t)i * m + j], Ti = Hr[(int64_t)i * m + i], Tj = Hr[(int64_t)j * m + j];
+    H[hoff[r] + (int64_t)i * m + j] = tau[r] * (double)(hS[r] - 2 * Ti - 2 * Tj + 4 * T);
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -611,7 +774,8 @@ void i8_get_v(void *p, const int8_t **Vq, const double **tau) {
 void i8_free(void *p) {
     I8Ws *w = static_cast<I8Ws *>(p);
     if (!w) return;
-    void *ptrs[] = {w->Tq, w->Vq, w->Gacc, w->sigma, w->tau, w->invtau, w->qconst, w->csum, w->asum, w->pairs};
+    void *ptrs[] = {w->Tq, w->Vq, w->Gacc, w->sigma, w->tau, w->invtau, w->qconst, w->csum, w->asum, w->pairs,
+                    w->Mt, w->Hq, w->hS, w->H64};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete w;
@@ -638,6 +802,65 @@ static int i8_ensure(void **wsp, const DevProblem &d, int Rp, int LF, std::strin
     I8CHK(hipMemset(w->Vq, 0, (size_t)Rp * LB * d.Kp));
     w->rows = Rp;
     *wsp = w;
+    return GML_OK;
+}
+
+
+// Working-set Hessians from the int8 limb planes of the last pass.  Returns GML_EUNSUPPORTED when a
+// working set exceeds 128 entries (the caller then uses the FP64 kernel).
+int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF, const int *dMt, const int *hMt,
+               const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh, double *dH, hipStream_t st,
+               std::string *err) {
+    I8Ws *w = static_cast<I8Ws *>(wsp);
+    if (!w) {
+        if (err) *err = "no int8 pass has run on this handle";
+        return GML_EINVAL;
+    }
+    int maxm = 0;
+    for (int r = 0; r < R; ++r) maxm = hMt[r] > maxm ? hMt[r] : maxm;
+    if (maxm > 4) return GML_EUNSUPPORTED; // > 128 entries: accumulators no longer fit the register file
+    if (w->hKh != Kh) {
+        if (w->Mt) (void)hipFree(w->Mt);
+        if (w->Hq) (void)hipFree(w->Hq);
+        if (w->hS) (void)hipFree(w->hS);
+        w->Mt = w->Hq = nullptr;
+        w->hS = nullptr;
+        I8CHK(hipMalloc(&w->Mt, (size_t)d.Qp * Kh));
+        I8CHK(hipMalloc(&w->Hq, (size_t)w->rows * LB * Kh));
+        I8CHK(hipMalloc(&w->hS, sizeof(long long) * w->rows));
+        hipLaunchKernelGGL(k_make_masks, dim3((unsigned)(Kh / 256), (unsigned)d.Qp), dim3(256), 0, st, d.Xt, d.Kp, Kh, w->Mt);
+        w->hKh = Kh;
+    }
+    const int64_t need = htotal;
+    if (need > w->hcap_elems) {
+        if (w->H64) (void)hipFree(w->H64);
+        w->H64 = nullptr;
+        I8CHK(hipMalloc(&w->H64, sizeof(long long) * need));
+        w->hcap_elems = need;
+    }
+    I8CHK(hipMemsetAsync(w->H64, 0, sizeof(long long) * need, st));
+    I8CHK(hipMemsetAsync(w->hS, 0, sizeof(long long) * w->rows, st));
+    hipLaunchKernelGGL(k_make_hw, dim3((unsigned)(Kh / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Xt, d.w, w->tau, dRowcol,
+                       dMt, d.Kp, Kh, form, w->Hq, w->hS);
+    // k-split so that the grid fills the chip: ~2048 workgroups
+    int nsplit = (int)((2048 + R - 1) / R);
+    const int maxsplit = (int)(Kh / 1024);
+    if (nsplit > maxsplit) nsplit = maxsplit;
+    if (nsplit < 1) nsplit = 1;
+    int64_t kchunk = (Kh + nsplit - 1) / nsplit;
+    kchunk = (kchunk + 63) / 64 * 64;
+    nsplit = (int)((Kh + kchunk - 1) / kchunk);
+    const dim3 grid((unsigned)nsplit, (unsigned)R);
+    // one launch per working-set size class (rows of other classes exit immediately)
+    bool cls[6] = {false, false, false, false, false, false};
+    for (int r = 0; r < R; ++r) cls[hMt[r]] = true;
+    if (cls[1]) hipLaunchKernelGGL((k_hess_i8<1>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, kchunk, w->H64);
+    if (cls[2]) hipLaunchKernelGGL((k_hess_i8<2>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, kchunk, w->H64);
+    if (cls[3]) hipLaunchKernelGGL((k_hess_i8<3>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, kchunk, w->H64);
+    if (cls[4]) hipLaunchKernelGGL((k_hess_i8<4>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, kchunk, w->H64);
+    hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64,
+                       w->hS, w->tau, dMt, dHoff, dH);
+    I8CHK(hipGetLastError());
     return GML_OK;
 }
 
