@@ -184,7 +184,7 @@ extern "C" void gml_default_opts(gml_opts *o) {
     o->tol = 1e-9;
     o->max_iter = 100;
     o->precision = GML_PREC_F64;
-    o->max_working = 256;
+    o->max_working = 128;
     o->max_add = 32;
     o->verbose = 0;
 }
@@ -750,7 +750,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     else gml_default_opts(&o);
     if (!(o.tol > 0)) o.tol = 1e-9;
     if (o.max_iter <= 0) o.max_iter = 100;
-    if (o.max_working < 32) o.max_working = 256;
+    if (o.max_working < 32) o.max_working = 128;
     o.max_working = (int)round_up(o.max_working, 32);
     if (o.max_add <= 0) o.max_add = 32;
     HIPCHK(hipSetDevice(p->device));
@@ -795,8 +795,8 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         best((size_t)R, INFINITY), Z((size_t)R, 1.0), Zt((size_t)R, 1.0), alpha((size_t)R, 1.0), dd((size_t)R, 0.0),
         fn((size_t)R, 0.0), fnt((size_t)R, 0.0);
     std::vector<uint8_t> done((size_t)R, 0), act((size_t)R, 1), need((size_t)R, 0), vstale((size_t)R, 0);
-    std::vector<int> stall((size_t)R, 0), msz((size_t)R, 0);
-    std::vector<std::vector<int>> Fset((size_t)R);
+    std::vector<int> stall((size_t)R, 0), msz((size_t)R, 0), mtot((size_t)R, 0);
+    std::vector<std::vector<int>> Fset((size_t)R), Weak((size_t)R);
     std::vector<std::vector<double>> Dset((size_t)R), PGset((size_t)R);
 
     // logRISE post-processing of a pass: f = log Z, g = grad Z / Z   (:279)
@@ -852,19 +852,42 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             } else {
                 ++stall[r];
             }
-            if (worst <= o.tol || stall[r] >= 4) {
+            if (worst <= o.tol || stall[r] >= 10) {
                 done[r] = 1;
                 return;
             }
-            int room = std::min<int>(o.max_add, o.max_working - (int)Fs.size());
-            if (room < 0) room = 0;
-            if ((int)viol.size() > room) {
-                std::nth_element(viol.begin(), viol.begin() + room, viol.end());
-                viol.resize(room);
+            // Newton block W: everything free if it fits the cap; otherwise the unpenalised slot plus the
+            // strongest coordinates by max(|pg|, |x| * f) (f ~ the Hessian's diagonal scale).  The rest of
+            // the free coordinates ("weak": many small noise-driven coefficients when lambda is close to
+            // the sampling noise) take a diagonal-Newton proximal step, see below.
+            // Only the max_add largest violators are admitted per iteration: at theta = 0 most
+            // coordinates violate |g| <= lambda merely through <s_u><s_c> (non-zero magnetisations), and
+            // stop doing so once the field and the strongest couplings have been fitted.
+            if ((int)viol.size() > o.max_add) {
+                std::nth_element(viol.begin(), viol.begin() + o.max_add, viol.end());
+                viol.resize(o.max_add);
             }
-            for (auto &v : viol) Fs.push_back(v.second);
+            const int capW = o.max_working;
+            std::vector<int> &Wk = Weak[r];
+            Wk.clear();
+            if ((int)(Fs.size() + viol.size()) <= capW) {
+                for (auto &v : viol) Fs.push_back(v.second);
+            } else {
+                std::vector<std::pair<double, int>> cand;
+                cand.reserve(Fs.size() + viol.size());
+                const double fs = std::max(std::fabs(formulation == GML_LOGRISE ? 1.0 : f[r]), 1e-300);
+                for (int c : Fs) {
+                    const double l = kr[c] == 2 ? lambda : 0.0;
+                    const double sc = kr[c] == 1 ? INFINITY : std::max(std::fabs(pseudo_grad(x[c], g[c], l)), std::fabs(x[c]) * fs);
+                    cand.emplace_back(-sc, c);
+                }
+                for (auto &v : viol) cand.emplace_back(v.first, v.second);
+                std::nth_element(cand.begin(), cand.begin() + capW, cand.end());
+                Fs.clear();
+                for (int a = 0; a < (int)cand.size(); ++a) (a < capW ? Fs : Wk).push_back(cand[a].second);
+                std::sort(Wk.begin(), Wk.end());
+            }
             std::sort(Fs.begin(), Fs.end());
-            if ((int)Fs.size() > o.max_working) Fs.resize(o.max_working); // |support| above the cap: block Newton
         });
         int64_t nactive = 0;
         double worst_all = 0;
@@ -947,6 +970,37 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 ridge = ridge == 0.0 ? 1e-12 : ridge * 100.0;
                 bw.assign(m, 0.0);
             }
+            // weak coordinates: exact minimiser of the separable model with the Hessian diagonal
+            // (for +-1 statistics H_cc = sum_k h_k for every c: read it off the constant column)
+            std::vector<int> &Wk = Weak[r];
+            if (!Wk.empty()) {
+                int pc = -1;
+                for (int a = 0; a < m; ++a)
+                    if (Fs[a] == cconst) pc = a;
+                double S = pc >= 0 ? hscale * Hr[(size_t)pc * hp + pc] : std::fabs(f[r]);
+                if (formulation == GML_LOGRISE) S /= Z[r];
+                for (int c : Wk) {
+                    double q = S;
+                    if (formulation == GML_LOGRISE) q -= g[c] * g[c];
+                    if (!(q > 1e-300)) q = 1e-300;
+                    const double zc = x[c] - g[c] / q, th = lambda / q;
+                    const double xn = zc > th ? zc - th : (zc < -th ? zc + th : 0.0);
+                    bw.push_back(xn - x[c]);
+                    pgv.push_back(pseudo_grad(x[c], g[c], lambda));
+                    Fset[r].push_back(c);
+                }
+            }
+            mtot[r] = (int)Fset[r].size();
+            if (o.verbose >= 2 && r == 0) {
+                double sd = 0, sx = 0, mxd = 0;
+                for (size_t a = 0; a < bw.size(); ++a) {
+                    sd += std::fabs(bw[a]);
+                    mxd = std::max(mxd, std::fabs(bw[a]));
+                }
+                for (int64_t c = 0; c < Q; ++c) sx += std::fabs(x[c]);
+                fprintf(stderr, "[gml]   row0: f %.6e F %.6e kkt %.3e |W| %d |weak| %zu sum|d| %.3e max|d| %.3e sum|x| %.3e fn %.3e H00 %.4e\n",
+                        f[r], Fobj[r], kkt[r], m, Wk.size(), sd, mxd, sx, fn[r], hscale * Hr[0]);
+            }
             Dset[r] = bw;
             PGset[r] = pgv;
         });
@@ -975,7 +1029,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 std::memcpy(xt, x, sizeof(double) * Qp);
                 const std::vector<int> &Fs = Fset[r];
                 double d_ = 0;
-                for (int a = 0; a < msz[r]; ++a) {
+                for (int a = 0; a < mtot[r]; ++a) {
                     const int c = Fs[a];
                     double v = x[c] + alpha[r] * Dset[r][a];
                     if (kr[c] == 2 && lambda > 0) {
@@ -987,7 +1041,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                     d_ += PGset[r][a] * (v - x[c]);
                 }
                 dd[r] = d_;
-                nreg[r] = !(-1e-4 * d_ > 8.0 * fn[r]);
+                nreg[r] = !(-0.1 * d_ > 8.0 * fn[r]); // the step's expected decrease (~|dd|/2) vs the uncertainty of f
             });
             for (int64_t r = 0; r < R; ++r) {
                 any |= need[r] != 0;
@@ -1008,22 +1062,30 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 const uint8_t *kr = kind.data() + r * Qp;
                 bool ok;
                 if (nreg[r]) {
-                    const double *gt = Gt.data() + r * Qp;
-                    double kt = 0;
-                    for (int64_t c = 0; c < Q; ++c) {
-                        if (!kr[c]) continue;
-                        const double pg = pseudo_grad(xt[c], gt[c], kr[c] == 2 ? lambda : 0.0);
-                        kt = std::max(kt, std::fabs(pg));
+                    // F is convex: F(x) >= F(xt) + F'(xt; x - xt).  So a trial whose directional derivative
+                    // BACK towards x is >= 0 cannot have increased F; a small negative value (overshoot of at
+                    // most ~1.5x the minimiser along the step) is tolerated.  Coordinates clipped to zero
+                    // contribute lambda|s_c| - g_c s_c >= 0 whenever they belong at zero.
+                    const double *gt = Gt.data() + r * Qp, *x0 = X.data() + r * Qp;
+                    double back = 0;
+                    for (int a = 0; a < mtot[r]; ++a) {
+                        const int c = Fset[r][a];
+                        const double sc = x0[c] - xt[c]; // direction back to x
+                        if (sc == 0.0) continue;
+                        double gl = gt[c] * sc;
+                        if (kr[c] == 2) gl += lambda * (xt[c] != 0.0 ? (xt[c] > 0 ? sc : -sc) : std::fabs(sc));
+                        back += gl;
                     }
-                    ok = std::isfinite(ft[r]) && kt < kkt[r];
+                    ok = std::isfinite(ft[r]) && std::isfinite(back) && back >= -0.5 * std::fabs(dd[r]);
                 } else {
                     double Fn = ft[r];
-                    for (int a = 0; a < msz[r]; ++a) {
-                        const int c = Fset[r][a];
-                        if (kr[c] == 2) Fn += lambda * std::fabs(xt[c]);
-                    }
+                    for (int64_t c = 0; c < Q; ++c)
+                        if (kr[c] == 2 && xt[c] != 0.0) Fn += lambda * std::fabs(xt[c]);
                     ok = std::isfinite(Fn) && Fn <= Fobj[r] + 1e-4 * dd[r] + fn[r] + fnt[r];
                 }
+                if (o.verbose >= 2 && r == 0)
+                    fprintf(stderr, "[gml]   row0: ls %d alpha %.3g nreg %d ft %.6e dd %.3e fnt %.3e ok %d\n", ls, alpha[r], (int)nreg[r], ft[r],
+                            dd[r], fnt[r], (int)ok);
                 if (ok) {
                     std::memcpy(X.data() + r * Qp, xt, sizeof(double) * Qp);
                     f[r] = ft[r];
