@@ -51,4 +51,9 @@ void launch_hess_f64(const DevProblem &P, const double *V, const int8_t *Vq, con
 // Kh (multiple of 32, <= Kp): the Hessian is accumulated over the first Kh configurations only
 // (sub-sampled Newton: the gradient stays exact, so only the convergence rate is affected).
 
+// Batched Newton solve on the ragged Hessian blocks: A = s1[r]*H_r - s2*gF gF^T, A d = -pgF, in place
+// (Cholesky, ridge restart).  gF/pgF/dout are R x cap; Sdiag[r] = A[m-1][m-1].
+void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
+                         const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st);
+
 } // namespace gml

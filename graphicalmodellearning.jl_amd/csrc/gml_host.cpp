@@ -162,7 +162,7 @@ struct gml_problem {
     int64_t hs_rows = 0, hs_cap = 0, hs_elems = 0;
     int *dFidx = nullptr, *dMt = nullptr;
     long long *dHoff = nullptr;
-    double *dH = nullptr, *hH = nullptr;
+    double *dH = nullptr, *dVec = nullptr;
     // i8 path workspace lives in gml_i8 (allocated lazily)
     void *i8ws = nullptr;
 };
@@ -184,7 +184,7 @@ extern "C" void gml_default_opts(gml_opts *o) {
     o->tol = 1e-9;
     o->max_iter = 100;
     o->precision = GML_PREC_F64;
-    o->max_working = 128;
+    o->max_working = 256;
     o->max_add = 32;
     o->verbose = 0;
 }
@@ -418,10 +418,11 @@ extern "C" void gml_problem_destroy(gml_problem *p) {
     void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dGroups, p->dFidx, p->dMt, p->dH};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    void *hptrs[] = {p->hTh, p->hG, p->hF, p->hH};
+    void *hptrs[] = {p->hTh, p->hG, p->hF};
     for (void *q : hptrs)
         if (q) (void)hipHostFree(q);
     if (p->dHoff) (void)hipFree(p->dHoff);
+    if (p->dVec) (void)hipFree(p->dVec);
     if (p->i8ws) gml::i8_free(p->i8ws);
     if (p->st) (void)hipStreamDestroy(p->st);
     delete p;
@@ -607,40 +608,41 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
 // FP64 MFMA kernel over V).  Fidx: R x cap column ids (padding = Qp-1), m[r] = working-set size
 // (0 = skip).  The result is ragged: row r's block starts at hoff[r] in Hout and is mp x mp with
 // mp = 32*ceil(m[r]/32) (lower 32x32 tiles filled).
-static int device_hessian(gml_problem *p, const RowSet &rs, const std::vector<int> &Fidx, const std::vector<int> &m,
-                          int cap, int form, int precision, int64_t Kh, std::vector<long long> &hoff, double **Hout,
-                          gml_stats *stats) {
+static int device_newton(gml_problem *p, const RowSet &rs, const std::vector<int> &Fidx, const std::vector<int> &m,
+                         int cap, int form, int precision, int64_t Kh, const std::vector<double> &s1, double s2,
+                         const std::vector<double> &gF, const std::vector<double> &pgF, std::vector<double> &dout,
+                         std::vector<double> &sdiag, gml_stats *stats) {
+    std::vector<long long> hoff;
     const int64_t R = rs.R;
     const double t0 = now_s();
-    std::vector<int> mt2((size_t)2 * R);
+    std::vector<int> mt2((size_t)3 * R);
     hoff.assign((size_t)R + 1, 0);
     for (int64_t r = 0; r < R; ++r) {
         mt2[r] = (m[r] + 31) / 32;
         mt2[R + r] = (int)rs.node[r];
+        mt2[2 * R + r] = m[r];
         hoff[r + 1] = hoff[r] + (long long)mt2[r] * 32 * mt2[r] * 32;
     }
     const int64_t htotal = std::max<long long>(hoff[R], 1);
     if (R > p->hs_rows || (int64_t)R * cap > p->hs_cap || htotal > p->hs_elems) {
-        void *ptrs[] = {p->dFidx, p->dMt, p->dH, p->dHoff};
+        void *ptrs[] = {p->dFidx, p->dMt, p->dH, p->dHoff, p->dVec};
         for (void *q : ptrs)
             if (q) (void)hipFree(q);
-        if (p->hH) (void)hipHostFree(p->hH);
         p->dFidx = p->dMt = nullptr;
-        p->dH = nullptr;
+        p->dH = p->dVec = nullptr;
         p->dHoff = nullptr;
-        p->hH = nullptr;
         p->hs_rows = std::max(R, p->hs_rows);
         p->hs_cap = std::max<int64_t>((int64_t)R * cap, p->hs_cap);
         p->hs_elems = std::max<int64_t>(htotal + htotal / 4, p->hs_elems);
         HIPCHK(hipMalloc(&p->dFidx, sizeof(int) * p->hs_cap));
-        HIPCHK(hipMalloc(&p->dMt, sizeof(int) * 2 * p->hs_rows));
+        HIPCHK(hipMalloc(&p->dMt, sizeof(int) * 3 * p->hs_rows));
         HIPCHK(hipMalloc(&p->dHoff, sizeof(long long) * (p->hs_rows + 1)));
         HIPCHK(hipMalloc(&p->dH, sizeof(double) * p->hs_elems));
-        HIPCHK(hipHostMalloc(&p->hH, sizeof(double) * p->hs_elems));
+        HIPCHK(hipMalloc(&p->dVec, sizeof(double) * (3 * p->hs_cap + 2 * p->hs_rows))); // gF | pgF | d | s1 | Sdiag
     }
     hipStream_t st = p->st;
     HIPCHK(hipMemcpyAsync(p->dFidx, Fidx.data(), sizeof(int) * R * cap, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->dMt, mt2.data(), sizeof(int) * 2 * R, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->dMt, mt2.data(), sizeof(int) * 3 * R, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(p->dHoff, hoff.data(), sizeof(long long) * (R + 1), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(p->dH, 0, sizeof(double) * htotal, st));
     bool done = false;
@@ -662,9 +664,19 @@ static int device_hessian(gml_problem *p, const RowSet &rs, const std::vector<in
                         p->dH, st);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(p->hH, p->dH, sizeof(double) * htotal, hipMemcpyDeviceToHost, st));
+    // Newton systems solved in place on the device; only the directions come back
+    double *dg = p->dVec, *dpg = dg + (int64_t)R * cap, *dd = dpg + (int64_t)R * cap, *ds1 = dd + (int64_t)R * cap,
+           *dsd = ds1 + R;
+    HIPCHK(hipMemcpyAsync(dg, gF.data(), sizeof(double) * R * cap, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dpg, pgF.data(), sizeof(double) * R * cap, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ds1, s1.data(), sizeof(double) * R, hipMemcpyHostToDevice, st));
+    launch_newton_solve(p->dH, p->dHoff, p->dMt, p->dMt + 2 * R, ds1, s2, dg, dpg, (int)R, cap, dd, dsd, st);
+    HIPCHK(hipGetLastError());
+    dout.resize((size_t)R * cap);
+    sdiag.resize((size_t)R);
+    HIPCHK(hipMemcpyAsync(dout.data(), dd, sizeof(double) * R * cap, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(sdiag.data(), dsd, sizeof(double) * R, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    *Hout = p->hH;
     if (stats) {
         stats->t_hess += now_s() - t0;
         ++stats->hessian_passes;
@@ -686,35 +698,6 @@ static void build_layout(const gml_problem *p, int64_t u, NodeLayout &L) {
     } else {
         node_cols(p, u, L.cols);
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// dense Cholesky solve (host, small systems)
-// ------------------------------------------------------------------------------------------
-static bool chol_solve(std::vector<double> &A, std::vector<double> &b, int m) {
-    for (int j = 0; j < m; ++j) {
-        double d = A[(size_t)j * m + j];
-        for (int k = 0; k < j; ++k) d -= A[(size_t)j * m + k] * A[(size_t)j * m + k];
-        if (!(d > 0) || !std::isfinite(d)) return false;
-        d = std::sqrt(d);
-        A[(size_t)j * m + j] = d;
-        for (int i = j + 1; i < m; ++i) {
-            double s = A[(size_t)i * m + j];
-            for (int k = 0; k < j; ++k) s -= A[(size_t)i * m + k] * A[(size_t)j * m + k];
-            A[(size_t)i * m + j] = s / d;
-        }
-    }
-    for (int i = 0; i < m; ++i) {
-        double s = b[i];
-        for (int k = 0; k < i; ++k) s -= A[(size_t)i * m + k] * b[k];
-        b[i] = s / A[(size_t)i * m + i];
-    }
-    for (int i = m - 1; i >= 0; --i) {
-        double s = b[i];
-        for (int k = i + 1; k < m; ++k) s -= A[(size_t)k * m + i] * b[k];
-        b[i] = s / A[(size_t)i * m + i];
-    }
-    return true;
 }
 
 static inline double pseudo_grad(double x, double g, double lam) {
@@ -750,7 +733,8 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     else gml_default_opts(&o);
     if (!(o.tol > 0)) o.tol = 1e-9;
     if (o.max_iter <= 0) o.max_iter = 100;
-    if (o.max_working < 32) o.max_working = 128;
+    if (o.max_working < 32) o.max_working = 256;
+    if (o.max_working > 512) o.max_working = 512;
     o.max_working = (int)round_up(o.max_working, 32);
     if (o.max_add <= 0) o.max_add = 32;
     HIPCHK(hipSetDevice(p->device));
@@ -920,65 +904,42 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 if (need[r]) vstale[r] = 0;
         }
 
-        // ---- Hessians on the working sets -----------------------------------------------
+        // ---- Newton directions on the working sets (Hessian + Cholesky solve on the device) ----
+        const double th1 = now_s();
         const int cap = (int)round_up(std::max(maxm, 1), 32);
         std::vector<int> Fidx((size_t)R * cap, (int)(Qp - 1));
-        for (int64_t r = 0; r < R; ++r) {
+        std::vector<double> gFm((size_t)R * cap, 0.0), pgFm((size_t)R * cap, 0.0), s1v((size_t)R, 1.0);
+        parallel_for(R, [&](int64_t r) {
             msz[r] = done[r] ? 0 : (int)Fset[r].size();
-            for (int a = 0; a < msz[r]; ++a) Fidx[(size_t)r * cap + a] = Fset[r][a];
-        }
-        std::vector<long long> hoff;
-        double *H = nullptr;
-        rc = device_hessian(p, rs, Fidx, msz, cap, formulation, o.precision, Kh, hoff, &H, stats);
+            const double *x = X.data() + r * Qp, *g = G.data() + r * Qp;
+            const uint8_t *kr = kind.data() + r * Qp;
+            for (int a = 0; a < msz[r]; ++a) {
+                const int c = Fset[r][a];
+                Fidx[(size_t)r * cap + a] = c;
+                gFm[(size_t)r * cap + a] = g[c];
+                pgFm[(size_t)r * cap + a] = pseudo_grad(x[c], g[c], kr[c] == 2 ? lambda : 0.0);
+            }
+            s1v[r] = formulation == GML_LOGRISE ? hscale / Z[r] : hscale; // Hess log Z = Hess Z / Z - g g^T
+        });
+        stats->t_host += now_s() - th1;
+        std::vector<double> Dn, Sd;
+        rc = device_newton(p, rs, Fidx, msz, cap, formulation, o.precision, Kh, s1v, formulation == GML_LOGRISE ? 1.0 : 0.0,
+                           gFm, pgFm, Dn, Sd, stats);
         if (rc) return rc;
-
-        // ---- Newton directions -------------------------------------------------------------
-        const double th1 = now_s();
+        const double th1b = now_s();
         parallel_for(R, [&](int64_t r) {
             if (done[r]) return;
             const int m = msz[r];
-            const std::vector<int> &Fs = Fset[r];
             const double *x = X.data() + r * Qp, *g = G.data() + r * Qp;
-            const uint8_t *kr = kind.data() + r * Qp;
-            std::vector<double> A((size_t)m * m), b((size_t)m), pgv((size_t)m), gF((size_t)m);
-            const double *Hr = H + hoff[r];
-            const int hp = ((m + 31) / 32) * 32;
-            for (int a = 0; a < m; ++a) {
-                const int c = Fs[a];
-                const double l = kr[c] == 2 ? lambda : 0.0;
-                pgv[a] = pseudo_grad(x[c], g[c], l);
-                gF[a] = g[c];
-            }
-            for (int a = 0; a < m; ++a)
-                for (int bb = 0; bb <= a; ++bb) {
-                    // tile (a/32, bb/32) with a/32 >= bb/32 is stored; inside a diagonal tile both halves are
-                    double h = hscale * Hr[(size_t)a * hp + bb];
-                    if (formulation == GML_LOGRISE) h = h / Z[r] - gF[a] * gF[bb]; // Hess log Z
-                    A[(size_t)a * m + bb] = h;
-                    A[(size_t)bb * m + a] = h;
-                }
-            double ridge = 0.0;
-            std::vector<double> Aw, bw;
-            for (int tries = 0; tries < 12; ++tries) {
-                Aw = A;
-                bw.assign(m, 0.0);
-                for (int a = 0; a < m; ++a) {
-                    Aw[(size_t)a * m + a] += ridge;
-                    bw[a] = -pgv[a];
-                }
-                if (chol_solve(Aw, bw, m)) break;
-                ridge = ridge == 0.0 ? 1e-12 : ridge * 100.0;
-                bw.assign(m, 0.0);
-            }
+            std::vector<double> bw(Dn.begin() + (size_t)r * cap, Dn.begin() + (size_t)r * cap + m);
+            std::vector<double> pgv(pgFm.begin() + (size_t)r * cap, pgFm.begin() + (size_t)r * cap + m);
             // weak coordinates: exact minimiser of the separable model with the Hessian diagonal
-            // (for +-1 statistics H_cc = sum_k h_k for every c: read it off the constant column)
+            // (for +-1 statistics H_cc = sum_k h_k for every c: the constant column's diagonal entry,
+            // which is the last one of the sorted working set)
             std::vector<int> &Wk = Weak[r];
             if (!Wk.empty()) {
-                int pc = -1;
-                for (int a = 0; a < m; ++a)
-                    if (Fs[a] == cconst) pc = a;
-                double S = pc >= 0 ? hscale * Hr[(size_t)pc * hp + pc] : std::fabs(f[r]);
-                if (formulation == GML_LOGRISE) S /= Z[r];
+                double S = Sd[r];
+                if (formulation == GML_LOGRISE) S += g[cconst] * g[cconst];
                 for (int c : Wk) {
                     double q = S;
                     if (formulation == GML_LOGRISE) q -= g[c] * g[c];
@@ -991,20 +952,10 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 }
             }
             mtot[r] = (int)Fset[r].size();
-            if (o.verbose >= 2 && r == 0) {
-                double sd = 0, sx = 0, mxd = 0;
-                for (size_t a = 0; a < bw.size(); ++a) {
-                    sd += std::fabs(bw[a]);
-                    mxd = std::max(mxd, std::fabs(bw[a]));
-                }
-                for (int64_t c = 0; c < Q; ++c) sx += std::fabs(x[c]);
-                fprintf(stderr, "[gml]   row0: f %.6e F %.6e kkt %.3e |W| %d |weak| %zu sum|d| %.3e max|d| %.3e sum|x| %.3e fn %.3e H00 %.4e\n",
-                        f[r], Fobj[r], kkt[r], m, Wk.size(), sd, mxd, sx, fn[r], hscale * Hr[0]);
-            }
             Dset[r] = bw;
             PGset[r] = pgv;
         });
-        stats->t_host += now_s() - th1;
+        stats->t_host += now_s() - th1b;
 
         // ---- projected backtracking line search ----------------------------------------
         // Two acceptance regimes per row:

@@ -368,4 +368,96 @@ void launch_hess_f64(const DevProblem &P, const double *V, const int8_t *Vq, con
                        (int)nsplit, form, H);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Batched Newton solve on the device: for every row r, A d = -pg with
+//   A = s1[r] * H_r  -  s2 * gF gF^T        (s2 = 1 for logRISE: Hess log Z = Hess Z / Z - g g^T)
+// H_r is row r's ragged block (lower 32x32 tiles valid, pitch hp).  Left-looking Cholesky in place:
+// L^T is written into the strict upper triangle (U[k][i] = L[i][k]: column steps read rows of U,
+// coalesced), the diagonal of L lives in LDS, the lower triangle keeps A for a ridge restart.
+// One workgroup per row.  Sdiag[r] = A[m-1][m-1] (the constant column, the Hessian's diagonal scale).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_newton_solve(double *__restrict__ H, const long long *__restrict__ hoff,
+                                                      const int *__restrict__ mt, const int *__restrict__ msz,
+                                                      const double *__restrict__ s1, double s2,
+                                                      const double *__restrict__ gF, const double *__restrict__ pgF,
+                                                      int cap, double *__restrict__ dout, double *__restrict__ Sdiag) {
+    const int r = blockIdx.x;
+    const int m = msz[r];
+    if (m == 0) return;
+    const int hp = 32 * mt[r];
+    double *A = H + hoff[r];
+    const double sc = s1[r];
+    const double *g = gF + (int64_t)r * cap, *pg = pgF + (int64_t)r * cap;
+    extern __shared__ double sm[]; // dg[cap] | y[cap] | gg[cap]
+    double *dg = sm, *y = sm + cap, *gg = sm + 2 * cap;
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < m; i += 256) gg[i] = s2 != 0.0 ? g[i] : 0.0;
+    __syncthreads();
+    auto a_at = [&](int i, int j) { return sc * A[(int64_t)i * hp + j] - s2 * gg[i] * gg[j]; }; // i >= j
+    double dmax = 0;
+    for (int i = tid; i < m; i += 256) dmax = fmax(dmax, fabs(a_at(i, i)));
+    for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
+    __shared__ double red[4];
+    if ((tid & 63) == 0) red[tid >> 6] = dmax;
+    __syncthreads();
+    dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (tid == 0) Sdiag[r] = a_at(m - 1, m - 1);
+    double ridge = 0.0;
+    for (int attempt = 0; attempt < 10; ++attempt) {
+        if (tid == 0) bad = 0;
+        __syncthreads();
+        for (int j = 0; j < m; ++j) {
+            // rows i = j + tid, j + tid + 256, ... of column j
+            double v[4];
+            int cnt = 0;
+            for (int i = j + tid; i < m; i += 256, ++cnt) {
+                double acc = a_at(i, j) + (i == j ? ridge : 0.0);
+                for (int k = 0; k < j; ++k) acc -= A[(int64_t)k * hp + i] * A[(int64_t)k * hp + j];
+                v[cnt & 3] = acc;
+            }
+            if (tid == 0) {
+                if (!(v[0] > 1e-300 * dmax) || !isfinite(v[0])) bad = 1;
+                dg[j] = sqrt(fmax(v[0], 1e-300));
+            }
+            __syncthreads();
+            if (bad) break;
+            const double inv = 1.0 / dg[j];
+            cnt = 0;
+            for (int i = j + tid; i < m; i += 256, ++cnt)
+                if (i > j) A[(int64_t)j * hp + i] = v[cnt & 3] * inv; // U[j][i] = L[i][j]
+            __syncthreads();
+        }
+        if (!bad) break;
+        __syncthreads();
+        ridge = ridge == 0.0 ? 1e-12 * fmax(dmax, 1e-300) : ridge * 100.0;
+    }
+    // forward substitution L y = -pg
+    for (int i = tid; i < m; i += 256) y[i] = -pg[i];
+    __syncthreads();
+    for (int j = 0; j < m; ++j) {
+        if (tid == 0) y[j] /= dg[j];
+        __syncthreads();
+        const double yj = y[j];
+        for (int i = j + 1 + tid; i < m; i += 256) y[i] -= A[(int64_t)j * hp + i] * yj;
+        __syncthreads();
+    }
+    // back substitution L^T d = y
+    for (int j = m - 1; j >= 0; --j) {
+        if (tid == 0) y[j] /= dg[j];
+        __syncthreads();
+        const double xj = y[j];
+        for (int i = tid; i < j; i += 256) y[i] -= A[(int64_t)i * hp + j] * xj; // L[j][i] = U[i][j]
+        __syncthreads();
+    }
+    for (int i = tid; i < m; i += 256) dout[(int64_t)r * cap + i] = bad ? 0.0 : y[i];
+}
+
+void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
+                         const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st) {
+    hipLaunchKernelGGL(k_newton_solve, dim3((unsigned)R), dim3(256), sizeof(double) * 3 * cap, st, H, hoff, mt, msz, s1, s2, gF,
+                       pgF, cap, dout, Sdiag);
+}
+
 } // namespace gml

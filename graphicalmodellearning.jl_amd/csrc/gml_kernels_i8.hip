@@ -738,6 +738,123 @@ __global__ __launch_bounds__(256) void k_hess_i8(const int8_t *__restrict__ Mt, 
         }
 }
 
+
+// Blocked variant for working sets above 128 entries (mt > 4 tiles): a workgroup handles, for one row
+// and one k-chunk, the 2 x 4 block of 32x32 tile pairs (tile rows 2a, 2a+1; tile columns 4b..4b+3),
+// wave l again owning digit plane l.  Blocks entirely above the diagonal are never launched; tiles
+// above the diagonal inside a block are computed and dropped.
+__global__ __launch_bounds__(256) void k_hess_i8_blk(const int8_t *__restrict__ Mt, const int8_t *__restrict__ Hq,
+                                                     const int *__restrict__ F, const int *__restrict__ mt,
+                                                     const long long *__restrict__ hoff, int cap, int64_t Kh,
+                                                     int64_t kchunk, long long *__restrict__ H64) {
+    constexpr int AR = 64, BR = 128, ROWS = AR + BR + 4;
+    constexpr int NCH = (ROWS * 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) int8_t lds[2][(ROWS + 12) * 64];
+    const int r = blockIdx.z;
+    const int m = mt[r];
+    if (m <= 4) return; // handled by the single-block kernels
+    // decode the block index: a = tile-row pair, b = group of 4 tile columns, needed iff 4b <= 2a+1
+    int a = 0, b = blockIdx.y;
+    for (;;) {
+        const int nb = (2 * a + 1) / 4 + 1;
+        if (b < nb) break;
+        b -= nb;
+        ++a;
+        if (2 * a >= m) return;
+    }
+    if (2 * a >= m) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, h = lane >> 5;
+    const int64_t kb = (int64_t)blockIdx.x * kchunk;
+    if (kb >= Kh) return;
+    const int64_t ke = (kb + kchunk < Kh) ? kb + kchunk : Kh;
+    const int tile = r >> 5, rl = r & 31;
+    const int *Fr = F + (int64_t)r * cap;
+    const int mrows = m * 32;
+
+    const int8_t *src[NCH];
+    int dst[NCH];
+    bool have[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int q = tid + 256 * j, row = q >> 2, slot = q & 3;
+        have[j] = row < ROWS;
+        if (row < AR) {
+            int fr = 2 * a * 32 + row;
+            if (fr >= mrows) fr = 0;
+            src[j] = Mt + (int64_t)Fr[fr] * Kh + slot * 16;
+        } else if (row < AR + BR) {
+            int fr = 4 * b * 32 + (row - AR);
+            if (fr >= mrows) fr = 0;
+            src[j] = Mt + (int64_t)Fr[fr] * Kh + slot * 16;
+        } else {
+            const int l = row - AR - BR < 4 ? row - AR - BR : 0;
+            src[j] = Hq + ((int64_t)tile * 128 + l * 32 + rl) * Kh + slot * 16;
+        }
+        dst[j] = lds_off(row, slot);
+    }
+    v16i acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0;
+    v4i rg[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+        if (have[j]) rg[j] = *reinterpret_cast<const v4i *>(src[j] + kb);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+        if (have[j]) *reinterpret_cast<v4i *>(&lds[0][dst[j]]) = rg[j];
+    __syncthreads();
+    int it = 0;
+    for (int64_t kk = kb; kk < ke; kk += 64, ++it) {
+        const int cur = it & 1;
+        const bool more = kk + 64 < ke;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+                if (have[j]) rg[j] = *reinterpret_cast<const v4i *>(src[j] + kk + 64);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int slot = 2 * t + h;
+            const v4i mg = *reinterpret_cast<const v4i *>(&lds[cur][lds_off(AR + BR + wave, slot)]);
+            v4i fa[2], fb[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const v4i *>(&lds[cur][lds_off(i * 32 + lr, slot)]) & mg;
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) fb[jn] = *reinterpret_cast<const v4i *>(&lds[cur][lds_off(AR + jn * 32 + lr, slot)]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) acc[i][jn] = MFMA_I8(fa[i], fb[jn], acc[i][jn]);
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+                if (have[j]) *reinterpret_cast<v4i *>(&lds[cur ^ 1][dst[j]]) = rg[j];
+        }
+        __syncthreads();
+    }
+    long long *Hr = H64 + hoff[r];
+    const int hp = 32 * m;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) {
+            const int ti = 2 * a + i, tj = 4 * b + jn;
+            if (ti < m && tj <= ti) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ii = ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, jj = tj * 32 + lr;
+                    const long long v = -((long long)acc[i][jn][e]) * (1ll << (8 * wave));
+                    if (v != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&Hr[(int64_t)ii * hp + jj]), (unsigned long long)v);
+                }
+            }
+        }
+}
+
 // H[i][j] = tau * (S - 2 T_ii - 2 T_jj + 4 T_ij) on the lower-triangular tiles
 __global__ __launch_bounds__(256) void k_hess_i8_fin(const long long *__restrict__ H64, const long long *__restrict__ hS,
                                                      const double *__restrict__ tau, const int *__restrict__ mt,
@@ -818,7 +935,7 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF
     }
     int maxm = 0;
     for (int r = 0; r < R; ++r) maxm = hMt[r] > maxm ? hMt[r] : maxm;
-    if (maxm > 4) return GML_EUNSUPPORTED; // > 128 entries: accumulators no longer fit the register file
+    if (maxm > 16) return GML_EUNSUPPORTED; // > 512 entries: not expected (the caller caps the Newton block)
     if (w->hKh != Kh) {
         if (w->Mt) (void)hipFree(w->Mt);
         if (w->Hq) (void)hipFree(w->Hq);
@@ -853,11 +970,24 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF
     const dim3 grid((unsigned)nsplit, (unsigned)R);
     // one launch per working-set size class (rows of other classes exit immediately)
     bool cls[6] = {false, false, false, false, false, false};
-    for (int r = 0; r < R; ++r) cls[hMt[r]] = true;
+    for (int r = 0; r < R; ++r) cls[hMt[r] <= 4 ? hMt[r] : 5] = true;
     if (cls[1]) hipLaunchKernelGGL((k_hess_i8<1>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, kchunk, w->H64);
     if (cls[2]) hipLaunchKernelGGL((k_hess_i8<2>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, kchunk, w->H64);
     if (cls[3]) hipLaunchKernelGGL((k_hess_i8<3>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, kchunk, w->H64);
     if (cls[4]) hipLaunchKernelGGL((k_hess_i8<4>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, kchunk, w->H64);
+    if (cls[5]) {
+        // blocks (a, b) with 4b <= 2a+1 for a < ceil(maxm/2)
+        int nblk = 0;
+        for (int a = 0; 2 * a < maxm; ++a) nblk += (2 * a + 1) / 4 + 1;
+        int ns2 = (int)((4096 + (int64_t)R * nblk - 1) / ((int64_t)R * nblk));
+        if (ns2 > maxsplit) ns2 = maxsplit;
+        if (ns2 < 1) ns2 = 1;
+        int64_t kc2 = (Kh + ns2 - 1) / ns2;
+        kc2 = (kc2 + 63) / 64 * 64;
+        ns2 = (int)((Kh + kc2 - 1) / kc2);
+        hipLaunchKernelGGL(k_hess_i8_blk, dim3((unsigned)ns2, (unsigned)nblk, (unsigned)R), dim3(256), 0, st, w->Mt, w->Hq, dF, dMt,
+                           dHoff, cap, Kh, kc2, w->H64);
+    }
     hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64,
                        w->hS, w->tau, dMt, dHoff, dH);
     I8CHK(hipGetLastError());
