@@ -813,7 +813,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             if (done[r]) return;
             const double *x = X.data() + r * Qp, *g = G.data() + r * Qp;
             const uint8_t *kr = kind.data() + r * Qp;
-            double F = f[r], worst = 0;
+            double F = f[r], worst = 0, worstW = 0;
             std::vector<std::pair<double, int>> viol;
             std::vector<int> &Fs = Fset[r];
             Fs.clear();
@@ -823,8 +823,12 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 F += l * std::fabs(x[c]);
                 const double pg = pseudo_grad(x[c], g[c], l);
                 if (std::fabs(pg) > worst) worst = std::fabs(pg);
-                if (x[c] != 0.0 || kr[c] == 1) Fs.push_back((int)c);
-                else if (pg != 0.0) viol.emplace_back(-std::fabs(pg), (int)c);
+                if (x[c] != 0.0 || kr[c] == 1) {
+                    Fs.push_back((int)c);
+                    worstW = std::max(worstW, std::fabs(pg));
+                } else if (pg != 0.0) {
+                    viol.emplace_back(-std::fabs(pg), (int)c);
+                }
             }
             if (!std::isfinite(worst)) worst = INFINITY;
             Fobj[r] = F;
@@ -847,6 +851,9 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             // Only the max_add largest violators are admitted per iteration: at theta = 0 most
             // coordinates violate |g| <= lambda merely through <s_u><s_c> (non-zero magnetisations), and
             // stop doing so once the field and the strongest couplings have been fitted.
+            // ... and none at all while the residual on the current support still dominates: the
+            // violations outside are then largely an artefact of the unconverged support.
+            if (worstW > worst * 0.999999 && worstW > 0 && !viol.empty() && (int)Fs.size() > 1) viol.clear();
             if ((int)viol.size() > o.max_add) {
                 std::nth_element(viol.begin(), viol.begin() + o.max_add, viol.end());
                 viol.resize(o.max_add);
