@@ -779,8 +779,8 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         best((size_t)R, INFINITY), Z((size_t)R, 1.0), Zt((size_t)R, 1.0), alpha((size_t)R, 1.0), dd((size_t)R, 0.0),
         fn((size_t)R, 0.0), fnt((size_t)R, 0.0);
     std::vector<uint8_t> done((size_t)R, 0), act((size_t)R, 1), need((size_t)R, 0), vstale((size_t)R, 0);
-    std::vector<int> stall((size_t)R, 0), msz((size_t)R, 0), mtot((size_t)R, 0);
-    std::vector<std::vector<int>> Fset((size_t)R), Weak((size_t)R);
+    std::vector<int> stall((size_t)R, 0), msz((size_t)R, 0), mtot((size_t)R, 0), blk((size_t)R, 0);
+    std::vector<std::vector<int>> Fset((size_t)R);
     std::vector<std::vector<double>> Dset((size_t)R), PGset((size_t)R);
 
     // logRISE post-processing of a pass: f = log Z, g = grad Z / Z   (:279)
@@ -844,39 +844,45 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 done[r] = 1;
                 return;
             }
-            // Newton block W: everything free if it fits the cap; otherwise the unpenalised slot plus the
-            // strongest coordinates by max(|pg|, |x| * f) (f ~ the Hessian's diagonal scale).  The rest of
-            // the free coordinates ("weak": many small noise-driven coefficients when lambda is close to
-            // the sampling noise) take a diagonal-Newton proximal step, see below.
             // Only the max_add largest violators are admitted per iteration: at theta = 0 most
             // coordinates violate |g| <= lambda merely through <s_u><s_c> (non-zero magnetisations), and
-            // stop doing so once the field and the strongest couplings have been fitted.
-            // ... and none at all while the residual on the current support still dominates: the
-            // violations outside are then largely an artefact of the unconverged support.
+            // stop doing so once the field and the strongest couplings have been fitted; and none at all
+            // while the residual on the current support still dominates (the violations outside are then
+            // largely an artefact of the unconverged support).
             if (worstW > worst * 0.999999 && worstW > 0 && !viol.empty() && (int)Fs.size() > 1) viol.clear();
             if ((int)viol.size() > o.max_add) {
                 std::nth_element(viol.begin(), viol.begin() + o.max_add, viol.end());
                 viol.resize(o.max_add);
             }
+            // Newton block W: everything free if it fits the cap.  Otherwise (a denser optimum than the
+            // cap: lambda at or below the sampling noise) block Gauss-Seidel: the free coordinates are
+            // ranked by max(|pg|, |x| * f) and the iterations cycle through consecutive blocks of that
+            // ranking (the unpenalised slot is in every block); all other coordinates stay fixed, so the
+            // block Newton step cannot overshoot through couplings it ignores.
             const int capW = o.max_working;
-            std::vector<int> &Wk = Weak[r];
-            Wk.clear();
             if ((int)(Fs.size() + viol.size()) <= capW) {
                 for (auto &v : viol) Fs.push_back(v.second);
+                blk[r] = 0;
             } else {
                 std::vector<std::pair<double, int>> cand;
                 cand.reserve(Fs.size() + viol.size());
                 const double fs = std::max(std::fabs(formulation == GML_LOGRISE ? 1.0 : f[r]), 1e-300);
+                int cfree = -1;
                 for (int c : Fs) {
-                    const double l = kr[c] == 2 ? lambda : 0.0;
-                    const double sc = kr[c] == 1 ? INFINITY : std::max(std::fabs(pseudo_grad(x[c], g[c], l)), std::fabs(x[c]) * fs);
-                    cand.emplace_back(-sc, c);
+                    if (kr[c] == 1) {
+                        cfree = c;
+                        continue;
+                    }
+                    cand.emplace_back(-std::max(std::fabs(pseudo_grad(x[c], g[c], lambda)), std::fabs(x[c]) * fs), c);
                 }
                 for (auto &v : viol) cand.emplace_back(v.first, v.second);
-                std::nth_element(cand.begin(), cand.begin() + capW, cand.end());
+                std::sort(cand.begin(), cand.end());
+                const int per = capW - 1, nblk = ((int)cand.size() + per - 1) / per;
+                const int b = blk[r] % nblk;
+                blk[r] = (blk[r] + 1) % nblk;
                 Fs.clear();
-                for (int a = 0; a < (int)cand.size(); ++a) (a < capW ? Fs : Wk).push_back(cand[a].second);
-                std::sort(Wk.begin(), Wk.end());
+                if (cfree >= 0) Fs.push_back(cfree);
+                for (int a = b * per; a < std::min<int>((b + 1) * per, (int)cand.size()); ++a) Fs.push_back(cand[a].second);
             }
             std::sort(Fs.begin(), Fs.end());
         });
@@ -937,27 +943,8 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         parallel_for(R, [&](int64_t r) {
             if (done[r]) return;
             const int m = msz[r];
-            const double *x = X.data() + r * Qp, *g = G.data() + r * Qp;
             std::vector<double> bw(Dn.begin() + (size_t)r * cap, Dn.begin() + (size_t)r * cap + m);
             std::vector<double> pgv(pgFm.begin() + (size_t)r * cap, pgFm.begin() + (size_t)r * cap + m);
-            // weak coordinates: exact minimiser of the separable model with the Hessian diagonal
-            // (for +-1 statistics H_cc = sum_k h_k for every c: the constant column's diagonal entry,
-            // which is the last one of the sorted working set)
-            std::vector<int> &Wk = Weak[r];
-            if (!Wk.empty()) {
-                double S = Sd[r];
-                if (formulation == GML_LOGRISE) S += g[cconst] * g[cconst];
-                for (int c : Wk) {
-                    double q = S;
-                    if (formulation == GML_LOGRISE) q -= g[c] * g[c];
-                    if (!(q > 1e-300)) q = 1e-300;
-                    const double zc = x[c] - g[c] / q, th = lambda / q;
-                    const double xn = zc > th ? zc - th : (zc < -th ? zc + th : 0.0);
-                    bw.push_back(xn - x[c]);
-                    pgv.push_back(pseudo_grad(x[c], g[c], lambda));
-                    Fset[r].push_back(c);
-                }
-            }
             mtot[r] = (int)Fset[r].size();
             Dset[r] = bw;
             PGset[r] = pgv;

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const int8_t *__restrict__ Xs, const int8_t *__restrict__ Xt, const int8_t *__restrict__ Tq,
     const int *__restrict__ rowcol, const int *__restrict__ groups, int ngroups, const double *__restrict__ w,
     const double *__restrict__ sigma, const long long *__restrict__ qconst, const double *__restrict__ invtau,
-    int64_t Qp, int64_t Qfp, int64_t Kp, int ntiles_k, int dbg, int stagger, int8_t *__restrict__ Vq,
+    int64_t Qp, int64_t Qfp, int64_t Kp, int ntiles_k, int8_t *__restrict__ Vq,
     long long *__restrict__ csum, long long *__restrict__ asum, double *__restrict__ fsum) {
     constexpr int WM = 2;                 // 32-sample MFMA tiles per wave
     constexpr int AR = 256, BR = 32 * LF; // stage image rows
@@ -227,7 +227,6 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const int tgi = bi / (ntk8 * TG), rem = bi % (ntk8 * TG);
     const int st = (rem / TG) * 8 + xcd, gi = tgi * TG + rem % TG;
     if (st >= ntiles_k || gi >= ngroups) return;
-    (void)stagger;
     const int64_t k0 = (int64_t)st * AR;
     const int mytile = groups[gi];
 
@@ -278,10 +277,6 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
         }
     }
     __syncthreads(); // every wave is done with the ring: it becomes the epilogue's staging area
-    if (dbg >= 100) { // timing experiment: GEMM only
-        if (acc[0][0][0] == 0x7fffffff) Vq[0] = 1;
-        return;
-    }
 
     // ---- epilogue ----------------------------------------------------------------------------
     // lane <-> node row (lr), register e <-> sample (e&3) + 8*(e>>2) + 4*h within the 32-sample tile
@@ -378,98 +373,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 
 // ------------------------------------------------------------------------------------------
 // backward: Gacc[m][c] += sum_k Vq[m][k] * Xt[c][k]  (i32, split-K with integer atomics).
-// Workgroup tile: TM node tiles (TM*128 rows of Vq: 4 limbs x 32 nodes each) x 256 columns;
-// waves 2 x 2, each (64*TM) x 128.  TM = 2 halves the bytes staged per MFMA (1 wave/SIMD).
+// Workgroup tile: 2 node tiles (256 rows of Vq: 4 limbs x 32 nodes each) x 256 columns of Xt,
+// 8 waves as 2 (M) x 4 (N), each 128 x 64, 3-stage LDS-DMA ring of 32 KB stages, 2 waves/SIMD.
+// All (tile, column-tile) blocks of one k-chunk run on one XCD so that the chunk's slabs of Vq and
+// Xt are fetched from HBM once and shared through that XCD's L2.
 // ------------------------------------------------------------------------------------------
-template <int TM>
-__global__ __launch_bounds__(256, (TM == 1 ? 2 : 1)) void k_bwd_i8(
-    const int8_t *__restrict__ Vq, const int8_t *__restrict__ Xt, const int *__restrict__ groups, int ngroups_t,
-    int nNt, int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit, int32_t *__restrict__ Gacc) {
-    constexpr int AR = 128 * TM, BR = 256, STAGE = (AR + BR) * 64;
-    constexpr int NPIECE = (AR + BR) / 16, NP = NPIECE / 4;
-    constexpr int WMT = 2 * TM; // 32-row MFMA tiles per wave along M
-    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int lr = lane & 31, h = lane >> 5;
-    const int wm = wave & 1, wn = wave >> 1;
-    const int T = ngroups_t * nNt; // ngroups_t = number of TM-groups of node tiles
-    const int b = blockIdx.x, xcd = b & 7, bi = b >> 3;
-    const int chunk = (bi / T) * 8 + xcd, ti = bi % T; // all tiles of one k-chunk on one XCD
-    if (chunk >= nsplit) return;
-    const int gi = ti / nNt, nt = ti % nNt;
-    int tiles[TM];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) tiles[t] = groups[gi * TM + t]; // -1: padding (computed on tile 0, not stored)
-    const int64_t kb = (int64_t)chunk * kchunk;
-    const int64_t ke = (kb + kchunk < Kp) ? kb + kchunk : Kp;
-    const int64_t n0 = (int64_t)nt * BR;
-
-    const int8_t *src[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int pc = wave + 4 * j;
-        const int row = pc * 16 + (lane >> 2);
-        const int slot = (lane & 3) ^ ((row >> 2) & 3);
-        if (row < AR) {
-            int tl = tiles[row >> 7];
-            if (tl < 0) tl = tiles[0];
-            src[j] = Vq + ((int64_t)tl * 128 + (row & 127)) * Kp + slot * 16;
-        } else {
-            int64_t c = n0 + (row - AR);
-            if (c >= Qfp) c = Qfp - 1; // columns beyond the matrix: computed, never stored
-            src[j] = Xt + c * Kp + slot * 16;
-        }
-    }
-    v16i acc[WMT][4];
-#pragma unroll
-    for (int i = 0; i < WMT; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0;
-
-    const int nk = (int)((ke - kb) / 64);
-    ring_issue<NP>(src, kb, lds, wave, NPIECE);
-    if (nk > 1) ring_issue<NP>(src, kb + 64, lds + STAGE, wave, NPIECE);
-    for (int kt = 0; kt < nk; ++kt) {
-        ring_wait<NP>(kt + 1 < nk);
-        if (kt + 2 < nk) ring_issue<NP>(src, kb + (int64_t)(kt + 2) * 64, lds + ((kt + 2) % 3) * STAGE, wave, NPIECE);
-        const int8_t *cur = lds + (kt % 3) * STAGE;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int slot = 2 * t + h;
-            v4i fa[WMT], fb[4];
-#pragma unroll
-            for (int i = 0; i < WMT; ++i)
-                fa[i] = *reinterpret_cast<const v4i *>(cur + lds_off(wm * 32 * WMT + i * 32 + lr, slot));
-#pragma unroll
-            for (int jn = 0; jn < 4; ++jn)
-                fb[jn] = *reinterpret_cast<const v4i *>(cur + AR * 64 + lds_off(wn * 128 + jn * 32 + lr, slot));
-#pragma unroll
-            for (int i = 0; i < WMT; ++i)
-#pragma unroll
-                for (int jn = 0; jn < 4; ++jn) acc[i][jn] = MFMA_I8(fa[i], fb[jn], acc[i][jn]);
-        }
-    }
-    // C layout: column (lane&31) <-> Xt row (c), register e <-> Vq row (e&3)+8*(e>>2)+4*h
-#pragma unroll
-    for (int i = 0; i < WMT; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) {
-            const int64_t c = n0 + wn * 128 + jn * 32 + lr;
-            const int grow = wm * 32 * WMT + i * 32; // first row of this MFMA tile within the workgroup tile
-            const int tl = tiles[grow >> 7];
-            if (c < Qfp && tl >= 0) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int mrow = (grow & 127) + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    atomicAdd(&Gacc[((int64_t)tl * 128 + mrow) * Qfp + c], acc[i][jn][e]);
-                }
-            }
-        }
-}
-
-__global__ __launch_bounds__(512, 2) void k_bwd_i8w8(
+__global__ __launch_bounds__(512, 2) void k_bwd_i8(
     const int8_t *__restrict__ Vq, const int8_t *__restrict__ Xt, const int *__restrict__ groups, int ngroups_t,
     int nNt, int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit, int32_t *__restrict__ Gacc) {
     constexpr int TM = 2;
@@ -1015,9 +924,8 @@ static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, 
     }
     const int ntk = (int)(d.Kp / 256);
     const int grid = ((ntk + 7) / 8) * 8 * ((ngroups + 7) / 8) * 8;
-    static const int dbg = getenv("GML_DEBUG_NOEPI") ? 100 : 0;
     hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xs, d.Xt, w->Tq, dRowcol, w->pairs,
-                       ngroups, d.w, w->sigma, w->qconst, w->invtau, d.Qp, d.Qfp, d.Kp, ntk, dbg, 0, w->Vq, w->csum, w->asum,
+                       ngroups, d.w, w->sigma, w->qconst, w->invtau, d.Qp, d.Qfp, d.Kp, ntk, w->Vq, w->csum, w->asum,
                        dF);
 }
 
@@ -1085,42 +993,20 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
         kchunk = (kchunk + 63) / 64 * 64;
         if (kchunk < 1024) kchunk = 1024;
         nsplit = (int)((d.Kp + kchunk - 1) / kchunk);
-        static const int TM = [] {
-            const char *e = getenv("GML_I8_BWD_TM");
-            return (e && atoi(e) == 1) ? 1 : 2;
-        }();
+        constexpr int TM = 2;
         const int ngt = (ngroups + TM - 1) / TM;
         const int T = ngt * nNt;
         const int grid = ((nsplit + 7) / 8) * 8 * T;
         const int shmem = 3 * (128 * TM + 256) * 64;
         static bool bwd_attr = false;
         if (!bwd_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      3 * (128 + 256) * 64);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      3 * (256 + 256) * 64);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      shmem);
             bwd_attr = true;
         }
         // w->pairs holds the active tile list padded with -1 to an even count
-        static const bool w8 = [] {
-            const char *e = getenv("GML_I8_BWD_W8");
-            return !(e && atoi(e) == 0);
-        }();
-        if (TM == 2 && w8) {
-            static bool a8 = false;
-            if (!a8) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8w8), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          3 * (256 + 256) * 64);
-                a8 = true;
-            }
-            hipLaunchKernelGGL(k_bwd_i8w8, dim3(grid), dim3(512), shmem, st, w->Vq, d.Xt, w->pairs, ngt, nNt, d.Qfp, d.Kp, kchunk,
-                               nsplit, w->Gacc);
-        } else if (TM == 2)
-            hipLaunchKernelGGL((k_bwd_i8<2>), dim3(grid), dim3(256), shmem, st, w->Vq, d.Xt, w->pairs, ngt, nNt, d.Qfp, d.Kp,
-                               kchunk, nsplit, w->Gacc);
-        else
-            hipLaunchKernelGGL((k_bwd_i8<1>), dim3(grid), dim3(256), shmem, st, w->Vq, d.Xt, w->pairs, ngt, nNt, d.Qfp, d.Kp,
-                               kchunk, nsplit, w->Gacc);
+        hipLaunchKernelGGL(k_bwd_i8, dim3(grid), dim3(512), shmem, st, w->Vq, d.Xt, w->pairs, ngt, nNt, d.Qfp, d.Kp, kchunk, nsplit,
+                           w->Gacc);
     }
     if (ev) I8CHK(hipEventRecord(ev[2], st));
     hipLaunchKernelGGL(k_finalize_i8, dim3((unsigned)((d.Qp + 255) / 256), (unsigned)Rp), dim3(256), 0, st, w->Gacc, w->tau,

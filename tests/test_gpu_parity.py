@@ -269,3 +269,46 @@ def test_i8x_linearity_in_counts_full_size_property():
     with gml.Problem(counts=2 * np.ones(K), spins=spins) as p:
         fc, gc = p.objgrad("RISE", np.arange(n), theta, precision="i8x")
     assert np.array_equal(fc, fb) and np.array_equal(gc, gb)  # exact integer arithmetic: bitwise equal
+
+
+def _kkt_from_oracle(spins, out, nodes, lam):
+    K, n = spins.shape
+    f, g = O.objgrad_rise_nodes(np.ones(K), spins, np.asarray(nodes), out[nodes])
+    worst = 0.0
+    for a, u in enumerate(nodes):
+        x = out[u]
+        pg = np.where(x > 0, g[a] + lam, np.where(x < 0, g[a] - lam, np.sign(g[a]) * np.maximum(np.abs(g[a]) - lam, 0)))
+        pg[u] = g[a][u]  # the field slot is not penalised
+        worst = max(worst, np.abs(pg).max())
+    return worst
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_dense_solutions_large_working_sets(prec):
+    # small regulariser -> hundreds of non-zeros per node: exercises the blocked int8 Hessian (> 128
+    # entries), the device Cholesky solve and, with a small Newton-block cap, the cyclic block
+    # Gauss-Seidel Newton iteration.  All variants must reach the same optimum.
+    n, K = 192, 30000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=7)
+    lam = O.lam(0.05, n, K)
+    with gml.Problem(spins=spins) as p:
+        full, kkt_f, st_f = p.learn("RISE", 0.05, tol=1e-9, precision=prec, max_working=512, max_iter=200)
+        # a cap below the support size: cyclic block Gauss-Seidel (linear convergence, looser tolerance)
+        capped, kkt_c, st_c = p.learn("RISE", 0.05, tol=1e-6, precision=prec, max_working=128, max_iter=400,
+                                      raise_on_fail=False)
+    assert st_f["not_converged"] == 0
+    nnz = (full != 0).sum(1)
+    assert nnz.max() > 128  # the large-block path really ran
+    assert kkt_c.max() <= 1e-4 and np.abs(full - capped).max() <= 1e-3
+    assert _kkt_from_oracle(spins, full, [0, 50, 191], lam) <= 5e-9
+
+
+def test_subsampled_hessian_does_not_change_the_optimum():
+    n, K = 64, 40000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=8)
+    with gml.Problem(spins=spins) as p:
+        a, _, sa = p.learn("RISE", 0.4, tol=1e-10, precision="f64", hess_samples=-1)
+        b, _, sb = p.learn("RISE", 0.4, tol=1e-10, precision="f64", hess_samples=4096)
+    assert sa["not_converged"] == 0 and sb["not_converged"] == 0
+    assert np.abs(a - b).max() <= 1e-8
+    assert ((a == 0) == (b == 0)).all()
