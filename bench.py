@@ -115,6 +115,21 @@ def main():
         roofline["note"] = ("achieved counts algorithmic flops once; the kernel issues limb_products int8 MFMA products per "
                             "algorithmic product (exact fixed point), so frac <= 1/limb_products")
 
+    # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
+    # the value measured with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same command
+    # (profiles/r1_i8x_pmc_traffic.json, separate passes) is reported.  gfx950 correction per
+    # MI355X_MICROARCH.md: FETCH_SIZE counts half the bytes of 16-B/lane loads -> doubled.
+    try:
+        if args.precision == "i8x" and (n, K, world) == (1024, 1000000, 1):
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_i8x_pmc_traffic.json")))
+            kn = [k for k in pm if ("k_fwd_i8" in k if dom == "fwd" else "k_bwd_i8" in k)][0]
+            roofline["traffic"] = (2.0 * pm[kn]["FETCH_SIZE_KB"] + pm[kn]["WRITE_SIZE_KB"]) * 1024.0
+            roofline["traffic_note"] = ("bytes per launch from profiles/r1_i8x_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KB); "
+                                        "algorithmic bytes per launch: %.3g" % ((K * n + 4.0 * K * nloc) if dom == "fwd"
+                                                                                else (4.0 * K * nloc + K * n)))
+    except Exception:
+        pass
+
     extra = {}
     if not args.no_learn:
         sync()
