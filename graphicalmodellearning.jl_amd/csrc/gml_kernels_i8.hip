@@ -988,14 +988,17 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
     if (ev) I8CHK(hipEventRecord(ev[1], st));
     if (want_grad) {
         const int nNt = (int)((d.Qfp + 255) / 256);
-        int nsplit = 16;
-        int64_t kchunk = (d.Kp + nsplit - 1) / nsplit;
-        kchunk = (kchunk + 63) / 64 * 64;
-        if (kchunk < 1024) kchunk = 1024;
-        nsplit = (int)((d.Kp + kchunk - 1) / kchunk);
         constexpr int TM = 2;
         const int ngt = (ngroups + TM - 1) / TM;
         const int T = ngt * nNt;
+        // split-K: a multiple of 8 chunks (one XCD each), at least 16, and enough workgroups (~1024) to
+        // fill the chip when few node tiles are active (node-sharded ranks, late solver iterations)
+        int nsplit = ((1024 + T - 1) / T + 7) / 8 * 8;
+        if (nsplit < 16) nsplit = 16;
+        int64_t kchunk = (d.Kp + nsplit - 1) / nsplit;
+        kchunk = (kchunk + 63) / 64 * 64;
+        if (kchunk < 2048) kchunk = 2048;
+        nsplit = (int)((d.Kp + kchunk - 1) / kchunk);
         const int grid = ((nsplit + 7) / 8) * 8 * T;
         const int shmem = 3 * (128 * TM + 256) * 64;
         static bool bwd_attr = false;
