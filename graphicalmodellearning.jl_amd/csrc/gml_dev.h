@@ -20,6 +20,11 @@ struct DevProblem {
     int8_t *Xs, *Xt;
     double *w;
     double wmax;      // max_k w_k
+    // Chunked mode (design matrices whose two orientations do not both fit in HBM, e.g. order-3
+    // statistics of 512 spins x 1e6 samples = 131 GB each): Xt is fully resident, Xs holds only
+    // xs_cols columns at a time and is refilled by transposing slices of Xt inside the forward pass.
+    int64_t xs_cols;  // columns held by Xs (== Qp when not chunked); also the row pitch of Xs
+    bool chunked;
 };
 
 // ---- packing -----------------------------------------------------------------------------

@@ -50,8 +50,8 @@ void launch_transpose_i8(const int8_t *src, int64_t rows, int64_t cols, int64_t 
 __global__ __launch_bounds__(256) void k_expand_features(const int8_t *__restrict__ St, int64_t K,
                                                          int64_t Kp, const int32_t *__restrict__ keys,
                                                          int order, int64_t Q, int8_t *__restrict__ Xt) {
-    const int64_t c = blockIdx.y;
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t c = blockIdx.x; // features on x: there can be more than 65535 of them
+    const int64_t k = (int64_t)blockIdx.y * 256 + threadIdx.x;
     if (c >= Q || k >= K) return;
     int v = 1;
     for (int t = 0; t < order; ++t) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_expand_features(const int8_t *__restric
 void launch_expand_features(const int8_t *St, int64_t n, int64_t K, int64_t Kp, const int32_t *keys,
                             int order, int64_t Q, int8_t *Xt, hipStream_t st) {
     (void)n;
-    dim3 grid((unsigned)((K + 255) / 256), (unsigned)Q);
+    dim3 grid((unsigned)Q, (unsigned)((K + 255) / 256));
     hipLaunchKernelGGL(k_expand_features, grid, dim3(256), 0, st, St, K, Kp, keys, order, Q, Xt);
 }
 

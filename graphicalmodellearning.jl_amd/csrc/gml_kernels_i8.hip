@@ -20,6 +20,7 @@
 // register <-> sample, and the limbs combine lane-locally.
 #include "../../include/gml.h"
 #include "gml_dev.h"
+#include <algorithm>
 #include <string>
 
 namespace gml {
@@ -41,6 +42,7 @@ struct I8Ws {
     int64_t hKh = 0, hcap_elems = 0;
     int8_t *Mt = nullptr, *Hq = nullptr; // bit masks of Xt (0x00 / 0xFF) and limb planes of the Hessian weights
     long long *hS = nullptr, *H64 = nullptr;
+    double *Eacc = nullptr; // [Kp][rows] partial energies (chunked design matrices only)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -202,8 +204,10 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const int8_t *__restrict__ Xs, const int8_t *__restrict__ Xt, const int8_t *__restrict__ Tq,
     const int *__restrict__ rowcol, const int *__restrict__ groups, int ngroups, const double *__restrict__ w,
     const double *__restrict__ sigma, const long long *__restrict__ qconst, const double *__restrict__ invtau,
-    int64_t Qp, int64_t Qfp, int64_t Kp, int ntiles_k, int8_t *__restrict__ Vq,
-    long long *__restrict__ csum, long long *__restrict__ asum, double *__restrict__ fsum) {
+    int64_t Qp /* pitch of Xs */, int64_t Qfp /* pitch of Tq */, int64_t Kp, int ntiles_k, int nk /* 64-column steps */,
+    double *__restrict__ Eacc /* [Kp][Rp] partial energies of earlier column chunks, or NULL */, int Rp, int chunk_first,
+    int chunk_last, int8_t *__restrict__ Vq, long long *__restrict__ csum, long long *__restrict__ asum,
+    double *__restrict__ fsum) {
     constexpr int WM = 2;                 // 32-sample MFMA tiles per wave
     constexpr int AR = 256, BR = 32 * LF; // stage image rows
     constexpr int STAGE = (AR + BR) * 64;
@@ -253,7 +257,6 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][l][e] = 0;
 
-    const int nk = (int)(Qfp / 64);
     ring_issue<NP>(src, 0, lds, wave, NPIECE);
     if (nk > 1) ring_issue<NP>(src, 64, lds + STAGE, wave, NPIECE);
     for (int kt = 0; kt < nk; ++kt) {
@@ -318,6 +321,14 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     const int lo = acc[i][0][e] + (acc[i][1][e] << 8);
                     a = fma((double)acc[i][2][e], 65536.0, (double)lo);
                 }
+                if (Eacc) { // column-chunked design matrix: integer-valued partial sums carried in FP64 (exact)
+                    double *ea = Eacc + (kk + j) * Rp + r;
+                    if (!chunk_first) a += *ea;
+                    if (!chunk_last) {
+                        if (active) *ea = a;
+                        continue;
+                    }
+                }
                 const double Ea = fma(a, sg, sgq0);                 // |E| pre-sign: sigma * (A + q0)
                 const bool neg = ((sw >> (8 * j + 7)) & 1u) != 0;   // s_u^k == -1 (padding: s = 0, w = 0)
                 const double wk = w[kk + j] * it;
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                 cs += vq;
                 dj[j] = ((unsigned)vq + 0x80808080u) ^ 0x80808080u; // 4 balanced base-256 digits
             }
+            if (Eacc && !chunk_last) continue;
             // 4 samples x 4 limbs byte transpose -> one dword per limb plane
 #pragma unroll
             for (int lb = 0; lb < LB; ++lb) {
@@ -348,6 +360,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
             }
         }
     }
+    if (Eacc && !chunk_last) return; // uniform over the workgroup
     cs += __shfl_xor(cs, 32);
     as += __shfl_xor(as, 32);
     if (active && h == 0) {
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_make_masks(const int8_t *__restrict__ Xt, int64_t Kp, int64_t Kh,
                                                     int8_t *__restrict__ Mt) {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    const int64_t k = (int64_t)blockIdx.y * 256 + threadIdx.x, c = blockIdx.x;
     if (k < Kh) Mt[c * Kh + k] = Xt[c * Kp + k] < 0 ? (int8_t)-1 : (int8_t)0;
 }
 
@@ -801,7 +814,7 @@ void i8_free(void *p) {
     I8Ws *w = static_cast<I8Ws *>(p);
     if (!w) return;
     void *ptrs[] = {w->Tq, w->Vq, w->Gacc, w->sigma, w->tau, w->invtau, w->qconst, w->csum, w->asum, w->pairs,
-                    w->Mt, w->Hq, w->hS, w->H64};
+                    w->Mt, w->Hq, w->hS, w->H64, w->Eacc};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete w;
@@ -824,6 +837,7 @@ static int i8_ensure(void **wsp, const DevProblem &d, int Rp, int LF, std::strin
     I8CHK(hipMalloc(&w->csum, sizeof(long long) * Rp));
     I8CHK(hipMalloc(&w->asum, sizeof(long long) * Rp));
     I8CHK(hipMalloc(&w->pairs, sizeof(int) * (Rp / 32 + 2)));
+    if (d.chunked) I8CHK(hipMalloc(&w->Eacc, sizeof(double) * (size_t)Rp * d.Kp));
     I8CHK(hipMemset(w->Tq, 0, (size_t)Rp * LF * d.Qfp));
     I8CHK(hipMemset(w->Vq, 0, (size_t)Rp * LB * d.Kp));
     w->rows = Rp;
@@ -854,7 +868,7 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF
         I8CHK(hipMalloc(&w->Mt, (size_t)d.Qp * Kh));
         I8CHK(hipMalloc(&w->Hq, (size_t)w->rows * LB * Kh));
         I8CHK(hipMalloc(&w->hS, sizeof(long long) * w->rows));
-        hipLaunchKernelGGL(k_make_masks, dim3((unsigned)(Kh / 256), (unsigned)d.Qp), dim3(256), 0, st, d.Xt, d.Kp, Kh, w->Mt);
+        hipLaunchKernelGGL(k_make_masks, dim3((unsigned)d.Qp, (unsigned)(Kh / 256)), dim3(256), 0, st, d.Xt, d.Kp, Kh, w->Mt);
         w->hKh = Kh;
     }
     const int64_t need = htotal;
@@ -924,9 +938,22 @@ static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, 
     }
     const int ntk = (int)(d.Kp / 256);
     const int grid = ((ntk + 7) / 8) * 8 * ((ngroups + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xs, d.Xt, w->Tq, dRowcol, w->pairs,
-                       ngroups, d.w, w->sigma, w->qconst, w->invtau, d.Qp, d.Qfp, d.Kp, ntk, w->Vq, w->csum, w->asum,
-                       dF);
+    const int Rp = (int)w->rows;
+    if (!d.chunked) {
+        hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xs, d.Xt, w->Tq, dRowcol, w->pairs,
+                           ngroups, d.w, w->sigma, w->qconst, w->invtau, d.Qp, d.Qfp, d.Kp, ntk, (int)(d.Qfp / 64),
+                           (double *)nullptr, Rp, 1, 1, w->Vq, w->csum, w->asum, dF);
+        return;
+    }
+    // column chunks: refill Xs from the resident Xt (transpose of a slice), accumulate the integer
+    // energies across chunks in Eacc, run the pointwise epilogue with the last chunk
+    for (int64_t c0 = 0; c0 < d.Qfp; c0 += d.xs_cols) {
+        const int64_t nc = std::min<int64_t>(d.xs_cols, d.Qfp - c0);
+        launch_transpose_i8(d.Xt + c0 * d.Kp, nc, d.K, d.Kp, d.Xs, d.xs_cols, st);
+        hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xs, d.Xt, w->Tq + c0, dRowcol, w->pairs,
+                           ngroups, d.w, w->sigma, w->qconst, w->invtau, d.xs_cols, d.Qfp, d.Kp, ntk, (int)(nc / 64), w->Eacc, Rp,
+                           c0 == 0 ? 1 : 0, c0 + nc >= d.Qfp ? 1 : 0, w->Vq, w->csum, w->asum, dF);
+    }
 }
 
 template <int LF>

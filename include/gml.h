@@ -50,7 +50,7 @@ typedef struct gml_opts {
     double tol;          /* KKT tolerance: max |pseudo-gradient| per node (default 1e-9)    */
     int32_t max_iter;    /* outer (Newton) iterations (default 100)                         */
     int32_t precision;   /* GML_PREC_*                                                      */
-    int32_t max_working; /* cap on a node's Newton block (default 256, max 512, multiple of 32); a
+    int32_t max_working; /* cap on a node's Newton block (default = max = 512, multiple of 32); a
                             denser optimum is solved by cycling blocks (block Gauss-Seidel)    */
     int32_t max_add;     /* new (violating) coordinates admitted per node per iteration (default 32) */
     int32_t verbose;     /* 0 silent, 1 per-iteration line on stderr                        */

@@ -312,3 +312,22 @@ def test_subsampled_hessian_does_not_change_the_optimum():
     assert sa["not_converged"] == 0 and sb["not_converged"] == 0
     assert np.abs(a - b).max() <= 1e-8
     assert ((a == 0) == (b == 0)).all()
+
+
+def test_chunked_design_matrix_is_bit_identical(monkeypatch):
+    # the column-chunked forward (used when both orientations of the design matrix do not fit in HBM,
+    # e.g. order-3 statistics of 512 spins) must reproduce the resident path exactly (integer partial sums)
+    spins, terms = synthetic.block_multibody(36, 20000, block=12, seed=3)
+    rng = np.random.default_rng(1)
+    with gml.Problem(spins=spins, order=3) as p:
+        theta = rng.normal(scale=0.05, size=(36, p.P))
+        f0, g0 = p.objgrad("RISE", np.arange(36), theta, precision="i8x")
+        ref, _, st0 = p.learn("RISE", 0.4, tol=1e-9, precision="i8x")
+    monkeypatch.setenv("GML_FORCE_CHUNK_COLS", "128")
+    with gml.Problem(spins=spins, order=3) as p:
+        f1, g1 = p.objgrad("RISE", np.arange(36), theta, precision="i8x")
+        got, _, st1 = p.learn("RISE", 0.4, tol=1e-9, precision="i8x")
+        with pytest.raises(gml.GMLError):
+            p.objgrad("RISE", np.arange(36), theta, precision="f64")
+    assert np.array_equal(f0, f1) and np.array_equal(g0, g1)
+    assert np.array_equal(ref, got) and st0["passes"] == st1["passes"]
