@@ -331,3 +331,17 @@ def test_chunked_design_matrix_is_bit_identical(monkeypatch):
             p.objgrad("RISE", np.arange(36), theta, precision="f64")
     assert np.array_equal(f0, f1) and np.array_equal(g0, g1)
     assert np.array_equal(ref, got) and st0["passes"] == st1["passes"]
+
+
+@pytest.mark.parametrize("n", [512, 1024])
+def test_wide_problems_i8x_matches_fp64_path(n):
+    # headline-width problems (8 / 16 column steps of 64 in the forward GEMM, 2 / 4 column tiles in the
+    # backward one) at a sample count small enough for a test: both device paths must agree
+    K = 6000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=11)
+    theta = J.copy()
+    nodes = np.arange(n)
+    with gml.Problem(spins=spins) as p:
+        f8, g8 = p.objgrad("RISE", nodes, theta, precision="i8x")
+        f64, g64 = p.objgrad("RISE", nodes, theta, precision="f64")
+    assert np.abs(f8 / f64 - 1).max() <= 1e-7 and np.abs(g8 - g64).max() <= 1e-7
