@@ -70,6 +70,8 @@ def lib():
     L.gml_lambda.argtypes = [dbl, i64, dbl]
     L.gml_problem_create.argtypes = [p, i32, i64, i64, i64, i32, i32, i64, i64, i32, C.POINTER(p)]
     L.gml_problem_create_spins.argtypes = [p, p, i64, i64, i32, i64, i64, i32, C.POINTER(p)]
+    L.gml_problem_create_sampled.argtypes = [p, i64, i64, C.c_uint64, i32, i64, i64, i32, C.POINTER(p)]
+    L.gml_problem_get_spins.argtypes = [p, p]
     L.gml_problem_destroy.argtypes = [p]
     L.gml_problem_destroy.restype = None
     L.gml_problem_info.argtypes = [p] + [p] * 6
@@ -94,10 +96,18 @@ def _ptr(a):
 class Problem:
     """RAII wrapper of a gml_problem handle (packed spins + weights resident in HBM)."""
 
-    def __init__(self, samples=None, *, counts=None, spins=None, order=2, node_range=None, device=0):
+    def __init__(self, samples=None, *, counts=None, spins=None, model=None, num_samples=None, seed=0, order=2,
+                 node_range=None, device=0):
         L = lib()
         h = C.c_void_p()
-        if samples is not None:
+        if model is not None:
+            # sample on the device from a pairwise model (n x n, diagonal = fields): sampling.jl:34-57
+            m = np.ascontiguousarray(model, dtype=np.float64)
+            n = m.shape[0]
+            n0, n1 = node_range if node_range is not None else (0, n)
+            check(L.gml_problem_create_sampled(_ptr(m), n, int(num_samples), int(seed), int(order), n0, n1, int(device),
+                                               C.byref(h)))
+        elif samples is not None:
             s = np.asarray(samples)
             if s.ndim != 2 or s.shape[1] < 2:
                 raise GMLError(GML_EINVAL, "samples must be a K x (1+n) histogram matrix")
@@ -142,6 +152,12 @@ class Problem:
 
     def __exit__(self, *a):
         self.close()
+
+    def spins(self):
+        """the +-1 configurations held by the handle (K x n int8)"""
+        out = np.zeros((self.K, self.n), dtype=np.int8)
+        check(lib().gml_problem_get_spins(self._h, _ptr(out)))
+        return out
 
     def multi_keys(self, u):
         keys = np.zeros((self.P, self.order), dtype=np.int32)

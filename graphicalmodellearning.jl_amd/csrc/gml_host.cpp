@@ -226,7 +226,8 @@ static void node_cols(const gml_problem *p, int64_t u, std::vector<int32_t> &col
     }
 }
 
-static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /*K x n row-major*/) {
+static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /*K x n row-major, host*/,
+                     int8_t *dspins = nullptr /* the same on the device (then owned and freed here) */) {
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipStreamCreate(&p->st));
     DevProblem &d = p->d;
@@ -299,12 +300,12 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
     }
     HIPCHK(hipMemcpyAsync(d.w, w.data(), sizeof(double) * p->K, hipMemcpyHostToDevice, p->st));
     // spins: upload sample-major, transpose to spin-major St [n][Kp], expand, transpose back
-    int8_t *dS = nullptr, *dSt = nullptr;
+    int8_t *dS = dspins, *dSt = nullptr;
     int32_t *dkeys = nullptr;
-    HIPCHK(hipMalloc(&dS, (size_t)p->K * p->n));
+    if (!dS) HIPCHK(hipMalloc(&dS, (size_t)p->K * p->n));
     HIPCHK(hipMalloc(&dSt, (size_t)p->n * d.Kp));
     HIPCHK(hipMalloc(&dkeys, sizeof(int32_t) * p->gkeys.size()));
-    HIPCHK(hipMemcpyAsync(dS, spins, (size_t)p->K * p->n, hipMemcpyHostToDevice, p->st));
+    if (!dspins) HIPCHK(hipMemcpyAsync(dS, spins, (size_t)p->K * p->n, hipMemcpyHostToDevice, p->st));
     HIPCHK(hipMemcpyAsync(dkeys, p->gkeys.data(), sizeof(int32_t) * p->gkeys.size(), hipMemcpyHostToDevice, p->st));
     HIPCHK(hipMemsetAsync(dSt, 0, (size_t)p->n * d.Kp, p->st));
     launch_transpose_i8(dS, p->K, p->n, p->n, dSt, d.Kp, p->st);
@@ -409,6 +410,130 @@ extern "C" int gml_problem_create(const void *samples, int dtype, int64_t K, int
     });
     if (bad >= 0) return fail(GML_EINVAL, "configuration %lld holds a spin that is not +-1", (long long)bad.load());
     return create_common(counts.data(), spins.data(), K, n, order, node0, node1, device, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// gml_problem_create_sampled: sample on the device, then build the handle from the device-resident
+// samples (the step before the path; src/sampling.jl:34-57, 94-106)
+// ------------------------------------------------------------------------------------------
+extern "C" int gml_problem_create_sampled(const double *model, int64_t n, int64_t N, uint64_t seed, int order,
+                                          int64_t node0, int64_t node1, int device, gml_problem **out) {
+    if (!model || !out) return fail(GML_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (n <= 0 || N <= 0) return fail(GML_EINVAL, "n and N must be positive");
+    if (order < 1 || order > 8) return fail(GML_EINVAL, "interaction order %d out of range [1,8]", order);
+    if (node0 < 0 || node1 > n || node0 >= node1)
+        return fail(GML_EINVAL, "bad node range [%lld,%lld) for n=%lld", (long long)node0, (long long)node1, (long long)n);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GML_EHIP, "no HIP device available (libgml_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(GML_EINVAL, "device %d out of range (%d devices)", device, ndev);
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < i; ++j)
+            if (model[i * n + j] != model[j * n + i]) return fail(GML_EINVAL, "the model matrix is not symmetric at (%lld,%lld)", (long long)i, (long long)j);
+    // connected components of the coupling graph
+    std::vector<int64_t> parent((size_t)n);
+    for (int64_t i = 0; i < n; ++i) parent[i] = i;
+    std::function<int64_t(int64_t)> find = [&](int64_t a) {
+        while (parent[a] != a) a = parent[a] = parent[parent[a]];
+        return a;
+    };
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < i; ++j)
+            if (model[i * n + j] != 0.0) parent[find(i)] = find(j);
+    std::vector<std::vector<int>> blocks;
+    {
+        std::vector<int64_t> id((size_t)n, -1);
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t r = find(i);
+            if (id[r] < 0) {
+                id[r] = (int64_t)blocks.size();
+                blocks.emplace_back();
+            }
+            blocks[(size_t)id[r]].push_back((int)i);
+        }
+    }
+    size_t maxsb = 0;
+    for (auto &b : blocks) maxsb = std::max(maxsb, b.size());
+    if (maxsb > 22)
+        return fail(GML_EUNSUPPORTED, "a connected component of the model has %zu spins: exact enumeration is limited to 22 "
+                                     "(an MCMC sampler is not implemented)", maxsb);
+    HIPCHK(hipSetDevice(device));
+    gml_problem *p = new gml_problem();
+    p->device = device;
+    p->n = n;
+    p->K = N;
+    p->M = (double)N;
+    p->order = order;
+    p->node0 = node0;
+    p->node1 = node1;
+    hipStream_t st = nullptr;
+    int8_t *dS = nullptr;
+    double *dA = nullptr, *den = nullptr, *dcdf = nullptr;
+    int *dmem = nullptr;
+    auto cleanup = [&](int rc) {
+        if (dA) (void)hipFree(dA);
+        if (den) (void)hipFree(den);
+        if (dcdf) (void)hipFree(dcdf);
+        if (dmem) (void)hipFree(dmem);
+        if (st) (void)hipStreamDestroy(st);
+        return rc;
+    };
+#define SCHK(expr)                                                                                              \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) {                                                                                 \
+            if (dS) (void)hipFree(dS);                                                                          \
+            delete p;                                                                                           \
+            return cleanup(fail(e_ == hipErrorOutOfMemory ? GML_ENOMEM : GML_EHIP, "%s failed: %s", #expr,      \
+                                hipGetErrorString(e_)));                                                        \
+        }                                                                                                       \
+    } while (0)
+    SCHK(hipStreamCreate(&st));
+    SCHK(hipMalloc(&dS, (size_t)N * n));
+    SCHK(hipMalloc(&dA, sizeof(double) * (maxsb * maxsb + maxsb)));
+    SCHK(hipMalloc(&den, sizeof(double) * ((size_t)1 << maxsb)));
+    SCHK(hipMalloc(&dcdf, sizeof(double) * ((size_t)1 << maxsb)));
+    SCHK(hipMalloc(&dmem, sizeof(int) * maxsb));
+    for (size_t b = 0; b < blocks.size(); ++b) {
+        const auto &mem = blocks[b];
+        const int sb = (int)mem.size();
+        std::vector<double> A((size_t)sb * sb + sb, 0.0);
+        for (int i = 0; i < sb; ++i) {
+            for (int j = 0; j < sb; ++j)
+                if (i != j) A[(size_t)i * sb + j] = model[(int64_t)mem[i] * n + mem[j]]; // adjacency (sampling.jl:40)
+            A[(size_t)sb * sb + i] = model[(int64_t)mem[i] * n + mem[i]];              // prior = diagonal (sampling.jl:41)
+        }
+        SCHK(hipMemcpyAsync(dA, A.data(), sizeof(double) * A.size(), hipMemcpyHostToDevice, st));
+        SCHK(hipMemcpyAsync(dmem, mem.data(), sizeof(int) * sb, hipMemcpyHostToDevice, st));
+        launch_block_sampler(dA, dA + (size_t)sb * sb, sb, dmem, N, n, (unsigned long long)seed, (int)b, den, dcdf, dS, st);
+        SCHK(hipGetLastError());
+        SCHK(hipStreamSynchronize(st)); // A / mem are reused by the next block
+    }
+#undef SCHK
+    cleanup(0);
+    int rc = alloc_dev(p, nullptr, nullptr, dS);
+    if (rc != GML_OK) {
+        std::string keep = g_err;
+        gml_problem_destroy(p);
+        g_err = keep;
+        return rc;
+    }
+    *out = p;
+    return GML_OK;
+}
+
+// the +-1 configurations held by the handle, K x n row-major (for tests and for callers that want the
+// samples back, e.g. to build the reference's histogram)
+extern "C" int gml_problem_get_spins(gml_problem *p, int8_t *spins) {
+    if (!p || !spins) return fail(GML_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(p->device));
+    std::vector<int8_t> row((size_t)p->K);
+    for (int64_t i = 0; i < p->n; ++i) {
+        HIPCHK(hipMemcpy(row.data(), p->d.Xt + i * p->d.Kp, (size_t)p->K, hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < p->K; ++k) spins[k * p->n + i] = row[(size_t)k];
+    }
+    return GML_OK;
 }
 
 namespace gml {

@@ -827,6 +827,7 @@ static int i8_ensure(void **wsp, const DevProblem &d, int Rp, int LF, std::strin
     *wsp = nullptr;
     w = new I8Ws();
     w->LF = LF;
+    *wsp = w; // owned by the handle from here on: a failed allocation below is released by i8_free
     I8CHK(hipMalloc(&w->Tq, (size_t)Rp * LF * d.Qfp));
     I8CHK(hipMalloc(&w->Vq, (size_t)Rp * LB * d.Kp));
     I8CHK(hipMalloc(&w->Gacc, sizeof(int32_t) * (size_t)Rp * LB * d.Qfp));
@@ -841,7 +842,6 @@ static int i8_ensure(void **wsp, const DevProblem &d, int Rp, int LF, std::strin
     I8CHK(hipMemset(w->Tq, 0, (size_t)Rp * LF * d.Qfp));
     I8CHK(hipMemset(w->Vq, 0, (size_t)Rp * LB * d.Kp));
     w->rows = Rp;
-    *wsp = w;
     return GML_OK;
 }
 
@@ -930,12 +930,8 @@ template <int LF, int FORM, bool WANTF>
 static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, int ngroups, double *dF, hipStream_t st) {
     constexpr int STAGE = (256 + 32 * LF) * 64;
     constexpr int shmem = 3 * STAGE + 512; // ring + exp table (the epilogue staging aliases the ring)
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-        attr = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
     const int ntk = (int)(d.Kp / 256);
     const int grid = ((ntk + 7) / 8) * 8 * ((ngroups + 7) / 8) * 8;
     const int Rp = (int)w->rows;
@@ -1028,12 +1024,7 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
         nsplit = (int)((d.Kp + kchunk - 1) / kchunk);
         const int grid = ((nsplit + 7) / 8) * 8 * T;
         const int shmem = 3 * (128 * TM + 256) * 64;
-        static bool bwd_attr = false;
-        if (!bwd_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      shmem);
-            bwd_attr = true;
-        }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
         // w->pairs holds the active tile list padded with -1 to an even count
         hipLaunchKernelGGL(k_bwd_i8, dim3(grid), dim3(512), shmem, st, w->Vq, d.Xt, w->pairs, ngt, nNt, d.Qfp, d.Kp, kchunk, nsplit,
                            w->Gacc);

@@ -101,6 +101,20 @@ int gml_problem_create_spins(const double *counts, const int8_t *spins, int64_t 
                              int order, int64_t node0, int64_t node1, int device,
                              gml_problem **out);
 
+/*
+ * gml_problem_create_sampled -- the step BEFORE the path: replaces `sample(gm, N)` for pairwise models
+ * (src/sampling.jl:34-57, 94-106) and feeds the result straight into a handle, all on the device.
+ * `model` is the n x n symmetric matrix of FactorGraph(matrix) (models.jl:105-134): off-diagonal =
+ * couplings, diagonal = fields.  Sampling is exact (enumeration + CDF inversion, the reference's own
+ * method) per connected component of the coupling graph, so every component must have <= 22 spins
+ * (GML_EUNSUPPORTED otherwise).  The handle holds N rows with count 1 each (M = N).
+ */
+int gml_problem_create_sampled(const double *model, int64_t n, int64_t N, uint64_t seed, int order,
+                               int64_t node0, int64_t node1, int device, gml_problem **out);
+
+/* The +-1 configurations held by a handle, K x n row-major (host pointer). */
+int gml_problem_get_spins(gml_problem *p, int8_t *spins);
+
 void gml_problem_destroy(gml_problem *p);
 
 /* sizes: n, K (rows given), M = sum(counts) (:79), P = parameters per node

@@ -1,0 +1,77 @@
+"""On-device exact sampler (the step before the learn() path) against the exact state
+probabilities restated from src/sampling.jl:26-30, and the reference's sampler/accuracy tests
+(test/runtests.jl:55-63, 105-127, 188-196) re-run with it."""
+import numpy as np
+import pytest
+
+import gml_amd as gml
+from conftest import MODELS
+
+pytestmark = pytest.mark.gpu
+
+
+def exact_probabilities(m):
+    n = m.shape[0]
+    states = ((np.arange(2 ** n)[:, None] >> np.arange(n)) & 1) * 2 - 1  # int_to_spin (sampling.jl:11-14)
+    sf = states.astype(float)
+    A = m - np.diag(np.diag(m))
+    en = 0.5 * ((sf @ A) * sf).sum(1) + sf @ np.diag(m)  # weigh_proba (sampling.jl:26-30)
+    p = np.exp(en - en.max())
+    return states, p / p.sum()
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_sampler_matches_exact_distribution(name):
+    m = MODELS[name]
+    N = 1000000
+    hist = gml.sample(gml.FactorGraph(m), N, seed=0)
+    assert hist[:, 0].sum() == N  # runtests.jl:60
+    states, p = exact_probabilities(m)
+    lookup = {tuple(s): pi for s, pi in zip(states, p)}
+    assert len(hist) == len(states)  # every state of these small models is observed at N = 1e6
+    for row in hist:
+        expect = lookup[tuple(row[1:])] * N
+        assert abs(row[0] - expect) <= 6 * np.sqrt(expect) + 1  # 6 sigma of the binomial count
+
+
+def test_sampler_replicates_and_seeds():
+    m = MODELS["c"]
+    reps = gml.sample(gml.FactorGraph(m), 20000, 3, seed=1)
+    assert len(reps) == 3 and all(r[:, 0].sum() == 20000 for r in reps)  # runtests.jl:55-63
+    assert not np.array_equal(reps[0], reps[1])
+    again = gml.sample(gml.FactorGraph(m), 20000, seed=1)
+    assert np.array_equal(again, reps[0])  # counter-based RNG: reproducible
+
+
+def test_block_structured_model_beyond_enumeration():
+    # 64 spins in 4 independent blocks of 16: 2^64 states overall, sampled exactly block by block
+    synthetic = __import__("importlib").import_module("gml_amd.synthetic")
+    _, J = synthetic.block_ising(64, 10, block=16, seed=5)
+    with gml.Problem(model=J, num_samples=200000, seed=3) as p:
+        assert (p.K, p.n, p.M) == (200000, 64, 200000.0)
+        spins = p.spins()
+        out, kkt, st = p.learn("RISE", 0.4, tol=1e-9)
+    assert set(np.unique(spins)) == {-1, 1}
+    # first block marginal distribution against the exact one
+    states, pr = exact_probabilities(J[:16, :16])
+    idx = ((spins[:, :16] > 0) * (1 << np.arange(16))).sum(1)
+    emp = np.bincount(idx, minlength=2 ** 16) / len(idx)
+    assert np.abs(emp - pr).max() <= 6 * np.sqrt(pr.max() / len(idx))
+    assert np.abs(0.5 * (out + out.T) - J).max() <= 0.1  # and the learner recovers the model from them
+    with pytest.raises(gml.GMLError):  # a 24-spin component cannot be enumerated
+        big = np.zeros((24, 24))
+        big[np.arange(23), np.arange(1, 24)] = 0.1
+        gml.Problem(model=big + big.T, num_samples=10)
+
+
+def test_learned_model_accuracy_with_device_sampler():
+    # runtests.jl:105-127 and the docs example :188-196, samples drawn on the device
+    for name, m in MODELS.items():
+        for N, thr in ((1000, 0.15), (10000, 0.05)):
+            hist = gml.sample(gml.FactorGraph(m), N, seed=0)
+            for F in (gml.RISE, gml.logRISE, gml.RPLE):
+                R = gml.learn(hist, F(), gml.HIP(tol=1e-9))
+                assert np.abs(R - m).max() <= thr
+    model = np.array([[0.0, 0.1, 0.2], [0.1, 0.0, 0.3], [0.2, 0.3, 0.0]])
+    learned = gml.learn(gml.sample(gml.FactorGraph(model), 100000, seed=0))
+    assert np.abs(learned - model).max() <= 0.01
