@@ -345,3 +345,24 @@ def test_wide_problems_i8x_matches_fp64_path(n):
         f8, g8 = p.objgrad("RISE", nodes, theta, precision="i8x")
         f64, g64 = p.objgrad("RISE", nodes, theta, precision="f64")
     assert np.abs(f8 / f64 - 1).max() <= 1e-7 and np.abs(g8 - g64).max() <= 1e-7
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_awkward_shapes(prec):
+    # n not a multiple of 32/64, K not a multiple of any tile, a node range that starts and ends inside
+    # 32-node tiles: padding rows/columns/samples must not leak into the result
+    n, K = 100, 7777
+    spins, J = synthetic.block_ising(96, K, block=16, seed=9)
+    extra = np.where(np.random.default_rng(2).random((K, 4)) < 0.5, 1, -1).astype(np.int8)
+    spins = np.concatenate([spins, extra], axis=1)  # 100 spins
+    lam = O.lam(0.4, n, K)
+    with gml.Problem(spins=spins, node_range=(5, 71)) as p:
+        out, kkt, st = p.learn("RISE", 0.4, tol=1e-9, precision=prec)
+        th = np.zeros((3, n)); th[:, :3] = 0.1
+        f, g = p.objgrad("RISE", np.array([0, 50, 99]), th, precision=prec)
+    assert out.shape == (66, n) and st["not_converged"] == 0
+    full = np.zeros((n, n)); full[5:71] = out
+    assert _kkt_from_oracle(spins, full, [5, 37, 70], lam) <= 5e-9
+    for a, u in enumerate([0, 50, 99]):
+        f0, g0 = O.objgrad_pair(hist_from_spins(spins), "RISE", u, th[a])
+        assert f[a] == pytest.approx(f0, rel=1e-7) and np.abs(g[a] - g0).max() <= 1e-7
