@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgml_hip.so")
+LIB_PATH = os.environ.get("GML_LIB_OVERRIDE") or os.path.join(_HERE, "libgml_hip.so")  # override: A/B builds
 
 GML_OK, GML_EINVAL, GML_ENOTCONV, GML_EHIP, GML_ENOMEM, GML_EUNSUPPORTED = range(6)
 FORMULATION_IDS = {"RISE": 0, "RISEA": 0, "multiRISE": 0, "logRISE": 1, "RPLE": 2}

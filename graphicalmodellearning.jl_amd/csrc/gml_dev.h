@@ -20,6 +20,7 @@ struct DevProblem {
     int8_t *Xs, *Xt;
     double *w;
     double wmax;      // max_k w_k
+    double wuni;      // the common weight when all K samples weigh the same (counts all equal), else 0
     // Chunked mode (design matrices whose two orientations do not both fit in HBM, e.g. order-3
     // statistics of 512 spins x 1e6 samples = 131 GB each): Xt is fully resident, Xs holds only
     // xs_cols columns at a time and is refilled by transposing slices of Xt inside the forward pass.

@@ -289,6 +289,12 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
         w[k] = (counts ? counts[k] : 1.0) / p->M;
         d.wmax = std::max(d.wmax, w[k]);
     }
+    d.wuni = w[0];
+    for (int64_t k = 1; k < p->K; ++k)
+        if (w[k] != w[0]) {
+            d.wuni = 0.0;
+            break;
+        }
     p->wprefix.assign((size_t)(d.Kp / 1024) + 1, 0.0);
     {
         double acc = 0;

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const double *__restrict__ sigma, const long long *__restrict__ qconst, const double *__restrict__ invtau,
     int64_t Qp /* pitch of Xs */, int64_t Qfp /* pitch of Tq */, int64_t Kp, int ntiles_k, int nk /* 64-column steps */,
     double *__restrict__ Eacc /* [Kp][Rp] partial energies of earlier column chunks, or NULL */, int Rp, int chunk_first,
-    int chunk_last, int8_t *__restrict__ Vq, long long *__restrict__ csum, long long *__restrict__ asum,
+    int chunk_last, double wuni /* > 0: every real sample has this weight */, int64_t Kreal, int8_t *__restrict__ Vq, long long *__restrict__ csum, long long *__restrict__ asum,
     double *__restrict__ fsum) {
     constexpr int WM = 2;                 // 32-sample MFMA tiles per wave
     constexpr int AR = 256, BR = 32 * LF; // stage image rows
@@ -257,6 +257,20 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][l][e] = 0;
 
+    // the epilogue's per-lane inputs are fetched now, so that their latency hides under the GEMM
+    const int r = mytile * 32 + lr;
+    const int rc = rowcol[r];
+    const bool active = rc >= 0;
+    unsigned swp[WM][4];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            swp[i][g] = active ? *reinterpret_cast<const unsigned *>(Xt + (int64_t)rc * Kp + k0 + wave * 64 + i * 32 + 8 * g + 4 * h) : 0u;
+    const double sg = active ? sigma[r] : 0.0;
+    const double q0 = active ? (double)qconst[r] : 0.0;
+    const double it = active ? invtau[r] : 0.0;
+
     ring_issue<NP>(src, 0, lds, wave, NPIECE);
     if (nk > 1) ring_issue<NP>(src, 64, lds + STAGE, wave, NPIECE);
     for (int kt = 0; kt < nk; ++kt) {
@@ -283,12 +297,6 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 
     // ---- epilogue ----------------------------------------------------------------------------
     // lane <-> node row (lr), register e <-> sample (e&3) + 8*(e>>2) + 4*h within the 32-sample tile
-    const int r = mytile * 32 + lr;
-    const int rc = rowcol[r];
-    const bool active = rc >= 0;
-    const double sg = active ? sigma[r] : 0.0;
-    const double q0 = active ? (double)qconst[r] : 0.0;
-    const double it = active ? invtau[r] : 0.0;
     int8_t *stage = lds + wave * (LB * 32 * PITCH);
     const int form = FORM;
     long long cs = 0, as = 0;
@@ -300,8 +308,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int64_t kk = kw + i * 32 + 8 * g + 4 * h;
-            unsigned sw = 0;
-            if (active) sw = *reinterpret_cast<const unsigned *>(Xt + (int64_t)rc * Kp + kk);
+            const unsigned sw = swp[i][g];
             unsigned dj[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                 }
                 const double Ea = fma(a, sg, sgq0);                 // |E| pre-sign: sigma * (A + q0)
                 const bool neg = ((sw >> (8 * j + 7)) & 1u) != 0;   // s_u^k == -1 (padding: s = 0, w = 0)
-                const double wk = w[kk + j] * it;
+                const double wk = (wuni > 0.0 ? (kk + j < Kreal ? wuni : 0.0) : w[kk + j]) * it;
                 int vq;
                 if (FORM == 2) { // RPLE (:317): V = -2 w s / (1 + exp(2E)), E = s * Ea
                     const double E = neg ? -Ea : Ea;
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     const int mag = (int)rint(2.0 * wk / (1.0 + ex));
                     vq = neg ? mag : -mag;
                     const double tt = -2.0 * E;
-                    fp += w[kk + j] * (tt > 0 ? tt + log1p(exp(-tt)) : log1p(exp(tt)));
+                    fp += (wuni > 0.0 ? (kk + j < Kreal ? wuni : 0.0) : w[kk + j]) * (tt > 0 ? tt + log1p(exp(-tt)) : log1p(exp(tt)));
                 } else { // RISE (:196,:204) / logRISE Z (:279): V = -w exp(-E) s
                     const int mag = (int)rint(wk * exp_tab32(neg ? Ea : -Ea, etab));
                     vq = neg ? mag : -mag;
@@ -938,7 +945,7 @@ static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, 
     if (!d.chunked) {
         hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xs, d.Xt, w->Tq, dRowcol, w->pairs,
                            ngroups, d.w, w->sigma, w->qconst, w->invtau, d.Qp, d.Qfp, d.Kp, ntk, (int)(d.Qfp / 64),
-                           (double *)nullptr, Rp, 1, 1, w->Vq, w->csum, w->asum, dF);
+                           (double *)nullptr, Rp, 1, 1, d.wuni, d.K, w->Vq, w->csum, w->asum, dF);
         return;
     }
     // column chunks: refill Xs from the resident Xt (transpose of a slice), accumulate the integer
@@ -948,7 +955,7 @@ static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, 
         launch_transpose_i8(d.Xt + c0 * d.Kp, nc, d.K, d.Kp, d.Xs, d.xs_cols, st);
         hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xs, d.Xt, w->Tq + c0, dRowcol, w->pairs,
                            ngroups, d.w, w->sigma, w->qconst, w->invtau, d.xs_cols, d.Qfp, d.Kp, ntk, (int)(nc / 64), w->Eacc, Rp,
-                           c0 == 0 ? 1 : 0, c0 + nc >= d.Qfp ? 1 : 0, w->Vq, w->csum, w->asum, dF);
+                           c0 == 0 ? 1 : 0, c0 + nc >= d.Qfp ? 1 : 0, d.wuni, d.K, w->Vq, w->csum, w->asum, dF);
     }
 }
 
