@@ -545,6 +545,7 @@ extern "C" int gml_problem_get_spins(gml_problem *p, int8_t *spins) {
 namespace gml {
 void i8_free(void *ws);
 void i8_get_v(void *ws, const int8_t **Vq, const double **tau);
+int64_t i8_hess_kmax(const DevProblem &d);
 int i8_hessian(void *ws, const DevProblem &d, const int *dRowcol, const int *dF, const int *dMt, const int *hMt,
                const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh, double *dH, hipStream_t st,
                std::string *err);
@@ -888,17 +889,28 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     const int32_t cconst = (int32_t)p->d.cconst;
     const double lambda = gml_lambda(regularizer_c, p->n, p->M);
     stats->lambda = lambda;
-    // sub-sampled Newton: Hessians over the first Kh configurations, rescaled by M / M_h
+    // sub-sampled Newton: Hessians over the first Kh configurations, rescaled by M / M_h.  The budget
+    // (rows x configurations) is kept roughly constant: as nodes converge, the remaining ones get more
+    // configurations, up to all of them -- an inexact Hessian only costs iterations, and it costs the
+    // most on the few ill-conditioned nodes that are still active at the end.
+    const int64_t Kh_max = o.precision == GML_PREC_I8X ? gml::i8_hess_kmax(p->d) : p->d.Kp;
+    const int64_t Kh_base = o.hess_samples == 0 ? 131072 : (o.hess_samples < 0 ? p->d.Kp : (int64_t)o.hess_samples);
     int64_t Kh = p->d.Kp;
     double hscale = 1.0;
-    {
-        int64_t want = o.hess_samples == 0 ? 131072 : (o.hess_samples < 0 ? p->d.Kp : (int64_t)o.hess_samples);
+    auto set_kh = [&](int64_t nactive) {
+        int64_t want = Kh_base;
+        if (o.hess_samples == 0 && nactive > 0) want = Kh_base * std::max<int64_t>(1, R / nactive);
         want = round_up(std::max<int64_t>(want, 1024), 1024);
+        want = std::min(want, Kh_max);
         if (want < p->K) {
             Kh = want;
             hscale = 1.0 / p->wprefix[(size_t)(Kh / 1024)];
+        } else {
+            Kh = std::min(p->d.Kp, Kh_max);
+            hscale = Kh < p->K ? 1.0 / p->wprefix[(size_t)(Kh / 1024)] : 1.0;
         }
-    }
+    };
+    set_kh(R);
 
     RowSet rs;
     rs.R = R;
@@ -1041,6 +1053,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             fprintf(stderr, "[gml] it %3d active %6lld  max-kkt %.3e  max|F| %d  passes %d fwd %d\n", it,
                     (long long)nactive, worst_all, maxm, stats->passes, stats->forward_passes);
         if (nactive == 0) break;
+        set_kh(nactive);
 
         // rows whose V was overwritten by a rejected trial need a fresh pass before the Hessian
         bool anystale = false;

@@ -39,7 +39,7 @@ struct I8Ws {
     long long *qconst = nullptr, *csum = nullptr, *asum = nullptr;
     int *pairs = nullptr;
     // working-set Hessian on the int8 cores
-    int64_t hKh = 0, hcap_elems = 0;
+    int64_t hKh = 0, hbuilt = 0, hcap_elems = 0;
     int8_t *Mt = nullptr, *Hq = nullptr; // bit masks of Xt (0x00 / 0xFF) and limb planes of the Hessian weights
     long long *hS = nullptr, *H64 = nullptr;
     double *Eacc = nullptr; // [Kp][rows] partial energies (chunked design matrices only)
@@ -531,17 +531,17 @@ __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__
 // With the masks m = -b (bytes 0x00 / 0xFF) the products become (h_l & m_i) * m_j = -h_l b_i b_j
 // for each base-256 digit plane h_l of the (non-negative, 31-bit) weight: exact integer GEMMs.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_make_masks(const int8_t *__restrict__ Xt, int64_t Kp, int64_t Kh,
-                                                    int8_t *__restrict__ Mt) {
-    const int64_t k = (int64_t)blockIdx.y * 256 + threadIdx.x, c = blockIdx.x;
-    if (k < Kh) Mt[c * Kh + k] = Xt[c * Kp + k] < 0 ? (int8_t)-1 : (int8_t)0;
+__global__ __launch_bounds__(256) void k_make_masks(const int8_t *__restrict__ Xt, int64_t Kp, int64_t k0, int64_t k1,
+                                                    int64_t pitch, int8_t *__restrict__ Mt) {
+    const int64_t k = k0 + (int64_t)blockIdx.y * 256 + threadIdx.x, c = blockIdx.x;
+    if (k < k1) Mt[c * pitch + k] = Xt[c * Kp + k] < 0 ? (int8_t)-1 : (int8_t)0;
 }
 
 // Hessian weights of the active rows as limb planes: RISE / logRISE h = |V|; RPLE h = 2a(1 - a/(2w)), a = |V|
 __global__ __launch_bounds__(256) void k_make_hw(const int8_t *__restrict__ Vq, const int8_t *__restrict__ Xt,
                                                  const double *__restrict__ w, const double *__restrict__ tau,
                                                  const int *__restrict__ rowcol, const int *__restrict__ mt, int64_t Kp,
-                                                 int64_t Kh, int form, int8_t *__restrict__ Hq,
+                                                 int64_t Kh /* pitch of Hq */, int form, int8_t *__restrict__ Hq,
                                                  long long *__restrict__ hS) {
     const int r = blockIdx.y;
     if (mt[r] == 0) return;
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void k_make_hw(const int8_t *__restrict__ Vq, 
 template <int MT>
 __global__ __launch_bounds__(256) void k_hess_i8(const int8_t *__restrict__ Mt, const int8_t *__restrict__ Hq,
                                                  const int *__restrict__ F, const int *__restrict__ mt,
-                                                 const long long *__restrict__ hoff, int cap, int64_t Kh,
+                                                 const long long *__restrict__ hoff, int cap, int64_t Kh, int64_t Kpitch,
                                                  int64_t kchunk, long long *__restrict__ H64) {
     constexpr int ROWS = MT * 32 + 4; // mask rows + the four weight planes
     constexpr int NCH = (ROWS * 4 + 255) / 256;
@@ -599,8 +599,8 @@ __global__ __launch_bounds__(256) void k_hess_i8(const int8_t *__restrict__ Mt, 
     for (int j = 0; j < NCH; ++j) {
         const int q = tid + 256 * j, row = q >> 2, slot = q & 3;
         have[j] = row < ROWS;
-        if (row < MT * 32) src[j] = Mt + (int64_t)Fr[row < m * 32 ? row : 0] * Kh + slot * 16;
-        else src[j] = Hq + ((int64_t)tile * 128 + (row - MT * 32 < 4 ? row - MT * 32 : 0) * 32 + rl) * Kh + slot * 16;
+        if (row < MT * 32) src[j] = Mt + (int64_t)Fr[row < m * 32 ? row : 0] * Kpitch + slot * 16;
+        else src[j] = Hq + ((int64_t)tile * 128 + (row - MT * 32 < 4 ? row - MT * 32 : 0) * 32 + rl) * Kpitch + slot * 16;
         dst[j] = lds_off(row, slot);
     }
     v16i acc[NPAIR];
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void k_hess_i8(const int8_t *__restrict__ Mt, 
 // above the diagonal inside a block are computed and dropped.
 __global__ __launch_bounds__(256) void k_hess_i8_blk(const int8_t *__restrict__ Mt, const int8_t *__restrict__ Hq,
                                                      const int *__restrict__ F, const int *__restrict__ mt,
-                                                     const long long *__restrict__ hoff, int cap, int64_t Kh,
+                                                     const long long *__restrict__ hoff, int cap, int64_t Kh, int64_t Kpitch,
                                                      int64_t kchunk, long long *__restrict__ H64) {
     constexpr int AR = 64, BR = 128, ROWS = AR + BR + 4;
     constexpr int NCH = (ROWS * 4 + 255) / 256;
@@ -710,14 +710,14 @@ __global__ __launch_bounds__(256) void k_hess_i8_blk(const int8_t *__restrict__ 
         if (row < AR) {
             int fr = 2 * a * 32 + row;
             if (fr >= mrows) fr = 0;
-            src[j] = Mt + (int64_t)Fr[fr] * Kh + slot * 16;
+            src[j] = Mt + (int64_t)Fr[fr] * Kpitch + slot * 16;
         } else if (row < AR + BR) {
             int fr = 4 * b * 32 + (row - AR);
             if (fr >= mrows) fr = 0;
-            src[j] = Mt + (int64_t)Fr[fr] * Kh + slot * 16;
+            src[j] = Mt + (int64_t)Fr[fr] * Kpitch + slot * 16;
         } else {
             const int l = row - AR - BR < 4 ? row - AR - BR : 0;
-            src[j] = Hq + ((int64_t)tile * 128 + l * 32 + rl) * Kh + slot * 16;
+            src[j] = Hq + ((int64_t)tile * 128 + l * 32 + rl) * Kpitch + slot * 16;
         }
         dst[j] = lds_off(row, slot);
     }
@@ -853,6 +853,14 @@ static int i8_ensure(void **wsp, const DevProblem &d, int Rp, int LF, std::strin
 }
 
 
+// Largest number of configurations the int8 Hessian can use (pitch of its mask / weight planes): all of
+// them unless the masks would exceed ~16 GB.
+int64_t i8_hess_kmax(const DevProblem &d) {
+    int64_t k = (int64_t)(16e9 / (double)d.Qp) / 1024 * 1024;
+    if (k < 131072) k = 131072;
+    return k < d.Kp ? k : d.Kp;
+}
+
 // Working-set Hessians from the int8 limb planes of the last pass.  Returns GML_EUNSUPPORTED when a
 // working set exceeds 128 entries (the caller then uses the FP64 kernel).
 int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF, const int *dMt, const int *hMt,
@@ -866,17 +874,26 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF
     int maxm = 0;
     for (int r = 0; r < R; ++r) maxm = hMt[r] > maxm ? hMt[r] : maxm;
     if (maxm > 16) return GML_EUNSUPPORTED; // > 512 entries: not expected (the caller caps the Newton block)
-    if (w->hKh != Kh) {
+    // masks and weight planes are allocated once with the pitch i8_hess_kmax(d); mask columns are built on
+    // demand when a call asks for more configurations than any earlier one
+    const int64_t pitch = i8_hess_kmax(d);
+    if (Kh > pitch) Kh = pitch;
+    if (w->hKh != pitch) {
         if (w->Mt) (void)hipFree(w->Mt);
         if (w->Hq) (void)hipFree(w->Hq);
         if (w->hS) (void)hipFree(w->hS);
         w->Mt = w->Hq = nullptr;
         w->hS = nullptr;
-        I8CHK(hipMalloc(&w->Mt, (size_t)d.Qp * Kh));
-        I8CHK(hipMalloc(&w->Hq, (size_t)w->rows * LB * Kh));
+        w->hbuilt = 0;
+        I8CHK(hipMalloc(&w->Mt, (size_t)d.Qp * pitch));
+        I8CHK(hipMalloc(&w->Hq, (size_t)w->rows * LB * pitch));
         I8CHK(hipMalloc(&w->hS, sizeof(long long) * w->rows));
-        hipLaunchKernelGGL(k_make_masks, dim3((unsigned)d.Qp, (unsigned)(Kh / 256)), dim3(256), 0, st, d.Xt, d.Kp, Kh, w->Mt);
-        w->hKh = Kh;
+        w->hKh = pitch;
+    }
+    if (Kh > w->hbuilt) {
+        hipLaunchKernelGGL(k_make_masks, dim3((unsigned)d.Qp, (unsigned)((Kh - w->hbuilt + 255) / 256)), dim3(256), 0, st, d.Xt, d.Kp,
+                           w->hbuilt, Kh, pitch, w->Mt);
+        w->hbuilt = Kh;
     }
     const int64_t need = htotal;
     if (need > w->hcap_elems) {
@@ -888,7 +905,7 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF
     I8CHK(hipMemsetAsync(w->H64, 0, sizeof(long long) * need, st));
     I8CHK(hipMemsetAsync(w->hS, 0, sizeof(long long) * w->rows, st));
     hipLaunchKernelGGL(k_make_hw, dim3((unsigned)(Kh / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Xt, d.w, w->tau, dRowcol,
-                       dMt, d.Kp, Kh, form, w->Hq, w->hS);
+                       dMt, d.Kp, pitch, form, w->Hq, w->hS);
     // k-split so that the grid fills the chip: ~2048 workgroups
     int nsplit = (int)((2048 + R - 1) / R);
     const int maxsplit = (int)(Kh / 1024);
@@ -901,10 +918,10 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF
     // one launch per working-set size class (rows of other classes exit immediately)
     bool cls[6] = {false, false, false, false, false, false};
     for (int r = 0; r < R; ++r) cls[hMt[r] <= 4 ? hMt[r] : 5] = true;
-    if (cls[1]) hipLaunchKernelGGL((k_hess_i8<1>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, kchunk, w->H64);
-    if (cls[2]) hipLaunchKernelGGL((k_hess_i8<2>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, kchunk, w->H64);
-    if (cls[3]) hipLaunchKernelGGL((k_hess_i8<3>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, kchunk, w->H64);
-    if (cls[4]) hipLaunchKernelGGL((k_hess_i8<4>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, kchunk, w->H64);
+    if (cls[1]) hipLaunchKernelGGL((k_hess_i8<1>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, pitch, kchunk, w->H64);
+    if (cls[2]) hipLaunchKernelGGL((k_hess_i8<2>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, pitch, kchunk, w->H64);
+    if (cls[3]) hipLaunchKernelGGL((k_hess_i8<3>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, pitch, kchunk, w->H64);
+    if (cls[4]) hipLaunchKernelGGL((k_hess_i8<4>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, pitch, kchunk, w->H64);
     if (cls[5]) {
         // blocks (a, b) with 4b <= 2a+1 for a < ceil(maxm/2)
         int nblk = 0;
@@ -916,7 +933,7 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF
         kc2 = (kc2 + 63) / 64 * 64;
         ns2 = (int)((Kh + kc2 - 1) / kc2);
         hipLaunchKernelGGL(k_hess_i8_blk, dim3((unsigned)ns2, (unsigned)nblk, (unsigned)R), dim3(256), 0, st, w->Mt, w->Hq, dF, dMt,
-                           dHoff, cap, Kh, kc2, w->H64);
+                           dHoff, cap, Kh, pitch, kc2, w->H64);
     }
     hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64,
                        w->hS, w->tau, dMt, dHoff, dH);

@@ -54,8 +54,9 @@ typedef struct gml_opts {
                             denser optimum is solved by cycling blocks (block Gauss-Seidel)    */
     int32_t max_add;     /* new (violating) coordinates admitted per node per iteration (default 32) */
     int32_t verbose;     /* 0 silent, 1 per-iteration line on stderr                        */
-    int32_t hess_samples; /* Newton Hessians use the first hess_samples configurations (0 = default
-                            131072, < 0 = all); the gradient always uses all of them           */
+    int32_t hess_samples; /* Newton Hessians use the first hess_samples configurations (< 0 = all;
+                            0 = adaptive: 131072 x (local nodes / nodes still active), so the
+                            last few nodes get all of them); the gradient always uses all     */
     int32_t reserved[2];
 } gml_opts;
 
