@@ -6,8 +6,10 @@
 namespace gml {
 
 // Device-resident problem data.  Layout (all padded, padding is zero):
-//   Xs [Kp][Qp] int8   sample-major design matrix: Xs[k][c] = prod_{i in key_c} s_i^k
-//   Xt [Qp][Kp] int8   the same matrix feature-major
+//   Xt [Qp][Kp] int8   feature-major design matrix: Xt[c][k] = prod_{i in key_c} s_i^k
+//   Xb                 the same matrix sample-major, one bit per entry (set <=> -1), in the piece
+//                      layout of k_pack_bits (gml_kernels_i8.hip): the forward operand of the int8 path
+//   Xs [Kp][Qp] int8   sample-major bytes; built on first use by the FP64 path only
 //   w  [Kp]     f64    c_k / M   (samples[k,1]/num_samples, GraphicalModelLearning.jl:170)
 // Columns 0..n-1 are the single spins, then pairs (i<j) in lexicographic order, ... (multi-body,
 // :94-108); column `cconst` is the empty key (constant 1: the node's field).  Node u's sign
@@ -18,19 +20,16 @@ struct DevProblem {
     int64_t cconst;   // column of the constant statistic (= Qfp)
     int64_t Qp;       // row pitch of Xs / number of rows of Xt (= Qfp + 64)
     int8_t *Xs, *Xt;
+    unsigned *Xb;
     double *w;
     double wmax;      // max_k w_k
     double wuni;      // the common weight when all K samples weigh the same (counts all equal), else 0
-    // Chunked mode (design matrices whose two orientations do not both fit in HBM, e.g. order-3
-    // statistics of 512 spins x 1e6 samples = 131 GB each): Xt is fully resident, Xs holds only
-    // xs_cols columns at a time and is refilled by transposing slices of Xt inside the forward pass.
-    int64_t xs_cols;  // columns held by Xs (== Qp when not chunked); also the row pitch of Xs
-    bool chunked;
 };
 
 // ---- packing -----------------------------------------------------------------------------
 void launch_transpose_i8(const int8_t *src, int64_t rows, int64_t cols, int64_t ld_src,
                          int8_t *dst, int64_t ld_dst, hipStream_t st);
+void launch_pack_bits(const DevProblem &d, hipStream_t st); // Xt -> Xb
 void launch_expand_features(const int8_t *St, int64_t n, int64_t K, int64_t Kp,
                             const int32_t *keys, int order, int64_t Q, int8_t *Xt,
                             hipStream_t st);

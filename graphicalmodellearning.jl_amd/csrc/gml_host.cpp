@@ -253,16 +253,10 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
     d.Qp = d.Qfp + 64;
     d.Kp = round_up(p->K, 1024);
     const int64_t Q = Qf;
-    if ((double)d.Kp * (double)d.Qp > 200e9)
+    // resident: Xt (bytes, feature-major) + Xb (bits, sample-major) = 1.125 bytes per entry
+    if ((double)d.Kp * (double)d.Qp * 1.125 > 240e9)
         return fail(GML_ENOMEM, "design matrix %lld x %lld does not fit in HBM", (long long)d.Kp, (long long)d.Qp);
-    const char *force_chunk = getenv("GML_FORCE_CHUNK_COLS"); // test hook: chunk small problems too
-    d.chunked = force_chunk != nullptr || (double)d.Kp * (double)d.Qp * 2.0 > 150e9;
-    d.xs_cols = d.Qp;
-    if (d.chunked) { // Xs holds 16 GB worth of columns at a time (multiple of 64)
-        d.xs_cols = std::max<int64_t>(64, (int64_t)(16e9 / (double)d.Kp) / 64 * 64);
-        if (force_chunk) d.xs_cols = std::max<int64_t>(64, (int64_t)atoll(force_chunk) / 64 * 64);
-        if (d.xs_cols > d.Qfp) d.xs_cols = d.Qfp;
-    }
+    if (d.Qfp / 64 > 32000) return fail(GML_EUNSUPPORTED, "more than 2^21 statistics per node");
     // feature keys
     p->gkeys.assign((size_t)std::max<int64_t>(Q, 1) * p->ko, -1);
     {
@@ -276,10 +270,10 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
             } while (next_comb(idx, p->n));
         }
     }
-    HIPCHK(hipMalloc(&d.Xs, (size_t)d.Kp * d.xs_cols));
+    d.Xs = nullptr; // FP64 path only, built on first use (ensure_f64)
     HIPCHK(hipMalloc(&d.Xt, (size_t)d.Kp * d.Qp));
+    HIPCHK(hipMalloc(&d.Xb, (size_t)d.Kp * (d.Qfp / 8)));
     HIPCHK(hipMalloc(&d.w, sizeof(double) * d.Kp));
-    HIPCHK(hipMemsetAsync(d.Xs, 0, (size_t)d.Kp * d.xs_cols, p->st));
     HIPCHK(hipMemsetAsync(d.Xt, 0, (size_t)d.Kp * d.Qp, p->st));
     HIPCHK(hipMemsetAsync(d.w, 0, sizeof(double) * d.Kp, p->st));
     // weights w_k = counts[k]/M  (:170)
@@ -317,7 +311,7 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
     launch_transpose_i8(dS, p->K, p->n, p->n, dSt, d.Kp, p->st);
     if (Q > 0) launch_expand_features(dSt, p->n, p->K, d.Kp, dkeys, p->ko, Q, d.Xt, p->st);
     HIPCHK(hipMemsetAsync(d.Xt + d.cconst * d.Kp, 1, (size_t)p->K, p->st)); // the constant statistic
-    if (!d.chunked) launch_transpose_i8(d.Xt, d.cconst + 1, p->K, d.Kp, d.Xs, d.Qp, p->st);
+    launch_pack_bits(d, p->st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(p->st));
     HIPCHK(hipFree(dS));
@@ -555,7 +549,7 @@ extern "C" void gml_problem_destroy(gml_problem *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->st) (void)hipStreamSynchronize(p->st);
-    void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dGroups, p->dFidx, p->dMt, p->dH};
+    void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.Xb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dGroups, p->dFidx, p->dMt, p->dH};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     void *hptrs[] = {p->hTh, p->hG, p->hF};
@@ -622,22 +616,43 @@ static int ensure_ws(gml_problem *p, int64_t rows) {
     p->ws_rows = 0;
     size_t freeb = 0, totalb = 0;
     HIPCHK(hipMemGetInfo(&freeb, &totalb));
-    const double need = (p->d.chunked ? 0.0 : (double)Rp * p->d.Kp * 8.0) + 2.0 * Rp * p->d.Qp * 8.0;
+    const double need = 2.0 * Rp * p->d.Qp * 8.0;
     if (need > 0.9 * (double)freeb)
         return fail(GML_ENOMEM, "workspace of %.1f GB for %lld rows does not fit in %.1f GB free HBM", need / 1e9,
                     (long long)Rp, freeb / 1e9);
     HIPCHK(hipMalloc(&p->dTheta, sizeof(double) * Rp * p->d.Qp));
     HIPCHK(hipMalloc(&p->dG, sizeof(double) * Rp * p->d.Qp));
-    if (!p->d.chunked) HIPCHK(hipMalloc(&p->dV, sizeof(double) * Rp * p->d.Kp)); // only the FP64 path needs V
     HIPCHK(hipMalloc(&p->dF, sizeof(double) * Rp));
     HIPCHK(hipMalloc(&p->dRowcol, sizeof(int) * Rp));
     HIPCHK(hipMalloc(&p->dGroups, sizeof(int) * (Rp / 32 + 4)));
     HIPCHK(hipHostMalloc(&p->hTh, sizeof(double) * Rp * p->d.Qp));
     HIPCHK(hipHostMalloc(&p->hG, sizeof(double) * Rp * p->d.Qp));
     HIPCHK(hipHostMalloc(&p->hF, sizeof(double) * Rp));
-    if (p->dV) HIPCHK(hipMemsetAsync(p->dV, 0, sizeof(double) * Rp * p->d.Kp, p->st));
     HIPCHK(hipMemsetAsync(p->dTheta, 0, sizeof(double) * Rp * p->d.Qp, p->st));
     p->ws_rows = Rp;
+    return GML_OK;
+}
+
+// What only the FP64 path needs: the sample-major byte image Xs and V [ws_rows][Kp].
+static int ensure_f64(gml_problem *p) {
+    DevProblem &d = p->d;
+    size_t freeb = 0, totalb = 0;
+    if (!d.Xs) {
+        HIPCHK(hipMemGetInfo(&freeb, &totalb));
+        if ((double)d.Kp * d.Qp > 0.9 * (double)freeb)
+            return fail(GML_EUNSUPPORTED, "the FP64 path needs a %.1f GB byte image of the design matrix: use precision i8x",
+                        (double)d.Kp * d.Qp / 1e9);
+        HIPCHK(hipMalloc(&d.Xs, (size_t)d.Kp * d.Qp));
+        HIPCHK(hipMemsetAsync(d.Xs, 0, (size_t)d.Kp * d.Qp, p->st));
+        launch_transpose_i8(d.Xt, d.cconst + 1, p->K, d.Kp, d.Xs, d.Qp, p->st);
+    }
+    if (!p->dV) {
+        HIPCHK(hipMemGetInfo(&freeb, &totalb));
+        if ((double)p->ws_rows * d.Kp * 8.0 > 0.9 * (double)freeb)
+            return fail(GML_ENOMEM, "FP64 workspace of %.1f GB does not fit: use precision i8x", (double)p->ws_rows * d.Kp * 8.0 / 1e9);
+        HIPCHK(hipMalloc(&p->dV, sizeof(double) * p->ws_rows * d.Kp));
+        HIPCHK(hipMemsetAsync(p->dV, 0, sizeof(double) * p->ws_rows * d.Kp, p->st));
+    }
     return GML_OK;
 }
 
@@ -693,8 +708,8 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
                           (int)Rp, form, want_grad, p->dF, p->dG, st, ms ? ev : nullptr, &err);
         if (rc) return fail(rc, "%s", err.c_str());
     } else {
-        if (p->d.chunked)
-            return fail(GML_EUNSUPPORTED, "this design matrix is only resident in one orientation: use precision i8x");
+        rc = ensure_f64(p);
+        if (rc) return rc;
         if (ms) HIPCHK(hipEventRecord(ev[0], st));
         launch_fwd_f64(p->d, p->dTheta, p->dRowcol, p->dGroups, (int)gpad.size(), form, p->dV, p->dF, st);
         if (ms) HIPCHK(hipEventRecord(ev[1], st));

@@ -14,10 +14,16 @@
 // deterministic and independent of tiling, split-K order and GPU count.
 //
 // Layout of the limb planes ("planar tiles"): rows are grouped by 32-node tile `t` and limb `l`:
-//   Tq row (t*LF + l)*32 + rl  holds limb l of node row t*32+rl, pitch Qfp      (forward B operand)
+//   Tq image (t, kt) = [LF*32 rows][64 B]: row l*32 + rl holds limb l of node row t*32+rl, columns
+//                      [64kt, 64kt+64); images are contiguous (t major)            (forward B operand)
 //   Vq row (t*LB + l)*32 + rl  holds limb l of V   row t*32+rl, pitch Kp        (backward A operand)
 // so that a wave's 32x32 MFMA tiles of the different limbs share lane <-> node and
 // register <-> sample, and the limbs combine lane-locally.
+//
+// The +-1 operand of the forward GEMM is kept as ONE BIT per entry (Xb, bit set <=> -1) and expanded
+// to 0/1 bytes in registers: sum_c q_c x_c = sum_c q_c - 2 sum_c q_c b_c.  An int8 image of it would
+// make the kernel L2->LDS bandwidth bound (measured: 98 MAC per loaded byte against the ~140 the CU
+// needs); with bits the loop loads 12 KB instead of 26.6 KB per 64-column step.
 #include "../../include/gml.h"
 #include "gml_dev.h"
 #include <algorithm>
@@ -42,7 +48,6 @@ struct I8Ws {
     int64_t hKh = 0, hbuilt = 0, hcap_elems = 0;
     int8_t *Mt = nullptr, *Hq = nullptr; // bit masks of Xt (0x00 / 0xFF) and limb planes of the Hessian weights
     long long *hS = nullptr, *H64 = nullptr;
-    double *Eacc = nullptr; // [Kp][rows] partial energies (chunked design matrices only)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -77,15 +82,19 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
     const double sg = ldexp(1.0, ex - (8 * LF - 2));
     const double isg = ldexp(1.0, (8 * LF - 2) - ex);
     const int tile = r >> 5, rl = r & 31;
+    const int64_t nk = Qfp >> 6;
     double sabs = 0.0;
+    long long ssum = 0; // sum_c q_c: the energy of the all-(+1) configuration (the forward GEMM runs on b = [x = -1])
     for (int64_t c = tid; c < Qfp; c += 256) {
         long long q = (long long)rint(th[c] * isg);
         sabs += fabs((double)q);
+        ssum += q;
+        int8_t *img = Tq + ((((int64_t)tile * nk + (c >> 6)) * LF) * 32 + rl) * 64 + (c & 63);
 #pragma unroll
         for (int l = 0; l < LF; ++l) {
             const long long dgt = ((q + 128) & 255) - 128;
             q = (q - dgt) >> 8;
-            Tq[((int64_t)(tile * LF + l) * 32 + rl) * Qfp + c] = (int8_t)dgt;
+            img[l * 32 * 64] = (int8_t)dgt;
         }
     }
     long long q0 = 0;
@@ -93,12 +102,18 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
         q0 = (long long)rint(th[cconst] * isg);
         sabs += fabs((double)q0);
     }
+    __shared__ long long redl[256];
     red[tid] = sabs;
+    redl[tid] = ssum;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
+        if (tid < s) {
+            red[tid] += red[tid + s];
+            redl[tid] += redl[tid + s];
+        }
         __syncthreads();
     }
+    q0 += redl[0];
     if (tid == 0) {
         // |E| <= sigma * sum|q|  (|X| <= 1)  =>  bound on |V|
         const double emax = red[0] * sg;
@@ -194,27 +209,65 @@ __device__ __forceinline__ void ring_wait(bool more) {
 }
 
 // ------------------------------------------------------------------------------------------
-// forward: C[k][m] = sum_c Xs[k][c] * Tq[m][c] on i8 MFMA, then the pointwise epilogue
-//   E = s * sigma_r * (sum_l 256^l C_l + q0),  V = -w_k exp(-E) s  (RISE / logRISE),
+// bit image of the design matrix for the forward GEMM.  One dword per (sample k, 64-column step kt,
+// half h): bit e + 8b  <->  column 64kt + 32(e>>2) + 16h + 4(e&3) + b  (e = 0..7, b = 0..3), set where
+// x = -1, so that dword e of the two MFMA fragments of the step is (v >> e) & 0x01010101.
+// Stored as 1-KB pieces [K/128][nk][128 rows][2 h]: one LDS-DMA instruction moves one piece.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_bits(const int8_t *__restrict__ Xt, int64_t Kp, int nk,
+                                                   unsigned *__restrict__ Xb) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int kt = blockIdx.y >> 1, h = blockIdx.y & 1;
+    unsigned v = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t c = 64 * (int64_t)kt + 32 * (e >> 2) + 16 * h + 4 * (e & 3) + b;
+            if (Xt[c * Kp + k] < 0) v |= 1u << (e + 8 * b);
+        }
+    Xb[((((k >> 7) * nk + kt) * 128) + (k & 127)) * 2 + h] = v;
+}
+
+void launch_pack_bits(const DevProblem &d, hipStream_t st) {
+    const int nk = (int)(d.Qfp / 64);
+    hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)(d.Kp / 256), (unsigned)(2 * nk)), dim3(256), 0, st, d.Xt, d.Kp, nk, d.Xb);
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: C[k][m] = sum_c b[k][c] * Tq[m][c] on i8 MFMA (b = [x = -1] from the bit image), then the
+// pointwise epilogue
+//   E = s * sigma_r * (q0 + S - 2 sum_l 256^l C_l),  V = -w_k exp(-E) s  (RISE / logRISE),
 //   V -> LB balanced limbs -> Vq planes (via an LDS transpose so that global stores are 16 B).
 // Workgroup = 4 waves along the samples: 256 samples x one 32-node tile x LF limb planes.
+// Stage image of the 4-deep LDS-DMA ring: 2 KB of bits (two 128-sample pieces) + the (tile, kt) image
+// of Tq.  The A fragments never touch LDS as bytes: each lane expands its dword of bits in registers.
 // ------------------------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ void ring_wait_ahead(int ahead) {
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int LF, int FORM /* 0: exp forms (RISE, logRISE), 2: RPLE */, bool WANTF>
 __global__ __launch_bounds__(256, 2) void k_fwd_i8(
-    const int8_t *__restrict__ Xs, const int8_t *__restrict__ Xt, const int8_t *__restrict__ Tq,
+    const unsigned *__restrict__ Xb, const int8_t *__restrict__ Xt, const int8_t *__restrict__ Tq,
     const int *__restrict__ rowcol, const int *__restrict__ groups, int ngroups, const double *__restrict__ w,
     const double *__restrict__ sigma, const long long *__restrict__ qconst, const double *__restrict__ invtau,
-    int64_t Qp /* pitch of Xs */, int64_t Qfp /* pitch of Tq */, int64_t Kp, int ntiles_k, int nk /* 64-column steps */,
-    double *__restrict__ Eacc /* [Kp][Rp] partial energies of earlier column chunks, or NULL */, int Rp, int chunk_first,
-    int chunk_last, double wuni /* > 0: every real sample has this weight */, int64_t Kreal, int8_t *__restrict__ Vq, long long *__restrict__ csum, long long *__restrict__ asum,
+    int64_t Kp, int ntiles_k, int nk /* 64-column steps */, double wuni /* > 0: every real sample has this weight */,
+    int64_t Kreal, int8_t *__restrict__ Vq, long long *__restrict__ csum, long long *__restrict__ asum,
     double *__restrict__ fsum) {
     constexpr int WM = 2;                 // 32-sample MFMA tiles per wave
-    constexpr int AR = 256, BR = 32 * LF; // stage image rows
-    constexpr int STAGE = (AR + BR) * 64;
-    constexpr int NPIECE = (AR + BR) / 16, NP = (NPIECE + 3) / 4;
+    constexpr int BR = 32 * LF;           // rows of the Tq image
+    constexpr int NPIECE = 2 + BR / 16, NP = (NPIECE + 3) / 4;
+    constexpr int STAGE = NPIECE * 1024, NS = 4;
     constexpr int PITCH = 32 * WM + 16;   // epilogue staging row pitch (bytes)
-    extern __shared__ __attribute__((aligned(16))) int8_t lds[]; // 3 stages, then the exp table
-    double *etab = reinterpret_cast<double *>(lds + 3 * STAGE);
+    constexpr int RING = NS * STAGE > 4 * LB * 32 * PITCH ? NS * STAGE : 4 * LB * 32 * PITCH;
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[]; // ring (aliased by the epilogue staging), exp table
+    double *etab = reinterpret_cast<double *>(lds + RING);
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lr = lane & 31, h = lane >> 5;
@@ -222,32 +275,43 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 
     // XCD-aware L2 blocking.  Blocks b and b+8 share an XCD (round-robin dispatch); XCD x owns the
     // sample tiles st = 8*i + x.  Within an XCD: groups of TG node tiles (outer), sample tiles
-    // (middle), the TG node tiles (inner): the ~64 resident workgroups of an XCD cover 8 sample
-    // tiles x 8 node tiles = 2 MB of Xs + 1.3 MB of Tq in its 4 MB L2; Tq stays resident over the
-    // sweep and each Xs tile is fetched once per node-tile group.
+    // (middle), the TG node tiles (inner): Tq of the group stays resident in the XCD's L2 over the
+    // sweep and each bit piece is fetched once per node-tile group.
     constexpr int TG = 8;
     const int b = blockIdx.x, xcd = b & 7, bi = b >> 3;
     const int ntk8 = (ntiles_k + 7) >> 3;
     const int tgi = bi / (ntk8 * TG), rem = bi % (ntk8 * TG);
     const int st = (rem / TG) * 8 + xcd, gi = tgi * TG + rem % TG;
     if (st >= ntiles_k || gi >= ngroups) return;
-    const int64_t k0 = (int64_t)st * AR;
+    const int64_t k0 = (int64_t)st * 256;
     const int mytile = groups[gi];
 
-    // per-lane source of each 1-KB piece this wave loads (swizzle applied to the source)
+    // per-lane source of each 1-KB piece this wave loads, and its advance per 64-column step
     const int8_t *src[NP];
+    int adv[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         int pc = wave + 4 * j;
-        if (pc >= NPIECE) pc = NPIECE - 1;
-        const int row = pc * 16 + (lane >> 2);
-        const int slot = (lane & 3) ^ ((row >> 2) & 3);
-        if (row < AR) src[j] = Xs + (k0 + row) * Qp + slot * 16;
-        else {
-            const int br = row - AR, l = br >> 5, rl = br & 31;
-            src[j] = Tq + ((int64_t)(mytile * LF + l) * 32 + rl) * Qfp + slot * 16;
+        if (pc >= NPIECE) pc = NPIECE - 1; // duplicate piece: keeps the per-wave vmcnt count uniform
+        if (pc < 2) {
+            src[j] = reinterpret_cast<const int8_t *>(Xb) + ((int64_t)(2 * st + pc) * nk) * 1024 + lane * 16;
+            adv[j] = 1024;
+        } else {
+            const int row = (pc - 2) * 16 + (lane >> 2);
+            const int slot = (lane & 3) ^ ((row >> 2) & 3); // XOR swizzle applied to the source (LDS side is linear)
+            src[j] = Tq + ((int64_t)mytile * nk * BR + row) * 64 + slot * 16;
+            adv[j] = BR * 64;
         }
     }
+    auto issue = [&](int kt) {
+        int8_t *stage_base = lds + (kt & (NS - 1)) * STAGE;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            int pc = wave + 4 * j;
+            if (pc >= NPIECE) pc = NPIECE - 1;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (int64_t)kt * adv[j]), (lptr_t)(stage_base + pc * 1024), 16, 0, 0);
+        }
+    };
 
     v16i acc[WM][LF];
 #pragma unroll
@@ -271,22 +335,29 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const double q0 = active ? (double)qconst[r] : 0.0;
     const double it = active ? invtau[r] : 0.0;
 
-    ring_issue<NP>(src, 0, lds, wave, NPIECE);
-    if (nk > 1) ring_issue<NP>(src, 64, lds + STAGE, wave, NPIECE);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s);
     for (int kt = 0; kt < nk; ++kt) {
-        ring_wait<NP>(kt + 1 < nk);
-        if (kt + 2 < nk) ring_issue<NP>(src, (int64_t)(kt + 2) * 64, lds + ((kt + 2) % 3) * STAGE, wave, NPIECE);
-        const int8_t *cur = lds + (kt % 3) * STAGE;
+        ring_wait_ahead<NP>(nk - 1 - kt);
+        if (kt + NS - 1 < nk) issue(kt + NS - 1);
+        const int8_t *cur = lds + (kt & (NS - 1)) * STAGE;
+        unsigned vb[WM];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int row = wave * 64 + i * 32 + lr;
+            vb[i] = *reinterpret_cast<const unsigned *>(cur + (row >> 7) * 1024 + (((row & 127) * 2 + h) << 2));
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int slot = 2 * t + h;
             v4i fa[WM], fb[LF];
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
-                fa[i] = *reinterpret_cast<const v4i *>(cur + lds_off(wave * 64 + i * 32 + lr, slot));
-#pragma unroll
             for (int l = 0; l < LF; ++l)
-                fb[l] = *reinterpret_cast<const v4i *>(cur + AR * 64 + lds_off(l * 32 + lr, slot));
+                fb[l] = *reinterpret_cast<const v4i *>(cur + 2048 + lds_off(l * 32 + lr, 2 * t + h));
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fa[i][e] = (int)((vb[i] >> (4 * t + e)) & 0x01010101u);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -302,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     long long cs = 0, as = 0;
     double fp = 0.0;
     const int64_t kw = k0 + wave * 64; // first sample of this wave
-    const double sgq0 = sg * q0;
+    const double sgq0 = sg * q0, sg2 = -2.0 * sg;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -313,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int e = 4 * g + j;
-                // exact recombination of the limb planes: pairs in int32 (|acc| <= 2^18), then FP64
+                // exact recombination of the limb planes: pairs in int32 (|acc| <= 2^17), then FP64
                 double a;
                 if (LF == 5) {
                     const int lo = acc[i][0][e] + (acc[i][1][e] << 8);
@@ -328,15 +399,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     const int lo = acc[i][0][e] + (acc[i][1][e] << 8);
                     a = fma((double)acc[i][2][e], 65536.0, (double)lo);
                 }
-                if (Eacc) { // column-chunked design matrix: integer-valued partial sums carried in FP64 (exact)
-                    double *ea = Eacc + (kk + j) * Rp + r;
-                    if (!chunk_first) a += *ea;
-                    if (!chunk_last) {
-                        if (active) *ea = a;
-                        continue;
-                    }
-                }
-                const double Ea = fma(a, sg, sgq0);                 // |E| pre-sign: sigma * (A + q0)
+                const double Ea = fma(a, sg2, sgq0);                // |E| pre-sign: sigma * (q0 + S - 2 A)
                 const bool neg = ((sw >> (8 * j + 7)) & 1u) != 0;   // s_u^k == -1 (padding: s = 0, w = 0)
                 const double wk = (wuni > 0.0 ? (kk + j < Kreal ? wuni : 0.0) : w[kk + j]) * it;
                 int vq;
@@ -355,7 +418,6 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                 cs += vq;
                 dj[j] = ((unsigned)vq + 0x80808080u) ^ 0x80808080u; // 4 balanced base-256 digits
             }
-            if (Eacc && !chunk_last) continue;
             // 4 samples x 4 limbs byte transpose -> one dword per limb plane
 #pragma unroll
             for (int lb = 0; lb < LB; ++lb) {
@@ -367,7 +429,6 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
             }
         }
     }
-    if (Eacc && !chunk_last) return; // uniform over the workgroup
     cs += __shfl_xor(cs, 32);
     as += __shfl_xor(as, 32);
     if (active && h == 0) {
@@ -821,7 +882,7 @@ void i8_free(void *p) {
     I8Ws *w = static_cast<I8Ws *>(p);
     if (!w) return;
     void *ptrs[] = {w->Tq, w->Vq, w->Gacc, w->sigma, w->tau, w->invtau, w->qconst, w->csum, w->asum, w->pairs,
-                    w->Mt, w->Hq, w->hS, w->H64, w->Eacc};
+                    w->Mt, w->Hq, w->hS, w->H64};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete w;
@@ -845,7 +906,6 @@ static int i8_ensure(void **wsp, const DevProblem &d, int Rp, int LF, std::strin
     I8CHK(hipMalloc(&w->csum, sizeof(long long) * Rp));
     I8CHK(hipMalloc(&w->asum, sizeof(long long) * Rp));
     I8CHK(hipMalloc(&w->pairs, sizeof(int) * (Rp / 32 + 2)));
-    if (d.chunked) I8CHK(hipMalloc(&w->Eacc, sizeof(double) * (size_t)Rp * d.Kp));
     I8CHK(hipMemset(w->Tq, 0, (size_t)Rp * LF * d.Qfp));
     I8CHK(hipMemset(w->Vq, 0, (size_t)Rp * LB * d.Kp));
     w->rows = Rp;
@@ -952,28 +1012,15 @@ int i8_limbs_forward() {
 
 template <int LF, int FORM, bool WANTF>
 static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, int ngroups, double *dF, hipStream_t st) {
-    constexpr int STAGE = (256 + 32 * LF) * 64;
-    constexpr int shmem = 3 * STAGE + 512; // ring + exp table (the epilogue staging aliases the ring)
+    constexpr int STAGE = (2 + 2 * LF) * 1024, STG = 4 * LB * 32 * (32 * 2 + 16);
+    constexpr int shmem = (4 * STAGE > STG ? 4 * STAGE : STG) + 512; // ring (aliased by the epilogue staging) + exp table
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
     const int ntk = (int)(d.Kp / 256);
     const int grid = ((ntk + 7) / 8) * 8 * ((ngroups + 7) / 8) * 8;
-    const int Rp = (int)w->rows;
-    if (!d.chunked) {
-        hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xs, d.Xt, w->Tq, dRowcol, w->pairs,
-                           ngroups, d.w, w->sigma, w->qconst, w->invtau, d.Qp, d.Qfp, d.Kp, ntk, (int)(d.Qfp / 64),
-                           (double *)nullptr, Rp, 1, 1, d.wuni, d.K, w->Vq, w->csum, w->asum, dF);
-        return;
-    }
-    // column chunks: refill Xs from the resident Xt (transpose of a slice), accumulate the integer
-    // energies across chunks in Eacc, run the pointwise epilogue with the last chunk
-    for (int64_t c0 = 0; c0 < d.Qfp; c0 += d.xs_cols) {
-        const int64_t nc = std::min<int64_t>(d.xs_cols, d.Qfp - c0);
-        launch_transpose_i8(d.Xt + c0 * d.Kp, nc, d.K, d.Kp, d.Xs, d.xs_cols, st);
-        hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xs, d.Xt, w->Tq + c0, dRowcol, w->pairs,
-                           ngroups, d.w, w->sigma, w->qconst, w->invtau, d.xs_cols, d.Qfp, d.Kp, ntk, (int)(nc / 64), w->Eacc, Rp,
-                           c0 == 0 ? 1 : 0, c0 + nc >= d.Qfp ? 1 : 0, d.wuni, d.K, w->Vq, w->csum, w->asum, dF);
-    }
+    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xb, d.Xt, w->Tq, dRowcol, w->pairs,
+                       ngroups, d.w, w->sigma, w->qconst, w->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, w->Vq, w->csum,
+                       w->asum, dF);
 }
 
 template <int LF>

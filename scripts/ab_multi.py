@@ -1,0 +1,13 @@
+"""Interleaved timing of several builds of libgml_hip (argv: tag=path ...) on one GPU; prints (step, fwd, bwd) ms."""
+import subprocess, sys, json, os
+libs = [a.split("=", 1) for a in sys.argv[1:]]
+res = {t: [] for t, _ in libs}
+for rnd in range(2):
+    for tag, path in libs:
+        env = dict(os.environ)
+        if path: env["GML_LIB_OVERRIDE"] = path
+        out = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "1", "--no-cpu", "--no-learn"], env=env,
+                             capture_output=True, text=True).stdout.strip().splitlines()[-1]
+        d = json.loads(out)
+        res[tag].append((round(d["ms_per_step"], 3), round(d["roofline"]["fwd_ms"], 3), round(d["roofline"]["bwd_ms"], 3)))
+        print(tag, res[tag][-1], flush=True)

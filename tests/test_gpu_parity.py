@@ -314,23 +314,20 @@ def test_subsampled_hessian_does_not_change_the_optimum():
     assert ((a == 0) == (b == 0)).all()
 
 
-def test_chunked_design_matrix_is_bit_identical(monkeypatch):
-    # the column-chunked forward (used when both orientations of the design matrix do not fit in HBM,
-    # e.g. order-3 statistics of 512 spins) must reproduce the resident path exactly (integer partial sums)
+def test_multibody_objgrad_bit_image_matches_oracle_and_fp64_path():
+    # order-3 statistics: 666 columns = 11 column steps (10.4 used) of the forward GEMM's bit image, whose
+    # FP64 twin reads the byte image instead; both must agree with the oracle's explicit products
     spins, terms = synthetic.block_multibody(36, 20000, block=12, seed=3)
     rng = np.random.default_rng(1)
+    hist = np.column_stack([np.ones(len(spins), dtype=np.int64), spins.astype(np.int64)])
     with gml.Problem(spins=spins, order=3) as p:
-        theta = rng.normal(scale=0.05, size=(36, p.P))
-        f0, g0 = p.objgrad("RISE", np.arange(36), theta, precision="i8x")
-        ref, _, st0 = p.learn("RISE", 0.4, tol=1e-9, precision="i8x")
-    monkeypatch.setenv("GML_FORCE_CHUNK_COLS", "128")
-    with gml.Problem(spins=spins, order=3) as p:
-        f1, g1 = p.objgrad("RISE", np.arange(36), theta, precision="i8x")
-        got, _, st1 = p.learn("RISE", 0.4, tol=1e-9, precision="i8x")
-        with pytest.raises(gml.GMLError):
-            p.objgrad("RISE", np.arange(36), theta, precision="f64")
-    assert np.array_equal(f0, f1) and np.array_equal(g0, g1)
-    assert np.array_equal(ref, got) and st0["passes"] == st1["passes"]
+        theta = rng.normal(scale=0.005, size=(36, p.P))  # sum|theta| ~ 2.5: i8x scales V by exp(sum|theta|)
+        f8, g8 = p.objgrad("RISE", np.arange(36), theta, precision="i8x")
+        f64, g64 = p.objgrad("RISE", np.arange(36), theta, precision="f64")
+    assert np.abs(f8 / f64 - 1).max() <= 1e-7 and np.abs(g8 - g64).max() <= 1e-7
+    for u in (0, 17, 35):
+        fo, go = O.objgrad_multi(hist, 3, u, theta[u])
+        assert abs(f8[u] / fo - 1) <= FTOL["i8x"] and np.abs(g8[u] - go).max() <= GTOL["i8x"]
 
 
 @pytest.mark.parametrize("n", [512, 1024])
