@@ -9,6 +9,7 @@ namespace gml {
 //   Xt [Qp][Kp] int8   feature-major design matrix: Xt[c][k] = prod_{i in key_c} s_i^k
 //   Xb                 the same matrix sample-major, one bit per entry (set <=> -1), in the piece
 //                      layout of k_pack_bits (gml_kernels_i8.hip): the forward operand of the int8 path
+//   Xtb                the bits of Xt in the piece layout of k_pack_bits_t: the backward operand
 //   Xs [Kp][Qp] int8   sample-major bytes; built on first use by the FP64 path only
 //   w  [Kp]     f64    c_k / M   (samples[k,1]/num_samples, GraphicalModelLearning.jl:170)
 // Columns 0..n-1 are the single spins, then pairs (i<j) in lexicographic order, ... (multi-body,
@@ -20,7 +21,7 @@ struct DevProblem {
     int64_t cconst;   // column of the constant statistic (= Qfp)
     int64_t Qp;       // row pitch of Xs / number of rows of Xt (= Qfp + 64)
     int8_t *Xs, *Xt;
-    unsigned *Xb;
+    unsigned *Xb, *Xtb; // bit images: sample-major (forward operand) and feature-major (backward operand)
     double *w;
     double wmax;      // max_k w_k
     double wuni;      // the common weight when all K samples weigh the same (counts all equal), else 0
@@ -29,7 +30,14 @@ struct DevProblem {
 // ---- packing -----------------------------------------------------------------------------
 void launch_transpose_i8(const int8_t *src, int64_t rows, int64_t cols, int64_t ld_src,
                          int8_t *dst, int64_t ld_dst, hipStream_t st);
-void launch_pack_bits(const DevProblem &d, hipStream_t st); // Xt -> Xb
+void launch_pack_bits(const DevProblem &d, hipStream_t st); // Xt -> Xb, Xtb
+int64_t xtb_bytes(const DevProblem &d);
+
+// Byte offset of limb l of V[r][k] in the int8 limb image Vq of the exact fixed-point pass:
+// images [node tile r/32][k/64] of [4 limbs x 32 rows][64 samples], contiguous (8 KB each).
+__host__ __device__ inline int64_t vq_off(int64_t r, int l, int64_t k, int64_t Kp) {
+    return ((((r >> 5) * (Kp >> 6) + (k >> 6)) * 4 + l) * 32 + (r & 31)) * 64 + (k & 63);
+}
 void launch_expand_features(const int8_t *St, int64_t n, int64_t K, int64_t Kp,
                             const int32_t *keys, int order, int64_t Q, int8_t *Xt,
                             hipStream_t st);

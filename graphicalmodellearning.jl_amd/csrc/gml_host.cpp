@@ -253,8 +253,8 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
     d.Qp = d.Qfp + 64;
     d.Kp = round_up(p->K, 1024);
     const int64_t Q = Qf;
-    // resident: Xt (bytes, feature-major) + Xb (bits, sample-major) = 1.125 bytes per entry
-    if ((double)d.Kp * (double)d.Qp * 1.125 > 240e9)
+    // resident: Xt (bytes, feature-major) + the two bit images = 1.25 bytes per entry
+    if ((double)d.Kp * (double)d.Qp * 1.25 > 240e9)
         return fail(GML_ENOMEM, "design matrix %lld x %lld does not fit in HBM", (long long)d.Kp, (long long)d.Qp);
     if (d.Qfp / 64 > 32000) return fail(GML_EUNSUPPORTED, "more than 2^21 statistics per node");
     // feature keys
@@ -273,6 +273,7 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
     d.Xs = nullptr; // FP64 path only, built on first use (ensure_f64)
     HIPCHK(hipMalloc(&d.Xt, (size_t)d.Kp * d.Qp));
     HIPCHK(hipMalloc(&d.Xb, (size_t)d.Kp * (d.Qfp / 8)));
+    HIPCHK(hipMalloc(&d.Xtb, (size_t)xtb_bytes(d)));
     HIPCHK(hipMalloc(&d.w, sizeof(double) * d.Kp));
     HIPCHK(hipMemsetAsync(d.Xt, 0, (size_t)d.Kp * d.Qp, p->st));
     HIPCHK(hipMemsetAsync(d.w, 0, sizeof(double) * d.Kp, p->st));
@@ -549,7 +550,7 @@ extern "C" void gml_problem_destroy(gml_problem *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->st) (void)hipStreamSynchronize(p->st);
-    void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.Xb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dGroups, p->dFidx, p->dMt, p->dH};
+    void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.Xb, p->d.Xtb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dGroups, p->dFidx, p->dMt, p->dH};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     void *hptrs[] = {p->hTh, p->hG, p->hF};

@@ -291,8 +291,7 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) brow[ni] = Xt + (int64_t)Fr[tj * 32 + 16 * ni + li] * Kp + 8 * q;
     const double *vrow = V ? V + (int64_t)r * Kp + 8 * q : nullptr;
-    // int8-limb V of the exact fixed-point pass: row ((r/32)*4 + l)*32 + r%32 holds limb l
-    const int8_t *vqrow = Vq ? Vq + ((int64_t)(r >> 5) * 128 + (r & 31)) * Kp + 8 * q : nullptr;
+    // int8-limb V of the exact fixed-point pass (image layout: vq_off)
     const double tr = Vq ? tau[r] : 0.0;
     const int8_t *srow = Xt + (int64_t)rc * Kp + 8 * q;
     const double *wrow = w + 8 * q;
@@ -309,10 +308,11 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
             load8d(vrow + t0, h);
         } else {
             double l0[8], l1[8], l2[8], l3[8];
-            load8b(vqrow + t0, l0);
-            load8b(vqrow + 32 * Kp + t0, l1);
-            load8b(vqrow + 64 * Kp + t0, l2);
-            load8b(vqrow + 96 * Kp + t0, l3);
+            const int8_t *vq8 = Vq + vq_off(r, 0, t0 + 8 * q, Kp);
+            load8b(vq8, l0);
+            load8b(vq8 + 32 * 64, l1);
+            load8b(vq8 + 64 * 64, l2);
+            load8b(vq8 + 96 * 64, l3);
 #pragma unroll
             for (int s = 0; s < 8; ++s) h[s] = tr * (((l3[s] * 256.0 + l2[s]) * 256.0 + l1[s]) * 256.0 + l0[s]);
         }

@@ -16,7 +16,8 @@
 // Layout of the limb planes ("planar tiles"): rows are grouped by 32-node tile `t` and limb `l`:
 //   Tq image (t, kt) = [LF*32 rows][64 B]: row l*32 + rl holds limb l of node row t*32+rl, columns
 //                      [64kt, 64kt+64); images are contiguous (t major)            (forward B operand)
-//   Vq row (t*LB + l)*32 + rl  holds limb l of V   row t*32+rl, pitch Kp        (backward A operand)
+//   Vq image (t, k/64) = [LB*32 rows][64 B]: row l*32 + rl holds limb l of V row t*32+rl, samples
+//                      [64(k/64), +64); images are contiguous (t major), see vq_off()  (backward A operand)
 // so that a wave's 32x32 MFMA tiles of the different limbs share lane <-> node and
 // register <-> sample, and the limbs combine lane-locally.
 //
@@ -229,9 +230,36 @@ __global__ __launch_bounds__(256) void k_pack_bits(const int8_t *__restrict__ Xt
     Xb[((((k >> 7) * nk + kt) * 128) + (k & 127)) * 2 + h] = v;
 }
 
+// The same for the backward GEMM (rows = columns c of the design matrix, depth = samples): dword
+// (c, kt, h): bit e + 8b <-> sample 64kt + 32(e>>2) + 16h + 4(e&3) + b; pieces [Qc/128][Kp/64][128][2 h],
+// Qc = Qfp rounded up to 256 (columns beyond Qfp: zero bits).
+__global__ __launch_bounds__(256) void k_pack_bits_t(const int8_t *__restrict__ Xt, int64_t Kp, int64_t Qfp, int64_t nkk,
+                                                     unsigned *__restrict__ Xtb) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; // (kt, h)
+    const int64_t c = blockIdx.y;
+    if (j >= 2 * nkk) return;
+    const int64_t kt = j >> 1;
+    const int h = (int)(j & 1);
+    unsigned v = 0;
+    if (c < Qfp) {
+        const int8_t *row = Xt + c * Kp + 64 * kt + 16 * h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (row[32 * (e >> 2) + 4 * (e & 3) + b] < 0) v |= 1u << (e + 8 * b);
+    }
+    Xtb[((((c >> 7) * nkk + kt) * 128) + (c & 127)) * 2 + h] = v;
+}
+
+int64_t xtb_bytes(const DevProblem &d) { return (d.Qfp + 255) / 256 * 256 * (d.Kp / 8); }
+
 void launch_pack_bits(const DevProblem &d, hipStream_t st) {
     const int nk = (int)(d.Qfp / 64);
     hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)(d.Kp / 256), (unsigned)(2 * nk)), dim3(256), 0, st, d.Xt, d.Kp, nk, d.Xb);
+    const int64_t nkk = d.Kp / 64, Qc = (d.Qfp + 255) / 256 * 256;
+    hipLaunchKernelGGL(k_pack_bits_t, dim3((unsigned)((2 * nkk + 255) / 256), (unsigned)Qc), dim3(256), 0, st, d.Xt, d.Kp, d.Qfp, nkk,
+                       d.Xtb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -448,23 +476,23 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
         const int lb = row >> 5, rl = row & 31;
         const v4i dat = *reinterpret_cast<const v4i *>(stage + row * PITCH + slot * 16);
         if (rowcol[mytile * 32 + rl] >= 0)
-            *reinterpret_cast<v4i *>(Vq + ((int64_t)(mytile * LB + lb) * 32 + rl) * Kp + kw + slot * 16) = dat;
+            *reinterpret_cast<v4i *>(Vq + vq_off(mytile * 32 + rl, lb, kw + slot * 16, Kp)) = dat;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// backward: Gacc[m][c] += sum_k Vq[m][k] * Xt[c][k]  (i32, split-K with integer atomics).
-// Workgroup tile: 2 node tiles (256 rows of Vq: 4 limbs x 32 nodes each) x 256 columns of Xt,
-// 8 waves as 2 (M) x 4 (N), each 128 x 64, 3-stage LDS-DMA ring of 32 KB stages, 2 waves/SIMD.
-// All (tile, column-tile) blocks of one k-chunk run on one XCD so that the chunk's slabs of Vq and
-// Xt are fetched from HBM once and shared through that XCD's L2.
+// backward: Gacc[m][c] += sum_k Vq[m][k] * b[k][c]  (i32, split-K with integer atomics), b = [x = -1]
+// from the feature-major bit image; the gradient is tau * (sum_k V - 2 sum_l 256^l Gacc_l).
+// Workgroup tile: 2 node tiles (256 rows of Vq: 4 limbs x 32 nodes each) x 256 columns,
+// 8 waves as 2 (M) x 4 (N), each 128 x 64; 4-deep LDS-DMA ring of 18-KB stages (two 8-KB Vq images +
+// 2 KB of bits), 2 waves/SIMD.  All (tile, column-tile) blocks of one k-chunk run on one XCD so that
+// the chunk's slabs of Vq and of the bit image are fetched from HBM once and shared through that XCD's L2.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void k_bwd_i8(
-    const int8_t *__restrict__ Vq, const int8_t *__restrict__ Xt, const int *__restrict__ groups, int ngroups_t,
+    const int8_t *__restrict__ Vq, const unsigned *__restrict__ Xtb, const int *__restrict__ groups, int ngroups_t,
     int nNt, int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit, int32_t *__restrict__ Gacc) {
     constexpr int TM = 2;
-    constexpr int AR = 128 * TM, BR = 256, STAGE = (AR + BR) * 64;
-    constexpr int NPIECE = (AR + BR) / 16, NP = NPIECE / 8;
+    constexpr int AR = 128 * TM, NPIECE = 8 * TM + 2, STAGE = NPIECE * 1024, NS = 4;
     constexpr int WMT = 4, WNT = 2; // wave tile 128 x 64
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -480,24 +508,36 @@ __global__ __launch_bounds__(512, 2) void k_bwd_i8(
     for (int t = 0; t < TM; ++t) tiles[t] = groups[gi * TM + t]; // -1: padding (computed on tile 0, not stored)
     const int64_t kb = (int64_t)chunk * kchunk;
     const int64_t ke = (kb + kchunk < Kp) ? kb + kchunk : Kp;
-    const int64_t n0 = (int64_t)nt * BR;
+    const int64_t n0 = (int64_t)nt * 256, nkk = Kp >> 6, kt0 = kb >> 6;
 
-    const int8_t *src[NP];
+    // 18 pieces over 8 waves: waves 0 and 1 load three (the third is a piece of bits), the others two
+    const bool three = wave < 2;
+    const int8_t *src[3];
+    int adv[3];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
+    for (int j = 0; j < 3; ++j) {
         const int pc = wave + 8 * j;
-        const int row = pc * 16 + (lane >> 2);
-        const int slot = (lane & 3) ^ ((row >> 2) & 3);
-        if (row < AR) {
-            int tl = tiles[row >> 7];
+        if (pc < 8 * TM) {
+            int tl = tiles[pc >> 3];
             if (tl < 0) tl = tiles[0];
-            src[j] = Vq + ((int64_t)tl * 128 + (row & 127)) * Kp + slot * 16;
+            const int row = (pc & 7) * 16 + (lane >> 2);
+            const int slot = (lane & 3) ^ ((row >> 2) & 3);
+            src[j] = Vq + ((int64_t)tl * nkk + kt0) * 8192 + row * 64 + slot * 16;
+            adv[j] = 8192;
         } else {
-            int64_t c = n0 + (row - AR);
-            if (c >= Qfp) c = Qfp - 1; // columns beyond the matrix: computed, never stored
-            src[j] = Xt + c * Kp + slot * 16;
+            const int pb = pc < NPIECE ? pc - 8 * TM : 0;
+            src[j] = reinterpret_cast<const int8_t *>(Xtb) + ((int64_t)(2 * nt + pb) * nkk + kt0) * 1024 + lane * 16;
+            adv[j] = 1024;
         }
     }
+    auto issue = [&](int kt) {
+        int8_t *stage_base = lds + (kt & (NS - 1)) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (int64_t)kt * adv[j]), (lptr_t)(stage_base + (wave + 8 * j) * 1024), 16, 0, 0);
+        if (three)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[2] + (int64_t)kt * adv[2]), (lptr_t)(stage_base + (wave + 16) * 1024), 16, 0, 0);
+    };
     v16i acc[WMT][WNT];
 #pragma unroll
     for (int i = 0; i < WMT; ++i)
@@ -507,29 +547,37 @@ __global__ __launch_bounds__(512, 2) void k_bwd_i8(
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0;
 
     const int nk = (int)((ke - kb) / 64);
-    ring_issue8<NP>(src, kb, lds, wave, NPIECE);
-    if (nk > 1) ring_issue8<NP>(src, kb + 64, lds + STAGE, wave, NPIECE);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s);
     for (int kt = 0; kt < nk; ++kt) {
-        ring_wait<NP>(kt + 1 < nk);
-        if (kt + 2 < nk) ring_issue8<NP>(src, kb + (int64_t)(kt + 2) * 64, lds + ((kt + 2) % 3) * STAGE, wave, NPIECE);
-        const int8_t *cur = lds + (kt % 3) * STAGE;
+        if (three) ring_wait_ahead<3>(nk - 1 - kt);
+        else ring_wait_ahead<2>(nk - 1 - kt);
+        if (kt + NS - 1 < nk) issue(kt + NS - 1);
+        const int8_t *cur = lds + (kt & (NS - 1)) * STAGE;
+        unsigned vb[WNT];
+#pragma unroll
+        for (int jn = 0; jn < WNT; ++jn) {
+            const int cw = wn * 64 + jn * 32 + lr;
+            vb[jn] = *reinterpret_cast<const unsigned *>(cur + AR * 64 + (cw >> 7) * 1024 + (((cw & 127) * 2 + h) << 2));
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int slot = 2 * t + h;
             v4i fa[WMT], fb[WNT];
 #pragma unroll
             for (int i = 0; i < WMT; ++i)
-                fa[i] = *reinterpret_cast<const v4i *>(cur + lds_off(wm * 32 * WMT + i * 32 + lr, slot));
+                fa[i] = *reinterpret_cast<const v4i *>(cur + lds_off(wm * 32 * WMT + i * 32 + lr, 2 * t + h));
 #pragma unroll
             for (int jn = 0; jn < WNT; ++jn)
-                fb[jn] = *reinterpret_cast<const v4i *>(cur + AR * 64 + lds_off(wn * 64 + jn * 32 + lr, slot));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fb[jn][e] = (int)((vb[jn] >> (4 * t + e)) & 0x01010101u);
 #pragma unroll
             for (int i = 0; i < WMT; ++i)
 #pragma unroll
                 for (int jn = 0; jn < WNT; ++jn) acc[i][jn] = MFMA_I8(fa[i], fb[jn], acc[i][jn]);
         }
     }
-    // C layout: column (lane&31) <-> Xt row (c), register e <-> Vq row (e&3)+8*(e>>2)+4*h
+    // C layout: column (lane&31) <-> column c, register e <-> Vq row (e&3)+8*(e>>2)+4*h
 #pragma unroll
     for (int i = 0; i < WMT; ++i)
 #pragma unroll
@@ -547,12 +595,12 @@ __global__ __launch_bounds__(512, 2) void k_bwd_i8(
         }
 }
 
-// G[r][c] = tau_r * sum_l 256^l Gacc[(t*4+l)*32+rl][c];  G[r][cconst] = tau_r * csum[r];
+// G[r][c] = tau_r * (csum[r] - 2 sum_l 256^l Gacc[(t*4+l)*32+rl][c])  (x = 1 - 2b);  G[r][cconst] = tau_r * csum[r];
 // f[r] = tau_r * asum[r]  (= sum_k w_k exp(-E) for RISE / logRISE; RPLE keeps its FP64 sum)
 __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__ Gacc, const double *__restrict__ tau,
                                                      const long long *__restrict__ csum,
                                                      const long long *__restrict__ asum,
-                                                     const int *__restrict__ rowcol, int64_t Qp, int64_t Qfp,
+                                                     const int *__restrict__ rowcol, int64_t Qp, int64_t Qfp, int64_t Qf,
                                                      int64_t cconst, int form, int want_grad,
                                                      double *__restrict__ G, double *__restrict__ f) {
     const int r = blockIdx.y;
@@ -565,19 +613,19 @@ __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__
             long long s = 0;
 #pragma unroll
             for (int l = LB - 1; l >= 0; --l) s = s * 256 + (long long)Gacc[((int64_t)(tile * LB + l) * 32 + rl) * Qfp + u];
-            f[r] = -t * (double)s;
+            f[r] = -t * (double)(csum[r] - 2 * s);
         } else {
             f[r] = t * (double)asum[r];
         }
     }
     if (!want_grad || c >= Qp) return;
     double v = 0.0;
-    if (c < Qfp) {
+    if (c < Qf) {
         const int tile = r >> 5, rl = r & 31;
         long long s = 0;
 #pragma unroll
         for (int l = LB - 1; l >= 0; --l) s = s * 256 + (long long)Gacc[((int64_t)(tile * LB + l) * 32 + rl) * Qfp + c];
-        v = t * (double)s;
+        v = t * (double)(csum[r] - 2 * s);
     } else if (c == cconst) {
         v = t * (double)csum[r];
     }
@@ -609,8 +657,8 @@ __global__ __launch_bounds__(256) void k_make_hw(const int8_t *__restrict__ Vq, 
     const int u = rowcol[r];
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int tile = r >> 5, rl = r & 31;
-    const int8_t *vq = Vq + ((int64_t)tile * 128 + rl) * Kp + k;
-    const int q = (int)vq[0] + 256 * ((int)vq[32 * Kp] + 256 * ((int)vq[64 * Kp] + 256 * (int)vq[96 * Kp]));
+    const int8_t *vq = Vq + vq_off(r, 0, k, Kp);
+    const int q = (int)vq[0] + 256 * ((int)vq[32 * 64] + 256 * ((int)vq[64 * 64] + 256 * (int)vq[96 * 64]));
     const int s = (int)Xt[(int64_t)u * Kp + k];
     int mag = -q * s; // >= 0
     if (form == 2) {
@@ -1094,15 +1142,15 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
         if (kchunk < 2048) kchunk = 2048;
         nsplit = (int)((d.Kp + kchunk - 1) / kchunk);
         const int grid = ((nsplit + 7) / 8) * 8 * T;
-        const int shmem = 3 * (128 * TM + 256) * 64;
+        const int shmem = 4 * (8 * TM + 2) * 1024;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
         // w->pairs holds the active tile list padded with -1 to an even count
-        hipLaunchKernelGGL(k_bwd_i8, dim3(grid), dim3(512), shmem, st, w->Vq, d.Xt, w->pairs, ngt, nNt, d.Qfp, d.Kp, kchunk, nsplit,
+        hipLaunchKernelGGL(k_bwd_i8, dim3(grid), dim3(512), shmem, st, w->Vq, d.Xtb, w->pairs, ngt, nNt, d.Qfp, d.Kp, kchunk, nsplit,
                            w->Gacc);
     }
     if (ev) I8CHK(hipEventRecord(ev[2], st));
     hipLaunchKernelGGL(k_finalize_i8, dim3((unsigned)((d.Qp + 255) / 256), (unsigned)Rp), dim3(256), 0, st, w->Gacc, w->tau,
-                       w->csum, w->asum, dRowcol, d.Qp, d.Qfp, d.cconst, form, want_grad ? 1 : 0, dG, dF);
+                       w->csum, w->asum, dRowcol, d.Qp, d.Qfp, d.Qf, d.cconst, form, want_grad ? 1 : 0, dG, dF);
     I8CHK(hipGetLastError());
     return GML_OK;
 }
