@@ -488,16 +488,17 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 // 2 KB of bits), 2 waves/SIMD.  All (tile, column-tile) blocks of one k-chunk run on one XCD so that
 // the chunk's slabs of Vq and of the bit image are fetched from HBM once and shared through that XCD's L2.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void k_bwd_i8(
+template <int TM /* node tiles per workgroup: 1 (4 waves, two workgroups per CU) or 2 (8 waves) */>
+__global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
     const int8_t *__restrict__ Vq, const unsigned *__restrict__ Xtb, const int *__restrict__ groups, int ngroups_t,
     int nNt, int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit, int32_t *__restrict__ Gacc) {
-    constexpr int TM = 2;
+    constexpr int NW = 4 * TM;
     constexpr int AR = 128 * TM, NPIECE = 8 * TM + 2, STAGE = NPIECE * 1024, NS = 4;
     constexpr int WMT = 4, WNT = 2; // wave tile 128 x 64
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lr = lane & 31, h = lane >> 5;
-    const int wm = wave & 1, wn = wave >> 1; // wn in 0..3
+    const int wm = wave % TM, wn = wave / TM; // wn in 0..3
     const int T = ngroups_t * nNt; // ngroups_t = number of TM-groups of node tiles
     const int b = blockIdx.x, xcd = b & 7, bi = b >> 3;
     const int chunk = (bi / T) * 8 + xcd, ti = bi % T; // all tiles of one k-chunk on one XCD
@@ -510,13 +511,13 @@ __global__ __launch_bounds__(512, 2) void k_bwd_i8(
     const int64_t ke = (kb + kchunk < Kp) ? kb + kchunk : Kp;
     const int64_t n0 = (int64_t)nt * 256, nkk = Kp >> 6, kt0 = kb >> 6;
 
-    // 18 pieces over 8 waves: waves 0 and 1 load three (the third is a piece of bits), the others two
+    // 8*TM + 2 pieces over 4*TM waves: waves 0 and 1 load three (the third is a piece of bits), the others two
     const bool three = wave < 2;
     const int8_t *src[3];
     int adv[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int pc = wave + 8 * j;
+        const int pc = wave + NW * j;
         if (pc < 8 * TM) {
             int tl = tiles[pc >> 3];
             if (tl < 0) tl = tiles[0];
@@ -534,9 +535,9 @@ __global__ __launch_bounds__(512, 2) void k_bwd_i8(
         int8_t *stage_base = lds + (kt & (NS - 1)) * STAGE;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (int64_t)kt * adv[j]), (lptr_t)(stage_base + (wave + 8 * j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (int64_t)kt * adv[j]), (lptr_t)(stage_base + (wave + NW * j) * 1024), 16, 0, 0);
         if (three)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[2] + (int64_t)kt * adv[2]), (lptr_t)(stage_base + (wave + 16) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[2] + (int64_t)kt * adv[2]), (lptr_t)(stage_base + (wave + 2 * NW) * 1024), 16, 0, 0);
     };
     v16i acc[WMT][WNT];
 #pragma unroll
@@ -1130,12 +1131,12 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
     if (ev) I8CHK(hipEventRecord(ev[1], st));
     if (want_grad) {
         const int nNt = (int)((d.Qfp + 255) / 256);
-        constexpr int TM = 2;
+        static const int TM = [] { const char *e = getenv("GML_BWD_TM"); return e && atoi(e) == 2 ? 2 : 1; }();
         const int ngt = (ngroups + TM - 1) / TM;
         const int T = ngt * nNt;
-        // split-K: a multiple of 8 chunks (one XCD each), at least 16, and enough workgroups (~1024) to
+        // split-K: a multiple of 8 chunks (one XCD each), at least 16, and enough workgroups (~1024 x 2/TM) to
         // fill the chip when few node tiles are active (node-sharded ranks, late solver iterations)
-        int nsplit = ((1024 + T - 1) / T + 7) / 8 * 8;
+        int nsplit = ((2048 / TM + T - 1) / T + 7) / 8 * 8;
         if (nsplit < 16) nsplit = 16;
         int64_t kchunk = (d.Kp + nsplit - 1) / nsplit;
         kchunk = (kchunk + 63) / 64 * 64;
@@ -1143,10 +1144,16 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
         nsplit = (int)((d.Kp + kchunk - 1) / kchunk);
         const int grid = ((nsplit + 7) / 8) * 8 * T;
         const int shmem = 4 * (8 * TM + 2) * 1024;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
         // w->pairs holds the active tile list padded with -1 to an even count
-        hipLaunchKernelGGL(k_bwd_i8, dim3(grid), dim3(512), shmem, st, w->Vq, d.Xtb, w->pairs, ngt, nNt, d.Qfp, d.Kp, kchunk, nsplit,
-                           w->Gacc);
+        if (TM == 2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+            hipLaunchKernelGGL(k_bwd_i8<2>, dim3(grid), dim3(512), shmem, st, w->Vq, d.Xtb, w->pairs, ngt, nNt, d.Qfp, d.Kp, kchunk,
+                               nsplit, w->Gacc);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+            hipLaunchKernelGGL(k_bwd_i8<1>, dim3(grid), dim3(256), shmem, st, w->Vq, d.Xtb, w->pairs, ngt, nNt, d.Qfp, d.Kp, kchunk,
+                               nsplit, w->Gacc);
+        }
     }
     if (ev) I8CHK(hipEventRecord(ev[2], st));
     hipLaunchKernelGGL(k_finalize_i8, dim3((unsigned)((d.Qp + 255) / 256), (unsigned)Rp), dim3(256), 0, st, w->Gacc, w->tau,
