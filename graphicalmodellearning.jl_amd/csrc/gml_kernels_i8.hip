@@ -153,22 +153,25 @@ __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ t
     return ldexp(tab[n & 63] * p, n >> 6);
 }
 
-// exp(x) to ~3e-10 relative (the 31-bit quantisation of V needs no more): the reduced argument
-// |r| <= ln2/128 goes through an FP32 polynomial for expm1(r) -- its rounding error is relative to
-// |r|, i.e. 2^-24 * 0.0054 of the result -- and only the range reduction and the final table
-// multiply stay in FP64.  Returns tab[j] * (1 + expm1(r)) * 2^m.
-__device__ __forceinline__ double exp_tab32(double x, const double *__restrict__ tab) {
-    const double t = rint(x * 92.33248261689366);  // 64/ln2
-    double r = fma(t, -0.01083042469326756, x);    // ln2/64 high part
-    r = fma(t, -2.9815858269852933e-12, r);        // low part
+// |V| / tau of one element: rint(wkit * exp(x)) for x = -s E, to 3e-10 relative before the rounding.
+// FP64 range reduction with one FMA (the product t * ln2/64 is not rounded inside an FMA), FP32
+// polynomial for expm1 of the reduced argument, table of 2^(j/64), exponent added as an integer, and
+// the final rounding to an integer through the 1.5 * 2^52 trick (round-to-nearest-even, like rint).
+__device__ __forceinline__ int mag_exp(double x, double wkit, const double *__restrict__ tab) {
+    const double MAGIC = 6755399441055744.0;
+    const double tm = fma(x, 92.33248261689366, MAGIC); // 64/ln2
+    const int n = __double2loint(tm);
+    const double t = tm - MAGIC;
+    const double r = fma(t, -0.010830424696249145, x); // ln2/64
     const float rf = (float)r;
     float d = fmaf(rf, 4.1666668e-02f, 1.6666667e-01f);
     d = fmaf(d, rf, 0.5f);
     d = fmaf(d, rf, 1.0f);
     d = d * rf; // expm1(r)
-    const int n = (int)t;
-    const double tj = tab[n & 63];
-    return ldexp(fma(tj, (double)d, tj), n >> 6);
+    const double tj0 = tab[n & 63];
+    const double tj = __hiloint2double(__double2hiint(tj0) + ((n >> 6) << 20), __double2loint(tj0)); // * 2^(n>>6)
+    const double res = fma(tj, (double)d, tj);
+    return __double2loint(fma(wkit, res, MAGIC));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     long long cs = 0, as = 0;
     double fp = 0.0;
     const int64_t kw = k0 + wave * 64; // first sample of this wave
-    const double sgq0 = sg * q0, sg2 = -2.0 * sg;
+    const double sgq0 = sg * q0, sg2 = -2.0 * sg, wkit = wuni * it;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -428,18 +431,23 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     a = fma((double)acc[i][2][e], 65536.0, (double)lo);
                 }
                 const double Ea = fma(a, sg2, sgq0);                // |E| pre-sign: sigma * (q0 + S - 2 A)
-                const bool neg = ((sw >> (8 * j + 7)) & 1u) != 0;   // s_u^k == -1 (padding: s = 0, w = 0)
-                const double wk = (wuni > 0.0 ? (kk + j < Kreal ? wuni : 0.0) : w[kk + j]) * it;
+                const unsigned sbyte = sw >> (8 * j);               // s_u^k: 0x01, 0xFF, or 0 for a padding sample
+                const bool neg = (sbyte & 0x80u) != 0;
                 int vq;
                 if (FORM == 2) { // RPLE (:317): V = -2 w s / (1 + exp(2E)), E = s * Ea
+                    const double wk0 = wuni > 0.0 ? (kk + j < Kreal ? wuni : 0.0) : w[kk + j];
                     const double E = neg ? -Ea : Ea;
                     const double ex = exp_tab(2.0 * E, etab);
-                    const int mag = (int)rint(2.0 * wk / (1.0 + ex));
+                    const int mag = (int)rint(2.0 * wk0 * it / (1.0 + ex));
                     vq = neg ? mag : -mag;
                     const double tt = -2.0 * E;
-                    fp += (wuni > 0.0 ? (kk + j < Kreal ? wuni : 0.0) : w[kk + j]) * (tt > 0 ? tt + log1p(exp(-tt)) : log1p(exp(tt)));
+                    fp += wk0 * (tt > 0 ? tt + log1p(exp(-tt)) : log1p(exp(tt)));
                 } else { // RISE (:196,:204) / logRISE Z (:279): V = -w exp(-E) s
-                    const int mag = (int)rint(wk * exp_tab32(neg ? Ea : -Ea, etab));
+                    // x = -s E: flip the sign of Ea unless s = -1
+                    const double x = __hiloint2double(__double2hiint(Ea) ^ (int)(((sbyte & 0x80u) ^ 0x80u) << 24), __double2loint(Ea));
+                    int mag;
+                    if (wuni > 0.0) mag = mag_exp(x, wkit, etab) & -(int)(sbyte & 1u); // padding samples carry no weight
+                    else mag = mag_exp(x, w[kk + j] * it, etab);
                     vq = neg ? mag : -mag;
                     if (WANTF) as += mag;
                 }
@@ -467,8 +475,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
         fp += __shfl_xor(fp, 32);
         if (active && h == 0) unsafeAtomicAdd(&fsum[r], fp);
     }
-    __syncthreads();
-    // coalesced store of the wave's LB*32 rows x 32*WM bytes
+    // coalesced store of the wave's LB*32 rows x 32*WM bytes (its own staging rows: no workgroup barrier needed)
     constexpr int CH = 2 * WM; // 16-byte chunks per row
 #pragma unroll
     for (int ps = 0; ps < (LB * 32 * CH) / 64; ++ps) {
