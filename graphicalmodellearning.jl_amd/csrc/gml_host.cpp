@@ -540,6 +540,7 @@ extern "C" int gml_problem_get_spins(gml_problem *p, int8_t *spins) {
 namespace gml {
 void i8_free(void *ws);
 void i8_get_v(void *ws, const int8_t **Vq, const double **tau);
+const unsigned *i8_get_mmax(void *ws);
 int64_t i8_hess_kmax(const DevProblem &d);
 int i8_hessian(void *ws, const DevProblem &d, const int *dRowcol, const int *dF, const int *dMt, const int *hMt,
                const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh, double *dH, hipStream_t st,
@@ -599,7 +600,7 @@ namespace gml {
 // implemented in gml_kernels_i8.hip: the exact int8-limb pass (same contract as the f64 one)
 int i8_pass(void **ws, const DevProblem &d, const double *dTheta, const int *dRowcol, const int *hRowcol,
             const int *hGroups, int ngroups, int Rp, int form, bool want_grad, double *dF, double *dG,
-            hipStream_t st, hipEvent_t *ev /* [3] or NULL */, std::string *err);
+            hipStream_t st, hipEvent_t *ev /* [3] or NULL */, const double *hTauOvr, std::string *err);
 }
 
 static int ensure_ws(gml_problem *p, int64_t rows) {
@@ -667,7 +668,8 @@ struct RowSet {
 static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8_t> &act, const double *theta,
                        int form, int precision, bool want_grad, double *f, double *g, gml_stats *stats,
                        float *ms /* [2]: fwd, bwd or NULL */ = nullptr,
-                       double *fnoise /* R: absolute uncertainty of f[r] (before any log) or NULL */ = nullptr) {
+                       double *fnoise /* R: absolute uncertainty of f[r] (before any log) or NULL */ = nullptr,
+                       const std::vector<double> *tau_ovr = nullptr /* internal: rescaled re-run */, int depth = 0) {
     const int64_t R = rs.R, Qp = p->d.Qp;
     const int64_t Rp = round_up(R, 32);
     int rc = ensure_ws(p, R);
@@ -706,7 +708,8 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
     if (precision == GML_PREC_I8X) {
         std::string err;
         rc = gml::i8_pass(&p->i8ws, p->d, p->dTheta, p->dRowcol, rowcol.data(), groups.data(), (int)groups.size(),
-                          (int)Rp, form, want_grad, p->dF, p->dG, st, ms ? ev : nullptr, &err);
+                          (int)Rp, form, want_grad, p->dF, p->dG, st, ms ? ev : nullptr, tau_ovr ? tau_ovr->data() : nullptr,
+                          &err);
         if (rc) return fail(rc, "%s", err.c_str());
     } else {
         rc = ensure_f64(p);
@@ -723,12 +726,18 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
     if (want_grad)
         HIPCHK(hipMemcpyAsync(p->hG + ra * Qp, p->dG + ra * Qp, sizeof(double) * (rb - ra) * Qp, hipMemcpyDeviceToHost, st));
     std::vector<double> tauh;
-    if (fnoise && precision == GML_PREC_I8X) {
+    std::vector<unsigned> mmaxh;
+    const bool i8exp = precision == GML_PREC_I8X && form != GML_RPLE;
+    if (precision == GML_PREC_I8X) {
         const int8_t *Vq = nullptr;
         const double *tau = nullptr;
         gml::i8_get_v(p->i8ws, &Vq, &tau);
         tauh.resize((size_t)Rp);
         HIPCHK(hipMemcpyAsync(tauh.data(), tau, sizeof(double) * Rp, hipMemcpyDeviceToHost, st));
+        if (i8exp) {
+            mmaxh.resize((size_t)Rp);
+            HIPCHK(hipMemcpyAsync(mmaxh.data(), gml::i8_get_mmax(p->i8ws), sizeof(unsigned) * Rp, hipMemcpyDeviceToHost, st));
+        }
     }
     HIPCHK(hipStreamSynchronize(st));
     if (fnoise)
@@ -758,6 +767,24 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
         stats->node_evals += nact;
         if (want_grad) ++stats->passes;
         else ++stats->forward_passes;
+    }
+    if (i8exp) {
+        // Dynamic range of the fixed-point V: tau_r was derived from the bound w_max exp(sum_j |theta_rj|).  When
+        // the largest |V_rk| actually seen is more than 8 bits below that bound (dense theta), re-run the row with
+        // tau_r taken from it: (mmax + 1) tau bounds every |V_rk| rigorously, so the re-run cannot overflow.
+        std::vector<uint8_t> again((size_t)R, 0);
+        std::vector<double> ovr((size_t)Rp, 0.0);
+        int64_t nagain = 0;
+        for (int64_t r = 0; r < R; ++r)
+            if (act[r] && mmaxh[r] < (1u << 23)) {
+                again[r] = 1;
+                ovr[r] = ((double)mmaxh[r] + 1.0) * tauh[r] * (1.0 + 1e-12) / 2130000000.0;
+                ++nagain;
+            }
+        if (nagain > 0) {
+            if (depth >= 6) return fail(GML_EUNSUPPORTED, "precision i8x: the weights exp(-E) of a row underflow its fixed-point range; use precision f64");
+            return device_pass(p, rs, again, theta, form, precision, want_grad, f, g, stats, nullptr, fnoise, &ovr, depth + 1);
+        }
     }
     return GML_OK;
 }

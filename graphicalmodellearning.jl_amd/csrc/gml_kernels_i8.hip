@@ -44,6 +44,8 @@ struct I8Ws {
     int32_t *Gacc = nullptr;
     double *sigma = nullptr, *tau = nullptr, *invtau = nullptr;
     long long *qconst = nullptr, *csum = nullptr, *asum = nullptr;
+    unsigned *mmax = nullptr; // largest |V| / tau seen per row in the last pass (dynamic-range check)
+    double *tauovr = nullptr; // per-row tau imposed by the caller (rescaled re-run), 0 = derive from the bound
     int *pairs = nullptr;
     // working-set Hessian on the int8 cores
     int64_t hKh = 0, hbuilt = 0, hcap_elems = 0;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
                                                      int64_t Qfp, int64_t cconst, double wmax, int form,
                                                      int8_t *__restrict__ Tq, double *__restrict__ sigma,
                                                      double *__restrict__ tau, double *__restrict__ invtau,
-                                                     long long *__restrict__ qconst) {
+                                                     long long *__restrict__ qconst, const double *__restrict__ tauovr) {
     const int r = blockIdx.x;
     if (rowcol[r] < 0) return;
     const double *th = Theta + (int64_t)r * Qp;
@@ -121,7 +123,9 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
         const double B = (form == 2) ? 2.0 * wmax : wmax * exp(emax);
         // |V|/tau <= 2.13e9: the largest magnitude whose 4 balanced base-256 digits fit the packed
         // (q + 0x80808080) ^ 0x80808080 form used by the forward epilogue
-        const double t = B * (1.0 + 1e-12) / 2130000000.0;
+        // The bound exp(sum|theta|) can exceed the largest actual |V| by many orders of magnitude (dense
+        // theta); the caller then re-runs the row with tau taken from the largest |V| the first pass saw.
+        const double t = (tauovr && tauovr[r] > 0.0) ? tauovr[r] : B * (1.0 + 1e-12) / 2130000000.0;
         sigma[r] = sg;
         qconst[r] = q0;
         tau[r] = t;
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const double *__restrict__ sigma, const long long *__restrict__ qconst, const double *__restrict__ invtau,
     int64_t Kp, int ntiles_k, int nk /* 64-column steps */, double wuni /* > 0: every real sample has this weight */,
     int64_t Kreal, int8_t *__restrict__ Vq, long long *__restrict__ csum, long long *__restrict__ asum,
-    double *__restrict__ fsum) {
+    double *__restrict__ fsum, unsigned *__restrict__ mmax) {
     constexpr int WM = 2;                 // 32-sample MFMA tiles per wave
     constexpr int BR = 32 * LF;           // rows of the Tq image
     constexpr int NPIECE = 2 + BR / 16, NP = (NPIECE + 3) / 4;
@@ -403,6 +407,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const int form = FORM;
     long long cs = 0, as = 0;
     double fp = 0.0;
+    int mx = 0;
     const int64_t kw = k0 + wave * 64; // first sample of this wave
     const double sgq0 = sg * q0, sg2 = -2.0 * sg, wkit = wuni * it;
 #pragma unroll
@@ -449,6 +454,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     if (wuni > 0.0) mag = mag_exp(x, wkit, etab) & -(int)(sbyte & 1u); // padding samples carry no weight
                     else mag = mag_exp(x, w[kk + j] * it, etab);
                     vq = neg ? mag : -mag;
+                    mx = mag > mx ? mag : mx;
                     if (WANTF) as += mag;
                 }
                 cs += vq;
@@ -470,6 +476,11 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     if (active && h == 0) {
         atomicAdd(reinterpret_cast<unsigned long long *>(&csum[r]), (unsigned long long)cs);
         if (WANTF) atomicAdd(reinterpret_cast<unsigned long long *>(&asum[r]), (unsigned long long)as);
+    }
+    if (form != 2) {
+        const int mo = __shfl_xor(mx, 32);
+        mx = mo > mx ? mo : mx;
+        if (active && h == 0) atomicMax(&mmax[r], (unsigned)mx);
     }
     if (form == 2) {
         fp += __shfl_xor(fp, 32);
@@ -934,10 +945,12 @@ void i8_get_v(void *p, const int8_t **Vq, const double **tau) {
     *tau = w ? w->tau : nullptr;
 }
 
+const unsigned *i8_get_mmax(void *p) { return p ? static_cast<I8Ws *>(p)->mmax : nullptr; }
+
 void i8_free(void *p) {
     I8Ws *w = static_cast<I8Ws *>(p);
     if (!w) return;
-    void *ptrs[] = {w->Tq, w->Vq, w->Gacc, w->sigma, w->tau, w->invtau, w->qconst, w->csum, w->asum, w->pairs,
+    void *ptrs[] = {w->Tq, w->Vq, w->Gacc, w->sigma, w->tau, w->invtau, w->qconst, w->csum, w->asum, w->pairs, w->mmax, w->tauovr,
                     w->Mt, w->Hq, w->hS, w->H64};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -961,6 +974,8 @@ static int i8_ensure(void **wsp, const DevProblem &d, int Rp, int LF, std::strin
     I8CHK(hipMalloc(&w->qconst, sizeof(long long) * Rp));
     I8CHK(hipMalloc(&w->csum, sizeof(long long) * Rp));
     I8CHK(hipMalloc(&w->asum, sizeof(long long) * Rp));
+    I8CHK(hipMalloc(&w->mmax, sizeof(unsigned) * Rp));
+    I8CHK(hipMalloc(&w->tauovr, sizeof(double) * Rp));
     I8CHK(hipMalloc(&w->pairs, sizeof(int) * (Rp / 32 + 2)));
     I8CHK(hipMemset(w->Tq, 0, (size_t)Rp * LF * d.Qfp));
     I8CHK(hipMemset(w->Vq, 0, (size_t)Rp * LB * d.Kp));
@@ -1076,7 +1091,7 @@ static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, 
     const int grid = ((ntk + 7) / 8) * 8 * ((ngroups + 7) / 8) * 8;
     hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xb, d.Xt, w->Tq, dRowcol, w->pairs,
                        ngroups, d.w, w->sigma, w->qconst, w->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, w->Vq, w->csum,
-                       w->asum, dF);
+                       w->asum, dF, w->mmax);
 }
 
 template <int LF>
@@ -1089,7 +1104,7 @@ static void launch_fwd(const I8Ws *w, const DevProblem &d, const int *dRowcol, i
 
 int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dRowcol, const int *hRowcol,
             const int *hGroups, int ngroups, int Rp, int form, bool want_grad, double *dF, double *dG, hipStream_t st,
-            hipEvent_t *ev, std::string *err) {
+            hipEvent_t *ev, const double *hTauOvr /* Rp per-row tau overrides (0 = none) or NULL */, std::string *err) {
     (void)hRowcol;
     if (d.Kp > (int64_t)1 << 24) {
         if (err) *err = "GML_PREC_I8X supports up to 2^24 configurations per handle (i32 accumulators)";
@@ -1114,19 +1129,26 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
     }
     I8CHK(hipMemsetAsync(w->csum, 0, sizeof(long long) * Rp, st));
     I8CHK(hipMemsetAsync(w->asum, 0, sizeof(long long) * Rp, st));
+    I8CHK(hipMemsetAsync(w->mmax, 0, sizeof(unsigned) * Rp, st));
+    const double *dOvr = nullptr;
+    if (hTauOvr) {
+        I8CHK(hipMemcpyAsync(w->tauovr, hTauOvr, sizeof(double) * Rp, hipMemcpyHostToDevice, st));
+        I8CHK(hipStreamSynchronize(st)); // the caller's buffer is pageable
+        dOvr = w->tauovr;
+    }
     if (want_grad) I8CHK(hipMemsetAsync(w->Gacc, 0, sizeof(int32_t) * (size_t)Rp * LB * d.Qfp, st));
     switch (LF) {
     case 3:
         hipLaunchKernelGGL((k_quant_theta<3>), dim3(Rp), dim3(256), 0, st, dTheta, dRowcol, d.Qp, d.Qfp, d.cconst, d.wmax,
-                           form, w->Tq, w->sigma, w->tau, w->invtau, w->qconst);
+                           form, w->Tq, w->sigma, w->tau, w->invtau, w->qconst, dOvr);
         break;
     case 5:
         hipLaunchKernelGGL((k_quant_theta<5>), dim3(Rp), dim3(256), 0, st, dTheta, dRowcol, d.Qp, d.Qfp, d.cconst, d.wmax,
-                           form, w->Tq, w->sigma, w->tau, w->invtau, w->qconst);
+                           form, w->Tq, w->sigma, w->tau, w->invtau, w->qconst, dOvr);
         break;
     default:
         hipLaunchKernelGGL((k_quant_theta<4>), dim3(Rp), dim3(256), 0, st, dTheta, dRowcol, d.Qp, d.Qfp, d.cconst, d.wmax,
-                           form, w->Tq, w->sigma, w->tau, w->invtau, w->qconst);
+                           form, w->Tq, w->sigma, w->tau, w->invtau, w->qconst, dOvr);
     }
     if (ev) I8CHK(hipEventRecord(ev[0], st));
     switch (LF) {

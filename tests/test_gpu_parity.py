@@ -321,13 +321,37 @@ def test_multibody_objgrad_bit_image_matches_oracle_and_fp64_path():
     rng = np.random.default_rng(1)
     hist = np.column_stack([np.ones(len(spins), dtype=np.int64), spins.astype(np.int64)])
     with gml.Problem(spins=spins, order=3) as p:
-        theta = rng.normal(scale=0.005, size=(36, p.P))  # sum|theta| ~ 2.5: i8x scales V by exp(sum|theta|)
+        theta = rng.normal(scale=0.05, size=(36, p.P))  # sum|theta| ~ 25: exercises the rescaled re-run of i8x
         f8, g8 = p.objgrad("RISE", np.arange(36), theta, precision="i8x")
         f64, g64 = p.objgrad("RISE", np.arange(36), theta, precision="f64")
-    assert np.abs(f8 / f64 - 1).max() <= 1e-7 and np.abs(g8 - g64).max() <= 1e-7
+    tol = len(spins) / 2.0**32  # i8x worst case K * tau / 2 (sum|theta| ~ 25: wide spread of weights)
+    assert np.abs(f8 / f64 - 1).max() <= tol and (np.abs(g8 - g64) / f64[:, None]).max() <= tol
     for u in (0, 17, 35):
         fo, go = O.objgrad_multi(hist, 3, u, theta[u])
-        assert abs(f8[u] / fo - 1) <= FTOL["i8x"] and np.abs(g8[u] - go).max() <= GTOL["i8x"]
+        assert abs(f64[u] / fo - 1) <= 1e-12 and np.abs(g64[u] - go).max() <= 1e-11 * fo
+        assert abs(f8[u] / fo - 1) <= tol and np.abs(g8[u] - go).max() <= tol * fo
+
+
+def test_i8x_dense_theta_dynamic_range():
+    # i8x scales V by the bound w_max exp(sum|theta|); for a dense theta the largest actual weight lies far
+    # below it and the library must re-run the row with the scale it observed (here sum|theta| ~ 40, 80).
+    # With energies spread over +-40 most weights fall below one unit of the 31-bit scale and round to
+    # zero coherently: the documented worst case K * tau / 2, i.e. K / 2^32 relative to the largest weight.
+    n, K = 100, 30000
+    spins, J = synthetic.block_ising(n, K, block=10, seed=4)
+    rng = np.random.default_rng(0)
+    nodes = np.arange(n)
+    with gml.Problem(spins=spins) as p:
+        for scale in (0.5, 1.0):
+            theta = rng.normal(scale=scale, size=(n, n))
+            f8, g8 = p.objgrad("RISE", nodes, theta, precision="i8x")
+            f64, g64 = p.objgrad("RISE", nodes, theta, precision="f64")
+            tol = K / 2.0**32
+            assert np.abs(f8 / f64 - 1).max() <= tol
+            assert (np.abs(g8 - g64) / np.abs(f64)[:, None]).max() <= tol
+            l8, _ = p.objgrad("logRISE", nodes, theta, precision="i8x")
+            l64, _ = p.objgrad("logRISE", nodes, theta, precision="f64")
+            assert np.abs(l8 - l64).max() <= tol
 
 
 @pytest.mark.parametrize("n", [512, 1024])
