@@ -125,8 +125,8 @@ def main():
             kn = [k for k in pm if ("k_fwd_i8" in k if dom == "fwd" else "k_bwd_i8" in k)][0]
             roofline["traffic"] = (2.0 * pm[kn]["FETCH_SIZE_KB"] + pm[kn]["WRITE_SIZE_KB"]) * 1024.0
             roofline["traffic_note"] = ("bytes per launch from profiles/r1_i8x_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KB); "
-                                        "algorithmic bytes per launch: %.3g" % ((K * n + 4.0 * K * nloc) if dom == "fwd"
-                                                                                else (4.0 * K * nloc + K * n)))
+                                        "algorithmic bytes per launch: %.3g (bit image K*n/8 + the 4 int8 limb planes of V, 4*K*n_loc)"
+                                        % (K * n / 8.0 + 4.0 * K * nloc))
     except Exception:
         pass
 

@@ -173,7 +173,7 @@ class Problem:
                                       _ptr(nodes), _ptr(theta), theta.shape[1], _ptr(f), _ptr(g)))
         return f, g
 
-    def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="f64", max_working=512, max_add=32,
+    def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="f64", max_working=512, max_add=64,
               verbose=0, hess_samples=0, out_ptr=None, raise_on_fail=True):
         L = lib()
         o = Opts()

@@ -186,7 +186,7 @@ extern "C" void gml_default_opts(gml_opts *o) {
     o->max_iter = 100;
     o->precision = GML_PREC_F64;
     o->max_working = 512;
-    o->max_add = 32;
+    o->max_add = 64;
     o->verbose = 0;
 }
 
@@ -921,7 +921,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     if (o.max_working < 32) o.max_working = 512;
     if (o.max_working > 512) o.max_working = 512;
     o.max_working = (int)round_up(o.max_working, 32);
-    if (o.max_add <= 0) o.max_add = 32;
+    if (o.max_add <= 0) o.max_add = 64;
     HIPCHK(hipSetDevice(p->device));
     gml_stats stl;
     std::memset(&stl, 0, sizeof stl);
@@ -937,7 +937,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     // configurations, up to all of them -- an inexact Hessian only costs iterations, and it costs the
     // most on the few ill-conditioned nodes that are still active at the end.
     const int64_t Kh_max = o.precision == GML_PREC_I8X ? gml::i8_hess_kmax(p->d) : p->d.Kp;
-    const int64_t Kh_base = o.hess_samples == 0 ? 131072 : (o.hess_samples < 0 ? p->d.Kp : (int64_t)o.hess_samples);
+    const int64_t Kh_base = o.hess_samples == 0 ? 32768 : (o.hess_samples < 0 ? p->d.Kp : (int64_t)o.hess_samples);
     int64_t Kh = p->d.Kp;
     double hscale = 1.0;
     auto set_kh = [&](int64_t nactive) {

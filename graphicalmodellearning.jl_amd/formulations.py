@@ -61,7 +61,7 @@ class HIP(GMLMethod):
     device: Optional[int] = None
     max_iter: int = 100
     max_working: int = 512
-    max_add: int = 32
+    max_add: int = 64
     hess_samples: int = 0  # Newton Hessians use the first hess_samples configurations (0 = 131072, <0 = all)
     verbose: int = 0
     distributed: bool = False

@@ -80,7 +80,7 @@ function solve_rows(samples::Array{T,2}, formulation, method::HIP, order::Int) w
         R = n1 - n0
         out = Array{Float64}(undef, P[], R)          # C row-major (R x P) == Julia (P x R)
         opts = Ref(GmlOpts(method.tol, method.max_iter, method.precision == :i8x ? GML_PREC_I8X : GML_PREC_F64,
-                           256, 32, 0, 0, 0, 0))
+                           512, 64, 0, 0, 0, 0))
         stats = Ref{GmlStats}()
         rc = ccall((:gml_learn, libgml), Cint,
                    (Ptr{Cvoid}, Cint, Cdouble, Ref{GmlOpts}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{GmlStats}),

@@ -52,10 +52,10 @@ typedef struct gml_opts {
     int32_t precision;   /* GML_PREC_*                                                      */
     int32_t max_working; /* cap on a node's Newton block (default = max = 512, multiple of 32); a
                             denser optimum is solved by cycling blocks (block Gauss-Seidel)    */
-    int32_t max_add;     /* new (violating) coordinates admitted per node per iteration (default 32) */
+    int32_t max_add;     /* new (violating) coordinates admitted per node per iteration (default 64) */
     int32_t verbose;     /* 0 silent, 1 per-iteration line on stderr                        */
     int32_t hess_samples; /* Newton Hessians use the first hess_samples configurations (< 0 = all;
-                            0 = adaptive: 131072 x (local nodes / nodes still active), so the
+                            0 = adaptive: 32768 x (local nodes / nodes still active), so the
                             last few nodes get all of them); the gradient always uses all     */
     int32_t reserved[2];
 } gml_opts;
