@@ -1,3 +1,4 @@
+"""Sweep of a solver option (here: hess_samples) on three workloads: python scripts/gpu_solver_sweep.py c4|c3|rple"""
 import sys, time, json, numpy as np
 sys.path.insert(0, '.')
 import gml_amd as gml
