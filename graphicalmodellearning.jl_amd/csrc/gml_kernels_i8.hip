@@ -49,7 +49,8 @@ struct I8Ws {
     int *pairs = nullptr;
     // working-set Hessian on the int8 cores
     int64_t hKh = 0, hbuilt = 0, hcap_elems = 0;
-    int8_t *Mt = nullptr, *Hq = nullptr; // bit masks of Xt (0x00 / 0xFF) and limb planes of the Hessian weights
+    int8_t *Mt = nullptr, *Hq = nullptr; // byte masks of Xt (0x00 / 0xFF) and limb planes of the Hessian weights
+    unsigned *Mb = nullptr;              // row-major bit image of Xt (blocked Hessian kernel), built on first use
     long long *hS = nullptr, *H64 = nullptr;
 };
 
@@ -796,17 +797,43 @@ __global__ __launch_bounds__(256) void k_hess_i8(const int8_t *__restrict__ Mt, 
 }
 
 
-// Blocked variant for working sets above 128 entries (mt > 4 tiles): a workgroup handles, for one row
-// and one k-chunk, the 2 x 4 block of 32x32 tile pairs (tile rows 2a, 2a+1; tile columns 4b..4b+3),
-// wave l again owning digit plane l.  Blocks entirely above the diagonal are never launched; tiles
-// above the diagonal inside a block are computed and dropped.
-__global__ __launch_bounds__(256) void k_hess_i8_blk(const int8_t *__restrict__ Mt, const int8_t *__restrict__ Hq,
-                                                     const int *__restrict__ F, const int *__restrict__ mt,
-                                                     const long long *__restrict__ hoff, int cap, int64_t Kh, int64_t Kpitch,
-                                                     int64_t kchunk, long long *__restrict__ H64) {
-    constexpr int AR = 64, BR = 128, ROWS = AR + BR + 4;
-    constexpr int NCH = (ROWS * 4 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) int8_t lds[2][(ROWS + 12) * 64];
+
+// H[i][j] = tau * (S - 2 T_ii - 2 T_jj + 4 T_ij) on the lower-triangular tiles
+// ------------------------------------------------------------------------------------------
+// Blocked working-set Hessian on the ROW-MAJOR bit image Mb ([Qp][Kp/64][2 h] dwords, same dword
+// format as Xtb): with byte masks (the form the single-block kernels above still use) it was L2 -> LDS bound (12.5 KB per 64-sample step
+// for a 64 x 128 block, 0.8 POP/s); as bits the same rows are 1.75 KB and the kernel runs twice as fast.  Per group of 8 steps (512 samples) the
+// workgroup DMAs 64 + 128 gathered rows x 64 B of bits and 4 x 512 B of weight limbs into a 3-stage ring.
+// Per step the four waves first expand the operands cooperatively into LDS, in MFMA fragment layout --
+// wave w expands B tile w (0/1 bytes, both K-halves) and A-mask fragment (i = w >> 1, t = w & 1)
+// (0x00/0xFF bytes) -- then every wave runs the 2 x 4 tile block for ITS weight limb l = wave:
+//   acc[i][j] += (mask_i & h_l) * b_j  =  sum_k h_lk b_ik b_jk        (one barrier per step)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_bits_rows(const int8_t *__restrict__ Xt, int64_t Kp, int64_t nkk,
+                                                        unsigned *__restrict__ Mb) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; // (kt, h)
+    const int64_t c = blockIdx.y;
+    if (j >= 2 * nkk) return;
+    const int8_t *row = Xt + c * Kp + 64 * (j >> 1) + 16 * (j & 1);
+    unsigned v = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (row[32 * (e >> 2) + 4 * (e & 3) + b] < 0) v |= 1u << (e + 8 * b);
+    Mb[c * 2 * nkk + j] = v;
+}
+
+__global__ __launch_bounds__(256, 2) void k_hess_bits_blk(const unsigned *__restrict__ Mb, const int8_t *__restrict__ Hq,
+                                                          const int *__restrict__ F, const int *__restrict__ mt,
+                                                          const long long *__restrict__ hoff, int cap, int64_t Kh,
+                                                          int64_t Kp, int64_t Hpitch, int64_t kchunk /* multiple of 512 */,
+                                                          long long *__restrict__ H64) {
+    constexpr int AR = 64, BR = 128;
+    constexpr int STAGE = (AR + BR) * 64 + 4 * 512, NPIECE = STAGE / 1024, NSG = 3; // 14 pieces
+    constexpr int EBUF = (4 + 8) * 1024;                                              // expanded operands of one step
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    int8_t *eb = lds + NSG * STAGE;
     const int r = blockIdx.z;
     const int m = mt[r];
     if (m <= 4) return; // handled by the single-block kernels
@@ -820,35 +847,45 @@ __global__ __launch_bounds__(256) void k_hess_i8_blk(const int8_t *__restrict__ 
         if (2 * a >= m) return;
     }
     if (2 * a >= m) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 31, h = lane >> 5;
     const int64_t kb = (int64_t)blockIdx.x * kchunk;
     if (kb >= Kh) return;
     const int64_t ke = (kb + kchunk < Kh) ? kb + kchunk : Kh;
+    const int ngrp = (int)((ke - kb + 511) / 512);
     const int tile = r >> 5, rl = r & 31;
     const int *Fr = F + (int64_t)r * cap;
     const int mrows = m * 32;
+    const int64_t nkk = Kp >> 6;
 
-    const int8_t *src[NCH];
-    int dst[NCH];
-    bool have[NCH];
+    // DMA sources of this wave's pieces (wave, wave + 4, wave + 8, and wave + 12 for waves 0, 1); per group: + 64 B
+    // (bits: 8 steps x 8 B) resp. + 512 B (limb bytes)
+    const bool four = wave < NPIECE - 12;
+    const int8_t *src[4];
+    int adv[4];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const int q = tid + 256 * j, row = q >> 2, slot = q & 3;
-        have[j] = row < ROWS;
-        if (row < AR) {
-            int fr = 2 * a * 32 + row;
+    for (int j = 0; j < 4; ++j) {
+        const int pc = wave + 4 * j;
+        if (pc < 12) {
+            const int row = pc * 16 + (lane >> 2); // 0..191: A rows then B rows
+            int fr = row < AR ? 2 * a * 32 + row : 4 * b * 32 + (row - AR);
             if (fr >= mrows) fr = 0;
-            src[j] = Mt + (int64_t)Fr[fr] * Kpitch + slot * 16;
-        } else if (row < AR + BR) {
-            int fr = 4 * b * 32 + (row - AR);
-            if (fr >= mrows) fr = 0;
-            src[j] = Mt + (int64_t)Fr[fr] * Kpitch + slot * 16;
+            const int slot = (lane & 3) ^ ((row >> 2) & 3); // swizzle on the source (LDS side is linear)
+            src[j] = reinterpret_cast<const int8_t *>(Mb) + ((int64_t)Fr[fr] * nkk + (kb >> 6)) * 8 + slot * 16;
+            adv[j] = 64;
         } else {
-            const int l = row - AR - BR < 4 ? row - AR - BR : 0;
-            src[j] = Hq + ((int64_t)tile * 128 + l * 32 + rl) * Kpitch + slot * 16;
+            const int l = 2 * (pc < NPIECE ? pc - 12 : 0) + (lane >> 5);
+            src[j] = Hq + ((int64_t)tile * 128 + l * 32 + rl) * Hpitch + kb + (lane & 31) * 16;
+            adv[j] = 512;
         }
-        dst[j] = lds_off(row, slot);
     }
+    auto issue = [&](int g) {
+        int8_t *sb = lds + (g % NSG) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (int64_t)g * adv[j]), (lptr_t)(sb + (wave + 4 * j) * 1024), 16, 0, 0);
+        if (four)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[3] + (int64_t)g * adv[3]), (lptr_t)(sb + (wave + 12) * 1024), 16, 0, 0);
+    };
     v16i acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -856,43 +893,57 @@ __global__ __launch_bounds__(256) void k_hess_i8_blk(const int8_t *__restrict__ 
         for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0;
-    v4i rg[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-        if (have[j]) rg[j] = *reinterpret_cast<const v4i *>(src[j] + kb);
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-        if (have[j]) *reinterpret_cast<v4i *>(&lds[0][dst[j]]) = rg[j];
-    __syncthreads();
-    int it = 0;
-    for (int64_t kk = kb; kk < ke; kk += 64, ++it) {
-        const int cur = it & 1;
-        const bool more = kk + 64 < ke;
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < NCH; ++j)
-                if (have[j]) rg[j] = *reinterpret_cast<const v4i *>(src[j] + kk + 64);
+
+    // LDS offsets (stage-relative) of the dwords this lane expands: its row of B tile `wave` and of A tile wave >> 1
+    const int rowB = AR + wave * 32 + lr, rowA = (wave >> 1) * 32 + lr;
+    const int swB = (rowB >> 2) & 3, swA = (rowA >> 2) & 3;
+    issue(0);
+    if (ngrp > 1) issue(1);
+    for (int g = 0; g < ngrp; ++g) {
+        // this wave's pieces of stage g have landed (stage g + 1 may still be in flight), then every wave's
+        if (g + 1 < ngrp) {
+            if (four) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < ngrp) issue(g + 2);
+        const int8_t *st = lds + (g % NSG) * STAGE;
+        const int nsteps = (int)((ke - kb - (int64_t)g * 512 + 63) / 64) < 8 ? (int)((ke - kb - (int64_t)g * 512 + 63) / 64) : 8;
+        for (int ks = 0; ks < nsteps; ++ks) {
+            int8_t *e = eb + ((g * 8 + ks) & 1) * EBUF;
+            // cooperative expansion of step ks: logical 16-byte slot ks >> 1 of the row, dword (ks & 1) * 2 + h
+            {
+                const unsigned vB = *reinterpret_cast<const unsigned *>(st + rowB * 64 + ((((ks >> 1) ^ swB)) << 4) + (((ks & 1) * 2 + h) << 2));
+                const unsigned vA = *reinterpret_cast<const unsigned *>(st + rowA * 64 + ((((ks >> 1) ^ swA)) << 4) + (((ks & 1) * 2 + h) << 2));
+                v4i f0, f1, fm;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int slot = 2 * t + h;
-            const v4i mg = *reinterpret_cast<const v4i *>(&lds[cur][lds_off(AR + BR + wave, slot)]);
-            v4i fa[2], fb[4];
+                for (int d = 0; d < 4; ++d) {
+                    f0[d] = (int)((vB >> d) & 0x01010101u);
+                    f1[d] = (int)((vB >> (4 + d)) & 0x01010101u);
+                    fm[d] = (int)(((vA >> (4 * (wave & 1) + d)) & 0x01010101u) * 0xFFu);
+                }
+                *reinterpret_cast<v4i *>(e + 4096 + (wave * 2 + 0) * 1024 + lane * 16) = f0;
+                *reinterpret_cast<v4i *>(e + 4096 + (wave * 2 + 1) * 1024 + lane * 16) = f1;
+                *reinterpret_cast<v4i *>(e + wave * 1024 + lane * 16) = fm; // fragment (i = wave >> 1, t = wave & 1)
+            }
+            __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const v4i *>(&lds[cur][lds_off(i * 32 + lr, slot)]) & mg;
+            for (int t = 0; t < 2; ++t) {
+                const v4i mg = *reinterpret_cast<const v4i *>(st + (AR + BR) * 64 + wave * 512 + ks * 64 + (2 * t + h) * 16);
+                v4i fa[2], fb[4];
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn) fb[jn] = *reinterpret_cast<const v4i *>(&lds[cur][lds_off(AR + jn * 32 + lr, slot)]);
+                for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const v4i *>(e + (i * 2 + t) * 1024 + lane * 16) & mg;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int jn = 0; jn < 4; ++jn) fb[jn] = *reinterpret_cast<const v4i *>(e + 4096 + (jn * 2 + t) * 1024 + lane * 16);
 #pragma unroll
-                for (int jn = 0; jn < 4; ++jn) acc[i][jn] = MFMA_I8(fa[i], fb[jn], acc[i][jn]);
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 4; ++jn) acc[i][jn] = MFMA_I8(fa[i], fb[jn], acc[i][jn]);
+            }
         }
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < NCH; ++j)
-                if (have[j]) *reinterpret_cast<v4i *>(&lds[cur ^ 1][dst[j]]) = rg[j];
-        }
-        __syncthreads();
     }
     long long *Hr = H64 + hoff[r];
     const int hp = 32 * m;
@@ -905,14 +956,13 @@ __global__ __launch_bounds__(256) void k_hess_i8_blk(const int8_t *__restrict__ 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int ii = ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, jj = tj * 32 + lr;
-                    const long long v = -((long long)acc[i][jn][e]) * (1ll << (8 * wave));
+                    const long long v = ((long long)acc[i][jn][e]) * (1ll << (8 * wave));
                     if (v != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&Hr[(int64_t)ii * hp + jj]), (unsigned long long)v);
                 }
             }
         }
 }
 
-// H[i][j] = tau * (S - 2 T_ii - 2 T_jj + 4 T_ij) on the lower-triangular tiles
 __global__ __launch_bounds__(256) void k_hess_i8_fin(const long long *__restrict__ H64, const long long *__restrict__ hS,
                                                      const double *__restrict__ tau, const int *__restrict__ mt,
                                                      const long long *__restrict__ hoff, double *__restrict__ H) {
@@ -951,7 +1001,7 @@ void i8_free(void *p) {
     I8Ws *w = static_cast<I8Ws *>(p);
     if (!w) return;
     void *ptrs[] = {w->Tq, w->Vq, w->Gacc, w->sigma, w->tau, w->invtau, w->qconst, w->csum, w->asum, w->pairs, w->mmax, w->tauovr,
-                    w->Mt, w->Hq, w->hS, w->H64};
+                    w->Mt, w->Hq, w->hS, w->H64, w->Mb};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete w;
@@ -1063,8 +1113,17 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF
         int64_t kc2 = (Kh + ns2 - 1) / ns2;
         kc2 = (kc2 + 63) / 64 * 64;
         ns2 = (int)((Kh + kc2 - 1) / kc2);
-        hipLaunchKernelGGL(k_hess_i8_blk, dim3((unsigned)ns2, (unsigned)nblk, (unsigned)R), dim3(256), 0, st, w->Mt, w->Hq, dF, dMt,
-                           dHoff, cap, Kh, pitch, kc2, w->H64);
+        if (!w->Mb) {
+            I8CHK(hipMalloc(&w->Mb, (size_t)d.Qp * (d.Kp / 8)));
+            hipLaunchKernelGGL(k_pack_bits_rows, dim3((unsigned)((2 * (d.Kp / 64) + 255) / 256), (unsigned)d.Qp), dim3(256), 0, st,
+                               d.Xt, d.Kp, d.Kp / 64, w->Mb);
+        }
+        kc2 = (kc2 + 511) / 512 * 512;
+        ns2 = (int)((Kh + kc2 - 1) / kc2);
+        constexpr int shmem = 3 * ((64 + 128) * 64 + 4 * 512) + 2 * 12 * 1024;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hess_bits_blk), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+        hipLaunchKernelGGL(k_hess_bits_blk, dim3((unsigned)ns2, (unsigned)nblk, (unsigned)R), dim3(256), shmem, st, w->Mb, w->Hq, dF,
+                           dMt, dHoff, cap, Kh, d.Kp, pitch, kc2, w->H64);
     }
     hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64,
                        w->hS, w->tau, dMt, dHoff, dH);

@@ -283,6 +283,45 @@ def _kkt_from_oracle(spins, out, nodes, lam):
     return worst
 
 
+def test_headline_config_full_size_properties():
+    # BASELINE headline config at FULL size (n = 1024 spins, 1e6 configurations, 16-spin blocks), sampled on
+    # the device so that no 1 GB host matrix is built.  The oracle cannot reach this size; size-independent
+    # properties instead: (1) node-sharded handles evaluate bit-identically and learn the same rows, (2) the two
+    # device paths (exact int8 limbs / FP64 MFMA) agree, (3) the solution's KKT residual is certified by the
+    # other path, (4) the learned model is the generating one up to sampling noise, (5) two runs are identical.
+    n, K, blk = 1024, 1000000, 16
+    rng = np.random.default_rng(7)
+    J = np.zeros((n, n))
+    for b in range(0, n, blk):
+        A = np.triu(rng.uniform(0.15, 0.4, (blk, blk)) * rng.choice([-1.0, 1.0], (blk, blk)) * (rng.random((blk, blk)) < 0.3), 1)
+        J[b:b + blk, b:b + blk] = A + A.T
+    J[np.arange(n), np.arange(n)] = rng.uniform(-0.1, 0.1, n)
+    some = np.array([0, 17, 511, 1023])
+    with gml.Problem(model=J, num_samples=K, seed=11) as p:
+        out, kkt, st = p.learn("RISE", 0.4, tol=1e-9, precision="i8x")
+        out2, _, st2 = p.learn("RISE", 0.4, tol=1e-9, precision="i8x")
+        f8, g8 = p.objgrad("RISE", some, out[some], precision="i8x")
+        f64, g64 = p.objgrad("RISE", some, out[some], precision="f64")
+        lam = st["lambda_"]
+    assert st["not_converged"] == 0 and kkt.max() <= 1e-9
+    assert np.array_equal(out, out2) and st["passes"] == st2["passes"]                      # (5)
+    assert np.abs(f8 / f64 - 1).max() <= 3e-8 and np.abs(g8 - g64).max() <= 3e-8            # (2)
+    for a, u in enumerate(some):                                                            # (3)
+        x, g = out[u], g64[a]
+        pg = np.where(x > 0, g + lam, np.where(x < 0, g - lam, np.sign(g) * np.maximum(np.abs(g) - lam, 0)))
+        pg[u] = g[u]  # the field slot is not penalised
+        assert np.abs(pg).max() <= 5e-8
+    sym = 0.5 * (out + out.T)
+    assert np.abs(sym - J).max() <= 0.05 and np.abs(sym[J != 0] - J[J != 0]).max() <= 0.05   # (4)
+    with gml.Problem(model=J, num_samples=K, seed=11, node_range=(256, 384)) as p:           # (1)
+        part, _, _ = p.learn("RISE", 0.4, tol=1e-9, precision="i8x")
+        fp, gp = p.objgrad("RISE", np.array([300]), out[[300]], precision="i8x")
+    with gml.Problem(model=J, num_samples=K, seed=11, node_range=(0, 512)) as p:
+        fq, gq = p.objgrad("RISE", np.array([300]), out[[300]], precision="i8x")
+    assert np.abs(part - out[256:384]).max() <= 2e-8  # same optimum (the Newton trajectories differ: adaptive Hessian budget)
+    assert np.array_equal(fp, fq) and np.array_equal(gp, gq)
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_dense_solutions_large_working_sets(prec):
     # small regulariser -> hundreds of non-zeros per node: exercises the blocked int8 Hessian (> 128
