@@ -372,16 +372,20 @@ void launch_hess_f64(const DevProblem &P, const double *V, const int8_t *Vq, con
 // ------------------------------------------------------------------------------------------
 // Batched Newton solve on the device: for every row r, A d = -pg with
 //   A = s1[r] * H_r  -  s2 * gF gF^T        (s2 = 1 for logRISE: Hess log Z = Hess Z / Z - g g^T)
-// H_r is row r's ragged block (lower 32x32 tiles valid, pitch hp).  Left-looking Cholesky in place:
-// L^T is written into the strict upper triangle (U[k][i] = L[i][k]: column steps read rows of U,
-// coalesced), the diagonal of L lives in LDS, the lower triangle keeps A for a ridge restart.
-// One workgroup per row.  Sdiag[r] = A[m-1][m-1] (the constant column, the Hessian's diagonal scale).
+// H_r is row r's ragged block (lower 32x32 tiles valid, pitch hp).  Panel-blocked left-looking Cholesky
+// in place, one workgroup per row: for each panel of 32 columns every thread owns one matrix row and
+// keeps its 32 panel entries in registers -- 32 FMAs per loaded element of the factor (the previous
+// panels' rows of U = L^T, staged 32 x 32 at a time in LDS) -- wave 0 factors the 32 x 32 diagonal block
+// in LDS, then every row finishes its triangular solve against it.  L^T is written into the strict upper
+// triangle (U[k][i] = L[i][k]: coalesced row reads), the diagonal of L lives in LDS, the lower triangle
+// keeps A for a ridge restart.  Sdiag[r] = A[m-1][m-1] (the constant column, the Hessian's diagonal scale).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_newton_solve(double *__restrict__ H, const long long *__restrict__ hoff,
                                                       const int *__restrict__ mt, const int *__restrict__ msz,
                                                       const double *__restrict__ s1, double s2,
                                                       const double *__restrict__ gF, const double *__restrict__ pgF,
                                                       int cap, double *__restrict__ dout, double *__restrict__ Sdiag) {
+    constexpr int PW = 32;
     const int r = blockIdx.x;
     const int m = msz[r];
     if (m == 0) return;
@@ -389,8 +393,8 @@ __global__ __launch_bounds__(256) void k_newton_solve(double *__restrict__ H, co
     double *A = H + hoff[r];
     const double sc = s1[r];
     const double *g = gF + (int64_t)r * cap, *pg = pgF + (int64_t)r * cap;
-    extern __shared__ double sm[]; // dg[cap] | y[cap] | gg[cap]
-    double *dg = sm, *y = sm + cap, *gg = sm + 2 * cap;
+    extern __shared__ double sm[]; // dg[cap] | y[cap] | gg[cap] | Ul[32][33] | D[32][33]
+    double *dg = sm, *y = sm + cap, *gg = sm + 2 * cap, *Ul = sm + 3 * cap, *D = Ul + PW * (PW + 1);
     __shared__ int bad;
     const int tid = threadIdx.x;
     for (int i = tid; i < m; i += 256) gg[i] = s2 != 0.0 ? g[i] : 0.0;
@@ -408,27 +412,88 @@ __global__ __launch_bounds__(256) void k_newton_solve(double *__restrict__ H, co
     for (int attempt = 0; attempt < 10; ++attempt) {
         if (tid == 0) bad = 0;
         __syncthreads();
-        for (int j = 0; j < m; ++j) {
-            // rows i = j + tid, j + tid + 256, ... of column j
-            double v[4];
-            int cnt = 0;
-            for (int i = j + tid; i < m; i += 256, ++cnt) {
-                double acc = a_at(i, j) + (i == j ? ridge : 0.0);
-                for (int k = 0; k < j; ++k) acc -= A[(int64_t)k * hp + i] * A[(int64_t)k * hp + j];
-                v[cnt & 3] = acc;
+        for (int c0 = 0; c0 < m && !bad; c0 += PW) {
+            const int pw = m - c0 < PW ? m - c0 : PW;
+            // the diagonal rows (c0 .. c0+pw-1) belong to the first chunk's threads 0 .. pw-1
+            for (int rb = c0; rb < m; rb += 256) {
+                const int i = rb + tid;
+                const bool valid = i < m;
+                double acc[PW];
+#pragma unroll
+                for (int c = 0; c < PW; ++c)
+                    acc[c] = (valid && c < pw && c0 + c <= i) ? a_at(i, c0 + c) + (i == c0 + c ? ridge : 0.0) : 0.0;
+                for (int kb = 0; kb < c0; kb += PW) {
+                    __syncthreads(); // Ul free
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int e = tid + 256 * q, kk = e >> 5, c = e & 31;
+                        Ul[kk * (PW + 1) + c] = c < pw ? A[(int64_t)(kb + kk) * hp + c0 + c] : 0.0;
+                    }
+                    __syncthreads();
+                    if (valid) {
+                        for (int kk = 0; kk < PW; ++kk) {
+                            const double u = A[(int64_t)(kb + kk) * hp + i];
+#pragma unroll
+                            for (int c = 0; c < PW; ++c) acc[c] = fma(-u, Ul[kk * (PW + 1) + c], acc[c]);
+                        }
+                    }
+                }
+                if (rb == c0) {
+                    // factor the diagonal block: rows c0+t, t < pw (threads of wave 0)
+                    __syncthreads();
+                    if (tid < PW) {
+#pragma unroll
+                        for (int c = 0; c < PW; ++c) D[tid * (PW + 1) + c] = acc[c];
+                    }
+                    __syncthreads();
+                    if (tid < 64) { // one wave, lanes >= pw idle
+                        const int t = tid;
+                        for (int c = 0; c < pw; ++c) {
+                            double x = 0.0;
+                            if (t >= c && t < pw) {
+                                x = D[t * (PW + 1) + c];
+                                for (int k = 0; k < c; ++k) x -= D[t * (PW + 1) + k] * D[c * (PW + 1) + k];
+                            }
+                            const double piv = __shfl(x, c); // row c's value = L[c][c]^2
+                            if (!(piv > 1e-300 * dmax) || !isfinite(piv)) {
+                                if (t == 0) bad = 1;
+                                break;
+                            }
+                            const double dgc = sqrt(piv);
+                            if (t == c) {
+                                D[t * (PW + 1) + c] = dgc;
+                                dg[c0 + c] = dgc;
+                            } else if (t > c && t < pw) {
+                                D[t * (PW + 1) + c] = x / dgc;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (bad) break;
+                }
+                if (valid) {
+                    if (i >= c0 + pw) { // triangular solve of this row against the diagonal block
+#pragma unroll
+                        for (int c = 0; c < PW; ++c) {
+                            if (c < pw) {
+                                double x = acc[c];
+#pragma unroll
+                                for (int k = 0; k < c; ++k) x = fma(-acc[k], D[c * (PW + 1) + k], x);
+                                acc[c] = x / D[c * (PW + 1) + c];
+                            }
+                        }
+                    } else { // a diagonal row: its entries are in D
+#pragma unroll
+                        for (int c = 0; c < PW; ++c) acc[c] = D[(i - c0) * (PW + 1) + c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < PW; ++c)
+                        if (c < pw && i > c0 + c) A[(int64_t)(c0 + c) * hp + i] = acc[c]; // U[c0+c][i] = L[i][c0+c]
+                }
             }
-            if (tid == 0) {
-                if (!(v[0] > 1e-300 * dmax) || !isfinite(v[0])) bad = 1;
-                dg[j] = sqrt(fmax(v[0], 1e-300));
-            }
-            __syncthreads();
-            if (bad) break;
-            const double inv = 1.0 / dg[j];
-            cnt = 0;
-            for (int i = j + tid; i < m; i += 256, ++cnt)
-                if (i > j) A[(int64_t)j * hp + i] = v[cnt & 3] * inv; // U[j][i] = L[i][j]
             __syncthreads();
         }
+        __syncthreads();
         if (!bad) break;
         __syncthreads();
         ridge = ridge == 0.0 ? 1e-12 * fmax(dmax, 1e-300) : ridge * 100.0;
@@ -456,7 +521,7 @@ __global__ __launch_bounds__(256) void k_newton_solve(double *__restrict__ H, co
 
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
                          const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st) {
-    hipLaunchKernelGGL(k_newton_solve, dim3((unsigned)R), dim3(256), sizeof(double) * 3 * cap, st, H, hoff, mt, msz, s1, s2, gF,
+    hipLaunchKernelGGL(k_newton_solve, dim3((unsigned)R), dim3(256), sizeof(double) * (3 * cap + 2 * 32 * 33), st, H, hoff, mt, msz, s1, s2, gF,
                        pgF, cap, dout, Sdiag);
 }
 
