@@ -308,6 +308,11 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lr = lane & 31, h = lane >> 5;
     if (tid < 64) etab[tid] = exp2((double)tid / 64.0);
+    if (FORM == 2 && tid < 64) { // log table for RPLE: c_j = 1 + (j + 1/2)/64 -> 1/c_j, log c_j
+        const double cj = 1.0 + ((double)tid + 0.5) / 64.0;
+        etab[64 + tid] = 1.0 / cj;
+        etab[128 + tid] = log(cj);
+    }
 
     // XCD-aware L2 blocking.  Blocks b and b+8 share an XCD (round-robin dispatch); XCD x owns the
     // sample tiles st = 8*i + x.  Within an XCD: groups of TG node tiles (outer), sample tiles
@@ -410,7 +415,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     double fp = 0.0;
     int mx = 0;
     const int64_t kw = k0 + wave * 64; // first sample of this wave
-    const double sgq0 = sg * q0, sg2 = -2.0 * sg, wkit = wuni * it;
+    const double sgq0 = sg * q0, wkit = wuni * it;
+    double sg2 = -2.0 * sg;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -418,6 +424,10 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
             const int64_t kk = kw + i * 32 + 8 * g + 4 * h;
             const unsigned sw = swp[i][g];
             unsigned dj[4];
+            if (FORM == 2) { // RPLE: gate each 4-sample group on the previous one (its longer arithmetic otherwise
+                             // interleaves across groups and spills); pure arithmetic floats across sched_barriers
+                asm volatile("" : "+v"(sg2), "+v"(fp));
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int e = 4 * g + j;
@@ -440,14 +450,29 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                 const unsigned sbyte = sw >> (8 * j);               // s_u^k: 0x01, 0xFF, or 0 for a padding sample
                 const bool neg = (sbyte & 0x80u) != 0;
                 int vq;
-                if (FORM == 2) { // RPLE (:317): V = -2 w s / (1 + exp(2E)), E = s * Ea
+                if (FORM == 2) { // RPLE (:317): f = w log(1 + exp(-2E)), V = -2 w s / (1 + exp(2E)), E = s * Ea
                     const double wk0 = wuni > 0.0 ? (kk + j < Kreal ? wuni : 0.0) : w[kk + j];
-                    const double E = neg ? -Ea : Ea;
-                    const double ex = exp_tab(2.0 * E, etab);
-                    const int mag = (int)rint(2.0 * wk0 * it / (1.0 + ex));
+                    const double E2 = neg ? -2.0 * Ea : 2.0 * Ea;
+                    const double u = exp_tab(-fabs(E2), etab); // in (0, 1]
+                    const double opu = 1.0 + u;
+                    double rc = __builtin_amdgcn_rcp(opu); // 1 / (1 + u), two Newton steps
+                    rc = fma(fma(-opu, rc, 1.0), rc, rc);
+                    rc = fma(fma(-opu, rc, 1.0), rc, rc);
+                    const double sig = E2 >= 0.0 ? u * rc : rc; // 1 / (1 + exp(2E))
+                    const int mag = __double2loint(fma(2.0 * wk0 * it, sig, 6755399441055744.0));
                     vq = neg ? mag : -mag;
-                    const double tt = -2.0 * E;
-                    fp += wk0 * (tt > 0 ? tt + log1p(exp(-tt)) : log1p(exp(tt)));
+                    // log(1 + u), 1 + u in (1, 2]: table of log c_j on 64 intervals + log1p of the residual
+                    int jt = (int)(u * 64.0);
+                    jt = jt > 63 ? 63 : jt;
+                    const double r1 = fma(opu, etab[64 + jt], -1.0); // |r1| <= 1/128
+                    double lp = fma(r1, 1.0 / 7.0, -1.0 / 6.0);
+                    lp = fma(lp, r1, 0.2);
+                    lp = fma(lp, r1, -0.25);
+                    lp = fma(lp, r1, 1.0 / 3.0);
+                    lp = fma(lp, r1, -0.5);
+                    lp = fma(lp, r1, 1.0);
+                    const double l1p = fma(lp, r1, etab[128 + jt]);
+                    fp += wk0 * ((E2 < 0.0 ? -E2 : 0.0) + l1p);
                 } else { // RISE (:196,:204) / logRISE Z (:279): V = -w exp(-E) s
                     // x = -s E: flip the sign of Ea unless s = -1
                     const double x = __hiloint2double(__double2hiint(Ea) ^ (int)(((sbyte & 0x80u) ^ 0x80u) << 24), __double2loint(Ea));
@@ -1143,7 +1168,7 @@ int i8_limbs_forward() {
 template <int LF, int FORM, bool WANTF>
 static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, int ngroups, double *dF, hipStream_t st) {
     constexpr int STAGE = (2 + 2 * LF) * 1024, STG = 4 * LB * 32 * (32 * 2 + 16);
-    constexpr int shmem = (4 * STAGE > STG ? 4 * STAGE : STG) + 512; // ring (aliased by the epilogue staging) + exp table
+    constexpr int shmem = (4 * STAGE > STG ? 4 * STAGE : STG) + 512 + 1024; // ring (aliased by the epilogue staging) + exp, log tables
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
     const int ntk = (int)(d.Kp / 256);
