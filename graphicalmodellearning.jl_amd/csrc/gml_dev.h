@@ -32,15 +32,22 @@ void launch_transpose_i8(const int8_t *src, int64_t rows, int64_t cols, int64_t 
                          int8_t *dst, int64_t ld_dst, hipStream_t st);
 void launch_pack_bits(const DevProblem &d, hipStream_t st); // Xt -> Xb, Xtb
 int64_t xtb_bytes(const DevProblem &d);
-
-// Byte offset of limb l of V[r][k] in the int8 limb image Vq of the exact fixed-point pass:
-// images [node tile r/32][k/64] of [4 limbs x 32 rows][64 samples], contiguous (8 KB each).
-__host__ __device__ inline int64_t vq_off(int64_t r, int l, int64_t k, int64_t Kp) {
-    return ((((r >> 5) * (Kp >> 6) + (k >> 6)) * 4 + l) * 32 + (r & 31)) * 64 + (k & 63);
-}
 void launch_expand_features(const int8_t *St, int64_t n, int64_t K, int64_t Kp,
                             const int32_t *keys, int order, int64_t Q, int8_t *Xt,
                             hipStream_t st);
+
+// Byte offset of limb l of V[r][k] in the int8 limb image Vq of the exact fixed-point pass:
+// images [node tile r/32][k/64] of [4 limbs x 32 rows][64 B], contiguous (8 KB each).  Within a row the
+// 64 samples of the step are PERMUTED: the forward epilogue's lane (node, half h) owns the samples
+// 32 i + 8 g + 4 h + j (i < 2, g < 4, j < 4) and stores them at byte 32 h + 16 i + 4 g + j, so that its
+// 32 bytes per limb are contiguous and go out as two 16-byte stores without an LDS transpose.  The
+// feature-major bit image (k_pack_bits_t) uses the same order, so the backward GEMM contracts
+// position against position.
+__host__ __device__ inline int vq_pos(int s) { return ((s >> 2) & 1) * 32 + (s >> 5) * 16 + ((s >> 3) & 3) * 4 + (s & 3); }
+__host__ __device__ inline int vq_sample(int p) { return ((p >> 4) & 1) * 32 + ((p >> 2) & 3) * 8 + (p >> 5) * 4 + (p & 3); }
+__host__ __device__ inline int64_t vq_off(int64_t r, int l, int64_t k, int64_t Kp) {
+    return ((((r >> 5) * (Kp >> 6) + (k >> 6)) * 4 + l) * 32 + (r & 31)) * 64 + vq_pos((int)(k & 63));
+}
 
 // ---- FP64 path -----------------------------------------------------------------------------
 // Theta [Rp][Qp] (internal column layout, masked slots zero), rowcol[r] = u (row of Xt
@@ -55,9 +62,7 @@ void launch_bwd_f64(const DevProblem &P, const double *V, const int *groups, int
                     hipStream_t st);
 // H [Rp][cap][cap] += sum_k h_rk Xt[F_ri][k] Xt[F_rj][k], lower-triangular 32x32 tiles only.
 // F [Rp][cap] column ids (padding = Qp-1), mt[r] = number of 32-tiles used by row r.
-// The weights come either from V (FP64 pass) or, when V == NULL, from the int8 limb planes Vq
-// with per-row step tau (exact fixed-point pass).
-void launch_hess_f64(const DevProblem &P, const double *V, const int8_t *Vq, const double *tau,
+void launch_hess_f64(const DevProblem &P, const double *V,
                      const int *rowcol, const int *F, const int *mt, const long long *hoff, int R, int cap, int form,
                      int64_t Kh, double *H, hipStream_t st);
 // H is ragged: row r's block starts at hoff[r] and is (32 mt[r]) x (32 mt[r]) with that pitch.

@@ -839,14 +839,9 @@ static int device_newton(gml_problem *p, const RowSet &rs, const std::vector<int
         else if (hrc != GML_EUNSUPPORTED) return fail(hrc, "%s", err.c_str());
     }
     if (!done) {
-        const int8_t *Vq = nullptr;
-        const double *tau = nullptr;
-        if (precision == GML_PREC_I8X) { // a working set above 128 entries: FP64 kernel on the limb planes
-            gml::i8_get_v(p->i8ws, &Vq, &tau);
-            if (!Vq) return fail(GML_EINVAL, "no int8 pass has run on this handle");
-        }
-        launch_hess_f64(p->d, Vq ? nullptr : p->dV, Vq, tau, p->dMt + R, p->dFidx, p->dMt, p->dHoff, (int)R, cap, form, Kh,
-                        p->dH, st);
+        if (precision == GML_PREC_I8X)
+            return fail(GML_EUNSUPPORTED, "a Newton block above 512 entries (the solver caps max_working at 512)");
+        launch_hess_f64(p->d, p->dV, p->dMt + R, p->dFidx, p->dMt, p->dHoff, (int)R, cap, form, Kh, p->dH, st);
     }
     HIPCHK(hipGetLastError());
     // Newton systems solved in place on the device; only the directions come back

@@ -258,8 +258,6 @@ void launch_bwd_f64(const DevProblem &P, const double *V, const int *groups, int
 // One wave per (row, tile pair, k-split); grid = (ceil(nsplit/4), maxpairs, R).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
-                                                  const int8_t *__restrict__ Vq,
-                                                  const double *__restrict__ tau,
                                                   const int8_t *__restrict__ Xt,
                                                   const double *__restrict__ w,
                                                   const int *__restrict__ rowcol,
@@ -290,9 +288,7 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
     for (int mi = 0; mi < 2; ++mi) arow[mi] = Xt + (int64_t)Fr[ti * 32 + 16 * mi + li] * Kp + 8 * q;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) brow[ni] = Xt + (int64_t)Fr[tj * 32 + 16 * ni + li] * Kp + 8 * q;
-    const double *vrow = V ? V + (int64_t)r * Kp + 8 * q : nullptr;
-    // int8-limb V of the exact fixed-point pass (image layout: vq_off)
-    const double tr = Vq ? tau[r] : 0.0;
+    const double *vrow = V + (int64_t)r * Kp + 8 * q;
     const int8_t *srow = Xt + (int64_t)rc * Kp + 8 * q;
     const double *wrow = w + 8 * q;
 
@@ -304,18 +300,7 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
 
     for (int64_t t0 = kb; t0 < ke; t0 += 32) {
         double h[8], sg[8], a[2][8], b[2][8];
-        if (vrow) {
-            load8d(vrow + t0, h);
-        } else {
-            double l0[8], l1[8], l2[8], l3[8];
-            const int8_t *vq8 = Vq + vq_off(r, 0, t0 + 8 * q, Kp);
-            load8b(vq8, l0);
-            load8b(vq8 + 32 * 64, l1);
-            load8b(vq8 + 64 * 64, l2);
-            load8b(vq8 + 96 * 64, l3);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) h[s] = tr * (((l3[s] * 256.0 + l2[s]) * 256.0 + l1[s]) * 256.0 + l0[s]);
-        }
+        load8d(vrow + t0, h);
         load8b(srow + t0, sg);
 #pragma unroll
         for (int s = 0; s < 8; ++s) h[s] *= -sg[s]; // |V| = w |phi'|
@@ -351,7 +336,7 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
             }
 }
 
-void launch_hess_f64(const DevProblem &P, const double *V, const int8_t *Vq, const double *tau,
+void launch_hess_f64(const DevProblem &P, const double *V,
                      const int *rowcol, const int *F, const int *mt, const long long *hoff, int R, int cap, int form,
                      int64_t Kh, double *H, hipStream_t st) {
     const int tiles = cap / 32;
@@ -364,7 +349,7 @@ void launch_hess_f64(const DevProblem &P, const double *V, const int8_t *Vq, con
     kchunk = (kchunk + 31) / 32 * 32;
     nsplit = (Kh + kchunk - 1) / kchunk;
     dim3 grid((unsigned)((nsplit + 3) / 4), (unsigned)maxpairs, (unsigned)R);
-    hipLaunchKernelGGL(k_hess_f64, grid, dim3(256), 0, st, V, Vq, tau, P.Xt, P.w, rowcol, F, mt, hoff, cap, P.Kp, Kh, kchunk,
+    hipLaunchKernelGGL(k_hess_f64, grid, dim3(256), 0, st, V, P.Xt, P.w, rowcol, F, mt, hoff, cap, P.Kp, Kh, kchunk,
                        (int)nsplit, form, H);
 }
 

@@ -239,7 +239,8 @@ __global__ __launch_bounds__(256) void k_pack_bits(const int8_t *__restrict__ Xt
 }
 
 // The same for the backward GEMM (rows = columns c of the design matrix, depth = samples): dword
-// (c, kt, h): bit e + 8b <-> sample 64kt + 32(e>>2) + 16h + 4(e&3) + b; pieces [Qc/128][Kp/64][128][2 h],
+// (c, kt, h): bit e + 8b <-> operand position 32(e>>2) + 16h + 4(e&3) + b of step kt, which holds sample
+// 64kt + vq_sample(position) -- the sample order of the Vq images (gml_dev.h); pieces [Qc/128][Kp/64][128][2 h],
 // Qc = Qfp rounded up to 256 (columns beyond Qfp: zero bits).
 __global__ __launch_bounds__(256) void k_pack_bits_t(const int8_t *__restrict__ Xt, int64_t Kp, int64_t Qfp, int64_t nkk,
                                                      unsigned *__restrict__ Xtb) {
@@ -250,12 +251,12 @@ __global__ __launch_bounds__(256) void k_pack_bits_t(const int8_t *__restrict__ 
     const int h = (int)(j & 1);
     unsigned v = 0;
     if (c < Qfp) {
-        const int8_t *row = Xt + c * Kp + 64 * kt + 16 * h;
+        const int8_t *row = Xt + c * Kp + 64 * kt;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (row[32 * (e >> 2) + 4 * (e & 3) + b] < 0) v |= 1u << (e + 8 * b);
+            for (int b = 0; b < 4; ++b) // operand position 32(e>>2) + 16h + 4(e&3) + b holds sample vq_sample(position)
+                if (row[vq_sample(32 * (e >> 2) + 16 * h + 4 * (e & 3) + b)] < 0) v |= 1u << (e + 8 * b);
     }
     Xtb[((((c >> 7) * nkk + kt) * 128) + (c & 127)) * 2 + h] = v;
 }
@@ -300,9 +301,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     constexpr int BR = 32 * LF;           // rows of the Tq image
     constexpr int NPIECE = 2 + BR / 16, NP = (NPIECE + 3) / 4;
     constexpr int STAGE = NPIECE * 1024, NS = 4;
-    constexpr int PITCH = 32 * WM + 16;   // epilogue staging row pitch (bytes)
-    constexpr int RING = NS * STAGE > 4 * LB * 32 * PITCH ? NS * STAGE : 4 * LB * 32 * PITCH;
-    extern __shared__ __attribute__((aligned(16))) int8_t lds[]; // ring (aliased by the epilogue staging), exp table
+    constexpr int RING = NS * STAGE;
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[]; // ring, then the exp (and log) tables
     double *etab = reinterpret_cast<double *>(lds + RING);
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
         etab[64 + tid] = 1.0 / cj;
         etab[128 + tid] = log(cj);
     }
+    __syncthreads(); // tables visible to every wave (the ring uses raw s_barrier without an LDS wait)
 
     // XCD-aware L2 blocking.  Blocks b and b+8 share an XCD (round-robin dispatch); XCD x owns the
     // sample tiles st = 8*i + x.  Within an XCD: groups of TG node tiles (outer), sample tiles
@@ -405,12 +406,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                 for (int l = 0; l < LF; ++l) acc[i][l] = MFMA_I8(fa[i], fb[l], acc[i][l]);
         }
     }
-    __syncthreads(); // every wave is done with the ring: it becomes the epilogue's staging area
-
     // ---- epilogue ----------------------------------------------------------------------------
-    // lane <-> node row (lr), register e <-> sample (e&3) + 8*(e>>2) + 4*h within the 32-sample tile
-    int8_t *stage = lds + wave * (LB * 32 * PITCH);
+    // lane <-> node row (lr), register e <-> sample (e&3) + 8*(e>>2) + 4*h within the 32-sample tile.  The
+    // Vq image stores a step's samples in the order vq_pos() (gml_dev.h), in which this lane's 16 samples of
+    // tile i are 16 contiguous bytes per limb: no LDS transpose, two 16-byte stores per limb.
     const int form = FORM;
+    int8_t *vimg = Vq + vq_off(mytile * 32 + lr, 0, k0 + wave * 64, Kp) + h * 32; // row (limb 0, lr) of the wave's image
     long long cs = 0, as = 0;
     double fp = 0.0;
     int mx = 0;
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     double sg2 = -2.0 * sg;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
+        v4i pl[LB];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int64_t kk = kw + i * 32 + 8 * g + 4 * h;
@@ -492,9 +494,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                 const unsigned sel = ((4u + lb) << 8) | (unsigned)lb;
                 const unsigned t01 = __builtin_amdgcn_perm(dj[1], dj[0], sel);
                 const unsigned t23 = __builtin_amdgcn_perm(dj[3], dj[2], sel);
-                const unsigned pl = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
-                *reinterpret_cast<unsigned *>(stage + (lb * 32 + lr) * PITCH + i * 32 + 8 * g + 4 * h) = pl;
+                pl[lb][g] = (int)__builtin_amdgcn_perm(t23, t01, 0x05040100u);
             }
+        }
+        if (active) {
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb) *reinterpret_cast<v4i *>(vimg + lb * 32 * 64 + i * 16) = pl[lb];
         }
     }
     cs += __shfl_xor(cs, 32);
@@ -511,16 +516,6 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     if (form == 2) {
         fp += __shfl_xor(fp, 32);
         if (active && h == 0) unsafeAtomicAdd(&fsum[r], fp);
-    }
-    // coalesced store of the wave's LB*32 rows x 32*WM bytes (its own staging rows: no workgroup barrier needed)
-    constexpr int CH = 2 * WM; // 16-byte chunks per row
-#pragma unroll
-    for (int ps = 0; ps < (LB * 32 * CH) / 64; ++ps) {
-        const int q = ps * 64 + lane, row = q / CH, slot = q % CH;
-        const int lb = row >> 5, rl = row & 31;
-        const v4i dat = *reinterpret_cast<const v4i *>(stage + row * PITCH + slot * 16);
-        if (rowcol[mytile * 32 + rl] >= 0)
-            *reinterpret_cast<v4i *>(Vq + vq_off(mytile * 32 + rl, lb, kw + slot * 16, Kp)) = dat;
     }
 }
 
@@ -1167,8 +1162,8 @@ int i8_limbs_forward() {
 
 template <int LF, int FORM, bool WANTF>
 static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, int ngroups, double *dF, hipStream_t st) {
-    constexpr int STAGE = (2 + 2 * LF) * 1024, STG = 4 * LB * 32 * (32 * 2 + 16);
-    constexpr int shmem = (4 * STAGE > STG ? 4 * STAGE : STG) + 512 + 1024; // ring (aliased by the epilogue staging) + exp, log tables
+    constexpr int STAGE = (2 + 2 * LF) * 1024;
+    constexpr int shmem = 4 * STAGE + 512 + 1024; // ring + exp, log tables
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
     const int ntk = (int)(d.Kp / 256);
