@@ -157,6 +157,7 @@ struct gml_problem {
     // workspace (sized for ws_rows rows)
     int64_t ws_rows = 0;
     double *dTheta = nullptr, *dV = nullptr, *dG = nullptr, *dF = nullptr;
+    int *hCtl = nullptr; // pinned twin of dRowcol | dGroups
     int *dRowcol = nullptr, *dGroups = nullptr;
     double *hTh = nullptr, *hG = nullptr, *hF = nullptr; // pinned staging (ws_rows x Qp, ws_rows)
     // hessian workspace
@@ -551,10 +552,10 @@ extern "C" void gml_problem_destroy(gml_problem *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->st) (void)hipStreamSynchronize(p->st);
-    void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.Xb, p->d.Xtb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dGroups, p->dFidx, p->dMt, p->dH};
+    void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.Xb, p->d.Xtb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dFidx, p->dMt, p->dH};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    void *hptrs[] = {p->hTh, p->hG, p->hF};
+    void *hptrs[] = {p->hTh, p->hG, p->hF, p->hCtl};
     for (void *q : hptrs)
         if (q) (void)hipHostFree(q);
     if (p->dHoff) (void)hipFree(p->dHoff);
@@ -598,21 +599,22 @@ extern "C" int gml_multi_keys(const gml_problem *p, int64_t u, int32_t *keys) {
 // ------------------------------------------------------------------------------------------
 namespace gml {
 // implemented in gml_kernels_i8.hip: the exact int8-limb pass (same contract as the f64 one)
-int i8_pass(void **ws, const DevProblem &d, const double *dTheta, const int *dRowcol, const int *hRowcol,
-            const int *hGroups, int ngroups, int Rp, int form, bool want_grad, double *dF, double *dG,
+int i8_pass(void **ws, const DevProblem &d, const double *dTheta, const int *dRowcol, const int *dGroups, int ngroups,
+            int Rp, int form, bool want_grad, double *dF, double *dG,
             hipStream_t st, hipEvent_t *ev /* [3] or NULL */, const double *hTauOvr, std::string *err);
 }
 
 static int ensure_ws(gml_problem *p, int64_t rows) {
     const int64_t Rp = round_up(rows, 32);
     if (Rp <= p->ws_rows) return GML_OK;
-    void *ptrs[] = {p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dGroups};
+    void *ptrs[] = {p->dTheta, p->dV, p->dG, p->dF, p->dRowcol};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    void *hptrs[] = {p->hTh, p->hG, p->hF};
+    void *hptrs[] = {p->hTh, p->hG, p->hF, p->hCtl};
     for (void *q : hptrs)
         if (q) (void)hipHostFree(q);
     p->hTh = p->hG = p->hF = nullptr;
+    p->hCtl = nullptr;
     p->dTheta = p->dV = p->dG = p->dF = nullptr;
     p->dRowcol = p->dGroups = nullptr;
     p->ws_rows = 0;
@@ -625,8 +627,10 @@ static int ensure_ws(gml_problem *p, int64_t rows) {
     HIPCHK(hipMalloc(&p->dTheta, sizeof(double) * Rp * p->d.Qp));
     HIPCHK(hipMalloc(&p->dG, sizeof(double) * Rp * p->d.Qp));
     HIPCHK(hipMalloc(&p->dF, sizeof(double) * Rp));
-    HIPCHK(hipMalloc(&p->dRowcol, sizeof(int) * Rp));
-    HIPCHK(hipMalloc(&p->dGroups, sizeof(int) * (Rp / 32 + 4)));
+    // control block: rowcol [Rp] | active tiles, padded with -1 [Rp/32 + 4]; one pinned twin, one upload per pass
+    HIPCHK(hipMalloc(&p->dRowcol, sizeof(int) * (Rp + Rp / 32 + 4)));
+    p->dGroups = p->dRowcol + Rp;
+    HIPCHK(hipHostMalloc(&p->hCtl, sizeof(int) * (Rp + Rp / 32 + 4)));
     HIPCHK(hipHostMalloc(&p->hTh, sizeof(double) * Rp * p->d.Qp));
     HIPCHK(hipHostMalloc(&p->hG, sizeof(double) * Rp * p->d.Qp));
     HIPCHK(hipHostMalloc(&p->hF, sizeof(double) * Rp));
@@ -696,18 +700,22 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
         std::memcpy(p->hTh + r0 * Qp, theta + r0 * Qp, sizeof(double) * (r1 - r0) * Qp);
     });
     HIPCHK(hipMemcpyAsync(p->dTheta + ra * Qp, p->hTh + ra * Qp, sizeof(double) * (rb - ra) * Qp, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->dRowcol, rowcol.data(), sizeof(int) * Rp, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(p->dF, 0, sizeof(double) * Rp, st));
-    if (want_grad) HIPCHK(hipMemsetAsync(p->dG, 0, sizeof(double) * Rp * Qp, st));
+    // control block (row -> node, active tiles) through its pinned twin: one asynchronous upload
+    std::vector<int> gpad = groups;
+    while (gpad.size() % 4) gpad.push_back(-1);
+    std::memcpy(p->hCtl, rowcol.data(), sizeof(int) * Rp);
+    std::memcpy(p->hCtl + p->ws_rows, gpad.data(), sizeof(int) * gpad.size());
+    HIPCHK(hipMemcpyAsync(p->dRowcol, p->hCtl, sizeof(int) * (p->ws_rows + gpad.size()), hipMemcpyHostToDevice, st));
+    if (precision != GML_PREC_I8X) { // the int8 pass zeroes its own accumulators (one kernel)
+        HIPCHK(hipMemsetAsync(p->dF, 0, sizeof(double) * Rp, st));
+        if (want_grad) HIPCHK(hipMemsetAsync(p->dG, 0, sizeof(double) * Rp * Qp, st));
+    }
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     if (ms)
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
-    std::vector<int> gpad = groups;
-    while (gpad.size() % 4) gpad.push_back(-1);
-    HIPCHK(hipMemcpyAsync(p->dGroups, gpad.data(), sizeof(int) * gpad.size(), hipMemcpyHostToDevice, st));
     if (precision == GML_PREC_I8X) {
         std::string err;
-        rc = gml::i8_pass(&p->i8ws, p->d, p->dTheta, p->dRowcol, rowcol.data(), groups.data(), (int)groups.size(),
+        rc = gml::i8_pass(&p->i8ws, p->d, p->dTheta, p->dRowcol, p->dGroups, (int)groups.size(),
                           (int)Rp, form, want_grad, p->dF, p->dG, st, ms ? ev : nullptr, tau_ovr ? tau_ovr->data() : nullptr,
                           &err);
         if (rc) return fail(rc, "%s", err.c_str());

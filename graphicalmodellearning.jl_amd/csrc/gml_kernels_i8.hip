@@ -46,7 +46,6 @@ struct I8Ws {
     long long *qconst = nullptr, *csum = nullptr, *asum = nullptr;
     unsigned *mmax = nullptr; // largest |V| / tau seen per row in the last pass (dynamic-range check)
     double *tauovr = nullptr; // per-row tau imposed by the caller (rescaled re-run), 0 = derive from the bound
-    int *pairs = nullptr;
     // working-set Hessian on the int8 cores
     int64_t hKh = 0, hbuilt = 0, hcap_elems = 0;
     int8_t *Mt = nullptr, *Hq = nullptr; // byte masks of Xt (0x00 / 0xFF) and limb planes of the Hessian weights
@@ -1020,7 +1019,7 @@ const unsigned *i8_get_mmax(void *p) { return p ? static_cast<I8Ws *>(p)->mmax :
 void i8_free(void *p) {
     I8Ws *w = static_cast<I8Ws *>(p);
     if (!w) return;
-    void *ptrs[] = {w->Tq, w->Vq, w->Gacc, w->sigma, w->tau, w->invtau, w->qconst, w->csum, w->asum, w->pairs, w->mmax, w->tauovr,
+    void *ptrs[] = {w->Tq, w->Vq, w->Gacc, w->sigma, w->tau, w->invtau, w->qconst, w->csum, w->asum, w->mmax, w->tauovr,
                     w->Mt, w->Hq, w->hS, w->H64, w->Mb};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -1046,7 +1045,6 @@ static int i8_ensure(void **wsp, const DevProblem &d, int Rp, int LF, std::strin
     I8CHK(hipMalloc(&w->asum, sizeof(long long) * Rp));
     I8CHK(hipMalloc(&w->mmax, sizeof(unsigned) * Rp));
     I8CHK(hipMalloc(&w->tauovr, sizeof(double) * Rp));
-    I8CHK(hipMalloc(&w->pairs, sizeof(int) * (Rp / 32 + 2)));
     I8CHK(hipMemset(w->Tq, 0, (size_t)Rp * LF * d.Qfp));
     I8CHK(hipMemset(w->Vq, 0, (size_t)Rp * LB * d.Kp));
     w->rows = Rp;
@@ -1151,6 +1149,21 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF
     return GML_OK;
 }
 
+__global__ __launch_bounds__(256) void k_zero_pass(long long *__restrict__ csum, long long *__restrict__ asum,
+                                                   unsigned *__restrict__ mmax, double *__restrict__ f, int Rp,
+                                                   v4i *__restrict__ gacc, int64_t ngacc, v4i *__restrict__ g, int64_t ng) {
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    if (i0 < Rp) {
+        csum[i0] = 0;
+        asum[i0] = 0;
+        mmax[i0] = 0;
+        f[i0] = 0.0;
+    }
+    const v4i z = {0, 0, 0, 0};
+    for (int64_t i = i0; i < ngacc; i += stride) gacc[i] = z;
+    for (int64_t i = i0; i < ng; i += stride) g[i] = z;
+}
+
 int i8_limbs_forward() {
     static int lf = [] {
         const char *e = getenv("GML_I8_LF");
@@ -1161,30 +1174,30 @@ int i8_limbs_forward() {
 }
 
 template <int LF, int FORM, bool WANTF>
-static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, int ngroups, double *dF, hipStream_t st) {
+static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, const int *dGroups, int ngroups, double *dF,
+                        hipStream_t st) {
     constexpr int STAGE = (2 + 2 * LF) * 1024;
     constexpr int shmem = 4 * STAGE + 512 + 1024; // ring + exp, log tables
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
     const int ntk = (int)(d.Kp / 256);
     const int grid = ((ntk + 7) / 8) * 8 * ((ngroups + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xb, d.Xt, w->Tq, dRowcol, w->pairs,
+    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xb, d.Xt, w->Tq, dRowcol, dGroups,
                        ngroups, d.w, w->sigma, w->qconst, w->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, w->Vq, w->csum,
                        w->asum, dF, w->mmax);
 }
 
 template <int LF>
-static void launch_fwd(const I8Ws *w, const DevProblem &d, const int *dRowcol, int ngroups, int form, bool wantf, double *dF,
-                       hipStream_t st) {
-    if (form == 2) launch_fwd2<LF, 2, true>(w, d, dRowcol, ngroups, dF, st);
-    else if (wantf) launch_fwd2<LF, 0, true>(w, d, dRowcol, ngroups, dF, st);
-    else launch_fwd2<LF, 0, false>(w, d, dRowcol, ngroups, dF, st);
+static void launch_fwd(const I8Ws *w, const DevProblem &d, const int *dRowcol, const int *dGroups, int ngroups, int form, bool wantf,
+                       double *dF, hipStream_t st) {
+    if (form == 2) launch_fwd2<LF, 2, true>(w, d, dRowcol, dGroups, ngroups, dF, st);
+    else if (wantf) launch_fwd2<LF, 0, true>(w, d, dRowcol, dGroups, ngroups, dF, st);
+    else launch_fwd2<LF, 0, false>(w, d, dRowcol, dGroups, ngroups, dF, st);
 }
 
-int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dRowcol, const int *hRowcol,
-            const int *hGroups, int ngroups, int Rp, int form, bool want_grad, double *dF, double *dG, hipStream_t st,
+int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dRowcol, const int *dGroups /* active 32-node
+            tiles, padded with -1 to a multiple of 4 */, int ngroups, int Rp, int form, bool want_grad, double *dF, double *dG, hipStream_t st,
             hipEvent_t *ev, const double *hTauOvr /* Rp per-row tau overrides (0 = none) or NULL */, std::string *err) {
-    (void)hRowcol;
     if (d.Kp > (int64_t)1 << 24) {
         if (err) *err = "GML_PREC_I8X supports up to 2^24 configurations per handle (i32 accumulators)";
         return GML_EUNSUPPORTED;
@@ -1193,29 +1206,20 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
     int rc = i8_ensure(wsp, d, Rp, LF, err);
     if (rc) return rc;
     I8Ws *w = static_cast<I8Ws *>(*wsp);
-    // pairs of active node tiles (a workgroup of the forward kernel serves two)
-    int npairs = (ngroups + 1) / 2;
-    {
-        int tmp[4096];
-        if (ngroups + 1 > 4096) {
-            if (err) *err = "too many node tiles";
-            return GML_EUNSUPPORTED;
-        }
-        for (int i = 0; i < ngroups; ++i) tmp[i] = hGroups[i];
-        if (ngroups & 1) tmp[ngroups] = -1;
-        I8CHK(hipMemcpyAsync(w->pairs, tmp, sizeof(int) * 2 * npairs, hipMemcpyHostToDevice, st));
-        I8CHK(hipStreamSynchronize(st)); // tmp is a stack buffer
+    if (ngroups + 1 > 4096) {
+        if (err) *err = "too many node tiles";
+        return GML_EUNSUPPORTED;
     }
-    I8CHK(hipMemsetAsync(w->csum, 0, sizeof(long long) * Rp, st));
-    I8CHK(hipMemsetAsync(w->asum, 0, sizeof(long long) * Rp, st));
-    I8CHK(hipMemsetAsync(w->mmax, 0, sizeof(unsigned) * Rp, st));
+    // one launch zeroes every accumulator of the pass (row sums, maxima, the i32 gradient planes, f and G)
+    hipLaunchKernelGGL(k_zero_pass, dim3(1024), dim3(256), 0, st, w->csum, w->asum, w->mmax, dF, Rp,
+                       reinterpret_cast<v4i *>(w->Gacc), want_grad ? (int64_t)Rp * LB * d.Qfp / 4 : 0, reinterpret_cast<v4i *>(dG),
+                       want_grad ? (int64_t)Rp * d.Qp / 2 : 0);
     const double *dOvr = nullptr;
     if (hTauOvr) {
         I8CHK(hipMemcpyAsync(w->tauovr, hTauOvr, sizeof(double) * Rp, hipMemcpyHostToDevice, st));
         I8CHK(hipStreamSynchronize(st)); // the caller's buffer is pageable
         dOvr = w->tauovr;
     }
-    if (want_grad) I8CHK(hipMemsetAsync(w->Gacc, 0, sizeof(int32_t) * (size_t)Rp * LB * d.Qfp, st));
     switch (LF) {
     case 3:
         hipLaunchKernelGGL((k_quant_theta<3>), dim3(Rp), dim3(256), 0, st, dTheta, dRowcol, d.Qp, d.Qfp, d.cconst, d.wmax,
@@ -1232,9 +1236,9 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
     if (ev) I8CHK(hipEventRecord(ev[0], st));
     switch (LF) {
     // with the gradient requested, f comes out of the backward GEMM for free (column u of row u)
-    case 3: launch_fwd<3>(w, d, dRowcol, ngroups, form, !want_grad, dF, st); break;
-    case 5: launch_fwd<5>(w, d, dRowcol, ngroups, form, !want_grad, dF, st); break;
-    default: launch_fwd<4>(w, d, dRowcol, ngroups, form, !want_grad, dF, st);
+    case 3: launch_fwd<3>(w, d, dRowcol, dGroups, ngroups, form, !want_grad, dF, st); break;
+    case 5: launch_fwd<5>(w, d, dRowcol, dGroups, ngroups, form, !want_grad, dF, st); break;
+    default: launch_fwd<4>(w, d, dRowcol, dGroups, ngroups, form, !want_grad, dF, st);
     }
     if (ev) I8CHK(hipEventRecord(ev[1], st));
     if (want_grad) {
@@ -1252,14 +1256,14 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
         nsplit = (int)((d.Kp + kchunk - 1) / kchunk);
         const int grid = ((nsplit + 7) / 8) * 8 * T;
         const int shmem = 4 * (8 * TM + 2) * 1024;
-        // w->pairs holds the active tile list padded with -1 to an even count
+        // dGroups holds the active tile list padded with -1 to an even count
         if (TM == 2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-            hipLaunchKernelGGL(k_bwd_i8<2>, dim3(grid), dim3(512), shmem, st, w->Vq, d.Xtb, w->pairs, ngt, nNt, d.Qfp, d.Kp, kchunk,
+            hipLaunchKernelGGL(k_bwd_i8<2>, dim3(grid), dim3(512), shmem, st, w->Vq, d.Xtb, dGroups, ngt, nNt, d.Qfp, d.Kp, kchunk,
                                nsplit, w->Gacc);
         } else {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-            hipLaunchKernelGGL(k_bwd_i8<1>, dim3(grid), dim3(256), shmem, st, w->Vq, d.Xtb, w->pairs, ngt, nNt, d.Qfp, d.Kp, kchunk,
+            hipLaunchKernelGGL(k_bwd_i8<1>, dim3(grid), dim3(256), shmem, st, w->Vq, d.Xtb, dGroups, ngt, nNt, d.Qfp, d.Kp, kchunk,
                                nsplit, w->Gacc);
         }
     }
