@@ -71,6 +71,7 @@ def lib():
     L.gml_problem_create.argtypes = [p, i32, i64, i64, i64, i32, i32, i64, i64, i32, C.POINTER(p)]
     L.gml_problem_create_spins.argtypes = [p, p, i64, i64, i32, i64, i64, i32, C.POINTER(p)]
     L.gml_problem_create_sampled.argtypes = [p, i64, i64, C.c_uint64, i32, i64, i64, i32, C.POINTER(p)]
+    L.gml_problem_create_sampled_terms.argtypes = [p, i32, p, i64, i64, i64, C.c_uint64, i32, i64, i64, i32, C.POINTER(p)]
     L.gml_problem_get_spins.argtypes = [p, p]
     L.gml_problem_destroy.argtypes = [p]
     L.gml_problem_destroy.restype = None
@@ -96,11 +97,24 @@ def _ptr(a):
 class Problem:
     """RAII wrapper of a gml_problem handle (packed spins + weights resident in HBM)."""
 
-    def __init__(self, samples=None, *, counts=None, spins=None, model=None, num_samples=None, seed=0, order=2,
-                 node_range=None, device=0):
+    def __init__(self, samples=None, *, counts=None, spins=None, model=None, terms=None, n=None, num_samples=None, seed=0,
+                 order=2, node_range=None, device=0):
         L = lib()
         h = C.c_void_p()
-        if model is not None:
+        if terms is not None:
+            # sample on the device from a model of any order given as {1-based key tuple: weight}: sampling.jl:60-88
+            if n is None:
+                n = max(max(k) for k in terms if len(k))
+            stride = max(1, max(len(k) for k in terms))
+            keys = np.full((len(terms), stride), -1, dtype=np.int32)
+            wts = np.zeros(len(terms), dtype=np.float64)
+            for t, (k, v) in enumerate(terms.items()):
+                keys[t, :len(k)] = np.asarray(k, dtype=np.int64) - 1
+                wts[t] = v
+            n0, n1 = node_range if node_range is not None else (0, int(n))
+            check(L.gml_problem_create_sampled_terms(_ptr(keys), stride, _ptr(wts), len(terms), int(n), int(num_samples), int(seed),
+                                                     int(order), n0, n1, int(device), C.byref(h)))
+        elif model is not None:
             # sample on the device from a pairwise model (n x n, diagonal = fields): sampling.jl:34-57
             m = np.ascontiguousarray(model, dtype=np.float64)
             n = m.shape[0]

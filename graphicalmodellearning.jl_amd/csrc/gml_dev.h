@@ -69,9 +69,10 @@ void launch_hess_f64(const DevProblem &P, const double *V,
 // Kh (multiple of 32, <= Kp): the Hessian is accumulated over the first Kh configurations only
 // (sub-sampled Newton: the gradient stays exact, so only the convergence rate is affected).
 
-// Exact sampling of one block (connected component) of a pairwise model: energies of its 2^sb states,
-// CDF, N draws written into S [N][n] (sample-major, +-1) at the block's spin columns.
-void launch_block_sampler(const double *dA, const double *dh, int sb, const int *dmembers, int64_t N, int64_t n,
+// Exact sampling of one block (connected component) of a model given as terms (bit masks over the block's
+// spins + weights): energies of its 2^sb states, CDF, N draws written into S [N][n] (sample-major, +-1) at
+// the block's spin columns.
+void launch_block_sampler(const unsigned *dmasks, const double *dwts, int nt, int sb, const int *dmembers, int64_t N, int64_t n,
                           unsigned long long seed, int block, double *den, double *dcdf, int8_t *dS, hipStream_t st);
 
 // Batched Newton solve on the ragged Hessian blocks: A = s1[r]*H_r - s2*gF gF^T, A d = -pgF, in place

@@ -418,10 +418,13 @@ extern "C" int gml_problem_create(const void *samples, int dtype, int64_t K, int
 // gml_problem_create_sampled: sample on the device, then build the handle from the device-resident
 // samples (the step before the path; src/sampling.jl:34-57, 94-106)
 // ------------------------------------------------------------------------------------------
-extern "C" int gml_problem_create_sampled(const double *model, int64_t n, int64_t N, uint64_t seed, int order,
-                                          int64_t node0, int64_t node1, int device, gml_problem **out) {
-    if (!model || !out) return fail(GML_EINVAL, "NULL argument");
+// Terms of one model: spins of term t = keys[t*stride .. +stride) (0-based, -1 = unused slot).
+static int create_sampled_terms(const int32_t *keys, int stride, const double *weights, int64_t nterms, int64_t n,
+                                int64_t N, uint64_t seed, int order, int64_t node0, int64_t node1, int device,
+                                gml_problem **out) {
+    if (!out) return fail(GML_EINVAL, "out is NULL");
     *out = nullptr;
+    if ((nterms > 0 && (!keys || !weights)) || stride < 1) return fail(GML_EINVAL, "NULL or malformed term list");
     if (n <= 0 || N <= 0) return fail(GML_EINVAL, "n and N must be positive");
     if (order < 1 || order > 8) return fail(GML_EINVAL, "interaction order %d out of range [1,8]", order);
     if (node0 < 0 || node1 > n || node0 >= node1)
@@ -430,36 +433,68 @@ extern "C" int gml_problem_create_sampled(const double *model, int64_t n, int64_
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(GML_EHIP, "no HIP device available (libgml_hip has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(GML_EINVAL, "device %d out of range (%d devices)", device, ndev);
-    for (int64_t i = 0; i < n; ++i)
-        for (int64_t j = 0; j < i; ++j)
-            if (model[i * n + j] != model[j * n + i]) return fail(GML_EINVAL, "the model matrix is not symmetric at (%lld,%lld)", (long long)i, (long long)j);
-    // connected components of the coupling graph
+    for (int64_t t = 0; t < nterms; ++t) {
+        if (!std::isfinite(weights[t])) return fail(GML_EINVAL, "weight of term %lld is not finite", (long long)t);
+        for (int a = 0; a < stride; ++a) {
+            const int32_t v = keys[t * stride + a];
+            if (v < -1 || v >= n) return fail(GML_EINVAL, "term %lld names spin %d outside [0,%lld)", (long long)t, v, (long long)n);
+        }
+    }
+    // connected components of the term hypergraph
     std::vector<int64_t> parent((size_t)n);
     for (int64_t i = 0; i < n; ++i) parent[i] = i;
     std::function<int64_t(int64_t)> find = [&](int64_t a) {
         while (parent[a] != a) a = parent[a] = parent[parent[a]];
         return a;
     };
-    for (int64_t i = 0; i < n; ++i)
-        for (int64_t j = 0; j < i; ++j)
-            if (model[i * n + j] != 0.0) parent[find(i)] = find(j);
-    std::vector<std::vector<int>> blocks;
-    {
-        std::vector<int64_t> id((size_t)n, -1);
-        for (int64_t i = 0; i < n; ++i) {
-            const int64_t r = find(i);
-            if (id[r] < 0) {
-                id[r] = (int64_t)blocks.size();
-                blocks.emplace_back();
-            }
-            blocks[(size_t)id[r]].push_back((int)i);
+    for (int64_t t = 0; t < nterms; ++t) {
+        if (weights[t] == 0.0) continue;
+        int64_t first = -1;
+        for (int a = 0; a < stride; ++a) {
+            const int32_t v = keys[t * stride + a];
+            if (v < 0) continue;
+            if (first < 0) first = v;
+            else parent[find(v)] = find(first);
         }
+    }
+    std::vector<std::vector<int>> blocks;
+    std::vector<int64_t> id((size_t)n, -1);
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = find(i);
+        if (id[r] < 0) {
+            id[r] = (int64_t)blocks.size();
+            blocks.emplace_back();
+        }
+        blocks[(size_t)id[r]].push_back((int)i);
     }
     size_t maxsb = 0;
     for (auto &b : blocks) maxsb = std::max(maxsb, b.size());
     if (maxsb > 22)
         return fail(GML_EUNSUPPORTED, "a connected component of the model has %zu spins: exact enumeration is limited to 22 "
                                      "(an MCMC sampler is not implemented)", maxsb);
+    // per block: its terms as bit masks over the block's spins (a repeated spin cancels: s^2 = 1)
+    std::vector<int> local((size_t)n, 0);
+    for (auto &b : blocks)
+        for (size_t i = 0; i < b.size(); ++i) local[(size_t)b[i]] = (int)i;
+    std::vector<std::vector<unsigned>> bmask(blocks.size());
+    std::vector<std::vector<double>> bwt(blocks.size());
+    size_t maxnt = 1;
+    for (int64_t t = 0; t < nterms; ++t) {
+        if (weights[t] == 0.0) continue;
+        unsigned mask = 0;
+        int64_t any = -1;
+        for (int a = 0; a < stride; ++a) {
+            const int32_t v = keys[t * stride + a];
+            if (v < 0) continue;
+            mask ^= 1u << local[(size_t)v];
+            any = v;
+        }
+        if (any < 0) continue; // the empty term: a constant energy
+        const size_t b = (size_t)id[find(any)];
+        bmask[b].push_back(mask);
+        bwt[b].push_back(weights[t]);
+        maxnt = std::max(maxnt, bmask[b].size());
+    }
     HIPCHK(hipSetDevice(device));
     gml_problem *p = new gml_problem();
     p->device = device;
@@ -471,10 +506,12 @@ extern "C" int gml_problem_create_sampled(const double *model, int64_t n, int64_
     p->node1 = node1;
     hipStream_t st = nullptr;
     int8_t *dS = nullptr;
-    double *dA = nullptr, *den = nullptr, *dcdf = nullptr;
+    double *dwt = nullptr, *den = nullptr, *dcdf = nullptr;
+    unsigned *dmask = nullptr;
     int *dmem = nullptr;
     auto cleanup = [&](int rc) {
-        if (dA) (void)hipFree(dA);
+        if (dwt) (void)hipFree(dwt);
+        if (dmask) (void)hipFree(dmask);
         if (den) (void)hipFree(den);
         if (dcdf) (void)hipFree(dcdf);
         if (dmem) (void)hipFree(dmem);
@@ -493,24 +530,22 @@ extern "C" int gml_problem_create_sampled(const double *model, int64_t n, int64_
     } while (0)
     SCHK(hipStreamCreate(&st));
     SCHK(hipMalloc(&dS, (size_t)N * n));
-    SCHK(hipMalloc(&dA, sizeof(double) * (maxsb * maxsb + maxsb)));
+    SCHK(hipMalloc(&dwt, sizeof(double) * maxnt));
+    SCHK(hipMalloc(&dmask, sizeof(unsigned) * maxnt));
     SCHK(hipMalloc(&den, sizeof(double) * ((size_t)1 << maxsb)));
     SCHK(hipMalloc(&dcdf, sizeof(double) * ((size_t)1 << maxsb)));
     SCHK(hipMalloc(&dmem, sizeof(int) * maxsb));
     for (size_t b = 0; b < blocks.size(); ++b) {
         const auto &mem = blocks[b];
-        const int sb = (int)mem.size();
-        std::vector<double> A((size_t)sb * sb + sb, 0.0);
-        for (int i = 0; i < sb; ++i) {
-            for (int j = 0; j < sb; ++j)
-                if (i != j) A[(size_t)i * sb + j] = model[(int64_t)mem[i] * n + mem[j]]; // adjacency (sampling.jl:40)
-            A[(size_t)sb * sb + i] = model[(int64_t)mem[i] * n + mem[i]];              // prior = diagonal (sampling.jl:41)
+        const int sb = (int)mem.size(), nt = (int)bmask[b].size();
+        if (nt > 0) {
+            SCHK(hipMemcpyAsync(dmask, bmask[b].data(), sizeof(unsigned) * nt, hipMemcpyHostToDevice, st));
+            SCHK(hipMemcpyAsync(dwt, bwt[b].data(), sizeof(double) * nt, hipMemcpyHostToDevice, st));
         }
-        SCHK(hipMemcpyAsync(dA, A.data(), sizeof(double) * A.size(), hipMemcpyHostToDevice, st));
         SCHK(hipMemcpyAsync(dmem, mem.data(), sizeof(int) * sb, hipMemcpyHostToDevice, st));
-        launch_block_sampler(dA, dA + (size_t)sb * sb, sb, dmem, N, n, (unsigned long long)seed, (int)b, den, dcdf, dS, st);
+        launch_block_sampler(dmask, dwt, nt, sb, dmem, N, n, (unsigned long long)seed, (int)b, den, dcdf, dS, st);
         SCHK(hipGetLastError());
-        SCHK(hipStreamSynchronize(st)); // A / mem are reused by the next block
+        SCHK(hipStreamSynchronize(st)); // the staging buffers are reused by the next block
     }
 #undef SCHK
     cleanup(0);
@@ -523,6 +558,33 @@ extern "C" int gml_problem_create_sampled(const double *model, int64_t n, int64_
     }
     *out = p;
     return GML_OK;
+}
+
+extern "C" int gml_problem_create_sampled_terms(const int32_t *keys, int key_stride, const double *weights, int64_t nterms,
+                                                int64_t n, int64_t N, uint64_t seed, int order, int64_t node0,
+                                                int64_t node1, int device, gml_problem **out) {
+    return create_sampled_terms(keys, key_stride, weights, nterms, n, N, seed, order, node0, node1, device, out);
+}
+
+extern "C" int gml_problem_create_sampled(const double *model, int64_t n, int64_t N, uint64_t seed, int order,
+                                          int64_t node0, int64_t node1, int device, gml_problem **out) {
+    if (!model || !out) return fail(GML_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (n <= 0) return fail(GML_EINVAL, "n and N must be positive");
+    // the matrix as terms: 1/2 s^T A s = sum_{i<j} A_ij s_i s_j (sampling.jl:40), prior = diagonal (:41)
+    std::vector<int32_t> keys;
+    std::vector<double> wts;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j <= i; ++j) {
+            const double v = model[i * n + j];
+            if (j < i && v != model[j * n + i])
+                return fail(GML_EINVAL, "the model matrix is not symmetric at (%lld,%lld)", (long long)i, (long long)j);
+            if (v == 0.0) continue;
+            keys.push_back((int32_t)j);
+            keys.push_back(j < i ? (int32_t)i : -1);
+            wts.push_back(v);
+        }
+    return create_sampled_terms(keys.data(), 2, wts.data(), (int64_t)wts.size(), n, N, seed, order, node0, node1, device, out);
 }
 
 // the +-1 configurations held by the handle, K x n row-major (for tests and for callers that want the

@@ -1,8 +1,8 @@
 // On-device exact sampler: the step BEFORE the learn() path.
 //
-// The reference's `sample(gm, N)` enumerates all 2^n states, weighs them with
-// exp(1/2 s^T A s + h^T s) and draws N of them (src/sampling.jl:26-30, 34-57).  Here the same exact
-// scheme is applied per connected component ("block") of the pairwise model, so that models far
+// The reference's `sample(gm, N)` enumerates all 2^n states, weighs them with exp(sum_t w_t prod_{i in t} s_i)
+// (src/sampling.jl:26-30, 60-64) and draws N of them (:34-57, :67-88).  Here the same exact scheme is
+// applied per connected component ("block") of the term hypergraph, for any interaction order, so that models far
 // beyond n ~ 25 can be sampled as long as every block has at most 22 spins, and the +-1 samples are
 // written straight into HBM in the layout gml_problem_create_spins expects (no host histogram, no
 // PCIe upload).  Random numbers: a counter-based splitmix64 hash of (seed, block, sample).
@@ -11,21 +11,28 @@
 
 namespace gml {
 
-// energies of all 2^sb states of one block: e(state) = 1/2 s^T A s + h^T s, bit t of `state` = spin t
-// (int_to_spin, sampling.jl:11-14: little-endian bits -> +-1)
-__global__ __launch_bounds__(256) void k_block_energies(const double *__restrict__ A /* sb x sb */,
-                                                        const double *__restrict__ hf /* sb */, int sb,
-                                                        double *__restrict__ en) {
+// energies of all 2^sb states of one block: e(state) = sum_t w_t prod_{i in t} s_i (weigh_proba, sampling.jl:60-64;
+// the pairwise form 1/2 s^T A s + h^T s of :26-30 is the same sum over the pair and field terms).  Bit i of
+// `state` = spin i (int_to_spin, sampling.jl:11-14: little-endian bits -> +-1).  A term is a bit mask over the
+// block's spins: prod s_i = (-1)^(number of -1 spins in the term) = 1 - 2 (popcount(mask & ~state) & 1).
+__global__ __launch_bounds__(256) void k_block_energies(const unsigned *__restrict__ masks, const double *__restrict__ wts,
+                                                        int nt, int sb, double *__restrict__ en) {
+    __shared__ unsigned sm[1024];
+    __shared__ double sw[1024];
     const int64_t st = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (st >= ((int64_t)1 << sb)) return;
+    const unsigned nst = ~(unsigned)st;
     double e = 0.0;
-    for (int i = 0; i < sb; ++i) {
-        const double si = (st >> i) & 1 ? 1.0 : -1.0;
-        double row = 0.0;
-        for (int j = 0; j < sb; ++j) row += A[i * sb + j] * ((st >> j) & 1 ? 1.0 : -1.0);
-        e += si * (0.5 * row + hf[i]);
+    for (int t0 = 0; t0 < nt; t0 += 1024) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < 1024 && t0 + t < nt; t += 256) {
+            sm[t] = masks[t0 + t];
+            sw[t] = wts[t0 + t];
+        }
+        __syncthreads();
+        const int m = nt - t0 < 1024 ? nt - t0 : 1024;
+        for (int t = 0; t < m; ++t) e += (__popc(sm[t] & nst) & 1) ? -sw[t] : sw[t];
     }
-    en[st] = e;
+    if (st < ((int64_t)1 << sb)) en[st] = e;
 }
 
 // single-workgroup max + exclusive->inclusive scan of exp(en - max) into cdf (normalised to cdf[last] = 1)
@@ -94,10 +101,10 @@ __global__ __launch_bounds__(256) void k_block_draw(const double *__restrict__ c
     for (int t = 0; t < sb; ++t) S[k * n + members[t]] = (lo >> t) & 1 ? (int8_t)1 : (int8_t)-1;
 }
 
-void launch_block_sampler(const double *dA, const double *dh, int sb, const int *dmembers, int64_t N, int64_t n,
+void launch_block_sampler(const unsigned *dmasks, const double *dwts, int nt, int sb, const int *dmembers, int64_t N, int64_t n,
                           unsigned long long seed, int block, double *den, double *dcdf, int8_t *dS, hipStream_t st) {
     const int64_t ns = (int64_t)1 << sb;
-    hipLaunchKernelGGL(k_block_energies, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, dA, dh, sb, den);
+    hipLaunchKernelGGL(k_block_energies, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, dmasks, dwts, nt, sb, den);
     hipLaunchKernelGGL(k_block_cdf, dim3(1), dim3(1024), 0, st, den, ns, dcdf);
     hipLaunchKernelGGL(k_block_draw, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dcdf, ns, sb, dmembers, N, n, seed, block,
                        dS);

@@ -113,6 +113,14 @@ int gml_problem_create_spins(const double *counts, const int8_t *spins, int64_t 
 int gml_problem_create_sampled(const double *model, int64_t n, int64_t N, uint64_t seed, int order,
                                int64_t node0, int64_t node1, int device, gml_problem **out);
 
+/* Same for a model of any interaction order given as a term list (the reference's general sampler,
+ * src/sampling.jl:60-88, dispatch :94-106): term t couples the spins keys[t*key_stride .. +key_stride)
+ * (0-based, -1 = unused slot) with weight weights[t]; P(s) ~ exp(sum_t w_t prod_{i in t} s_i).  Exact per
+ * connected component of the term hypergraph (<= 22 spins each). */
+int gml_problem_create_sampled_terms(const int32_t *keys, int key_stride, const double *weights, int64_t nterms,
+                                     int64_t n, int64_t N, uint64_t seed, int order, int64_t node0,
+                                     int64_t node1, int device, gml_problem **out);
+
 /* The +-1 configurations held by a handle, K x n row-major (host pointer). */
 int gml_problem_get_spins(gml_problem *p, int8_t *spins);
 

@@ -75,3 +75,33 @@ def test_learned_model_accuracy_with_device_sampler():
     model = np.array([[0.0, 0.1, 0.2], [0.1, 0.0, 0.3], [0.2, 0.3, 0.0]])
     learned = gml.learn(gml.sample(gml.FactorGraph(model), 100000, seed=0))
     assert np.abs(learned - model).max() <= 0.01
+
+
+def test_multibody_sampler_matches_exact_distribution():
+    # the reference's general sampler (sampling.jl:60-88): P(s) ~ exp(sum_t w_t prod_{i in t} s_i) with 3- and
+    # 4-body terms; two independent components, one of them beyond what the test can enumerate jointly
+    terms = {(1,): 0.2, (2, 3): -0.4, (1, 2, 3): 0.5, (2, 3, 4): -0.3, (1, 2, 3, 4): 0.25, (4,): -0.1,
+             (5, 6, 7): 0.6, (5,): 0.1, (6, 7): 0.3}
+    fg = gml.FactorGraph(4, 7, "spin", terms)
+    N = 1000000
+    hist = gml.sample(fg, N, seed=2)
+    assert hist[:, 0].sum() == N
+    n = 7
+    states = ((np.arange(2 ** n)[:, None] >> np.arange(n)) & 1) * 2 - 1
+    en = np.zeros(2 ** n)
+    for k, w in terms.items():
+        en += w * np.prod(states[:, [i - 1 for i in k]], axis=1)
+    pr = np.exp(en - en.max())
+    pr /= pr.sum()
+    lookup = {tuple(s): pi for s, pi in zip(states, pr)}
+    assert len(hist) == 2 ** n
+    for row in hist:
+        expect = lookup[tuple(row[1:])] * N
+        assert abs(row[0] - expect) <= 6 * np.sqrt(expect) + 1
+    # and multiRISE recovers the terms from device-sampled data without a host round trip
+    with gml.Problem(terms=terms, n=7, num_samples=400000, seed=5, order=4) as p:
+        out, kkt, st = p.learn("RISE", 0.2, tol=1e-9)
+        keys0 = p.multi_keys(0)
+    got = {tuple(sorted(i + 1 for i in k)): v for k, v in zip(keys0, out[0])}
+    for k in [(1,), (1, 2, 3), (1, 2, 3, 4)]:
+        assert abs(got[k] - terms[k]) <= 0.03
