@@ -5,7 +5,7 @@ the GMLFormulation types, the GMLMethod types (NLP plus the new HIP), FactorGrap
 path is libgml_hip.so (hand-written HIP kernels for gfx950 behind the C ABI in include/gml.h).
 """
 from ._lib import GMLConvergenceError, GMLError, Problem, lib  # noqa: F401
-from .factor_graph import FactorGraph, matrix_to_terms  # noqa: F401
+from .factor_graph import FactorGraph, matrix_to_terms, permutations, check_model_data  # noqa: F401
 from .formulations import (HIP, ISODUS, NLP, RISE, RISEA, RPLE, GMLFormulation, GMLMethod,  # noqa: F401
                            logRISE, multiRISE)
 from .learn import learn  # noqa: F401

@@ -149,3 +149,31 @@ def test_node_partition_covers_everything():
             edges = [part(n, world, r) for r in range(world)]
             assert edges[0][0] == 0 and edges[-1][1] == n
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+
+
+def test_factor_graph_io_and_validation():
+    # models.jl:23-54 (validation), :56-76 (show, jsondata), :185-225 (term list / dict constructors),
+    # :228-246 (permutations); runtests.jl:17-30 for the matrix round trip of every fixture model
+    for name, m in MODELS.items():
+        gm = gml.FactorGraph(m)
+        gm2 = gml.FactorGraph(gm.to_matrix())
+        for key in gm.keys():
+            assert gm[key] == gm2[key]
+            assert gm[key] == (m[key[0] - 1, key[0] - 1] if len(key) == 1 else m[key[0] - 1, key[1] - 1])
+        back = gml.FactorGraph(gm.jsondata())  # JSON term list round trip
+        assert back.terms == gm.terms and back.order == gm.order and back.varible_count <= gm.varible_count
+    fg = gml.FactorGraph({(1,): 0.5, (2, 3): -0.25, (1, 2, 3): 0.125})
+    assert (fg.order, fg.varible_count, fg.alphabet, len(fg)) == (3, 3, "spin", 3)
+    assert [d["term"] for d in fg.jsondata()] == [[1], [2, 3], [1, 2, 3]]  # sorted by (length, key)
+    assert str(fg).splitlines()[:3] == ["alphabet: spin", "vars: 3", "terms: 3"]
+    assert gml.FactorGraph(2, 3, "spin", {(1, 1): 0.1, (3, 3): 0.2, (1, 2): 0.3}).diag_keys() == [(1, 1), (3, 3)]
+    assert gml.permutations(range(1, 4), 2) == [(1, 2), (1, 3), (2, 3)]
+    assert len(gml.permutations(range(1, 4), 2, asymmetric=True)) == 9
+    with pytest.raises(ValueError):
+        gml.FactorGraph(2, 3, "spin", {(1, 2, 3): 1.0})  # more indices than the order
+    with pytest.raises(ValueError):
+        gml.FactorGraph(2, 3, "spin", {(1, 4): 1.0})  # index out of range
+    with pytest.raises(ValueError):
+        gml.FactorGraph(2, 3, "letters", {(1, 2): 1.0})  # unsupported alphabet
+    with pytest.raises(ValueError):
+        gml.FactorGraph(2, 3, "spin", {(1, 2): 1.0}, variable_names=["a", "b"])
