@@ -9,7 +9,7 @@ from .factor_graph import FactorGraph, matrix_to_terms, permutations, check_mode
 from .formulations import (HIP, ISODUS, NLP, RISE, RISEA, RPLE, GMLFormulation, GMLMethod,  # noqa: F401
                            logRISE, multiRISE)
 from .learn import learn  # noqa: F401
-from .sampling import GMSampler, Gibbs, sample  # noqa: F401
+from .sampling import GMSampler, Gibbs, Glauber, sample  # noqa: F401
 
 __all__ = ["learn", "GMLFormulation", "RISE", "logRISE", "RPLE", "RISEA", "multiRISE", "ISODUS", "GMLMethod",
            "NLP", "HIP", "FactorGraph", "Problem", "GMLError", "GMLConvergenceError", "sample", "GMSampler", "Gibbs"]

@@ -72,6 +72,7 @@ def lib():
     L.gml_problem_create_spins.argtypes = [p, p, i64, i64, i32, i64, i64, i32, C.POINTER(p)]
     L.gml_problem_create_sampled.argtypes = [p, i64, i64, C.c_uint64, i32, i64, i64, i32, C.POINTER(p)]
     L.gml_problem_create_sampled_terms.argtypes = [p, i32, p, i64, i64, i64, C.c_uint64, i32, i64, i64, i32, C.POINTER(p)]
+    L.gml_problem_create_mcmc_terms.argtypes = [p, i32, p, i64, i64, i64, C.c_uint64, i32, i32, i64, i64, i32, C.POINTER(p)]
     L.gml_problem_get_spins.argtypes = [p, p]
     L.gml_problem_destroy.argtypes = [p]
     L.gml_problem_destroy.restype = None
@@ -98,7 +99,7 @@ class Problem:
     """RAII wrapper of a gml_problem handle (packed spins + weights resident in HBM)."""
 
     def __init__(self, samples=None, *, counts=None, spins=None, model=None, terms=None, n=None, num_samples=None, seed=0,
-                 order=2, node_range=None, device=0):
+                 mcmc_sweeps=None, order=2, node_range=None, device=0):
         L = lib()
         h = C.c_void_p()
         if terms is not None:
@@ -112,8 +113,12 @@ class Problem:
                 keys[t, :len(k)] = np.asarray(k, dtype=np.int64) - 1
                 wts[t] = v
             n0, n1 = node_range if node_range is not None else (0, int(n))
-            check(L.gml_problem_create_sampled_terms(_ptr(keys), stride, _ptr(wts), len(terms), int(n), int(num_samples), int(seed),
-                                                     int(order), n0, n1, int(device), C.byref(h)))
+            if mcmc_sweeps:  # Glauber chains instead of exact enumeration (components above 22 spins)
+                check(L.gml_problem_create_mcmc_terms(_ptr(keys), stride, _ptr(wts), len(terms), int(n), int(num_samples),
+                                                      int(seed), int(mcmc_sweeps), int(order), n0, n1, int(device), C.byref(h)))
+            else:
+                check(L.gml_problem_create_sampled_terms(_ptr(keys), stride, _ptr(wts), len(terms), int(n), int(num_samples),
+                                                         int(seed), int(order), n0, n1, int(device), C.byref(h)))
         elif model is not None:
             # sample on the device from a pairwise model (n x n, diagonal = fields): sampling.jl:34-57
             m = np.ascontiguousarray(model, dtype=np.float64)

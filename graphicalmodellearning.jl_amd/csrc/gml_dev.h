@@ -75,6 +75,10 @@ void launch_hess_f64(const DevProblem &P, const double *V,
 void launch_block_sampler(const unsigned *dmasks, const double *dwts, int nt, int sb, const int *dmembers, int64_t N, int64_t n,
                           unsigned long long seed, int block, double *den, double *dcdf, int8_t *dS, hipStream_t st);
 
+// Glauber dynamics (N independent chains, `sweeps` sweeps) on incidence lists; St [n][Np] spin-major.
+void launch_glauber(const int *dioff, const double *diw, const int *dooff, const int *doth, int64_t n, int64_t N, int64_t Np,
+                    int sweeps, unsigned long long seed, int8_t *dSt, hipStream_t st);
+
 // Batched Newton solve on the ragged Hessian blocks: A = s1[r]*H_r - s2*gF gF^T, A d = -pgF, in place
 // (Cholesky, ridge restart).  gF/pgF/dout are R x cap; Sdiag[r] = A[m-1][m-1].
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,

@@ -560,6 +560,113 @@ static int create_sampled_terms(const int32_t *keys, int stride, const double *w
     return GML_OK;
 }
 
+extern "C" int gml_problem_create_mcmc_terms(const int32_t *keys, int key_stride, const double *weights, int64_t nterms,
+                                             int64_t n, int64_t N, uint64_t seed, int sweeps, int order, int64_t node0,
+                                             int64_t node1, int device, gml_problem **out) {
+    if (!out) return fail(GML_EINVAL, "out is NULL");
+    *out = nullptr;
+    if ((nterms > 0 && (!keys || !weights)) || key_stride < 1) return fail(GML_EINVAL, "NULL or malformed term list");
+    if (n <= 0 || N <= 0 || sweeps < 1) return fail(GML_EINVAL, "n, N and sweeps must be positive");
+    if (order < 1 || order > 8) return fail(GML_EINVAL, "interaction order %d out of range [1,8]", order);
+    if (node0 < 0 || node1 > n || node0 >= node1)
+        return fail(GML_EINVAL, "bad node range [%lld,%lld) for n=%lld", (long long)node0, (long long)node1, (long long)n);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GML_EHIP, "no HIP device available (libgml_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(GML_EINVAL, "device %d out of range (%d devices)", device, ndev);
+    // incidence lists: for every spin the terms it belongs to (weight + the other spins; a spin named twice cancels)
+    std::vector<std::vector<std::pair<double, std::vector<int>>>> inc((size_t)n);
+    for (int64_t t = 0; t < nterms; ++t) {
+        if (!std::isfinite(weights[t])) return fail(GML_EINVAL, "weight of term %lld is not finite", (long long)t);
+        std::vector<int> sp;
+        for (int a = 0; a < key_stride; ++a) {
+            const int32_t v = keys[t * key_stride + a];
+            if (v < -1 || v >= n) return fail(GML_EINVAL, "term %lld names spin %d outside [0,%lld)", (long long)t, v, (long long)n);
+            if (v < 0) continue;
+            auto itv = std::find(sp.begin(), sp.end(), (int)v);
+            if (itv != sp.end()) sp.erase(itv); // s^2 = 1
+            else sp.push_back((int)v);
+        }
+        if (weights[t] == 0.0) continue;
+        for (size_t a = 0; a < sp.size(); ++a) {
+            std::vector<int> others;
+            for (size_t b = 0; b < sp.size(); ++b)
+                if (b != a) others.push_back(sp[b]);
+            inc[(size_t)sp[a]].emplace_back(weights[t], std::move(others));
+        }
+    }
+    std::vector<int> ioff((size_t)n + 1, 0), ooff(1, 0), oth;
+    std::vector<double> iw;
+    for (int64_t i = 0; i < n; ++i) {
+        for (auto &e : inc[(size_t)i]) {
+            iw.push_back(e.first);
+            for (int j : e.second) oth.push_back(j);
+            ooff.push_back((int)oth.size());
+        }
+        ioff[(size_t)i + 1] = (int)iw.size();
+    }
+    if (iw.empty()) iw.push_back(0.0);
+    if (oth.empty()) oth.push_back(0);
+    HIPCHK(hipSetDevice(device));
+    gml_problem *p = new gml_problem();
+    p->device = device;
+    p->n = n;
+    p->K = N;
+    p->M = (double)N;
+    p->order = order;
+    p->node0 = node0;
+    p->node1 = node1;
+    hipStream_t st = nullptr;
+    const int64_t Np = round_up(N, 256);
+    int8_t *dS = nullptr, *dSt = nullptr;
+    int *dioff = nullptr, *dooff = nullptr, *doth = nullptr;
+    double *diw = nullptr;
+    auto cleanup = [&](int rc) {
+        void *ptrs[] = {dSt, dioff, dooff, doth, diw};
+        for (void *q : ptrs)
+            if (q) (void)hipFree(q);
+        if (st) (void)hipStreamDestroy(st);
+        return rc;
+    };
+#define SCHK(expr)                                                                                              \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) {                                                                                 \
+            if (dS) (void)hipFree(dS);                                                                          \
+            delete p;                                                                                           \
+            return cleanup(fail(e_ == hipErrorOutOfMemory ? GML_ENOMEM : GML_EHIP, "%s failed: %s", #expr,      \
+                                hipGetErrorString(e_)));                                                        \
+        }                                                                                                       \
+    } while (0)
+    SCHK(hipStreamCreate(&st));
+    SCHK(hipMalloc(&dS, (size_t)N * n));
+    SCHK(hipMalloc(&dSt, (size_t)n * Np));
+    SCHK(hipMalloc(&dioff, sizeof(int) * ioff.size()));
+    SCHK(hipMalloc(&dooff, sizeof(int) * ooff.size()));
+    SCHK(hipMalloc(&doth, sizeof(int) * oth.size()));
+    SCHK(hipMalloc(&diw, sizeof(double) * iw.size()));
+    SCHK(hipMemcpyAsync(dioff, ioff.data(), sizeof(int) * ioff.size(), hipMemcpyHostToDevice, st));
+    SCHK(hipMemcpyAsync(dooff, ooff.data(), sizeof(int) * ooff.size(), hipMemcpyHostToDevice, st));
+    SCHK(hipMemcpyAsync(doth, oth.data(), sizeof(int) * oth.size(), hipMemcpyHostToDevice, st));
+    SCHK(hipMemcpyAsync(diw, iw.data(), sizeof(double) * iw.size(), hipMemcpyHostToDevice, st));
+    SCHK(hipMemsetAsync(dSt, 0, (size_t)n * Np, st));
+    launch_glauber(dioff, diw, dooff, doth, n, N, Np, sweeps, (unsigned long long)seed, dSt, st);
+    launch_transpose_i8(dSt, n, N, Np, dS, n, st); // spin-major -> the sample-major rows alloc_dev expects
+    SCHK(hipGetLastError());
+    SCHK(hipStreamSynchronize(st));
+#undef SCHK
+    cleanup(0);
+    int rc = alloc_dev(p, nullptr, nullptr, dS);
+    if (rc != GML_OK) {
+        std::string keep = g_err;
+        gml_problem_destroy(p);
+        g_err = keep;
+        return rc;
+    }
+    *out = p;
+    return GML_OK;
+}
+
 extern "C" int gml_problem_create_sampled_terms(const int32_t *keys, int key_stride, const double *weights, int64_t nterms,
                                                 int64_t n, int64_t N, uint64_t seed, int order, int64_t node0,
                                                 int64_t node1, int device, gml_problem **out) {

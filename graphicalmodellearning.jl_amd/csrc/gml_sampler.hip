@@ -101,6 +101,43 @@ __global__ __launch_bounds__(256) void k_block_draw(const double *__restrict__ c
     for (int t = 0; t < sb; ++t) S[k * n + members[t]] = (lo >> t) & 1 ? (int8_t)1 : (int8_t)-1;
 }
 
+// ------------------------------------------------------------------------------------------
+// Glauber (single-spin heat-bath) dynamics for models whose components are too large to enumerate: N
+// independent chains, one thread each, `sweeps` sequential-scan sweeps from a uniformly random start; the
+// final states are the samples.  (Beyond the reference, whose "Gibbs" sampler is exact enumeration; SURVEY.md
+// 8(f) #2 names this as the follow-up.)  State spin-major St [n][Np] so that a wave's reads of one spin are
+// contiguous; the model as incidence lists: spin i is in incidences [ioff[i], ioff[i+1]), incidence e has
+// weight iw[e] and the other spins of its term oth[ooff[e] .. ooff[e+1]).
+//   field_i = sum_e iw[e] prod_{j in others(e)} s_j,   P(s_i = +1 | rest) = 1 / (1 + exp(-2 field_i))
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_glauber(const int *__restrict__ ioff, const double *__restrict__ iw,
+                                                 const int *__restrict__ ooff, const int *__restrict__ oth, int64_t n,
+                                                 int64_t N, int64_t Np, int sweeps, unsigned long long seed,
+                                                 int8_t *__restrict__ St) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    for (int64_t i = 0; i < n; ++i) St[i * Np + k] = u01(seed, 0xFFFFFFFFull, (unsigned long long)(k * n + i)) < 0.5 ? (int8_t)1 : (int8_t)-1;
+    for (int sw = 0; sw < sweeps; ++sw) {
+        for (int64_t i = 0; i < n; ++i) {
+            double field = 0.0;
+            for (int e = ioff[i]; e < ioff[i + 1]; ++e) {
+                int pr = 1;
+                for (int a = ooff[e]; a < ooff[e + 1]; ++a) pr *= (int)St[(int64_t)oth[a] * Np + k];
+                field += iw[e] * (double)pr;
+            }
+            const double pup = 1.0 / (1.0 + exp(-2.0 * field));
+            const double u = u01(seed, (unsigned long long)sw, (unsigned long long)(k * n + i));
+            St[i * Np + k] = u < pup ? (int8_t)1 : (int8_t)-1;
+        }
+    }
+}
+
+void launch_glauber(const int *dioff, const double *diw, const int *dooff, const int *doth, int64_t n, int64_t N, int64_t Np,
+                    int sweeps, unsigned long long seed, int8_t *dSt, hipStream_t st) {
+    hipLaunchKernelGGL(k_glauber, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dioff, diw, dooff, doth, n, N, Np, sweeps, seed,
+                       dSt);
+}
+
 void launch_block_sampler(const unsigned *dmasks, const double *dwts, int nt, int sb, const int *dmembers, int64_t N, int64_t n,
                           unsigned long long seed, int block, double *den, double *dcdf, int8_t *dS, hipStream_t st) {
     const int64_t ns = (int64_t)1 << sb;

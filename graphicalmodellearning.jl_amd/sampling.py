@@ -16,6 +16,14 @@ class Gibbs(GMSampler):  # sampling.jl:9  (the reference's "Gibbs" sampler is ex
     pass
 
 
+class Glauber(GMSampler):
+    """Not in the reference: N independent heat-bath chains of `sweeps` sweeps on the device, for models whose
+    connected components exceed the 22 spins exact enumeration can handle (gml_problem_create_mcmc_terms)."""
+
+    def __init__(self, sweeps=200):
+        self.sweeps = int(sweeps)
+
+
 def _problem_args(model):
     """Keyword arguments of _lib.Problem for a model: matrix (order <= 2, :98-99) or term list (:100-101)."""
     if isinstance(model, FactorGraph):
@@ -33,6 +41,11 @@ def sample(model, number_sample, replicates=None, sampler=None, *, seed=0, devic
     """sample(gm, N) -> histogram matrix [count, s_1..s_n], one row per observed configuration
     (sampling.jl:52-54); sample(gm, N, replicates) -> list of such matrices (:91)."""
     args = _problem_args(model)
+    if isinstance(sampler, Glauber):
+        if "model" in args:  # the chains run on term lists
+            fg = model if isinstance(model, FactorGraph) else FactorGraph(np.asarray(model, dtype=np.float64))
+            args = {"terms": fg.terms, "n": fg.varible_count, "order": 2}
+        args["mcmc_sweeps"] = sampler.sweeps
     reps = 1 if replicates is None else int(replicates)
     out = []
     for b in range(reps):

@@ -121,6 +121,13 @@ int gml_problem_create_sampled_terms(const int32_t *keys, int key_stride, const 
                                      int64_t n, int64_t N, uint64_t seed, int order, int64_t node0,
                                      int64_t node1, int device, gml_problem **out);
 
+/* Beyond the reference (whose only sampler is exact enumeration): N independent Glauber (heat-bath) chains of
+ * `sweeps` sequential sweeps from a random start, for models whose components exceed 22 spins (lattices, ...).
+ * Same term-list arguments as above; the final states of the chains become the handle's samples. */
+int gml_problem_create_mcmc_terms(const int32_t *keys, int key_stride, const double *weights, int64_t nterms,
+                                  int64_t n, int64_t N, uint64_t seed, int sweeps, int order, int64_t node0,
+                                  int64_t node1, int device, gml_problem **out);
+
 /* The +-1 configurations held by a handle, K x n row-major (host pointer). */
 int gml_problem_get_spins(gml_problem *p, int8_t *spins);
 

@@ -105,3 +105,45 @@ def test_multibody_sampler_matches_exact_distribution():
     got = {tuple(sorted(i + 1 for i in k)): v for k, v in zip(keys0, out[0])}
     for k in [(1,), (1, 2, 3), (1, 2, 3, 4)]:
         assert abs(got[k] - terms[k]) <= 0.03
+
+
+def test_glauber_chains_match_exact_distribution_and_feed_the_learner():
+    # (beyond the reference) heat-bath chains on the device: on a 3 x 4 open lattice with fields the empirical
+    # distribution of 4e5 independent chains after 60 sweeps must match the exact one ...
+    rng = np.random.default_rng(3)
+    L1, L2 = 3, 4
+    n = L1 * L2
+    m = np.zeros((n, n))
+    for a in range(L1):
+        for b in range(L2):
+            i = a * L2 + b
+            if b + 1 < L2:
+                m[i, i + 1] = m[i + 1, i] = rng.uniform(0.2, 0.5) * rng.choice([-1, 1])
+            if a + 1 < L1:
+                m[i, i + L2] = m[i + L2, i] = rng.uniform(0.2, 0.5) * rng.choice([-1, 1])
+            m[i, i] = rng.uniform(-0.2, 0.2)
+    N = 400000
+    hist = gml.sample(gml.FactorGraph(m), N, sampler=gml.Glauber(60), seed=4)
+    assert hist[:, 0].sum() == N
+    states, p = exact_probabilities(m)
+    lookup = {tuple(s): pi for s, pi in zip(states, p)}
+    emp = np.zeros(len(states))
+    idx = {tuple(s): i for i, s in enumerate(states)}
+    for row in hist:
+        emp[idx[tuple(row[1:])]] = row[0] / N
+    assert np.abs(emp - p).max() <= 6 * np.sqrt(p.max() / N)
+    # ... and a 16 x 16 periodic lattice (256 spins in ONE component: far beyond enumeration) sampled this way
+    # lets RISE recover its couplings
+    Lx = 16
+    n = Lx * Lx
+    J = np.zeros((n, n))
+    for a in range(Lx):
+        for b in range(Lx):
+            i = a * Lx + b
+            for j in (a * Lx + (b + 1) % Lx, ((a + 1) % Lx) * Lx + b):
+                J[i, j] = J[j, i] = 0.3 * (1 if (a + b) % 3 else -1)
+    terms = {(i + 1, j + 1): J[i, j] for i in range(n) for j in range(i + 1, n) if J[i, j] != 0}
+    with gml.Problem(terms=terms, n=n, num_samples=300000, seed=9, mcmc_sweeps=150) as p:
+        out, kkt, st = p.learn("RISE", 0.4, tol=1e-9, precision="i8x")
+    assert st["not_converged"] == 0
+    assert np.abs(0.5 * (out + out.T) - J).max() <= 0.05
