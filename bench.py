@@ -108,7 +108,7 @@ def main():
                 "pass_tflops": 2 * flops_kernel / (km["pass_ms"] * 1e-3) / 1e12,
                 # `value` is wall-clock per pass through the host-pointer operator boundary, i.e. it includes the
                 # PCIe upload of Theta (n_loc x n doubles) and download of the gradient; the two GEMM kernels alone:
-                "kernels_ms_per_step": km["pass_ms"], "kernels_only_node_evals_per_s": n / (km["pass_ms"] * 1e-3) * (nloc / n)}
+                "kernels_ms_per_step": km["pass_ms"], "kernels_only_node_evals_per_s_per_gpu": nloc / (km["pass_ms"] * 1e-3)}
     if args.precision == "i8x":
         # the int8-limb pass issues LF forward + 4 backward digit-plane products per algorithmic one
         LF = int(os.environ.get("GML_I8_LF", "5"))
