@@ -1485,10 +1485,17 @@ extern "C" int gml_objgrad_batch(gml_problem *p, int formulation, int precision,
     rs.node.assign(nodes, nodes + nrows);
     std::vector<NodeLayout> lay((size_t)nrows);
     std::vector<double> Th((size_t)nrows * Qp, 0.0), Gi(g ? (size_t)nrows * Qp : 0);
+    std::vector<uint8_t> badrow((size_t)nrows, 0);
     parallel_for(nrows, [&](int64_t r) {
         build_layout(p, nodes[r], lay[r]);
-        for (int64_t j = 0; j < P; ++j) Th[(size_t)r * Qp + lay[r].cols[j]] = theta[r * ld + j];
+        for (int64_t j = 0; j < P; ++j) {
+            const double v = theta[r * ld + j];
+            if (!std::isfinite(v)) badrow[r] = 1;
+            Th[(size_t)r * Qp + lay[r].cols[j]] = v;
+        }
     });
+    for (int64_t r = 0; r < nrows; ++r)
+        if (badrow[r]) return fail(GML_EINVAL, "theta of row %lld contains a non-finite value", (long long)r);
     std::vector<uint8_t> act((size_t)nrows, 1);
     std::vector<double> fv((size_t)nrows);
     int rc = device_pass(p, rs, act, Th.data(), formulation, precision, g != nullptr, fv.data(), Gi.data(), nullptr);

@@ -206,6 +206,12 @@ def test_input_validation_errors():
         gml.Problem(s)
     with pytest.raises(gml.GMLError):
         gml.Problem(load_csv("a_samples.csv"), node_range=(2, 9))
+    with gml.Problem(load_csv("a_samples.csv")) as p:
+        th = np.zeros((1, p.P))
+        th[0, 1] = np.nan
+        with pytest.raises(gml.GMLError) as e:
+            p.objgrad("RISE", np.array([0]), th)
+        assert e.value.code == 1 and "non-finite" in str(e.value)
 
 
 def test_not_converged_raises_like_the_reference_assert():
