@@ -842,7 +842,9 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
                        int form, int precision, bool want_grad, double *f, double *g, gml_stats *stats,
                        float *ms /* [2]: fwd, bwd or NULL */ = nullptr,
                        double *fnoise /* R: absolute uncertainty of f[r] (before any log) or NULL */ = nullptr,
-                       const std::vector<double> *tau_ovr = nullptr /* internal: rescaled re-run */, int depth = 0) {
+                       const std::vector<double> *tau_ovr = nullptr /* Rp per-row tau (0 = from the bound): the solver's
+                       tracked scale, or the rescaled re-run below */,
+                       int depth = 0, double *vmax_out = nullptr /* R: rigorous bound on max_k |V_rk| of the evaluated rows */) {
     const int64_t R = rs.R, Qp = p->d.Qp;
     const int64_t Rp = round_up(R, 32);
     int rc = ensure_ws(p, R);
@@ -920,10 +922,11 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
     if (fnoise)
         for (int64_t r = 0; r < R; ++r) {
             if (!act[r]) continue;
-            // f64: summation rounding.  int8 limbs: every V_rk is rounded to a multiple of tau_r and
-            // the roundings can add coherently (few distinct energies): K * tau/2 worst case.
+            // f64: summation rounding.  int8 limbs: every V_rk is rounded to a multiple of tau_r with a dither
+            // that is equidistributed over the samples, so the errors (each within one unit, standard deviation
+            // 0.41 tau) add like a random walk: 8 sigma of sqrt(K) terms (the worst case K * tau is never approached).
             fnoise[r] = 1e-13 * std::max(1.0, std::fabs(fh[r]));
-            if (precision == GML_PREC_I8X && form != GML_RPLE) fnoise[r] += 0.5 * (double)p->K * tauh[r];
+            if (precision == GML_PREC_I8X && form != GML_RPLE) fnoise[r] += 3.3 * std::sqrt((double)p->K) * tauh[r];
         }
     if (ms) {
         HIPCHK(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
@@ -958,9 +961,12 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
                 ovr[r] = ((double)mmaxh[r] + 1.0) * tauh[r] * (1.0 + 1e-12) / 2130000000.0;
                 ++nagain;
             }
+        if (vmax_out)
+            for (int64_t r = 0; r < R; ++r)
+                if (act[r]) vmax_out[r] = ((double)mmaxh[r] + 1.0) * tauh[r];
         if (nagain > 0) {
             if (depth >= 6) return fail(GML_EUNSUPPORTED, "precision i8x: the weights exp(-E) of a row underflow its fixed-point range; use precision f64");
-            return device_pass(p, rs, again, theta, form, precision, want_grad, f, g, stats, nullptr, fnoise, &ovr, depth + 1);
+            return device_pass(p, rs, again, theta, form, precision, want_grad, f, g, stats, nullptr, fnoise, &ovr, depth + 1, vmax_out);
         }
     }
     return GML_OK;
@@ -1095,6 +1101,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     o.max_working = (int)round_up(o.max_working, 32);
     if (o.max_add <= 0) o.max_add = 64;
     HIPCHK(hipSetDevice(p->device));
+    const int64_t dbg_row = getenv("GML_DEBUG_ROW") ? atoll(getenv("GML_DEBUG_ROW")) : 0; // row traced at verbose >= 2
     gml_stats stl;
     std::memset(&stl, 0, sizeof stl);
     gml_stats *stats = &stl;
@@ -1150,6 +1157,28 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     std::vector<int> stall((size_t)R, 0), msz((size_t)R, 0), mtot((size_t)R, 0), blk((size_t)R, 0);
     std::vector<std::vector<int>> Fset((size_t)R);
     std::vector<std::vector<double>> Dset((size_t)R), PGset((size_t)R);
+    // Scale of the fixed-point V (int8 path): instead of the worst-case bound w_max exp(sum|theta|) every pass after
+    // a row's first uses vref = max_k |V_rk| measured by its previous pass, times exp(||theta - theta_ref||_1),
+    // which bounds the new weights rigorously (|E_k' - E_k| <= ||theta' - theta||_1).  Near the optimum the steps
+    // are tiny, so V keeps all 31 bits relative to its actual maximum and the noise floor of f and grad drops by the
+    // bits the bound would have wasted.
+    const bool track_scale = o.precision == GML_PREC_I8X && formulation != GML_RPLE;
+    std::vector<double> vref((size_t)R, 0.0), dref((size_t)R, 0.0), stepn((size_t)R, 0.0), vnew((size_t)R, 0.0),
+        ovr((size_t)round_up(R, 32), 0.0);
+    auto scale_for = [&](const std::vector<uint8_t> &rows, bool at_trial) -> const std::vector<double> * {
+        if (!track_scale) return nullptr;
+        for (int64_t r = 0; r < R; ++r)
+            ovr[r] = (rows[r] && vref[r] > 0.0) ? vref[r] * std::exp(dref[r] + (at_trial ? stepn[r] : 0.0)) * (1.0 + 1e-6) / 2130000000.0 : 0.0;
+        return &ovr;
+    };
+    auto scale_seen = [&](const std::vector<uint8_t> &rows, bool at_trial) {
+        if (!track_scale) return;
+        for (int64_t r = 0; r < R; ++r)
+            if (rows[r]) {
+                vref[r] = vnew[r];
+                dref[r] = at_trial ? stepn[r] : 0.0; // distance from the current iterate to the point just evaluated
+            }
+    };
 
     // logRISE post-processing of a pass: f = log Z, g = grad Z / Z   (:279)
     auto post = [&](const std::vector<uint8_t> &a, std::vector<double> &fv, std::vector<double> &gv,
@@ -1169,8 +1198,9 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     };
 
     int rc = device_pass(p, rs, act, X.data(), formulation, o.precision, true, f.data(), G.data(), stats, nullptr,
-                         fn.data());
+                         fn.data(), nullptr, 0, vnew.data());
     if (rc) return rc;
+    scale_seen(act, false);
     post(act, f, G, Z, fn, true);
 
     int it = 0;
@@ -1279,8 +1309,9 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         stats->t_host += now_s() - th0;
         if (anystale) {
             rc = device_pass(p, rs, need, X.data(), formulation, o.precision, true, f.data(), G.data(), stats, nullptr,
-                             fn.data());
+                             fn.data(), scale_for(need, false), 0, vnew.data());
             if (rc) return rc;
+            scale_seen(need, false);
             post(need, f, G, Z, fn, true);
             for (int64_t r = 0; r < R; ++r)
                 if (need[r]) vstale[r] = 0;
@@ -1354,7 +1385,27 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                     xt[c] = v;
                     d_ += PGset[r][a] * (v - x[c]);
                 }
+                if (!(d_ < 0)) {
+                    // The projected step is not a descent direction: some coordinate's Newton step crossed zero and
+                    // was clipped, while the other coordinates still carry the moves that were meant to accompany
+                    // it.  Take only the clipping (each such coordinate moves towards its 1-D minimiser, so F
+                    // decreases); the coordinate then leaves the working set and the next Newton system is right.
+                    std::memcpy(xt, x, sizeof(double) * Qp);
+                    d_ = 0;
+                    for (int a = 0; a < mtot[r]; ++a) {
+                        const int c = Fs[a];
+                        if (kr[c] != 2 || !(lambda > 0) || x[c] == 0.0) continue;
+                        const double v = x[c] + alpha[r] * Dset[r][a];
+                        if (v * x[c] < 0) {
+                            xt[c] = 0.0;
+                            d_ += PGset[r][a] * (0.0 - x[c]);
+                        }
+                    }
+                }
                 dd[r] = d_;
+                double sn = 0;
+                for (int a = 0; a < mtot[r]; ++a) sn += std::fabs(xt[Fs[a]] - x[Fs[a]]);
+                stepn[r] = sn; // ||trial - x||_1: bounds the change of every energy
                 nreg[r] = !(-0.1 * d_ > 8.0 * fn[r]); // the step's expected decrease (~|dd|/2) vs the uncertainty of f
             });
             for (int64_t r = 0; r < R; ++r) {
@@ -1365,8 +1416,9 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             if (!any) break;
             const bool full = (ls == 0) || anynoise;
             rc = device_pass(p, rs, need, Xt.data(), formulation, o.precision, full, ft.data(), Gt.data(), stats, nullptr,
-                             fnt.data());
+                             fnt.data(), scale_for(need, true), 0, vnew.data());
             if (rc) return rc;
+            scale_seen(need, true);
             post(need, ft, Gt, Zt, fnt, full);
             const double th3 = now_s();
             parallel_for(R, [&](int64_t r) {
@@ -1397,10 +1449,11 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                         if (kr[c] == 2 && xt[c] != 0.0) Fn += lambda * std::fabs(xt[c]);
                     ok = std::isfinite(Fn) && Fn <= Fobj[r] + 1e-4 * dd[r] + fn[r] + fnt[r];
                 }
-                if (o.verbose >= 2 && r == 0)
-                    fprintf(stderr, "[gml]   row0: ls %d alpha %.3g nreg %d ft %.6e dd %.3e fnt %.3e ok %d\n", ls, alpha[r], (int)nreg[r], ft[r],
-                            dd[r], fnt[r], (int)ok);
+                if (o.verbose >= 2 && r == dbg_row)
+                    fprintf(stderr, "[gml]   row %lld: ls %d alpha %.3g nreg %d ft %.12e Fobj %.12e dd %.3e fnt %.3e ok %d\n", (long long)r, ls, alpha[r],
+                            (int)nreg[r], ft[r], Fobj[r], dd[r], fnt[r], (int)ok);
                 if (ok) {
+                    dref[r] = 0.0; // the iterate moves onto the point the scale was measured at
                     std::memcpy(X.data() + r * Qp, xt, sizeof(double) * Qp);
                     f[r] = ft[r];
                     fn[r] = fnt[r];
@@ -1424,8 +1477,9 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         for (int64_t r = 0; r < R; ++r) anyf |= accepted_fwd[r] != 0;
         if (anyf) {
             rc = device_pass(p, rs, accepted_fwd, X.data(), formulation, o.precision, true, f.data(), G.data(), stats,
-                             nullptr, fn.data());
+                             nullptr, fn.data(), scale_for(accepted_fwd, false), 0, vnew.data());
             if (rc) return rc;
+            scale_seen(accepted_fwd, false);
             post(accepted_fwd, f, G, Z, fn, true);
             for (int64_t r = 0; r < R; ++r)
                 if (accepted_fwd[r]) vstale[r] = 0;

@@ -124,8 +124,10 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
         // |V|/tau <= 2.13e9: the largest magnitude whose 4 balanced base-256 digits fit the packed
         // (q + 0x80808080) ^ 0x80808080 form used by the forward epilogue
         // The bound exp(sum|theta|) can exceed the largest actual |V| by many orders of magnitude (dense
-        // theta); the caller then re-runs the row with tau taken from the largest |V| the first pass saw.
-        const double t = (tauovr && tauovr[r] > 0.0) ? tauovr[r] : B * (1.0 + 1e-12) / 2130000000.0;
+        // theta); the caller then re-runs the row with tau taken from the largest |V| the first pass saw, and
+        // the solver passes max|V| of its previous pass times exp(||step||_1), which bounds the new weights.
+        double t = B * (1.0 + 1e-12) / 2130000000.0;
+        if (tauovr && tauovr[r] > 0.0 && tauovr[r] < t) t = tauovr[r]; // a tighter rigorous scale from the caller
         sigma[r] = sg;
         qconst[r] = q0;
         tau[r] = t;
@@ -160,8 +162,12 @@ __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ t
 // |V| / tau of one element: rint(wkit * exp(x)) for x = -s E, to 3e-10 relative before the rounding.
 // FP64 range reduction with one FMA (the product t * ln2/64 is not rounded inside an FMA), FP32
 // polynomial for expm1 of the reduced argument, table of 2^(j/64), exponent added as an integer, and
-// the final rounding to an integer through the 1.5 * 2^52 trick (round-to-nearest-even, like rint).
-__device__ __forceinline__ int mag_exp(double x, double wkit, const double *__restrict__ tab) {
+// the final rounding to an integer through the 1.5 * 2^52 trick, after adding a dither in [-1/2, 1/2) that is a
+// fixed function of (node, sample): the rounding is then "stochastic" -- still
+// deterministic and within one unit, but uncorrelated across samples.  Round-to-nearest is coherent whenever a
+// sparse theta row leaves only a few distinct energies (thousands of samples share each rounding error), which
+// made the realised error of f and grad approach the K * tau / 2 worst case instead of ~ sqrt(K) * tau.
+__device__ __forceinline__ int mag_exp(double x, double wkit, double dith, const double *__restrict__ tab) {
     const double MAGIC = 6755399441055744.0;
     const double tm = fma(x, 92.33248261689366, MAGIC); // 64/ln2
     const int n = __double2loint(tm);
@@ -175,7 +181,7 @@ __device__ __forceinline__ int mag_exp(double x, double wkit, const double *__re
     const double tj0 = tab[n & 63];
     const double tj = __hiloint2double(__double2hiint(tj0) + ((n >> 6) << 20), __double2loint(tj0)); // * 2^(n>>6)
     const double res = fma(tj, (double)d, tj);
-    return __double2loint(fma(wkit, res, MAGIC));
+    return __double2loint(fma(wkit, res, dith) + MAGIC);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -417,6 +423,9 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const int64_t kw = k0 + wave * 64; // first sample of this wave
     const double sgq0 = sg * q0, wkit = wuni * it;
     double sg2 = -2.0 * sg;
+    // dither of the V rounding: golden-ratio (Weyl) sequence in the global sample index, offset per node --
+    // independent of tiling, node sharding and compaction, so results stay bit-identical across GPU counts
+    const unsigned dh0 = (unsigned)rc * 0x85EBCA6Bu + (unsigned)(kw + 4 * h) * 0x9E3779B9u;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         v4i pl[LB];
@@ -448,6 +457,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     a = fma((double)acc[i][2][e], 65536.0, (double)lo);
                 }
                 const double Ea = fma(a, sg2, sgq0);                // |E| pre-sign: sigma * (q0 + S - 2 A)
+                const double dith = (double)(int)(dh0 + (unsigned)(i * 32 + 8 * g + j) * 0x9E3779B9u) * 2.3283064365386963e-10; // [-1/2, 1/2)
                 const unsigned sbyte = sw >> (8 * j);               // s_u^k: 0x01, 0xFF, or 0 for a padding sample
                 const bool neg = (sbyte & 0x80u) != 0;
                 int vq;
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     rc = fma(fma(-opu, rc, 1.0), rc, rc);
                     rc = fma(fma(-opu, rc, 1.0), rc, rc);
                     const double sig = E2 >= 0.0 ? u * rc : rc; // 1 / (1 + exp(2E))
-                    const int mag = __double2loint(fma(2.0 * wk0 * it, sig, 6755399441055744.0));
+                    const int mag = __double2loint(fma(2.0 * wk0 * it, sig, dith) + 6755399441055744.0);
                     vq = neg ? mag : -mag;
                     // log(1 + u), 1 + u in (1, 2]: table of log c_j on 64 intervals + log1p of the residual
                     int jt = (int)(u * 64.0);
@@ -478,8 +488,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     // x = -s E: flip the sign of Ea unless s = -1
                     const double x = __hiloint2double(__double2hiint(Ea) ^ (int)(((sbyte & 0x80u) ^ 0x80u) << 24), __double2loint(Ea));
                     int mag;
-                    if (wuni > 0.0) mag = mag_exp(x, wkit, etab) & -(int)(sbyte & 1u); // padding samples carry no weight
-                    else mag = mag_exp(x, w[kk + j] * it, etab);
+                    if (wuni > 0.0) mag = mag_exp(x, wkit, dith, etab) & -(int)(sbyte & 1u); // padding samples carry no weight
+                    else mag = mag_exp(x, w[kk + j] * it, dith, etab);
                     vq = neg ? mag : -mag;
                     mx = mag > mx ? mag : mx;
                     if (WANTF) as += mag;
@@ -1216,8 +1226,8 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
                        want_grad ? (int64_t)Rp * d.Qp / 2 : 0);
     const double *dOvr = nullptr;
     if (hTauOvr) {
+        // (pageable source: the runtime stages it before returning, the caller keeps it alive until its final sync)
         I8CHK(hipMemcpyAsync(w->tauovr, hTauOvr, sizeof(double) * Rp, hipMemcpyHostToDevice, st));
-        I8CHK(hipStreamSynchronize(st)); // the caller's buffer is pageable
         dOvr = w->tauovr;
     }
     switch (LF) {
