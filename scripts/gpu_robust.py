@@ -20,4 +20,39 @@ for n, K, blk, seed in cases:
                 bad += st['not_converged'] != 0
                 print(f"n={n} K={K} blk={blk} seed={seed} {form}({c}) {prec}: {time.time()-t0:.3f}s it {st['iterations']} passes {st['passes']}+{st['forward_passes']} "
                       f"kkt {st['max_kkt']:.2e} nnz {int((out != 0).sum(1).max())}{flag}", flush=True)
+# histogram input with very uneven counts (the non-uniform-weight path), multi-body statistics, a lattice
+rng = np.random.default_rng(0)
+for n, N in [(10, 200000), (14, 2000000)]:
+    m = np.triu(rng.uniform(-0.5, 0.5, (n, n)) * (rng.random((n, n)) < 0.4), 1)
+    m = m + m.T + np.diag(rng.uniform(-0.2, 0.2, n))
+    hist = syn.enumerate_sample(m, N, seed=3)
+    with gml.Problem(hist) as p:
+        for form, c in [('RISE', 0.4), ('RISE', 1.5), ('logRISE', 0.8), ('RPLE', 0.2)]:
+            for prec in ('i8x', 'f64'):
+                out, kkt, st = p.learn(form, c, tol=1e-9, precision=prec, raise_on_fail=False)
+                flag = '' if st['not_converged'] == 0 else '  <-- NOT CONVERGED'
+                bad += st['not_converged'] != 0
+                print(f"histogram n={n} rows={len(hist)} {form}({c}) {prec}: it {st['iterations']} passes {st['passes']}+{st['forward_passes']} kkt {st['max_kkt']:.2e}{flag}", flush=True)
+spins, terms = syn.block_multibody(36, 100000, block=12, seed=2)
+with gml.Problem(spins=spins, order=3) as p:
+    for c in (0.2, 0.4, 1.5):
+        for prec in ('i8x', 'f64'):
+            out, kkt, st = p.learn('RISE', c, tol=1e-9, precision=prec, raise_on_fail=False)
+            flag = '' if st['not_converged'] == 0 else '  <-- NOT CONVERGED'
+            bad += st['not_converged'] != 0
+            print(f"multibody n=36 order 3 RISE({c}) {prec}: it {st['iterations']} passes {st['passes']}+{st['forward_passes']} kkt {st['max_kkt']:.2e} nnz {int((out != 0).sum(1).max())}{flag}", flush=True)
+Lx = 24
+n = Lx * Lx
+J = {}
+for a in range(Lx):
+    for b in range(Lx):
+        i = a * Lx + b
+        for j in (a * Lx + (b + 1) % Lx, ((a + 1) % Lx) * Lx + b):
+            J[(min(i, j) + 1, max(i, j) + 1)] = float(rng.uniform(0.1, 0.6) * rng.choice([-1, 1]))
+with gml.Problem(terms=J, n=n, num_samples=400000, seed=2, mcmc_sweeps=80) as p:
+    for form, c in [('RISE', 0.4), ('RISE', 0.1), ('RISE', 1.5), ('logRISE', 0.8), ('RPLE', 0.2)]:
+        out, kkt, st = p.learn(form, c, tol=1e-9, precision='i8x', raise_on_fail=False)
+        flag = '' if st['not_converged'] == 0 else '  <-- NOT CONVERGED'
+        bad += st['not_converged'] != 0
+        print(f"lattice 24x24 {form}({c}) i8x: it {st['iterations']} passes {st['passes']}+{st['forward_passes']} kkt {st['max_kkt']:.2e} nnz {int((out != 0).sum(1).max())}{flag}", flush=True)
 print('failures:', bad)
