@@ -227,6 +227,51 @@ static void node_cols(const gml_problem *p, int64_t u, std::vector<int32_t> &col
     }
 }
 
+// Host (pageable) -> device copy of a large buffer through two pinned staging buffers filled by the thread
+// pool: a plain hipMemcpy from pageable memory runs at 4-5 GB/s, this at the speed of the parallel memcpy.
+static int upload_pageable(void *dst, const void *src, size_t bytes, hipStream_t st) {
+    constexpr size_t CH = (size_t)64 << 20;
+    if (bytes < 2 * CH) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        return GML_OK;
+    }
+    void *stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int rc = GML_OK;
+    for (int i = 0; i < 2 && rc == GML_OK; ++i) {
+        if (hipHostMalloc(&stage[i], CH) != hipSuccess || hipEventCreate(&done[i]) != hipSuccess) rc = GML_ENOMEM;
+    }
+    if (rc == GML_OK) {
+        int b = 0;
+        for (size_t off = 0; off < bytes && rc == GML_OK; off += CH, b ^= 1) {
+            const size_t len = std::min(CH, bytes - off);
+            if (off >= 2 * CH && hipEventSynchronize(done[b]) != hipSuccess) rc = GML_EHIP; // its previous copy has left the buffer
+            const char *sp = static_cast<const char *>(src) + off;
+            char *dp = static_cast<char *>(stage[b]);
+            const int64_t parts = (int64_t)((len + ((size_t)4 << 20) - 1) / ((size_t)4 << 20));
+            parallel_for(parts, [&](int64_t q) {
+                const size_t o = (size_t)q << 22, l = std::min((size_t)4 << 20, len - o);
+                std::memcpy(dp + o, sp + o, l);
+            });
+            if (hipMemcpyAsync(static_cast<char *>(dst) + off, stage[b], len, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipEventRecord(done[b], st) != hipSuccess)
+                rc = GML_EHIP;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) rc = GML_EHIP;
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (stage[i]) (void)hipHostFree(stage[i]);
+        if (done[i]) (void)hipEventDestroy(done[i]);
+    }
+    if (rc == GML_ENOMEM) { // no pinned memory: fall back to the plain copy
+        (void)hipGetLastError();
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        return GML_OK;
+    }
+    if (rc) return fail(rc, "staged upload failed");
+    return GML_OK;
+}
+
 static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /*K x n row-major, host*/,
                      int8_t *dspins = nullptr /* the same on the device (then owned and freed here) */) {
     HIPCHK(hipSetDevice(p->device));
@@ -307,7 +352,22 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
     if (!dS) HIPCHK(hipMalloc(&dS, (size_t)p->K * p->n));
     HIPCHK(hipMalloc(&dSt, (size_t)p->n * d.Kp));
     HIPCHK(hipMalloc(&dkeys, sizeof(int32_t) * p->gkeys.size()));
-    if (!dspins) HIPCHK(hipMemcpyAsync(dS, spins, (size_t)p->K * p->n, hipMemcpyHostToDevice, p->st));
+    if (!dspins) {
+        int urc = upload_pageable(dS, spins, (size_t)p->K * p->n, p->st);
+        if (urc) return urc;
+        // validation of the +-1 alphabet (the reference validates nothing): first offending configuration
+        long long *dbad = nullptr, hbad = -1;
+        HIPCHK(hipMalloc(&dbad, sizeof(long long)));
+        HIPCHK(hipMemcpyAsync(dbad, &hbad, sizeof(long long), hipMemcpyHostToDevice, p->st));
+        launch_check_pm1(dS, p->K, p->n, dbad, p->st);
+        HIPCHK(hipMemcpyAsync(&hbad, dbad, sizeof(long long), hipMemcpyDeviceToHost, p->st));
+        HIPCHK(hipStreamSynchronize(p->st));
+        (void)hipFree(dbad);
+        if (hbad >= 0) {
+            (void)hipFree(dS);
+            return fail(GML_EINVAL, "configuration %lld holds a spin that is not +-1", hbad);
+        }
+    }
     HIPCHK(hipMemcpyAsync(dkeys, p->gkeys.data(), sizeof(int32_t) * p->gkeys.size(), hipMemcpyHostToDevice, p->st));
     HIPCHK(hipMemsetAsync(dSt, 0, (size_t)p->n * d.Kp, p->st));
     launch_transpose_i8(dS, p->K, p->n, p->n, dSt, d.Kp, p->st);
@@ -364,16 +424,7 @@ extern "C" int gml_problem_create_spins(const double *counts, const int8_t *spin
                                         int order, int64_t node0, int64_t node1, int device,
                                         gml_problem **out) {
     if (!spins) return fail(GML_EINVAL, "spins is NULL");
-    std::atomic<int64_t> bad(-1);
-    parallel_for((K + 65535) / 65536, [&](int64_t b) {
-        const int64_t k1 = std::min(K, (b + 1) * 65536);
-        for (int64_t k = b * 65536; k < k1; ++k)
-            for (int64_t i = 0; i < n; ++i) {
-                int8_t v = spins[k * n + i];
-                if (v != 1 && v != -1) bad = k;
-            }
-    });
-    if (bad >= 0) return fail(GML_EINVAL, "configuration %lld holds a spin that is not +-1", (long long)bad.load());
+    // the +-1 check runs on the device, on the uploaded copy (alloc_dev)
     return create_common(counts, spins, K, n, order, node0, node1, device, out);
 }
 

@@ -39,6 +39,22 @@ __global__ __launch_bounds__(256) void k_transpose_i8(const int8_t *__restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void k_check_pm1(const int8_t *__restrict__ S, int64_t total, int64_t n,
+                                                   long long *__restrict__ bad) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int8_t v = S[i];
+        if (v != 1 && v != -1) {
+            // first offender: bad starts at -1, so compare in the unsigned order (-1 = largest)
+            atomicMin(reinterpret_cast<unsigned long long *>(bad), (unsigned long long)(i / n));
+        }
+    }
+}
+
+void launch_check_pm1(const int8_t *S, int64_t K, int64_t n, long long *bad, hipStream_t st) {
+    hipLaunchKernelGGL(k_check_pm1, dim3(4096), dim3(256), 0, st, S, K * n, n, bad);
+}
+
 void launch_transpose_i8(const int8_t *src, int64_t rows, int64_t cols, int64_t ld_src, int8_t *dst,
                          int64_t ld_dst, hipStream_t st) {
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));

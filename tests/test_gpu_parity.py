@@ -206,6 +206,11 @@ def test_input_validation_errors():
         gml.Problem(s)
     with pytest.raises(gml.GMLError):
         gml.Problem(load_csv("a_samples.csv"), node_range=(2, 9))
+    bad_spins = np.ones((300, 5), dtype=np.int8)
+    bad_spins[123, 2] = 0
+    with pytest.raises(gml.GMLError) as e:
+        gml.Problem(spins=bad_spins)  # validated on the device after the upload
+    assert e.value.code == 1 and "123" in str(e.value)
     with gml.Problem(load_csv("a_samples.csv")) as p:
         th = np.zeros((1, p.P))
         th[0, 1] = np.nan
