@@ -32,6 +32,10 @@ void launch_transpose_i8(const int8_t *src, int64_t rows, int64_t cols, int64_t 
                          int8_t *dst, int64_t ld_dst, hipStream_t st);
 void launch_pack_bits(const DevProblem &d, hipStream_t st); // Xt -> Xb, Xtb
 // *bad = smallest configuration index holding an entry that is not +-1 (unchanged if there is none; init -1)
+// Histogram matrix (K x (1+n), element type `dtype` of gml.h, leading dimension ld) -> counts [K] and +-1 int8 spins:
+// column-major input gives spin-major output [n][K], row-major input sample-major [K][n].  *bad as in launch_check_pm1.
+void launch_convert_hist(const void *H, int dtype, int64_t K, int64_t n, int64_t ld, int col_major, double *counts, int8_t *spins,
+                         long long *bad, hipStream_t st);
 void launch_check_pm1(const int8_t *S, int64_t K, int64_t n, long long *bad, hipStream_t st);
 int64_t xtb_bytes(const DevProblem &d);
 void launch_expand_features(const int8_t *St, int64_t n, int64_t K, int64_t Kp,

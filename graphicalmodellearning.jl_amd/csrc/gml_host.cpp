@@ -383,7 +383,8 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
 }
 
 static int create_common(const double *counts, const int8_t *spins, int64_t K, int64_t n, int order,
-                         int64_t node0, int64_t node1, int device, gml_problem **out) {
+                         int64_t node0, int64_t node1, int device, gml_problem **out,
+                         int8_t *dspins = nullptr /* K x n on the device, validated; owned from here on */) {
     if (!out) return fail(GML_EINVAL, "out is NULL");
     *out = nullptr;
     if (K <= 0 || n <= 0) return fail(GML_EINVAL, "empty histogram (K=%lld, n=%lld)", (long long)K, (long long)n);
@@ -409,7 +410,7 @@ static int create_common(const double *counts, const int8_t *spins, int64_t K, i
     p->order = order;
     p->node0 = node0;
     p->node1 = node1;
-    int rc = alloc_dev(p, counts, spins);
+    int rc = alloc_dev(p, counts, spins, dspins);
     if (rc != GML_OK) {
         std::string keep = g_err;
         gml_problem_destroy(p);
@@ -436,6 +437,70 @@ extern "C" int gml_problem_create(const void *samples, int dtype, int64_t K, int
     if (dtype != GML_I8 && dtype != GML_I32 && dtype != GML_I64 && dtype != GML_F64)
         return fail(GML_EINVAL, "unknown dtype %d", dtype);
     if (ld < (col_major ? K : n + 1)) return fail(GML_EINVAL, "leading dimension %lld too small", (long long)ld);
+    if ((double)K * (double)n >= 16.0e6) {
+        if (!out) return fail(GML_EINVAL, "out is NULL");
+        *out = nullptr;
+        if (order < 1 || order > 8) return fail(GML_EINVAL, "interaction order %d out of range [1,8]", order);
+        if (node0 < 0 || node1 > n || node0 >= node1)
+            return fail(GML_EINVAL, "bad node range [%lld,%lld) for n=%lld", (long long)node0, (long long)node1, (long long)n);
+        // Large histogram (e.g. the 8 GB Matrix{Int64} of sample(), column-major): upload it as it is through
+        // the staged copy and convert / validate on the device; the host only sees the K counts.
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            return fail(GML_EHIP, "no HIP device available (libgml_hip has no CPU fallback)");
+        if (device < 0 || device >= ndev) return fail(GML_EINVAL, "device %d out of range (%d devices)", device, ndev);
+        HIPCHK(hipSetDevice(device));
+        const size_t esz = dtype == GML_I8 ? 1 : (dtype == GML_I32 ? 4 : 8);
+        const size_t bytes = esz * (size_t)(col_major ? ld * (n + 1) - (ld - K) : (K - 1) * ld + (n + 1));
+        void *dH = nullptr;
+        int8_t *dT = nullptr, *dS = nullptr;
+        double *dC = nullptr;
+        long long *dbad = nullptr, hbad = -1;
+        hipStream_t st = nullptr;
+        auto cleanup = [&](int rc) {
+            void *ptrs[] = {dH, dT, dC, dbad};
+            for (void *q : ptrs)
+                if (q) (void)hipFree(q);
+            if (st) (void)hipStreamDestroy(st);
+            if (rc != GML_OK && dS) (void)hipFree(dS);
+            return rc;
+        };
+#define CCHK(expr)                                                                                               \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess)                                                                                    \
+            return cleanup(fail(e_ == hipErrorOutOfMemory ? GML_ENOMEM : GML_EHIP, "%s failed: %s", #expr,       \
+                                hipGetErrorString(e_)));                                                         \
+    } while (0)
+        CCHK(hipStreamCreate(&st));
+        CCHK(hipMalloc(&dH, bytes));
+        CCHK(hipMalloc(&dT, (size_t)K * n));
+        CCHK(hipMalloc(&dS, (size_t)K * n));
+        CCHK(hipMalloc(&dC, sizeof(double) * K));
+        CCHK(hipMalloc(&dbad, sizeof(long long)));
+        CCHK(hipMemcpyAsync(dbad, &hbad, sizeof(long long), hipMemcpyHostToDevice, st));
+        int urc = upload_pageable(dH, samples, bytes, st);
+        if (urc) return cleanup(urc);
+        // column-major: spins land spin-major in dT and are transposed; row-major: straight into dS
+        launch_convert_hist(dH, dtype, K, n, ld, col_major, dC, col_major ? dT : dS, dbad, st);
+        if (col_major) launch_transpose_i8(dT, n, K, K, dS, n, st);
+        std::vector<double> counts((size_t)K);
+        CCHK(hipMemcpyAsync(counts.data(), dC, sizeof(double) * K, hipMemcpyDeviceToHost, st));
+        CCHK(hipMemcpyAsync(&hbad, dbad, sizeof(long long), hipMemcpyDeviceToHost, st));
+        CCHK(hipGetLastError());
+        CCHK(hipStreamSynchronize(st));
+#undef CCHK
+        if (hbad >= 0) return cleanup(fail(GML_EINVAL, "configuration %lld holds a spin that is not +-1", hbad));
+        double Msum = 0;
+        for (int64_t k = 0; k < K; ++k) {
+            if (!(counts[k] >= 0) || !std::isfinite(counts[k]))
+                return cleanup(fail(GML_EINVAL, "count of configuration %lld is negative or not finite", (long long)k));
+            Msum += counts[k];
+        }
+        if (!(Msum > 0)) return cleanup(fail(GML_EINVAL, "sum of counts is zero"));
+        cleanup(GML_OK); // every check create_common repeats has passed: it takes ownership of dS
+        return create_common(counts.data(), nullptr, K, n, order, node0, node1, device, out, dS);
+    }
     auto at = [&](int64_t k, int64_t j) -> double {
         const int64_t off = col_major ? k + j * ld : k * ld + j;
         switch (dtype) {

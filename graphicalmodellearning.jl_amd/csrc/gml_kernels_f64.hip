@@ -11,6 +11,7 @@
 // v_mfma_f64_16x16x4_f64 with the +-1 operand converted from int8 in registers; operands go
 // straight from global memory / L2 to VGPRs (one f64 MFMA takes 64 cycles per SIMD, which
 // leaves ample time for the few loads per step), no LDS.
+#include "../../include/gml.h"
 #include "gml_dev.h"
 
 namespace gml {
@@ -36,6 +37,45 @@ __global__ __launch_bounds__(256) void k_transpose_i8(const int8_t *__restrict__
     for (int i = ty; i < 64; i += 4) {
         int64_t c = c0 + i, r = r0 + tx;
         if (c < cols && r < rows) dst[c * ld_dst + r] = tile[tx][i];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_convert_hist(const T *__restrict__ H, int64_t K, int64_t n, int64_t ld, int col_major,
+                                                      double *__restrict__ counts, int8_t *__restrict__ spins,
+                                                      long long *__restrict__ bad) {
+    // one thread per element, the fastest-varying source index on threadIdx: both reads and writes coalesce
+    const int64_t total = K * (n + 1), stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        int64_t k, j;
+        if (col_major) {
+            j = e / K;
+            k = e - j * K;
+        } else {
+            k = e / (n + 1);
+            j = e - k * (n + 1);
+        }
+        const double v = (double)H[col_major ? k + j * ld : k * ld + j];
+        if (j == 0) {
+            counts[k] = v;
+        } else {
+            int8_t sv = 0;
+            if (v == 1.0) sv = 1;
+            else if (v == -1.0) sv = -1;
+            else atomicMin(reinterpret_cast<unsigned long long *>(bad), (unsigned long long)k);
+            spins[col_major ? (j - 1) * K + k : k * n + (j - 1)] = sv;
+        }
+    }
+}
+
+void launch_convert_hist(const void *H, int dtype, int64_t K, int64_t n, int64_t ld, int col_major, double *counts, int8_t *spins,
+                         long long *bad, hipStream_t st) {
+    const dim3 grid(8192), block(256);
+    switch (dtype) {
+    case GML_I8: hipLaunchKernelGGL(k_convert_hist<int8_t>, grid, block, 0, st, (const int8_t *)H, K, n, ld, col_major, counts, spins, bad); break;
+    case GML_I32: hipLaunchKernelGGL(k_convert_hist<int32_t>, grid, block, 0, st, (const int32_t *)H, K, n, ld, col_major, counts, spins, bad); break;
+    case GML_I64: hipLaunchKernelGGL(k_convert_hist<long long>, grid, block, 0, st, (const long long *)H, K, n, ld, col_major, counts, spins, bad); break;
+    default: hipLaunchKernelGGL(k_convert_hist<double>, grid, block, 0, st, (const double *)H, K, n, ld, col_major, counts, spins, bad);
     }
 }
 

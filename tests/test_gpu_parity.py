@@ -219,6 +219,33 @@ def test_input_validation_errors():
         assert e.value.code == 1 and "non-finite" in str(e.value)
 
 
+def test_large_histogram_is_converted_on_the_device():
+    # histograms of 16e6 entries or more (e.g. the Matrix{Int64} of sample(), column-major) are uploaded as they
+    # are and converted / validated on the device: same handle as from the int8 spins, for every element type
+    n, K = 1000, 17000
+    spins, J = synthetic.block_ising(n, K, block=10, seed=6)
+    counts = np.random.default_rng(0).integers(1, 4, K)
+    nodes = np.array([0, 499, 999])
+    with gml.Problem(counts=counts.astype(np.float64), spins=spins) as p:
+        f0, g0 = p.objgrad("RISE", nodes, J[nodes], precision="i8x")
+    for dt, order in ((np.int64, "F"), (np.float64, "F"), (np.int64, "C"), (np.int32, "C")):
+        h = np.empty((K, n + 1), dtype=dt, order=order)
+        h[:, 0] = counts
+        h[:, 1:] = spins
+        with gml.Problem(h) as p:
+            assert (p.K, p.n, p.M) == (K, n, float(counts.sum()))
+            f1, g1 = p.objgrad("RISE", nodes, J[nodes], precision="i8x")
+        assert np.array_equal(f0, f1) and np.array_equal(g0, g1)
+    h[1234, 77] = 3
+    with pytest.raises(gml.GMLError) as e:
+        gml.Problem(h)
+    assert e.value.code == 1 and "1234" in str(e.value)
+    h[1234, 77] = 1
+    h[5, 0] = -2
+    with pytest.raises(gml.GMLError):
+        gml.Problem(h)
+
+
 def test_not_converged_raises_like_the_reference_assert():
     s = load_csv("mvt_samples.csv")
     with pytest.raises(AssertionError):  # :180 @assert termination_status == LOCALLY_SOLVED
