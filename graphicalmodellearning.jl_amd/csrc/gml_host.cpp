@@ -1684,6 +1684,96 @@ extern "C" int gml_objgrad_batch(gml_problem *p, int formulation, int precision,
     return GML_OK;
 }
 
+// Timing hook with the parameters RESIDENT in HBM: Theta is uploaded once, then `warmup + steps` passes run back
+// to back on the handle's stream with no host round trip (a device-side optimiser would call the operator this
+// way); f and the gradient of the last pass are downloaded once at the end.  kernel_ms[3] = device time per pass.
+extern "C" int gml_bench_pass_resident(gml_problem *p, int formulation, int precision, const double *theta, int steps,
+                                       int warmup, double kernel_ms[4], double *f_out, double *g_out) {
+    if (!p || !kernel_ms || !theta || steps < 1 || warmup < 0) return fail(GML_EINVAL, "bad argument");
+    if (formulation < 0 || formulation > 2) return fail(GML_EINVAL, "unknown formulation %d", formulation);
+    HIPCHK(hipSetDevice(p->device));
+    const int64_t R = p->node1 - p->node0, Qp = p->d.Qp, P = p->P, Rp = round_up(R, 32);
+    int rc = ensure_ws(p, R);
+    if (rc) return rc;
+    hipStream_t st = p->st;
+    std::vector<NodeLayout> lay((size_t)R);
+    std::memset(p->hTh, 0, sizeof(double) * Rp * Qp);
+    parallel_for(R, [&](int64_t r) {
+        build_layout(p, p->node0 + r, lay[r]);
+        for (int64_t j = 0; j < P; ++j) p->hTh[(size_t)r * Qp + lay[r].cols[j]] = theta[r * P + j];
+    });
+    const int ngroups = (int)(Rp / 32);
+    for (int64_t r = 0; r < Rp; ++r) p->hCtl[r] = r < R ? (int)(p->node0 + r) : -1;
+    int npad = 0;
+    for (int g = 0; g < ngroups || (npad % 4); ++g, ++npad) p->hCtl[p->ws_rows + g] = g < ngroups ? g : -1;
+    HIPCHK(hipMemcpyAsync(p->dTheta, p->hTh, sizeof(double) * Rp * Qp, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->dRowcol, p->hCtl, sizeof(int) * (p->ws_rows + npad), hipMemcpyHostToDevice, st));
+    if (precision != GML_PREC_I8X) {
+        rc = ensure_f64(p);
+        if (rc) return rc;
+    }
+    std::vector<hipEvent_t> ev((size_t)3 * steps, nullptr);
+    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    for (int s = 0; s < warmup + steps; ++s) {
+        hipEvent_t *e3 = s >= warmup ? ev.data() + (size_t)3 * (s - warmup) : nullptr;
+        if (precision == GML_PREC_I8X) {
+            std::string err;
+            rc = gml::i8_pass(&p->i8ws, p->d, p->dTheta, p->dRowcol, p->dGroups, ngroups, (int)Rp, formulation, true, p->dF,
+                              p->dG, st, e3, nullptr, &err);
+            if (rc) return fail(rc, "%s", err.c_str());
+        } else {
+            HIPCHK(hipMemsetAsync(p->dF, 0, sizeof(double) * Rp, st));
+            HIPCHK(hipMemsetAsync(p->dG, 0, sizeof(double) * Rp * Qp, st));
+            if (e3) HIPCHK(hipEventRecord(e3[0], st));
+            launch_fwd_f64(p->d, p->dTheta, p->dRowcol, p->dGroups, npad, formulation, p->dV, p->dF, st);
+            if (e3) HIPCHK(hipEventRecord(e3[1], st));
+            launch_bwd_f64(p->d, p->dV, p->dGroups, ngroups, p->dG, st);
+            if (e3) HIPCHK(hipEventRecord(e3[2], st));
+        }
+    }
+    hipEvent_t e_end = nullptr;
+    HIPCHK(hipEventCreate(&e_end));
+    HIPCHK(hipEventRecord(e_end, st));
+    HIPCHK(hipMemcpyAsync(p->hF, p->dF, sizeof(double) * Rp, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(p->hG, p->dG, sizeof(double) * Rp * Qp, hipMemcpyDeviceToHost, st));
+    std::vector<unsigned> mm;
+    if (precision == GML_PREC_I8X && formulation != GML_RPLE) {
+        mm.resize((size_t)Rp);
+        HIPCHK(hipMemcpyAsync(mm.data(), gml::i8_get_mmax(p->i8ws), sizeof(unsigned) * Rp, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    for (size_t r = 0; r < mm.size() && (int64_t)r < R; ++r)
+        if (mm[r] < (1u << 23))
+            return fail(GML_EUNSUPPORTED, "row %zu uses fewer than 23 bits of the fixed-point range at this theta: time it through "
+                                         "gml_bench_pass (which rescales)", r);
+    double sum[2] = {0, 0};
+    float ms = 0;
+    for (int s = 0; s < steps; ++s) {
+        HIPCHK(hipEventElapsedTime(&ms, ev[(size_t)3 * s], ev[(size_t)3 * s + 1]));
+        sum[0] += ms;
+        HIPCHK(hipEventElapsedTime(&ms, ev[(size_t)3 * s + 1], ev[(size_t)3 * s + 2]));
+        sum[1] += ms;
+    }
+    HIPCHK(hipEventElapsedTime(&ms, ev[0], e_end));
+    kernel_ms[0] = sum[0] / steps;
+    kernel_ms[1] = sum[1] / steps;
+    kernel_ms[2] = kernel_ms[0] + kernel_ms[1];
+    kernel_ms[3] = ms / steps; // from the first timed forward launch to the end of the last pass (quantisation of pass 1 excluded)
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(e_end);
+    if (f_out || g_out)
+        parallel_for(R, [&](int64_t r) {
+            const double z = p->hF[r];
+            if (f_out) f_out[r] = formulation == GML_LOGRISE ? std::log(z) : z;
+            if (g_out)
+                for (int64_t j = 0; j < P; ++j) {
+                    const double v = p->hG[(size_t)r * Qp + lay[r].cols[j]];
+                    g_out[r * P + j] = formulation == GML_LOGRISE ? v / z : v;
+                }
+        });
+    return GML_OK;
+}
+
 extern "C" int gml_bench_pass(gml_problem *p, int formulation, int precision, const double *theta, int steps,
                               int warmup, double kernel_ms[3]) {
     if (!p || !kernel_ms) return fail(GML_EINVAL, "NULL argument");

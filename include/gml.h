@@ -189,6 +189,12 @@ int gml_learn(gml_problem *p, int formulation, double regularizer_c, const gml_o
 int gml_bench_pass(gml_problem *p, int formulation, int precision, const double *theta,
                    int steps, int warmup, double kernel_ms[3]);
 
+/* The same with Theta resident in HBM: uploaded once, then warmup + steps passes back to back without host round
+ * trips (how a device-side optimiser would drive the operator); f ((node1-node0)) and g ((node1-node0) x P) of the
+ * last pass are returned if not NULL.  kernel_ms[3] = device time per pass. */
+int gml_bench_pass_resident(gml_problem *p, int formulation, int precision, const double *theta, int steps,
+                            int warmup, double kernel_ms[4], double *f_out, double *g_out);
+
 #ifdef __cplusplus
 }
 #endif
