@@ -365,6 +365,8 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
         (void)hipFree(dbad);
         if (hbad >= 0) {
             (void)hipFree(dS);
+            (void)hipFree(dSt);
+            (void)hipFree(dkeys);
             return fail(GML_EINVAL, "configuration %lld holds a spin that is not +-1", hbad);
         }
     }
