@@ -29,7 +29,6 @@
 #include "gml_dev.h"
 #include <algorithm>
 #include <string>
-#include <type_traits>
 
 namespace gml {
 
@@ -526,302 +525,6 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     if (form == 2) {
         fp += __shfl_xor(fp, 32);
         if (active && h == 0) unsafeAtomicAdd(&fsum[r], fp);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// forward, wave-specialised variant (1024 statistics, uniform weights, exp forms): a persistent workgroup of
-// 8 waves, two per SIMD.  Waves 0-3 ("GEMM") only run the MFMA loop of their 64 samples and hand the
-// recombined energies of a finished tile to their partner through LDS; waves 4-7 ("EPI") issue all the
-// LDS-DMA of the ring and run the pointwise epilogue of the PREVIOUS tile, two elements per 64-column step.
-// Every SIMD thus always holds one MFMA stream and one VALU/VMEM stream, instead of two identical waves whose
-// MFMA and VALU phases only overlap by accident.
-// ------------------------------------------------------------------------------------------
-template <int LF, int NK, bool WANTF>
-__global__ __launch_bounds__(512, 2) void k_fwd_i8w(
-    const unsigned *__restrict__ Xb, const int8_t *__restrict__ Xt, const int8_t *__restrict__ Tq,
-    const int *__restrict__ rowcol, const int *__restrict__ groups, int ngroups, const double *__restrict__ sigma,
-    const long long *__restrict__ qconst, const double *__restrict__ invtau, int64_t Kp, int ntiles_k, double wuni,
-    int8_t *__restrict__ Vq, long long *__restrict__ csum, long long *__restrict__ asum, unsigned *__restrict__ mmax,
-    int nxw /* workgroups per XCD */) {
-    constexpr int WM = 2, BR = 32 * LF;
-    constexpr int NPIECE = 2 + BR / 16, NP = (NPIECE + 3) / 4;
-    constexpr int STAGE = NPIECE * 1024, NS = 4;
-    static_assert(NK == 16 && NK % NS == 0, "one epilogue unit per column step");
-    // LDS: ring | scratch stage (DMA issued past the last step) | 4 energy buffers of 32 x 64 doubles | exp table | tile list
-    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
-    int8_t *trash = lds + NS * STAGE;
-    constexpr int PAIRB = 32 * 64 * 8 + 8 * 64 * 4 + 64 * 8 + 64 * 4; // energies | sign words | 1/tau | row id, per wave pair
-    int8_t *ebuf = trash + STAGE;
-    double *etab = reinterpret_cast<double *>(ebuf + 4 * PAIRB);
-    int *tl = reinterpret_cast<int *>(etab + 64);
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int lr = lane & 31, h = lane >> 5, pw = wave & 3;
-    if (tid < 64) etab[tid] = exp2((double)tid / 64.0);
-    constexpr int TG = 8;
-    const int b = blockIdx.x, xcd = b & 7, bi = b >> 3;
-    const int ntk8 = (ntiles_k + 7) >> 3, ngrp8 = (ngroups + TG - 1) / TG;
-    const int QN = ntk8 * TG * ngrp8;
-    if (tid == 0) {
-        int cnt = 0;
-        for (int q = bi; q < QN; q += nxw) {
-            const int tgi = q / (ntk8 * TG), rem = q % (ntk8 * TG);
-            const int st = (rem / TG) * 8 + xcd, gi = tgi * TG + rem % TG;
-            if (st < ntiles_k && gi < ngroups) {
-                tl[2 * cnt + 2] = st;
-                tl[2 * cnt + 3] = groups[gi];
-                ++cnt;
-            }
-        }
-        tl[0] = cnt;
-    }
-    __syncthreads();
-    const int ntl = __builtin_amdgcn_readfirstlane(tl[0]);
-    if (ntl == 0) return;
-    auto tile_at = [&](int j, int &st, int &tile) {
-        st = __builtin_amdgcn_readfirstlane(tl[2 * j + 2]);
-        tile = __builtin_amdgcn_readfirstlane(tl[2 * j + 3]);
-    };
-    double *eb = reinterpret_cast<double *>(ebuf + pw * PAIRB);
-    unsigned *esw = reinterpret_cast<unsigned *>(ebuf + pw * PAIRB + 32 * 64 * 8);
-    double *eit = reinterpret_cast<double *>(ebuf + pw * PAIRB + 32 * 64 * 8 + 8 * 64 * 4);
-    int *erc = reinterpret_cast<int *>(ebuf + pw * PAIRB + 32 * 64 * 8 + 8 * 64 * 4 + 64 * 8);
-
-    if (wave < 4) {
-        // ------------------------------ GEMM role ------------------------------
-        v4i fb0[LF];
-        unsigned vbc[WM];
-        const int bitoff = ((pw * 64 + lr) >> 7) * 1024 + ((((pw * 64 + lr) & 127) * 2 + h) << 2); // i = 0; i = 1: + 256
-        for (int jt = 0; jt < ntl; ++jt) {
-            int st, tile;
-            tile_at(jt, st, tile);
-            const int r = tile * 32 + lr;
-            const int rc = rowcol[r];
-            const bool active = rc >= 0;
-            const double sg = active ? sigma[r] : 0.0;
-            const double q0 = active ? (double)qconst[r] : 0.0;
-            // the partner's per-lane epilogue inputs are fetched here (its VMEM queue must hold nothing but the
-            // ring's LDS-DMA, whose completion it counts with vmcnt) and handed over with the energies
-            const double it = active ? invtau[r] : 0.0;
-            const int64_t kw = (int64_t)st * 256 + pw * 64;
-            unsigned swp[WM][4];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-                    swp[i][g4] = active ? *reinterpret_cast<const unsigned *>(Xt + (int64_t)rc * Kp + kw + i * 32 + 8 * g4 + 4 * h) : 0u;
-            v16i acc[WM][LF];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int l = 0; l < LF; ++l)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][l][e] = 0;
-            for (int p = 0; p < NK; ++p) {
-                // The barrier of step p guarantees stage p AND stage p + 1 (the partner waits one stage ahead): the
-                // t = 0 operands of step p + 1 are read during step p, so that with a single MFMA stream per SIMD no
-                // MFMA waits for an LDS read that was issued after the barrier.
-                if (jt == 0 && p == 0) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int l = 0; l < LF; ++l) fb0[l] = *reinterpret_cast<const v4i *>(lds + 2048 + lds_off(l * 32 + lr, h));
-#pragma unroll
-                    for (int i = 0; i < WM; ++i) vbc[i] = *reinterpret_cast<const unsigned *>(lds + bitoff + i * 256);
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (p == 0: the hand-over written below is in LDS)
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                const int8_t *cur = lds + (p & (NS - 1)) * STAGE, *nxt = lds + ((p + 1) & (NS - 1)) * STAGE;
-                v4i fa[WM], fb1[LF], fbn[LF];
-                unsigned vbn[WM];
-#pragma unroll
-                for (int l = 0; l < LF; ++l) fb1[l] = *reinterpret_cast<const v4i *>(cur + 2048 + lds_off(l * 32 + lr, 2 + h));
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) fa[i][e] = (int)((vbc[i] >> e) & 0x01010101u);
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int l = 0; l < LF; ++l) acc[i][l] = MFMA_I8(fa[i], fb0[l], acc[i][l]);
-#pragma unroll
-                for (int l = 0; l < LF; ++l) fbn[l] = *reinterpret_cast<const v4i *>(nxt + 2048 + lds_off(l * 32 + lr, h));
-#pragma unroll
-                for (int i = 0; i < WM; ++i) vbn[i] = *reinterpret_cast<const unsigned *>(nxt + bitoff + i * 256);
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) fa[i][e] = (int)((vbc[i] >> (4 + e)) & 0x01010101u);
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int l = 0; l < LF; ++l) acc[i][l] = MFMA_I8(fa[i], fb1[l], acc[i][l]);
-#pragma unroll
-                for (int l = 0; l < LF; ++l) fb0[l] = fbn[l];
-#pragma unroll
-                for (int i = 0; i < WM; ++i) vbc[i] = vbn[i];
-            }
-            // exact recombination of the limb planes -> |E| pre-sign, handed to the partner wave
-            const double sgq0 = sg * q0, sg2 = -2.0 * sg;
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    static_assert(LF == 5, "recombination below is written for five limbs");
-                    const int lo = acc[i][0][e] + (acc[i][1][e] << 8);
-                    const int mid = acc[i][2][e] + (acc[i][3][e] << 8);
-                    double a = fma((double)acc[i][4][e], 65536.0, (double)mid);
-                    a = fma(a, 65536.0, (double)lo);
-                    eb[(i * 16 + e) * 64 + lane] = fma(a, sg2, sgq0);
-                }
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) esw[(i * 4 + g4) * 64 + lane] = swp[i][g4];
-            eit[lane] = it;
-            erc[lane] = rc;
-        }
-        for (int p = 0; p < NK; ++p) { // the partner's epilogue of the last tile
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        return;
-    }
-
-    // ------------------------------ EPI role ------------------------------
-    int voff[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int pc = pw + 4 * j;
-        const int row = (pc >= 2 ? pc - 2 : 0) * 16 + (lane >> 2);
-        voff[j] = pc < 2 ? lane * 16 : row * 64 + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
-    }
-    const int8_t *XbB = reinterpret_cast<const int8_t *>(Xb);
-    auto bases = [&](int st, int tile, const int8_t *(&base)[NP]) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int pc = pw + 4 * j;
-            base[j] = pc < 2 ? XbB + (int64_t)(2 * st + pc) * NK * 1024 : Tq + (int64_t)tile * NK * (BR * 64);
-        }
-    };
-    auto issue = [&](const int8_t *const (&base)[NP], int kt, int8_t *sb) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int pc = pw + 4 * j;
-            const int adv = pc < 2 ? 1024 : BR * 64;
-            __builtin_amdgcn_global_load_lds((gptr_t)(base[j] + kt * adv + voff[j]), (lptr_t)(sb + pc * 1024), 16, 0, 0);
-        }
-    };
-    int cst, ctile;
-    tile_at(0, cst, ctile);
-    const int8_t *bcur[NP], *bnxt[NP];
-    bases(cst, ctile, bcur);
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue(bcur, s, lds + s * STAGE);
-
-    double Ed[WM][16];
-    unsigned swp_p[WM][4];
-    double wkit_p = 0.0;
-    bool act_p = false;
-    int r_p = 0;
-    int64_t kw_p = 0;
-    int8_t *vimg_p = nullptr;
-    unsigned dh0_p = 0;
-    long long cs = 0, as = 0;
-    int mx = 0;
-    for (int jt = 0; jt <= ntl; ++jt) {
-        const bool have_cur = jt < ntl, have_prev = jt > 0, last = jt + 1 >= ntl;
-        int nst = cst, ntile = ctile;
-        if (jt + 1 < ntl) tile_at(jt + 1, nst, ntile);
-        bases(nst, ntile, bnxt);
-        v4i pl[LB];
-
-        auto step = [&](auto pc_) {
-            constexpr int p = decltype(pc_)::value;
-            constexpr int i = p >> 3, g4 = (p >> 1) & 3, jp = p & 1;
-            // this wave's pieces of stages p and p + 1 have landed (one younger stage, real or scratch, may be in flight)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                constexpr int ks = p + NS - 1;
-                if (ks < NK) issue(bcur, ks, have_cur ? lds + (ks & (NS - 1)) * STAGE : trash);
-                else issue(bnxt, ks - NK, (have_cur && !last) ? lds + (ks & (NS - 1)) * STAGE : trash);
-            }
-            if (!have_prev) return;
-            if (p == 0) { // the partner's hand-over of the previous tile
-#pragma unroll
-                for (int ii = 0; ii < WM; ++ii)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) Ed[ii][e] = eb[(ii * 16 + e) * 64 + lane];
-#pragma unroll
-                for (int ii = 0; ii < WM; ++ii)
-#pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) swp_p[ii][gg] = esw[(ii * 4 + gg) * 64 + lane];
-                const int rcp = erc[lane];
-                act_p = rcp >= 0;
-                wkit_p = wuni * eit[lane];
-                dh0_p = (unsigned)rcp * 0x85EBCA6Bu + (unsigned)(kw_p + 4 * h) * 0x9E3779B9u;
-            }
-            const unsigned sw = swp_p[i][g4];
-            unsigned dj[2];
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int j = 2 * jp + jj, e = 4 * g4 + j;
-                const unsigned sbyte = sw >> (8 * j);
-                const double Ea = Ed[i][e];
-                const double x = __hiloint2double(__double2hiint(Ea) ^ (int)(((sbyte & 0x80u) ^ 0x80u) << 24), __double2loint(Ea));
-                const double dith = (double)(int)(dh0_p + (unsigned)(i * 32 + 8 * g4 + j) * 0x9E3779B9u) * 2.3283064365386963e-10;
-                const int mag = mag_exp(x, wkit_p, dith, etab) & -(int)(sbyte & 1u);
-                const int vq = (sbyte & 0x80u) ? mag : -mag;
-                mx = mag > mx ? mag : mx;
-                if (WANTF) as += mag;
-                cs += vq;
-                dj[jj] = ((unsigned)vq + 0x80808080u) ^ 0x80808080u;
-            }
-            // byte transpose: the two samples' digits -> half a dword per limb plane; completed on odd steps
-#pragma unroll
-            for (int lb = 0; lb < LB; ++lb) {
-                const unsigned sel = ((4u + lb) << 8) | (unsigned)lb;
-                const unsigned t01 = __builtin_amdgcn_perm(dj[1], dj[0], sel); // bytes lb of dj[0], dj[1] in the low half
-                if (jp == 0) pl[lb][g4] = (int)(t01 & 0xFFFFu);
-                else pl[lb][g4] = (int)((unsigned)pl[lb][g4] | (t01 << 16));
-            }
-            if (p == 7 || p == 15) {
-                if (act_p) {
-#pragma unroll
-                    for (int lb = 0; lb < LB; ++lb) *reinterpret_cast<v4i *>(vimg_p + lb * 32 * 64 + i * 16) = pl[lb];
-                }
-            }
-        };
-#define GML_ST(P) step(std::integral_constant<int, P>{});
-        GML_ST(0) GML_ST(1) GML_ST(2) GML_ST(3) GML_ST(4) GML_ST(5) GML_ST(6) GML_ST(7)
-        GML_ST(8) GML_ST(9) GML_ST(10) GML_ST(11) GML_ST(12) GML_ST(13) GML_ST(14) GML_ST(15)
-#undef GML_ST
-        if (have_prev) {
-            cs += __shfl_xor(cs, 32);
-            as += __shfl_xor(as, 32);
-            const int mo = __shfl_xor(mx, 32);
-            mx = mo > mx ? mo : mx;
-            if (act_p && h == 0) {
-                atomicAdd(reinterpret_cast<unsigned long long *>(&csum[r_p]), (unsigned long long)cs);
-                if (WANTF) atomicAdd(reinterpret_cast<unsigned long long *>(&asum[r_p]), (unsigned long long)as);
-                atomicMax(&mmax[r_p], (unsigned)mx);
-            }
-            cs = 0;
-            as = 0;
-            mx = 0;
-        }
-        r_p = ctile * 32 + lr;
-        kw_p = (int64_t)cst * 256 + pw * 64;
-        vimg_p = Vq + vq_off(r_p, 0, kw_p, Kp) + h * 32;
-        cst = nst;
-        ctile = ntile;
-#pragma unroll
-        for (int j = 0; j < NP; ++j) bcur[j] = bnxt[j];
     }
 }
 
@@ -1494,34 +1197,9 @@ static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, 
                        w->asum, dF, w->mmax);
 }
 
-constexpr int WS_MAX_TILES = 1023; // tiles per persistent workgroup of k_fwd_i8w (its list lives in LDS)
-
-template <bool WANTF>
-static void launch_fwd_ws(const I8Ws *w, const DevProblem &d, const int *dRowcol, const int *dGroups, int ngroups, hipStream_t st) {
-    constexpr int LF = 5, NK = 16;
-    constexpr int shmem = 5 * (2 + 2 * LF) * 1024 + 4 * (32 * 64 * 8 + 8 * 64 * 4 + 64 * 8 + 64 * 4) + 512 + 8 * (WS_MAX_TILES + 1);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8w<LF, NK, WANTF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              shmem);
-    static const int ncu = [] {
-        int dev = 0, v = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-        return v;
-    }();
-    const int nxw = ncu >= 8 ? ncu / 8 : 1;
-    hipLaunchKernelGGL((k_fwd_i8w<LF, NK, WANTF>), dim3(8 * nxw), dim3(512), shmem, st, d.Xb, d.Xt, w->Tq, dRowcol, dGroups, ngroups,
-                       w->sigma, w->qconst, w->invtau, d.Kp, (int)(d.Kp / 256), d.wuni, w->Vq, w->csum, w->asum, w->mmax, nxw);
-}
-
 template <int LF>
 static void launch_fwd(const I8Ws *w, const DevProblem &d, const int *dRowcol, const int *dGroups, int ngroups, int form, bool wantf,
                        double *dF, hipStream_t st) {
-    static const bool ws = [] { const char *e = getenv("GML_FWD_WS"); return e && atoi(e) != 0; }();
-    const int64_t tiles_per_wg = ((d.Kp / 256 + 7) / 8) * 8 * (((int64_t)ngroups + 7) / 8) / 32 + 1;
-    if (ws && LF == 5 && form != 2 && d.wuni > 0.0 && d.Qfp == 16 * 64 && tiles_per_wg <= WS_MAX_TILES) {
-        if (wantf) launch_fwd_ws<true>(w, d, dRowcol, dGroups, ngroups, st);
-        else launch_fwd_ws<false>(w, d, dRowcol, dGroups, ngroups, st);
-        return;
-    }
     if (form == 2) launch_fwd2<LF, 2, true>(w, d, dRowcol, dGroups, ngroups, dF, st);
     else if (wantf) launch_fwd2<LF, 0, true>(w, d, dRowcol, dGroups, ngroups, dF, st);
     else launch_fwd2<LF, 0, false>(w, d, dRowcol, dGroups, ngroups, dF, st);
