@@ -15,12 +15,12 @@ pytestmark = pytest.mark.gpu
 synthetic = __import__("importlib").import_module("gml_amd.synthetic")
 FORMS = ["RISE", "logRISE", "RPLE"]
 PRECS = ["f64", "i8x"]
-# objective/gradient tolerances: FP64 path = rounding only; int8-limb path = 30-bit quantisation of
-# V relative to the per-node bound (worst case K * 2^-31 * bound; ~1e-7 on the tiny, very
-# non-uniform mvt histogram, ~1e-10 on benchmark-like inputs)
-FTOL = {"f64": 1e-12, "i8x": 2e-6}
-GTOL = {"f64": 1e-12, "i8x": 2e-6}
-SOLTOL = {"f64": 1e-9, "i8x": 2e-7}
+# objective/gradient tolerances: FP64 path = rounding only; int8-limb path = dithered 31-bit quantisation of
+# V relative to the per-node scale (errors ~ sqrt(K) * 2^-31 * scale: <1e-7 on the tiny, very non-uniform
+# mvt histogram whose few rows carry very different counts, ~2e-10 on benchmark-like inputs)
+FTOL = {"f64": 1e-12, "i8x": 1e-7}
+GTOL = {"f64": 1e-12, "i8x": 1e-7}
+SOLTOL = {"f64": 1e-9, "i8x": 1e-7}
 
 
 def hist_from_spins(spins):
@@ -244,6 +244,20 @@ def test_large_histogram_is_converted_on_the_device():
     h[5, 0] = -2
     with pytest.raises(gml.GMLError):
         gml.Problem(h)
+
+
+def test_resident_timing_hook_returns_the_operator_output():
+    # gml_bench_pass_resident (Theta uploaded once, passes back to back) must produce exactly what
+    # gml_objgrad_batch does: bench.py's timed region is the operator, not a shortcut
+    n, K = 256, 50000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=9)
+    with gml.Problem(spins=spins, node_range=(64, 192)) as p:
+        km, f1, g1 = p.bench_pass_resident("RISE", J[64:192], steps=3, warmup=1, precision="i8x", want_output=True)
+        f0, g0 = p.objgrad("RISE", np.arange(64, 192), J[64:192], precision="i8x")
+        assert np.array_equal(f0, f1) and np.array_equal(g0, g1) and km["device_ms_per_pass"] > 0
+        km, f1, g1 = p.bench_pass_resident("logRISE", J[64:192], steps=2, warmup=0, precision="f64", want_output=True)
+        f0, g0 = p.objgrad("logRISE", np.arange(64, 192), J[64:192], precision="f64")
+        assert np.abs(f0 - f1).max() <= 1e-12 and np.abs(g0 - g1).max() <= 1e-12  # FP64 atomics: order-dependent sums
 
 
 def test_not_converged_raises_like_the_reference_assert():
