@@ -1585,7 +1585,10 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                     need[r] = 0;
                 } else {
                     alpha[r] *= 0.5;
-                    if (nreg[r] && alpha[r] < 1.0 / 64) need[r] = 0; // cannot improve: the stall counter ends it
+                    if (nreg[r] && alpha[r] < 1.0 / 64) {
+                        need[r] = 0; // cannot improve along this direction: the stall counter ends the row,
+                        stall[r] += 3; // after at most three such line searches (each costs ~7 passes)
+                    }
                 }
             });
             stats->t_host += now_s() - th3;
