@@ -3,22 +3,30 @@
 
 A "step" is one objective+gradient pass of the RISE operator over all n node-wise problems
 (= n node evaluations: each node's f and grad over all K configurations) on the synthetic
-BASELINE workload: n=1024 spins, K=1e6 samples (block-Ising, 64 blocks x 16 spins, seed 0).
-Inputs (packed spins, weights, and the parameters Theta) are resident in HBM before the timed region;
-the PCIe-inclusive rate through the host-pointer boundary is reported next to it.  With --gpus N the
-nodes are sharded over N ranks (one process per GPU); no collective on the data path.
+BASELINE workload: n=1024 spins, K=1e6 samples (block-Ising, 64 blocks x 16 spins, seed 0), drawn on
+the device by the library's exact block sampler (no host sample matrix).  Inputs (packed spins,
+weights, and the parameters Theta) are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, algorithmic flops /
-HIP-event time vs the MFMA peak of the arithmetic type), "cpu_baseline" (the CPU oracle timed on
-this box's host cores on a bounded sample of the same workload), and the learn() wall-clock.
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no WORLD_SIZE in the environment this process only launches
+`python -m torch.distributed.run --nproc-per-node N ... bench.py` (before anything touches a GPU) and
+relays rank 0's line; under torchrun each rank takes the nodes [rank*n/N, (rank+1)*n/N) of the SAME
+problem (strong scaling; no collective on the data path, one RCCL all-gather of the learned rows).
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel: algorithmic flops /
+HIP-event time vs the MFMA peak of the arithmetic type), "f64" (the same pass on the FP64-MFMA path),
+"cpu_baseline" (the CPU oracle's blocked restatement timed on this box's host cores on a bounded
+sample, plus CPU learn() wall-clock at config 2 and an extrapolation to this config), and the
+learn() wall-clock of this config.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -27,49 +35,130 @@ sys.path.insert(0, ROOT)
 # ~2.5 PF dense, i8 = 2x bf16 per clock).  FP64: AMD datasheet (78.6 TF matrix = vector); the local
 # guide lists no FP64 figure.
 PEAKS = {"f64": 78.6e12, "i8x": 5.0e15}
+KERNELS = {"f64": {"fwd": "k_fwd_f64", "bwd": "k_bwd_f64"}, "i8x": {"fwd": "k_fwd_i8", "bwd": "k_bwd_i8"}}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=1024)
     ap.add_argument("--samples", type=int, default=1000000)
     ap.add_argument("--block", type=int, default=16)
     ap.add_argument("--precision", default=os.environ.get("GML_BENCH_PRECISION", "i8x"), choices=["f64", "i8x"],
-                    help="i8x: exact int8-limb MFMA pass (default, fastest); f64: FP64 MFMA pass")
+                    help="i8x: int8-limb MFMA pass (default, fastest); f64: FP64 MFMA pass")
     ap.add_argument("--no-learn", action="store_true", help="skip the full learn() wall-clock leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    args = ap.parse_args()
+    ap.add_argument("--no-f64", action="store_true", help="skip the FP64-path leg")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the timed CPU objective/gradient sample")
+    ap.add_argument("--cpu-learn-full", action="store_true", help="run the CPU learn() of THIS config in full instead of extrapolating")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: only the rank launch, node partition and rendezvous "
+                                                            "(gloo); used by the CPU test of the N > 1 launch path")
+    return ap.parse_args()
 
+
+def launch_ranks(args):
+    """N > 1 without torchrun: start the N ranks as children (this process never touches a GPU) and relay rank 0's
+    JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line)
+    sys.exit(r.returncode if r.returncode else (0 if line else 1))
+
+
+def pass_roofline(km, K, P, nloc, precision):
+    """roofline object of the dominant kernel of one pass: algorithmic flops = 2*K*P*n_loc per kernel (forward
+    energies or gradient accumulation; SURVEY.md 8(d): 4*K*P per node evaluation)."""
+    flops_kernel = 2.0 * K * P * nloc
+    dom = "bwd" if km["bwd_ms"] >= km["fwd_ms"] else "fwd"
+    achieved = flops_kernel / (km[dom + "_ms"] * 1e-3)
+    peak = PEAKS[precision]
+    rf = {"bound": "mfma", "kernel": KERNELS[precision][dom], "achieved": achieved / 1e12, "peak": peak / 1e12,
+          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "fwd_ms": km["fwd_ms"], "bwd_ms": km["bwd_ms"],
+          "pass_tflops": 2 * flops_kernel / (km["pass_ms"] * 1e-3) / 1e12, "kernels_ms_per_step": km["pass_ms"],
+          "device_ms_per_step": km["device_ms_per_pass"]}
+    if precision == "i8x":
+        # the int8-limb pass issues LF forward + 4 backward digit-plane products per algorithmic one
+        LF = int(os.environ.get("GML_I8_LF", "5"))
+        limbs = {"fwd": LF, "bwd": 4}[dom]
+        rf["limb_products"] = limbs
+        rf["mfma_issue_frac"] = limbs * achieved / peak
+        rf["note"] = ("achieved counts algorithmic flops once; the kernel issues limb_products int8 MFMA products per "
+                      "algorithmic product (fixed point), so frac <= 1/limb_products")
+    return rf, dom
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.dry_run:
+        if world > 1:
+            dist.init_process_group("gloo")
+        parts = [((r * args.n) // world, ((r + 1) * args.n) // world) for r in range(world)]
+        seen = [None] * world
+        if world > 1:
+            dist.all_gather_object(seen, (rank, parts[rank]))
+        else:
+            seen = [(0, parts[0])]
+        if rank == 0:
+            print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "n_gpus": world, "dry_run": True,
+                              "steps": args.steps, "warmup": args.warmup, "partition": [list(p) for _, p in sorted(seen)]}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    device = local_rank
+    # one rank per GPU over RCCL; on a box with fewer GPUs than ranks (the 1-GPU test box) the ranks share devices and
+    # the rendezvous falls back to gloo with host tensors -- same code path otherwise
+    ndev = torch.cuda.device_count()
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
+    backend = "nccl" if ndev >= world else "gloo"
+    cdev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     import gml_amd as gml
     synthetic = __import__("importlib").import_module("gml_amd.synthetic")
 
     n, K = args.n, args.samples
-    t0 = time.time()
-    spins, J = synthetic.block_ising(n, K, block=args.block, seed=0)
-    t_gen = time.time() - t0
+    J = synthetic.block_ising_model(n, block=args.block, seed=0)
     node0, node1 = (rank * n) // world, ((rank + 1) * n) // world
     nloc = node1 - node0
 
+    # every rank draws the same K configurations on its own GPU (same seed): exact block sampler of the library
     t0 = time.time()
-    prob = gml.Problem(spins=spins, node_range=(node0, node1), device=device)
+    prob = gml.Problem(model=J, num_samples=K, seed=0, node_range=(node0, node1), device=device)
     torch.cuda.synchronize()
-    t_pack = time.time() - t0
+    t_create = time.time() - t0
 
     # evaluation point: the generating couplings (rows of the true model; diagonal = fields)
     theta = np.ascontiguousarray(J[node0:node1])
@@ -80,119 +169,161 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Timed region: Theta resident in HBM (uploaded before the clock starts), K passes back to back on the library's
-    # stream, no host round trip inside; f and the gradient stay in HBM until the last pass has finished.
-    if args.warmup > 0:
-        prob.bench_pass_resident("RISE", theta, steps=args.warmup, warmup=0, precision=args.precision)
-    sync()
-    t0 = time.perf_counter()
-    km, f_res, g_res = prob.bench_pass_resident("RISE", theta, steps=args.steps, warmup=0, precision=args.precision, want_output=True)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def max_over_ranks(x):
+        if world == 1:
+            return float(x), [float(x)]
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        allt = torch.empty(world, dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allt, t)
+        v = allt.cpu().tolist()
+        return max(v), v
+
+    # Timed region: Theta resident in HBM (uploaded before the clock starts), the passes back to back on the library's
+    # stream, no host round trip inside; f and the gradient are downloaded once after the last pass.
+    def timed(precision, steps, warmup):
+        if warmup > 0:
+            prob.bench_pass_resident("RISE", theta, steps=warmup, warmup=0, precision=precision)
+        sync()
+        t0 = time.perf_counter()
+        km, f_res, g_res = prob.bench_pass_resident("RISE", theta, steps=steps, warmup=0, precision=precision, want_output=True)
+        sync()
+        elapsed, per_rank = max_over_ranks(time.perf_counter() - t0)
+        return elapsed, per_rank, km, f_res, g_res
+
+    elapsed, per_rank, km, f_res, g_res = timed(args.precision, args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
     value = n * args.steps / elapsed  # node evaluations per second, whole job
+
+    roofline, dom = pass_roofline(km, K, n, nloc, args.precision)
     # the same pass through the host-pointer operator boundary (Theta up and gradient down over PCIe every pass)
     t0 = time.perf_counter()
     prob.bench_pass("RISE", theta, steps=3, warmup=1, precision=args.precision)
     pcie_ms = (time.perf_counter() - t0) / 4 * 1e3
+    roofline["pcie_inclusive_ms_per_step"] = pcie_ms
+    roofline["pcie_inclusive_node_evals_per_s_per_gpu"] = nloc / (pcie_ms * 1e-3)
 
-    # roofline of the dominant kernel (rank 0's shard): algorithmic flops = 2*K*P*n_loc per
-    # kernel (forward energies or gradient accumulation; SURVEY.md 8(d): 4*K*P per node-eval)
-    P = n
-    flops_kernel = 2.0 * K * P * nloc
-    dom = "bwd" if km["bwd_ms"] >= km["fwd_ms"] else "fwd"
-    dom_ms = km[dom + "_ms"]
-    achieved = flops_kernel / (dom_ms * 1e-3)
-    peak = PEAKS[args.precision]
-    roofline = {"bound": "mfma", "kernel": {"f64": {"fwd": "k_fwd_f64", "bwd": "k_bwd_f64"},
-                                            "i8x": {"fwd": "k_fwd_i8", "bwd": "k_bwd_i8"}}[args.precision][dom],
-                "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": None, "fwd_ms": km["fwd_ms"], "bwd_ms": km["bwd_ms"],
-                "pass_tflops": 2 * flops_kernel / (km["pass_ms"] * 1e-3) / 1e12,
-                # `value`: wall clock of K passes with Theta resident in HBM (one upload before, one download of f and
-                # the gradient after the K passes, both inside the timed call).  For reference: the two GEMM kernels
-                # alone, and one pass through the host-pointer boundary (Theta up, gradient down over PCIe per pass)
-                "kernels_ms_per_step": km["pass_ms"], "device_ms_per_step": km["device_ms_per_pass"],
-                "pcie_inclusive_ms_per_step": pcie_ms, "pcie_inclusive_node_evals_per_s_per_gpu": nloc / (pcie_ms * 1e-3)}
-    if args.precision == "i8x":
-        # the int8-limb pass issues LF forward + 4 backward digit-plane products per algorithmic one
-        LF = int(os.environ.get("GML_I8_LF", "5"))
-        limbs = {"fwd": LF, "bwd": 4}[dom]
-        roofline["limb_products"] = limbs
-        roofline["mfma_issue_frac"] = limbs * achieved / peak
-        roofline["note"] = ("achieved counts algorithmic flops once; the kernel issues limb_products int8 MFMA products per "
-                            "algorithmic product (exact fixed point), so frac <= 1/limb_products")
-
-    # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
-    # the value measured with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same command
-    # (profiles/r1_i8x_pmc_traffic.json, separate passes) is reported.  gfx950 correction per
+    # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the value
+    # measured with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same command (separate passes;
+    # scripts/gpu_profile.sh) is reported from the committed summary, labelled with its file.  gfx950 correction per
     # MI355X_MICROARCH.md: FETCH_SIZE counts half the bytes of 16-B/lane loads -> doubled.
-    try:
-        if args.precision == "i8x" and (n, K, world) == (1024, 1000000, 1):
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_i8x_pmc_traffic.json")))
-            kn = [k for k in pm if ("k_fwd_i8" in k if dom == "fwd" else "k_bwd_i8" in k)][0]
-            roofline["traffic"] = (2.0 * pm[kn]["FETCH_SIZE_KB"] + pm[kn]["WRITE_SIZE_KB"]) * 1024.0
-            roofline["traffic_note"] = ("bytes per launch from profiles/r1_i8x_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KB); "
-                                        "algorithmic bytes per launch: %.3g (bit image K*n/8 + the 4 int8 limb planes of V, 4*K*n_loc)"
-                                        % (K * n / 8.0 + 4.0 * K * nloc))
-    except Exception:
-        pass
+    if args.precision == "i8x" and (n, K, world) == (1024, 1000000, 1):
+        for fn in ("r2_i8x_pmc_traffic.json", "r1_i8x_pmc_traffic.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                kn = [k for k in pm if KERNELS["i8x"][dom] in k][0]
+                roofline["traffic"] = (2.0 * pm[kn]["FETCH_SIZE_KB"] + pm[kn]["WRITE_SIZE_KB"]) * 1024.0
+                roofline["traffic_note"] = ("bytes per launch from profiles/%s (2*FETCH_SIZE + WRITE_SIZE, KB; a separate rocprofv3 "
+                                            "--pmc run of this command, not this run); algorithmic bytes per launch: %.3g (bit image "
+                                            "K*n/8 + the 4 int8 limb planes of V, 4*K*n_loc)" % (fn, K * n / 8.0 + 4.0 * K * nloc))
+                break
+            except Exception:
+                continue
 
-    extra = {}
+    extra = {"per_rank_ms_per_step": [e / args.steps * 1e3 for e in per_rank]}
+    if world > 1:
+        extra["collective_backend"] = dist.get_backend() + (" (RCCL)" if backend == "nccl" else " (ranks share a GPU: host tensors)")
+        extra["collective_ranks"] = dist.get_world_size()
+
+    # ---- the FP64-MFMA path on the same workload (fewer steps: ~85 ms each) ----------------------------------
+    f64 = None
+    if not args.no_f64 and args.precision == "i8x":
+        s64 = max(3, min(20, args.steps // 10))
+        e64, _, km64, f64_res, g64_res = timed("f64", s64, 1)
+        rf64, _ = pass_roofline(km64, K, n, nloc, "f64")
+        f64 = {"value": n * s64 / e64, "unit": "node-evals/s", "steps": s64, "ms_per_step": e64 / s64 * 1e3, "dtype": "f64",
+               "roofline": rf64,
+               "i8x_vs_f64_max_abs_grad_diff": float(np.abs(g64_res - g_res).max()),
+               "i8x_vs_f64_max_rel_f_diff": float(np.abs(f_res / f64_res - 1).max())}
+
+    # ---- learn() wall-clock of this config ---------------------------------------------------------------------
+    out = None
     if not args.no_learn:
         sync()
         t0 = time.perf_counter()
         out, kkt, st = prob.learn("RISE", 0.4, tol=1e-9, precision=args.precision, raise_on_fail=False)
         sync()
-        t_learn = time.perf_counter() - t0
+        t_learn, learn_per_rank = max_over_ranks(time.perf_counter() - t0)
         if world > 1:
-            t = torch.tensor([t_learn], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            t_learn = float(t.item())
             # final gather of the row blocks over RCCL/xGMI (the only collective of the path)
+            sync()
             tg = time.perf_counter()
-            buf = torch.from_numpy(out).cuda()
-            allb = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device="cuda")
+            buf = torch.from_numpy(out).to(cdev)
+            allb = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=cdev)
             dist.all_gather_into_tensor(allb, buf)
             torch.cuda.synchronize()
             extra["gather_s"] = time.perf_counter() - tg
-        sym_err = None
-        if world == 1:
-            sym_err = float(np.abs(0.5 * (out + out.T) - J).max())
-        extra.update({"learn_wall_s": t_learn, "learn_pack_s": t_pack, "learn_iterations": st["iterations"],
-                      "learn_passes": st["passes"], "learn_forward_passes": st["forward_passes"],
-                      "learn_node_evals": st["node_evals"], "learn_max_kkt": st["max_kkt"],
-                      "learn_not_converged": st["not_converged"], "learn_t_pass": st["t_pass"],
-                      "learn_t_hess": st["t_hess"], "learn_t_host": st["t_host"], "max_err_vs_true_model": sym_err})
+            full = allb.reshape(n, n).cpu().numpy()
+        else:
+            full = out
+        sym_err = float(np.abs(0.5 * (full + full.T) - J).max())
+        extra.update({"learn_wall_s": t_learn, "learn_per_rank_s": learn_per_rank, "learn_create_s": t_create,
+                      "learn_iterations": st["iterations"], "learn_passes": st["passes"],
+                      "learn_forward_passes": st["forward_passes"], "learn_node_evals": st["node_evals"],
+                      "learn_max_kkt": st["max_kkt"], "learn_not_converged": st["not_converged"],
+                      "learn_t_pass": st["t_pass"], "learn_t_hess": st["t_hess"], "learn_t_host": st["t_host"],
+                      "max_err_vs_true_model": sym_err})
 
+    # ---- CPU baseline (rank 0 of a 1-GPU run only) -----------------------------------------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        # CPU baseline: the oracle's RISE objgrad (same math, FP64, C -O3, OpenMP over nodes) on this
-        # box's host cores, on a bounded sample: `cores` node evaluations at full K and n per batch.
         from oracle import oracle as O
         cores = os.cpu_count() or 1
-        counts = np.ones(K)
-        nodes = np.arange(cores, dtype=np.int64) * (n // cores)
-        O.objgrad_rise_nodes(counts[:1000], spins[:1000], nodes[:1], theta[nodes[:1]])  # load/compile
-        done, t_cpu = 0, 0.0
-        while t_cpu < args.cpu_seconds and done < 4 * cores:
-            t0 = time.perf_counter()
-            f_cpu, g_cpu = O.objgrad_rise_nodes(counts, spins, nodes, theta[nodes])
-            t_cpu += time.perf_counter() - t0
-            done += len(nodes)
+        try:
+            cpu_model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+        except Exception:
+            cpu_model = "unknown"
+        spins = prob.spins()  # the K x n configurations the GPU path works on
+        # (1) objective/gradient rate: the oracle's blocked FP64 restatement (32 nodes share one sweep over the spins,
+        # OpenMP over node blocks x sample chunks, all host threads), on a bounded sample of nodes at full K and n
+        nodes = (np.arange(32, dtype=np.int64) * (n // 32)) % n
+        O.objgrad_nodes("RISE", None, spins[:4096], nodes, J[nodes])  # load the library, warm the threads
+        t0 = time.perf_counter()
+        O.objgrad_nodes("RISE", None, spins, nodes, J[nodes])
+        t1 = time.perf_counter() - t0
+        nn = int(min(n, max(32, (args.cpu_seconds / max(t1, 1e-3)) * 32 // 32 * 32)))
+        nodes = (np.arange(nn, dtype=np.int64) * max(1, n // nn)) % n
+        t0 = time.perf_counter()
+        f_cpu, g_cpu = O.objgrad_nodes("RISE", None, spins, nodes, J[nodes])
+        t_cpu = time.perf_counter() - t0
         # parity spot check of the timed GPU operator against the oracle on the same rows
-        f_gpu, g_gpu = prob.objgrad("RISE", nodes, theta[nodes], precision=args.precision)
+        f_gpu, g_gpu = prob.objgrad("RISE", nodes, J[nodes], precision=args.precision)
         assert np.array_equal(g_gpu, g_res[nodes]) and np.array_equal(f_gpu, f_res[nodes]), "timed passes != operator output"
-        cpu = {"value": done / t_cpu, "unit": "node-evals/s", "cores": cores, "kind": "port",
-               "sample": f"{done} node evaluations ({len(nodes)} nodes spread over 0..{n - 1}, one per core) at full K={K}, n={n}; oracle/gml_oracle.c "
-                         f"gml_oracle_objgrad_rise_nodes, OpenMP over nodes",
-               "seconds": t_cpu,
+        cpu = {"value": nn / t_cpu, "unit": "node-evals/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
+               "sample": f"{nn} node evaluations (nodes spread over 0..{n - 1}) at full K={K}, n={n}; oracle/gml_oracle_fast.c "
+                         f"gml_oracle_objgrad_nodes: FP64, 32-node blocks share one sweep over the spins, OpenMP over all "
+                         f"{cores} host threads",
+               "seconds": t_cpu, "gflops": 4.0 * K * n * nn / t_cpu / 1e9,
                "parity_max_abs_grad_diff": float(np.abs(g_gpu - g_cpu).max()),
                "parity_max_rel_f_diff": float(np.abs(f_gpu / f_cpu - 1).max())}
+        # (2) CPU learn() wall-clock, same method (batched working-set Newton), same tolerance:
+        #     config 2 (n=256, K=1e5) in full on both sides; this config extrapolated from the measured rate unless asked
+        J2 = synthetic.block_ising_model(256, block=16, seed=0)
+        with gml.Problem(model=J2, num_samples=100000, seed=0, device=device) as p2:
+            t0 = time.perf_counter()
+            o2, k2, s2 = p2.learn("RISE", 0.4, tol=1e-9, precision=args.precision, raise_on_fail=False)
+            t_gpu2 = time.perf_counter() - t0
+            sp2 = p2.spins()
+        t0 = time.perf_counter()
+        c2, ck2, cs2 = O.learn_pair_fast(None, sp2, "RISE", c=0.4, tol=1e-9)
+        t_cpu2 = time.perf_counter() - t0
+        cpu["learn_c2"] = {"config": "n=256, K=1e5, RISE(0.4), tol 1e-9", "cpu_s": t_cpu2, "gpu_s": t_gpu2,
+                           "speedup": t_cpu2 / t_gpu2, "cpu_passes": cs2["passes"], "cpu_node_evals": cs2["node_evals"],
+                           "cpu_max_kkt": float(ck2.max()), "gpu_max_kkt": float(k2.max()),
+                           "max_abs_diff_cpu_vs_gpu": float(np.abs(c2 - o2).max())}
+        if not args.no_learn:
+            if args.cpu_learn_full:
+                t0 = time.perf_counter()
+                c3, ck3, cs3 = O.learn_pair_fast(None, spins, "RISE", c=0.4, tol=1e-9)
+                t_cpu3 = time.perf_counter() - t0
+                cpu["learn_this_config"] = {"cpu_s": t_cpu3, "gpu_s": extra["learn_wall_s"], "speedup": t_cpu3 / extra["learn_wall_s"],
+                                            "kind": "measured", "cpu_max_kkt": float(ck3.max()),
+                                            "max_abs_diff_cpu_vs_gpu": float(np.abs(c3 - out).max())}
+            else:
+                t_cpu3 = extra["learn_node_evals"] / cpu["value"]
+                cpu["learn_this_config"] = {"cpu_s": t_cpu3, "gpu_s": extra["learn_wall_s"], "speedup": t_cpu3 / extra["learn_wall_s"],
+                                            "kind": "extrapolated: the GPU run's node evaluations / the measured CPU rate "
+                                                    "(Hessians and solves not counted); --cpu-learn-full measures it"}
+        del spins
 
     if rank == 0:
         line = {"metric": "obj/grad evals/sec (RISE, n=%d spins, %d samples)" % (n, K), "value": value,
@@ -200,10 +331,11 @@ def main():
                 "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": args.precision, "data": "synthetic",
                 "config": {"workload": "BASELINE configs[2]-shaped RISE pass: n=%d random block-Ising (%d-spin blocks), "
-                                       "%d samples, all n node-wise objective+gradient evaluations per step" % (n, args.block, K),
+                                       "%d samples drawn on the device, all n node-wise objective+gradient evaluations per step"
+                                       % (n, args.block, K),
                            "n": n, "samples": K, "nodes_per_gpu": nloc, "parallelism": "node-shard x%d" % world,
-                           "gen_s": t_gen, "pack_upload_s": t_pack},
-                "roofline": roofline, "cpu_baseline": cpu}
+                           "sample_and_pack_s": t_create},
+                "roofline": roofline, "f64": f64, "cpu_baseline": cpu}
         line.update(extra)
         print(json.dumps(line))
     prob.close()

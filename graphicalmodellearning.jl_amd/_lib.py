@@ -31,7 +31,7 @@ class GMLConvergenceError(AssertionError):
 class Opts(C.Structure):
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("precision", C.c_int32),
                 ("max_working", C.c_int32), ("max_add", C.c_int32), ("verbose", C.c_int32),
-                ("hess_samples", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("hess_samples", C.c_int32), ("polish", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class Stats(C.Structure):
@@ -39,7 +39,7 @@ class Stats(C.Structure):
                 ("hessian_passes", C.c_int32), ("node_evals", C.c_int64), ("max_kkt", C.c_double),
                 ("lambda_", C.c_double), ("t_pack", C.c_double), ("t_pass", C.c_double),
                 ("t_hess", C.c_double), ("t_host", C.c_double), ("t_total", C.c_double),
-                ("not_converged", C.c_int32), ("reserved", C.c_int32)]
+                ("not_converged", C.c_int32), ("polished", C.c_int32)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -193,14 +193,15 @@ class Problem:
                                       _ptr(nodes), _ptr(theta), theta.shape[1], _ptr(f), _ptr(g)))
         return f, g
 
-    def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="f64", max_working=512, max_add=64,
-              verbose=0, hess_samples=0, out_ptr=None, raise_on_fail=True):
+    def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="i8x", max_working=512, max_add=64,
+              verbose=0, hess_samples=0, polish=True, out_ptr=None, raise_on_fail=True):
         L = lib()
         o = Opts()
         L.gml_default_opts(C.byref(o))
         o.tol, o.max_iter, o.precision = float(tol), int(max_iter), PRECISIONS[precision]
         o.max_working, o.max_add, o.verbose = int(max_working), int(max_add), int(verbose)
         o.hess_samples = int(hess_samples)
+        o.polish = 0 if polish else -1
         R = self.node1 - self.node0
         out = None
         if out_ptr is None:
@@ -211,7 +212,9 @@ class Problem:
         rc = L.gml_learn(self._h, FORMULATION_IDS[formulation], float(c), C.byref(o), out_ptr, _ptr(kkt), C.byref(st))
         if rc == GML_ENOTCONV:
             if raise_on_fail:
-                raise GMLConvergenceError(L.gml_last_error().decode())
+                err = GMLConvergenceError(L.gml_last_error().decode())
+                err.stats, err.kkt = st.asdict(), kkt  # what the solver reached, for the caller's diagnostics
+                raise err
         else:
             check(rc)
         return out, kkt, st.asdict()

@@ -185,7 +185,7 @@ extern "C" void gml_default_opts(gml_opts *o) {
     std::memset(o, 0, sizeof *o);
     o->tol = 1e-9;
     o->max_iter = 100;
-    o->precision = GML_PREC_F64;
+    o->precision = GML_PREC_I8X; // the fast path; rows it leaves above tol are finished in FP64 (polish = 0)
     o->max_working = 512;
     o->max_add = 64;
     o->verbose = 0;
@@ -817,12 +817,20 @@ extern "C" int gml_problem_create_sampled(const double *model, int64_t n, int64_
 extern "C" int gml_problem_get_spins(gml_problem *p, int8_t *spins) {
     if (!p || !spins) return fail(GML_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(p->device));
-    std::vector<int8_t> row((size_t)p->K);
-    for (int64_t i = 0; i < p->n; ++i) {
-        HIPCHK(hipMemcpy(row.data(), p->d.Xt + i * p->d.Kp, (size_t)p->K, hipMemcpyDeviceToHost));
-        for (int64_t k = 0; k < p->K; ++k) spins[k * p->n + i] = row[(size_t)k];
+    // spin-major rows of Xt -> sample-major on the device (in slabs of <= 2^24 samples), one copy per slab
+    const int64_t slab = std::min<int64_t>(p->K, (int64_t)1 << 24);
+    int8_t *dT = nullptr;
+    HIPCHK(hipMalloc(&dT, (size_t)slab * p->n));
+    int rc = GML_OK;
+    for (int64_t k0 = 0; k0 < p->K && rc == GML_OK; k0 += slab) {
+        const int64_t kk = std::min(slab, p->K - k0);
+        launch_transpose_i8(p->d.Xt + k0, p->n, kk, p->d.Kp, dT, p->n, p->st);
+        if (hipMemcpyAsync(spins + k0 * p->n, dT, (size_t)kk * p->n, hipMemcpyDeviceToHost, p->st) != hipSuccess ||
+            hipStreamSynchronize(p->st) != hipSuccess)
+            rc = fail(GML_EHIP, "download of the spins failed: %s", hipGetErrorString(hipGetLastError()));
     }
-    return GML_OK;
+    (void)hipFree(dT);
+    return rc;
 }
 
 namespace gml {
@@ -1233,7 +1241,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     // (rows x configurations) is kept roughly constant: as nodes converge, the remaining ones get more
     // configurations, up to all of them -- an inexact Hessian only costs iterations, and it costs the
     // most on the few ill-conditioned nodes that are still active at the end.
-    const int64_t Kh_max = o.precision == GML_PREC_I8X ? gml::i8_hess_kmax(p->d) : p->d.Kp;
+    int64_t Kh_max = o.precision == GML_PREC_I8X ? gml::i8_hess_kmax(p->d) : p->d.Kp;
     const int64_t Kh_base = o.hess_samples == 0 ? 32768 : (o.hess_samples < 0 ? p->d.Kp : (int64_t)o.hess_samples);
     int64_t Kh = p->d.Kp;
     double hscale = 1.0;
@@ -1271,7 +1279,17 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     std::vector<double> f((size_t)R, 0.0), ft((size_t)R, 0.0), Fobj((size_t)R, 0.0), kkt((size_t)R, INFINITY),
         best((size_t)R, INFINITY), Z((size_t)R, 1.0), Zt((size_t)R, 1.0), alpha((size_t)R, 1.0), dd((size_t)R, 0.0),
         fn((size_t)R, 0.0), fnt((size_t)R, 0.0);
-    std::vector<uint8_t> done((size_t)R, 0), act((size_t)R, 1), need((size_t)R, 0), vstale((size_t)R, 0);
+    std::vector<uint8_t> done((size_t)R, 0), act((size_t)R, 1), need((size_t)R, 0), vstale((size_t)R, 0), atfloor((size_t)R, 0);
+    // FP64 polish of the rows the int8-limb path leaves above tol: possible when the FP64 workspaces fit
+    bool can_polish = false;
+    if (o.precision == GML_PREC_I8X && o.polish >= 0) {
+        size_t freeb = 0, totalb = 0;
+        if (hipMemGetInfo(&freeb, &totalb) == hipSuccess) {
+            const double need_b = (p->d.Xs ? 0.0 : 2.0 * (double)p->d.Kp * (double)p->d.Qp) + (p->dV ? 0.0 : 8.0 * (double)round_up(R, 32) * (double)p->d.Kp);
+            can_polish = need_b < 0.8 * (double)freeb;
+        }
+    }
+    int stall_cap = can_polish ? 4 : 10;
     std::vector<int> stall((size_t)R, 0), msz((size_t)R, 0), mtot((size_t)R, 0), blk((size_t)R, 0);
     std::vector<std::vector<int>> Fset((size_t)R);
     std::vector<std::vector<double>> Dset((size_t)R), PGset((size_t)R);
@@ -1280,7 +1298,8 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     // which bounds the new weights rigorously (|E_k' - E_k| <= ||theta' - theta||_1).  Near the optimum the steps
     // are tiny, so V keeps all 31 bits relative to its actual maximum and the noise floor of f and grad drops by the
     // bits the bound would have wasted.
-    const bool track_scale = o.precision == GML_PREC_I8X && formulation != GML_RPLE;
+    int prec = o.precision; // switches to FP64 for the rows the int8-limb path cannot bring below tol (see "polish" below)
+    bool track_scale = prec == GML_PREC_I8X && formulation != GML_RPLE;
     std::vector<double> vref((size_t)R, 0.0), dref((size_t)R, 0.0), stepn((size_t)R, 0.0), vnew((size_t)R, 0.0),
         ovr((size_t)round_up(R, 32), 0.0);
     auto scale_for = [&](const std::vector<uint8_t> &rows, bool at_trial) -> const std::vector<double> * {
@@ -1315,7 +1334,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         });
     };
 
-    int rc = device_pass(p, rs, act, X.data(), formulation, o.precision, true, f.data(), G.data(), stats, nullptr,
+    int rc = device_pass(p, rs, act, X.data(), formulation, prec, true, f.data(), G.data(), stats, nullptr,
                          fn.data(), nullptr, 0, vnew.data());
     if (rc) return rc;
     scale_seen(act, false);
@@ -1356,8 +1375,13 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             } else {
                 ++stall[r];
             }
-            if (worst <= o.tol || stall[r] >= 10) {
+            if (worst <= o.tol) {
                 done[r] = 1;
+                return;
+            }
+            if (stall[r] >= stall_cap) { // no progress: at the noise floor of the pass arithmetic (or a failed line search)
+                done[r] = 1;
+                atfloor[r] = 1;
                 return;
             }
             // Only the max_add largest violators are admitted per iteration: at theta = 0 most
@@ -1415,7 +1439,40 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         if (o.verbose)
             fprintf(stderr, "[gml] it %3d active %6lld  max-kkt %.3e  max|F| %d  passes %d fwd %d\n", it,
                     (long long)nactive, worst_all, maxm, stats->passes, stats->forward_passes);
-        if (nactive == 0) break;
+        if (nactive == 0) {
+            // Polish: rows that the int8-limb arithmetic could not bring below tol (its gradient carries ~sqrt(K) 2^-31
+            // of noise relative to the largest weight, which an ill-conditioned, weakly regularised problem amplifies)
+            // continue on the FP64 path from their best iterate, when that path fits in memory.
+            int64_t nfloor = 0;
+            for (int64_t r = 0; r < R; ++r) nfloor += (atfloor[r] && !(std::min(best[r], kkt[r]) <= o.tol));
+            if (!(prec == GML_PREC_I8X && can_polish && nfloor > 0)) break;
+            if (ensure_f64(p) != GML_OK) break; // does not fit after all: the rows stay as they are (reported not converged)
+            prec = GML_PREC_F64;
+            track_scale = false;
+            stall_cap = 10;
+            Kh_max = p->d.Kp;
+            std::fill(need.begin(), need.end(), 0);
+            for (int64_t r = 0; r < R; ++r) {
+                if (!atfloor[r] || std::min(best[r], kkt[r]) <= o.tol) continue;
+                if (best[r] <= kkt[r]) std::memcpy(X.data() + r * Qp, Xbest.data() + r * Qp, sizeof(double) * Qp);
+                done[r] = 0;
+                atfloor[r] = 0;
+                stall[r] = 0;
+                best[r] = INFINITY;
+                blk[r] = 0;
+                need[r] = 1;
+            }
+            if (o.verbose) fprintf(stderr, "[gml] polish: %lld rows continue on the FP64 path\n", (long long)nfloor);
+            rc = device_pass(p, rs, need, X.data(), formulation, prec, true, f.data(), G.data(), stats, nullptr, fn.data(), nullptr, 0,
+                             nullptr);
+            if (rc) return rc;
+            post(need, f, G, Z, fn, true);
+            for (int64_t r = 0; r < R; ++r)
+                if (need[r]) vstale[r] = 0;
+            set_kh(nfloor);
+            ++stats->polished;
+            continue;
+        }
         set_kh(nactive);
 
         // rows whose V was overwritten by a rejected trial need a fresh pass before the Hessian
@@ -1426,7 +1483,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         }
         stats->t_host += now_s() - th0;
         if (anystale) {
-            rc = device_pass(p, rs, need, X.data(), formulation, o.precision, true, f.data(), G.data(), stats, nullptr,
+            rc = device_pass(p, rs, need, X.data(), formulation, prec, true, f.data(), G.data(), stats, nullptr,
                              fn.data(), scale_for(need, false), 0, vnew.data());
             if (rc) return rc;
             scale_seen(need, false);
@@ -1454,7 +1511,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         });
         stats->t_host += now_s() - th1;
         std::vector<double> Dn, Sd;
-        rc = device_newton(p, rs, Fidx, msz, cap, formulation, o.precision, Kh, s1v, formulation == GML_LOGRISE ? 1.0 : 0.0,
+        rc = device_newton(p, rs, Fidx, msz, cap, formulation, prec, Kh, s1v, formulation == GML_LOGRISE ? 1.0 : 0.0,
                            gFm, pgFm, Dn, Sd, stats);
         if (rc) return rc;
         const double th1b = now_s();
@@ -1533,7 +1590,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             stats->t_host += now_s() - th2;
             if (!any) break;
             const bool full = (ls == 0) || anynoise;
-            rc = device_pass(p, rs, need, Xt.data(), formulation, o.precision, full, ft.data(), Gt.data(), stats, nullptr,
+            rc = device_pass(p, rs, need, Xt.data(), formulation, prec, full, ft.data(), Gt.data(), stats, nullptr,
                              fnt.data(), scale_for(need, true), 0, vnew.data());
             if (rc) return rc;
             scale_seen(need, true);
@@ -1597,7 +1654,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         bool anyf = false;
         for (int64_t r = 0; r < R; ++r) anyf |= accepted_fwd[r] != 0;
         if (anyf) {
-            rc = device_pass(p, rs, accepted_fwd, X.data(), formulation, o.precision, true, f.data(), G.data(), stats,
+            rc = device_pass(p, rs, accepted_fwd, X.data(), formulation, prec, true, f.data(), G.data(), stats,
                              nullptr, fn.data(), scale_for(accepted_fwd, false), 0, vnew.data());
             if (rc) return rc;
             scale_seen(accepted_fwd, false);

@@ -294,7 +294,8 @@ __device__ __forceinline__ void ring_wait_ahead(int ahead) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int LF, int FORM /* 0: exp forms (RISE, logRISE), 2: RPLE */, bool WANTF>
+template <int LF, int FORM /* 0: exp forms (RISE, logRISE), 2: RPLE */, bool WANTF,
+          bool WIDE /* more than 32768 statistics columns: |acc_l| <= 128 Qfp no longer leaves room for the int32 pairing */>
 __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const unsigned *__restrict__ Xb, const int8_t *__restrict__ Xt, const int8_t *__restrict__ Tq,
     const int *__restrict__ rowcol, const int *__restrict__ groups, int ngroups, const double *__restrict__ w,
@@ -441,9 +442,15 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int e = 4 * g + j;
-                // exact recombination of the limb planes: pairs in int32 (|acc| <= 2^17), then FP64
+                // exact recombination of the limb planes: pairs in int32 (|acc_l| <= 128 Qfp <= 2^22, so
+                // |acc_l + 256 acc_{l+1}| < 2^31), then FP64; beyond 32768 columns every plane goes through FP64
+                // (|a| < 2^53 always: a is the integer sum_c q_c b_c with |q_c| <= 2^38)
                 double a;
-                if (LF == 5) {
+                if (WIDE) {
+                    a = (double)acc[i][LF - 1][e];
+#pragma unroll
+                    for (int l = LF - 2; l >= 0; --l) a = fma(a, 256.0, (double)acc[i][l][e]);
+                } else if (LF == 5) {
                     const int lo = acc[i][0][e] + (acc[i][1][e] << 8);
                     const int mid = acc[i][2][e] + (acc[i][3][e] << 8);
                     a = fma((double)acc[i][4][e], 65536.0, (double)mid);
@@ -1183,18 +1190,25 @@ int i8_limbs_forward() {
     return lf;
 }
 
-template <int LF, int FORM, bool WANTF>
-static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, const int *dGroups, int ngroups, double *dF,
+template <int LF, int FORM, bool WANTF, bool WIDE>
+static void launch_fwd3(const I8Ws *w, const DevProblem &d, const int *dRowcol, const int *dGroups, int ngroups, double *dF,
                         hipStream_t st) {
     constexpr int STAGE = (2 + 2 * LF) * 1024;
     constexpr int shmem = 4 * STAGE + 512 + 1024; // ring + exp, log tables
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF, WIDE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
     const int ntk = (int)(d.Kp / 256);
     const int grid = ((ntk + 7) / 8) * 8 * ((ngroups + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF>), dim3(grid), dim3(256), shmem, st, d.Xb, d.Xt, w->Tq, dRowcol, dGroups,
+    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE>), dim3(grid), dim3(256), shmem, st, d.Xb, d.Xt, w->Tq, dRowcol, dGroups,
                        ngroups, d.w, w->sigma, w->qconst, w->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, w->Vq, w->csum,
                        w->asum, dF, w->mmax);
+}
+
+template <int LF, int FORM, bool WANTF>
+static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, const int *dGroups, int ngroups, double *dF,
+                        hipStream_t st) {
+    if (d.Qfp > 32768) launch_fwd3<LF, FORM, WANTF, true>(w, d, dRowcol, dGroups, ngroups, dF, st);
+    else launch_fwd3<LF, FORM, WANTF, false>(w, d, dRowcol, dGroups, ngroups, dF, st);
 }
 
 template <int LF>

@@ -52,17 +52,19 @@ class HIP(GMLMethod):
     """Solve every node-wise problem on MI355X through libgml_hip (include/gml.h).
 
     tol        KKT tolerance (max |pseudo-gradient| per node)
-    precision  "f64" (FP64 MFMA) or "i8x" (exact int8-limb fixed point on the i8 MFMA)
+    precision  "i8x" (int8-limb fixed point on the i8 MFMA: the fast path, the default; rows it cannot bring
+               below tol are finished on the FP64 path unless polish=False) or "f64" (FP64 MFMA throughout)
     device     HIP device ordinal; with distributed=True the local rank's device
     distributed  shard the nodes over torch.distributed ranks and gather the rows (RCCL)
     """
     tol: float = 1e-9
-    precision: str = "f64"
+    precision: str = "i8x"
     device: Optional[int] = None
     max_iter: int = 100
     max_working: int = 512
     max_add: int = 64
-    hess_samples: int = 0  # Newton Hessians use the first hess_samples configurations (0 = 131072, <0 = all)
+    hess_samples: int = 0  # configurations per Newton Hessian: 0 = adaptive (32768 x rows / active rows), < 0 = all
+    polish: bool = True
     verbose: int = 0
     distributed: bool = False
     node_range: Optional[Tuple[int, int]] = None

@@ -25,7 +25,7 @@ def _local_solve_hip(samples, formulation, method, order, node_range, device):
         out, kkt, st = prob.learn(_form_name(formulation), formulation.regularizer, tol=method.tol,
                                   max_iter=method.max_iter, precision=method.precision,
                                   max_working=method.max_working, max_add=method.max_add, verbose=method.verbose,
-                                  hess_samples=method.hess_samples)
+                                  hess_samples=method.hess_samples, polish=method.polish)
         keys = None
         if isinstance(formulation, multiRISE):
             if order == 2:  # the C ABI keeps the pairwise slot layout for order 2 (slot u = field)
@@ -89,7 +89,13 @@ def learn(samples, formulation=None, method=None, *, _local_solve=None):
             import torch
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
     solve = _local_solve or _local_solve_hip
-    out, kkt, st, keys = solve(samples, formulation, method, order, node_range, device)
+    try:
+        out, kkt, st, keys = solve(samples, formulation, method, order, node_range, device)
+    except _lib.GMLConvergenceError as e:  # the reference's @assert (:180): keep what the solver reached
+        method.stats.clear()
+        method.stats.update(getattr(e, "stats", {}) or {})
+        method.stats["kkt"] = getattr(e, "kkt", None)
+        raise
     method.stats.clear()
     method.stats.update(st or {})
     method.stats["kkt"] = kkt

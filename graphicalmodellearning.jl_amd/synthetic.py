@@ -34,6 +34,44 @@ def block_ising(n, K, block=16, seed=0, p_edge=0.3, jmin=0.2, jmax=0.6, hmax=0.1
     return spins, J
 
 
+def block_ising_model(n, block=16, seed=0, p_edge=0.3, jmin=0.2, jmax=0.6, hmax=0.1):
+    """The model only (n x n, fields on the diagonal), same family as block_ising: for sampling on the device
+    (gml.Problem(model=J, num_samples=K)), where no host sample matrix is built."""
+    assert n % block == 0
+    rng = np.random.default_rng(seed)
+    J = np.zeros((n, n))
+    iu = np.triu_indices(block, 1)
+    for B in range(n // block):
+        on = rng.random(len(iu[0])) < p_edge
+        vals = rng.choice([-1.0, 1.0], size=len(iu[0])) * rng.uniform(jmin, jmax, size=len(iu[0]))
+        A = np.zeros((block, block))
+        A[iu] = np.where(on, vals, 0.0)
+        A = A + A.T + np.diag(rng.uniform(-hmax, hmax, size=block))
+        J[B * block:(B + 1) * block, B * block:(B + 1) * block] = A
+    return J
+
+
+def block_multibody_terms(n, block=12, seed=0, p_edge=0.3, n_triples=None):
+    """The model only, as {1-based sorted key: weight}: blocks with fields, pairwise terms and random triples
+    (config C5), for sampling on the device (gml.Problem(terms=..., n=n, num_samples=K))."""
+    assert n % block == 0
+    rng = np.random.default_rng(seed)
+    terms = {}
+    n_triples = block if n_triples is None else n_triples
+    for B in range(n // block):
+        base = B * block
+        for i in range(block):
+            terms[(base + i + 1,)] = rng.uniform(-0.1, 0.1)
+            for j in range(i + 1, block):
+                if rng.random() < p_edge:
+                    terms[(base + i + 1, base + j + 1)] = rng.choice([-1.0, 1.0]) * rng.uniform(0.2, 0.6)
+        for _ in range(n_triples):
+            i, j, k = sorted(int(v) for v in rng.choice(block, size=3, replace=False))
+            key = (base + i + 1, base + j + 1, base + k + 1)
+            terms[key] = terms.get(key, 0.0) + rng.choice([-1.0, 1.0]) * rng.uniform(0.2, 0.5)
+    return terms
+
+
 def block_multibody(n, K, block=12, seed=0, p_edge=0.3, n_triples=None):
     """Blocks with pairwise terms plus random triples (config C5).  Returns (spins, terms dict
     with 1-based sorted keys)."""

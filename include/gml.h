@@ -57,7 +57,9 @@ typedef struct gml_opts {
     int32_t hess_samples; /* Newton Hessians use the first hess_samples configurations (< 0 = all;
                             0 = adaptive: 32768 x (local nodes / nodes still active), so the
                             last few nodes get all of them); the gradient always uses all     */
-    int32_t reserved[2];
+    int32_t polish;      /* precision i8x only: 0 = rows that stall above tol at the noise floor of the int8-limb
+                            arithmetic continue on the FP64 path when its workspaces fit (default); -1 = never */
+    int32_t reserved[1];
 } gml_opts;
 
 typedef struct gml_stats {
@@ -70,7 +72,7 @@ typedef struct gml_stats {
     double lambda;           /* the regulariser actually used (:157)                        */
     double t_pack, t_pass, t_hess, t_host, t_total; /* seconds                              */
     int32_t not_converged;   /* number of local nodes above tol                             */
-    int32_t reserved;
+    int32_t polished;        /* 1 if rows were finished on the FP64 path (precision i8x, see gml_opts.polish) */
 } gml_stats;
 
 const char *gml_last_error(void);

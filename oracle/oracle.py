@@ -18,8 +18,8 @@ FORMS = {"RISE": 0, "logRISE": 1, "RPLE": 2}
 
 def build(force=False):
     so = os.path.join(_HERE, "libgml_oracle.so")
-    src = os.path.join(_HERE, "gml_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("gml_oracle.c", "gml_oracle_fast.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libgml_oracle.so"])
     return so
 
@@ -45,6 +45,13 @@ def lib():
         L.gml_oracle_objgrad_multi.argtypes = [i64, i64, C.c_int, p, p, i64, p, p, p]
         L.gml_oracle_learn_multi.restype = dbl
         L.gml_oracle_learn_multi.argtypes = [i64, i64, C.c_int, p, p, dbl, dbl, p, p]
+        # gml_oracle_fast.c: blocked / OpenMP restatements for full-size checks and the CPU baseline
+        L.gml_oracle_objgrad_nodes.restype = None
+        L.gml_oracle_objgrad_nodes.argtypes = [C.c_int, i64, i64, p, p, p, i64, p, p, p]
+        L.gml_oracle_objgrad_multi3_nodes.restype = None
+        L.gml_oracle_objgrad_multi3_nodes.argtypes = [i64, i64, p, p, p, i64, p, p, p]
+        L.gml_oracle_learn_pair_fast.restype = dbl
+        L.gml_oracle_learn_pair_fast.argtypes = [C.c_int, i64, i64, p, p, i64, i64, dbl, dbl, C.c_int, p, p, p]
         _LIB = L
     return _LIB
 
@@ -87,6 +94,65 @@ def objgrad_rise_nodes(counts, spins, nodes, theta):
     lib().gml_oracle_objgrad_rise_nodes(K, n, _ptr(counts), _ptr(spins), _ptr(nodes), len(nodes),
                                         _ptr(theta), _ptr(f), _ptr(g))
     return f, g
+
+
+def objgrad_nodes(form, counts, spins, nodes, theta, want_grad=True):
+    """blocked batched objective/gradient (gml_oracle_fast.c) of the pairwise formulations for the listed
+    nodes; theta is len(nodes) x n (slot u = field); counts may be None (all ones)."""
+    spins = np.ascontiguousarray(spins, dtype=np.int8)
+    K, n = spins.shape
+    nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+    theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(len(nodes), n)
+    if counts is not None:
+        counts = np.ascontiguousarray(counts, dtype=np.float64)
+    f = np.zeros(len(nodes))
+    g = np.zeros((len(nodes), n)) if want_grad else None
+    lib().gml_oracle_objgrad_nodes(FORMS[form], K, n, None if counts is None else _ptr(counts), _ptr(spins), _ptr(nodes),
+                                   len(nodes), _ptr(theta), _ptr(f), None if g is None else _ptr(g))
+    return f, g
+
+
+def objgrad_multi3_nodes(counts, spins, nodes, theta):
+    """order-3 multiRISE objective/gradient (gml_oracle_fast.c) of the listed nodes; theta is len(nodes) x P in
+    the reference's key order."""
+    spins = np.ascontiguousarray(spins, dtype=np.int8)
+    K, n = spins.shape
+    nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+    P = lib().gml_oracle_multi_nparams(n, 3)
+    theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(len(nodes), P)
+    if counts is not None:
+        counts = np.ascontiguousarray(counts, dtype=np.float64)
+    f = np.zeros(len(nodes))
+    g = np.zeros((len(nodes), P))
+    lib().gml_oracle_objgrad_multi3_nodes(K, n, None if counts is None else _ptr(counts), _ptr(spins), _ptr(nodes), len(nodes),
+                                          _ptr(theta), _ptr(f), _ptr(g))
+    return f, g
+
+
+def learn_pair_fast(counts, spins, form="RISE", c=None, node_range=None, tol=1e-9, max_iter=100):
+    """CPU learn() by the batched working-set Newton method of gml_oracle_fast.c (the device solver's algorithm):
+    un-symmetrised rows of the node range.  Returns (rows, kkt, stats dict)."""
+    defaults = {"RISE": 0.4, "logRISE": 0.8, "RPLE": 0.2}
+    if c is None:
+        c = defaults[form]
+    spins = np.ascontiguousarray(spins, dtype=np.int8)
+    K, n = spins.shape
+    n0, n1 = node_range if node_range is not None else (0, n)
+    if counts is not None:
+        counts = np.ascontiguousarray(counts, dtype=np.float64)
+    out = np.zeros((n1 - n0, n))
+    kkt = np.zeros(n1 - n0)
+    st = np.zeros(3)
+    lib().gml_oracle_learn_pair_fast(FORMS[form], K, n, None if counts is None else _ptr(counts), _ptr(spins), n0, n1, float(c),
+                                     float(tol), int(max_iter), _ptr(out), _ptr(kkt), _ptr(st))
+    return out, kkt, {"iterations": int(st[0]), "passes": int(st[1]), "node_evals": int(st[2])}
+
+
+def kkt_residual(x, g, lam, u):
+    """max |minimum-norm subgradient| of f + lam * sum_{j != u} |x_j| at x given the smooth gradient g"""
+    pg = np.where(x > 0, g + lam, np.where(x < 0, g - lam, np.sign(g) * np.maximum(np.abs(g) - lam, 0)))
+    pg[u] = g[u]  # the field slot is not penalised (:171)
+    return float(np.abs(pg).max())
 
 
 def learn_pair(samples, form="RISE", c=None, symmetrize=True, tol=1e-12):

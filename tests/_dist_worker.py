@@ -1,4 +1,6 @@
-"""Worker for test_distributed_gloo.py: world_size-2 gloo run of the node-sharded learn()."""
+"""Worker for the world_size-2 gloo tests of the node-sharded learn(): `oracle` mode injects the CPU oracle as the
+per-rank solver (runs without a GPU); `hip` mode uses the product's HIP solver, every rank on a GPU (ranks share
+device 0 on a 1-GPU box)."""
 import os
 import sys
 
@@ -10,21 +12,36 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import gml_amd as gml  # noqa: E402
-from test_host_api import oracle_local_solve  # noqa: E402
 
 
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    out_dir = sys.argv[1]
+    out_dir, mode = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "oracle")
+    kw = {}
+    if mode == "oracle":
+        from test_host_api import oracle_local_solve
+        kw["_local_solve"] = oracle_local_solve
+        method = lambda: gml.HIP(distributed=True)  # noqa: E731
+    else:
+        import torch
+        dev = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+        method = lambda: gml.HIP(distributed=True, device=dev, tol=1e-11)  # noqa: E731
     s = np.loadtxt(os.path.join(ROOT, "tests", "golden", "mvt_samples.csv"), delimiter=",")
     res = {}
-    res["rise_sym"] = gml.learn(s, gml.RISE(0.2, True), gml.HIP(distributed=True), _local_solve=oracle_local_solve)
-    res["rise"] = gml.learn(s, gml.RISE(0.2, False), gml.HIP(distributed=True), _local_solve=oracle_local_solve)
+    res["rise_sym"] = gml.learn(s, gml.RISE(0.2, True), method(), **kw)
+    res["rise"] = gml.learn(s, gml.RISE(0.2, False), method(), **kw)
     c = np.loadtxt(os.path.join(ROOT, "tests", "golden", "c_samples.csv"), delimiter=",")
-    fg = gml.learn(c, gml.multiRISE(0.2, True, 3), gml.HIP(distributed=True), _local_solve=oracle_local_solve)
+    fg = gml.learn(c, gml.multiRISE(0.2, True, 3), method(), **kw)
     keys = sorted(fg.keys(), key=lambda k: (len(k), k))
     res["multi_vals"] = np.array([fg[k] for k in keys])
+    if mode == "hip":
+        # a problem wide enough that both ranks own several 32-node tiles, sampled identically by every rank
+        synthetic = __import__("importlib").import_module("gml_amd.synthetic")
+        spins, _ = synthetic.block_ising(160, 20000, block=16, seed=12)
+        hist = np.concatenate([np.ones((len(spins), 1)), spins.astype(np.float64)], axis=1)
+        m = gml.HIP(distributed=True, device=dev, tol=1e-9, precision="i8x")
+        res["wide"] = gml.learn(hist, gml.logRISE(0.8, False), m)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), world=world, **res)
     dist.barrier()
     dist.destroy_process_group()

@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 import gml_amd as gml
 from conftest import ROOT, load_csv
@@ -42,3 +43,61 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     assert np.allclose(r0["multi_vals"], [fg[k] for k in keys], atol=1e-15)
     assert np.array_equal(r0["multi_vals"], r1["multi_vals"])
     assert np.abs(r0["rise"] - load_csv("mvt_RISE_learned.csv")).max() <= 3e-4
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    # `python bench.py --gpus N` with no WORLD_SIZE starts N ranks itself (torch.distributed.run as a child, before
+    # anything touches a GPU) and relays rank 0's line; --dry-run keeps the rendezvous and the node partition only
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry-run"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["partition"] == [[0, 512], [512, 1024]]
+
+
+@pytest.mark.gpu
+def test_two_rank_hip_solver_matches_single_process(tmp_path):
+    # the sharded HIP path under real ranks: two processes, disjoint node ranges, the product's solver on the GPU
+    # (both ranks on device 0 of a 1-GPU box), rows gathered through torch.distributed
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_worker.py"),
+           str(tmp_path), "hip"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    assert int(r0["world"]) == 2
+    s = load_csv("mvt_samples.csv")
+    single = gml.learn(s, gml.RISE(0.2, False), gml.HIP(tol=1e-11))
+    single_sym = gml.learn(s, gml.RISE(0.2, True), gml.HIP(tol=1e-11))
+    for rr in (r0, r1):
+        assert np.abs(rr["rise"] - single).max() <= 1e-9
+        assert np.abs(rr["rise_sym"] - single_sym).max() <= 1e-9
+    assert np.array_equal(r0["rise"], r1["rise"]) and np.array_equal(r0["multi_vals"], r1["multi_vals"])
+    fg = gml.learn(load_csv("c_samples.csv"), gml.multiRISE(0.2, True, 3), gml.HIP(tol=1e-11))
+    keys = sorted(fg.keys(), key=lambda k: (len(k), k))
+    assert np.abs(r0["multi_vals"] - np.array([fg[k] for k in keys])).max() <= 1e-9
+    synthetic = __import__("importlib").import_module("gml_amd.synthetic")
+    spins, _ = synthetic.block_ising(160, 20000, block=16, seed=12)
+    hist = np.concatenate([np.ones((len(spins), 1)), spins.astype(np.float64)], axis=1)
+    wide = gml.learn(hist, gml.logRISE(0.8, False), gml.HIP(tol=1e-9, precision="i8x"))
+    assert r0["wide"].shape == (160, 160) and np.array_equal(r0["wide"], r1["wide"])
+    assert np.abs(r0["wide"] - wide).max() <= 2e-8  # same optimum from rows [0,80) + [80,160) as from one handle
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_the_gpu_box():
+    # bench.py --gpus 2 end to end on the 1-GPU box: its own launcher, both ranks on device 0, node-sharded passes,
+    # learn() and the gather; a small problem so that it takes seconds
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--n", "256", "--samples", "50000", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["nodes_per_gpu"] == 128 and len(line["per_rank_ms_per_step"]) == 2
+    assert line["value"] > 0 and line["learn_not_converged"] == 0 and line["max_err_vs_true_model"] < 0.1
+    assert line["collective_ranks"] == 2 and "gather_s" in line

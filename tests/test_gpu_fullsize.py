@@ -1,0 +1,101 @@
+"""BASELINE.json configs 3, 4 and 5 at FULL size on the MI355X, through the C ABI, checked against the CPU
+oracle's blocked restatement (oracle/gml_oracle_fast.c) on a sample of nodes -- the oracle cannot solve all
+nodes at these sizes in seconds, so parity is certified per node by (i) the oracle's objective/gradient at
+the same theta and (ii) the solver-independent KKT residual of the learned rows evaluated with the ORACLE's
+gradient (the optimum of each strictly convex node problem is unique, so a small residual pins the solution).
+Samples are drawn on the device (no multi-GB host matrix is built) and downloaded once for the oracle.
+
+Tolerances: objective/gradient of the int8-limb path vs the FP64 oracle 1e-8 (measured ~2e-10 at these
+sizes); KKT residual of the learned rows <= 5e-9 for tol = 1e-9.
+"""
+import time
+
+import numpy as np
+import pytest
+
+import gml_amd as gml
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+synthetic = __import__("importlib").import_module("gml_amd.synthetic")
+
+
+def _oracle_kkt(form, spins, rows, nodes, lam):
+    f, g = O.objgrad_nodes(form, None, spins, np.asarray(nodes), rows)
+    return max(O.kkt_residual(rows[a], g[a], lam, int(u)) for a, u in enumerate(nodes))
+
+
+def test_c3_logrise_full_size():
+    # config 3: n=1024 random (16-spin block) Ising, 1e6 samples, logRISE(0.8) with l1, one MI355X
+    n, K = 1024, 1000000
+    J = synthetic.block_ising_model(n, block=16, seed=0)
+    some = np.array([0, 333, 640, 1023])
+    with gml.Problem(model=J, num_samples=K, seed=3) as p:
+        t0 = time.time()
+        out, kkt, st = p.learn("logRISE", 0.8, tol=1e-9, precision="i8x")
+        t_learn = time.time() - t0
+        lam = st["lambda_"]
+        rng = np.random.default_rng(0)
+        th = out[some] + rng.normal(scale=0.02, size=(4, n)) * (rng.random((4, n)) < 0.05)  # off the optimum
+        f8, g8 = p.objgrad("logRISE", some, th, precision="i8x")
+        f64, g64 = p.objgrad("logRISE", some, th, precision="f64")
+        spins = p.spins()
+    assert st["not_converged"] == 0 and kkt.max() <= 1e-9 and st["polished"] == 0
+    assert t_learn < 5.0
+    fo, go = O.objgrad_nodes("logRISE", None, spins, some, th)
+    assert np.abs(f64 - fo).max() <= 1e-12 and np.abs(g64 - go).max() <= 1e-12      # FP64 path = the oracle
+    assert np.abs(f8 - fo).max() <= 1e-8 and np.abs(g8 - go).max() <= 1e-8          # int8-limb path
+    assert _oracle_kkt("logRISE", spins, out[some], some, lam) <= 5e-9              # the learned rows are the optimum
+    sym = 0.5 * (out + out.T)
+    assert np.abs(sym - J).max() <= 0.06                                             # and the generating model
+
+
+@pytest.mark.parametrize("node_range", [(0, 512), (3584, 4096)])
+def test_c4_sparse_ising_shard_full_size(node_range):
+    # config 4: n=4096 sparse (8-spin block) Ising, 1e6 samples, RISE(); the shard one rank of 8 owns
+    n, K = 4096, 1000000
+    J = synthetic.block_ising_model(n, block=8, seed=1)
+    n0, n1 = node_range
+    some = np.array([n0, n0 + 77, n0 + 300, n1 - 1])
+    with gml.Problem(model=J, num_samples=K, seed=4, node_range=node_range) as p:
+        out, kkt, st = p.learn("RISE", 0.4, tol=1e-9, precision="i8x")
+        lam = st["lambda_"]
+        f8, g8 = p.objgrad("RISE", some, J[some], precision="i8x")
+        spins = p.spins()
+    assert out.shape == (512, n) and st["not_converged"] == 0 and kkt.max() <= 1e-9
+    fo, go = O.objgrad_nodes("RISE", None, spins, some, J[some])
+    assert np.abs(f8 / fo - 1).max() <= 1e-8 and np.abs(g8 - go).max() <= 1e-8
+    assert _oracle_kkt("RISE", spins, out[some - n0], some, lam) <= 5e-9
+    assert np.abs(out[:, n0:n1] - J[n0:n1, n0:n1]).max() <= 0.06  # un-symmetrised rows vs the generating model
+    off = out.copy()
+    off[:, n0:n1] = 0
+    assert np.abs(off).max() <= 0.02                               # nothing outside the diagonal blocks
+
+
+def test_c5_multibody_order3_full_size():
+    # config 5: n=512 spins with 3-spin interactions, 1e6 samples, multiRISE/ISODUS order 3 (130 817 parameters
+    # per node, 131 k statistics columns).  Objective/gradient against the oracle's order-3 restatement on 2 nodes;
+    # learn() at the regulariser of the timing runs (c = 1.2: lambda from n^2 as in :86, sparse optimum).
+    n, K = 512, 1000000
+    terms = synthetic.block_multibody_terms(n, block=16, seed=0)
+    some = np.array([0, 511])
+    with gml.Problem(terms=terms, n=n, num_samples=K, seed=5, order=3) as p:
+        P = p.P
+        assert P == 1 + 511 + 511 * 510 // 2
+        out, kkt, st = p.learn("RISE", 1.2, tol=1e-8, precision="i8x", max_iter=60)
+        lam = st["lambda_"]
+        keys0 = p.multi_keys(0)
+        th = out[some].copy()
+        f8, g8 = p.objgrad("RISE", some, th, precision="i8x")
+        spins = p.spins()
+    assert st["not_converged"] == 0 and kkt.max() <= 1e-8
+    assert keys0[:3] == [(0,), (0, 1), (0, 2)] and keys0[512] == (0, 1, 2) and len(keys0) == P
+    fo, go = O.objgrad_multi3_nodes(None, spins, some, th)
+    assert np.abs(f8 / fo - 1).max() <= 1e-8 and np.abs(g8 - go).max() <= 1e-8
+    for a in range(2):  # KKT certificate from the oracle's gradient: slot 0 (the field, key (u,)) is not penalised (:118)
+        x, g = th[a], go[a]
+        pg = np.where(x > 0, g + lam, np.where(x < 0, g - lam, np.sign(g) * np.maximum(np.abs(g) - lam, 0)))
+        pg[0] = g[0]
+        assert np.abs(pg).max() <= 5e-8
+    err = max(abs(v - terms.get(tuple(sorted(i + 1 for i in key)), 0.0)) for key, v in zip(keys0, out[0]))
+    assert err <= 0.06  # node 0's terms are the generating ones up to sampling noise and the l1 shrinkage

@@ -139,3 +139,66 @@ def test_multi_objgrad_matches_numpy():
         f, g = O.objgrad_multi(s, 3, u, th)
         assert f == pytest.approx(e.sum(), rel=1e-13)
         np.testing.assert_allclose(g, -(stat * e[:, None]).sum(0), rtol=1e-11, atol=1e-14)
+
+
+# ---- gml_oracle_fast.c: the blocked / OpenMP restatements used for full-size checks and the CPU baseline ----
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+@pytest.mark.parametrize("form", FORMS)
+def test_fast_learn_abc_goldens(name, form):
+    # the batched working-set Newton (the device solver's algorithm on the CPU) against the reference's goldens
+    s = load_csv(f"{name}_samples.csv")
+    counts, spins = O.split_histogram(s)
+    R, kkt, st = O.learn_pair_fast(counts, spins, form, c=DEFAULT_C[form], tol=1e-12)
+    R = 0.5 * (R + R.T)  # :184-186
+    G = load_csv(f"{name}_{form}_learned.csv")
+    assert np.abs(R - G).max() <= 5e-8
+    assert np.linalg.norm(R - G) / np.linalg.norm(G) <= 1e-6
+    assert kkt.max() <= 1e-10
+
+
+@pytest.mark.parametrize("form", FORMS)
+def test_fast_learn_mvt_matches_dense_oracle(form):
+    s = load_csv("mvt_samples.csv")
+    counts, spins = O.split_histogram(s)
+    R, kkt, _ = O.learn_pair_fast(counts, spins, form, c=0.2, tol=1e-12)
+    R0, kkt0, _ = O.learn_pair(s, form, c=0.2, symmetrize=False)
+    assert kkt.max() <= 1e-10
+    assert np.abs(R - R0).max() <= 1e-8
+    assert np.abs(R - load_csv(f"mvt_{form}_learned.csv")).max() <= 3e-4
+
+
+@pytest.mark.parametrize("form", FORMS)
+def test_fast_objgrad_nodes_matches_generic(form):
+    # more than one 32-node block, ragged last block, repeated nodes, odd K, non-uniform counts
+    rng = np.random.default_rng(4)
+    K, n = 1001, 70
+    spins = np.where(rng.random((K, n)) < 0.5, 1, -1).astype(np.int8)
+    counts = rng.integers(0, 5, K).astype(float)
+    hist = np.column_stack([counts, spins])
+    nodes = np.concatenate([np.arange(n), [3, 3, 69]])
+    th = rng.normal(scale=0.1, size=(len(nodes), n))
+    f, g = O.objgrad_nodes(form, counts, spins, nodes, th)
+    for a in (0, 31, 32, 33, 69, 70, 72):
+        f0, g0 = O.objgrad_pair(hist, form, int(nodes[a]), th[a])
+        assert f[a] == pytest.approx(f0, rel=1e-12, abs=1e-13)
+        np.testing.assert_allclose(g[a], g0, rtol=1e-10, atol=1e-13)
+    f1, _ = O.objgrad_nodes(form, None, spins, nodes[:2], th[:2], want_grad=False)  # counts = None: all ones
+    f2, _ = O.objgrad_nodes(form, np.ones(K), spins, nodes[:2], th[:2])
+    assert np.allclose(f1, f2, rtol=1e-14)
+
+
+def test_fast_multi3_matches_generic():
+    rng = np.random.default_rng(5)
+    K, n = 403, 9
+    spins = np.where(rng.random((K, n)) < 0.5, 1, -1).astype(np.int8)
+    counts = rng.integers(1, 4, K).astype(float)
+    hist = np.column_stack([counts, spins])
+    P = 1 + 8 + 28
+    nodes = np.array([0, 4, 8])
+    th = rng.normal(scale=0.2, size=(3, P))
+    f, g = O.objgrad_multi3_nodes(counts, spins, nodes, th)
+    for a, u in enumerate(nodes):
+        f0, g0 = O.objgrad_multi(hist, 3, int(u), th[a])
+        assert f[a] == pytest.approx(f0, rel=1e-13)
+        np.testing.assert_allclose(g[a], g0, rtol=1e-11, atol=1e-14)
