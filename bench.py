@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=1024)
+    ap.add_argument("--spins", dest="n", type=int, default=1024, help="number of spins n (not --n: torchrun's own parser would call that an ambiguous abbreviation)")
     ap.add_argument("--samples", type=int, default=1000000)
     ap.add_argument("--block", type=int, default=16)
     ap.add_argument("--precision", default=os.environ.get("GML_BENCH_PRECISION", "i8x"), choices=["f64", "i8x"],

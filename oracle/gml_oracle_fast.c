@@ -150,27 +150,30 @@ void gml_oracle_objgrad_nodes(int form, int64_t K, int64_t n, const double *coun
         }
         free(sd);
     }
-    for (int64_t a = 0; a < nn; ++a) {
-        const int64_t b = a / NB, r = a % NB;
-        double fa = 0.0, ga = 0.0;
-        for (int64_t c = 0; c < nch; ++c) {
-            fa += fs[(b * nch + c) * NB + r];
-            ga += gus[(b * nch + c) * NB + r];
-        }
-        if (g) {
-            for (int64_t i = 0; i < n; ++i) {
-                double s = 0.0;
-                for (int64_t c = 0; c < nch; ++c) s += Gt[((b * nch + c) * n + i) * NB + r];
-                g[a * n + i] = -s;
+    /* reduce the per-chunk partial sums block by block (contiguous sweeps), then scatter to the caller's layout */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t b = 0; b < nblk; ++b) {
+        double *G0 = Gt + (b * nch) * n * NB, *f0 = fs + (b * nch) * NB, *g0 = gus + (b * nch) * NB;
+        for (int64_t c = 1; c < nch; ++c) {
+            const double *Gc = Gt + (b * nch + c) * n * NB;
+            for (int64_t e = 0; e < n * NB; ++e) G0[e] += Gc[e];
+            for (int r = 0; r < NB; ++r) {
+                f0[r] += fs[(b * nch + c) * NB + r];
+                g0[r] += gus[(b * nch + c) * NB + r];
             }
-            g[a * n + nodes[a]] = -ga;
         }
-        if (form == GML_LOGRISE) { /* f = log Z, g = grad Z / Z (:279) */
-            if (g)
-                for (int64_t i = 0; i < n; ++i) g[a * n + i] /= fa;
-            fa = log(fa);
+        for (int r = 0; r < NB && b * NB + r < nn; ++r) {
+            const int64_t a = b * NB + r;
+            double fa = f0[r];
+            if (g) {
+                double *ga = g + a * n;
+                for (int64_t i = 0; i < n; ++i) ga[i] = -G0[i * NB + r];
+                ga[nodes[a]] = -g0[r];
+                if (form == GML_LOGRISE) /* g = grad Z / Z (:279) */
+                    for (int64_t i = 0; i < n; ++i) ga[i] /= fa;
+            }
+            f[a] = form == GML_LOGRISE ? log(fa) : fa;
         }
-        f[a] = fa;
     }
     free(ThT); free(Gt); free(fs); free(gus); free(thu); free(uu);
 }

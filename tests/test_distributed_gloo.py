@@ -95,7 +95,7 @@ def test_bench_two_ranks_on_the_gpu_box():
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--n", "256", "--samples", "50000", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
+                        "--spins", "256", "--samples", "50000", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["nodes_per_gpu"] == 128 and len(line["per_rank_ms_per_step"]) == 2
