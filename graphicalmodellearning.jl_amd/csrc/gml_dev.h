@@ -2,26 +2,30 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "gml_bits.h"
 
 namespace gml {
 
-// Device-resident problem data.  Layout (all padded, padding is zero):
-//   Xt [Qp][Kp] int8   feature-major design matrix: Xt[c][k] = prod_{i in key_c} s_i^k
-//   Xb                 the same matrix sample-major, one bit per entry (set <=> -1), in the piece
-//                      layout of k_pack_bits (gml_kernels_i8.hip): the forward operand of the int8 path
-//   Xtb                the bits of Xt in the piece layout of k_pack_bits_t: the backward operand
-//   Xs [Kp][Qp] int8   sample-major bytes; built on first use by the FP64 path only
-//   w  [Kp]     f64    c_k / M   (samples[k,1]/num_samples, GraphicalModelLearning.jl:170)
-// Columns 0..n-1 are the single spins, then pairs (i<j) in lexicographic order, ... (multi-body,
-// :94-108); column `cconst` is the empty key (constant 1: the node's field).  Node u's sign
-// s_u^k is row u of Xt.  Column Qp-1 is always a zero (padding) column.
+// Device-resident problem data (all padded, padding is zero).  The samples are stored as ONE BIT per entry:
+//   Sb  [n][Kp/32]     sign bits of the spins, spin-major, natural order (bit j of word w <-> sample 32w + j; set <=> -1)
+//   Xb                 forward operand of the int8 path: the design matrix sample-major, in the piece layout of
+//                      k_build_xb (gml_kernels_i8.hip)
+//   Xtb                backward operand: the same matrix feature-major, piece layout of k_build_xtb
+//   keys [Qf][ko]      spins of every statistic column (-1 = unused slot): column c = prod of its spins = XOR of sign bits
+//   w   [Kp]     f64   c_k / M   (samples[k,1]/num_samples, GraphicalModelLearning.jl:170)
+//   Xs [Kp][Qp], Xt [Qp][Kp] int8   byte images, built on first use by the FP64 path only
+// Columns 0..n-1 are the single spins, then pairs (i<j) in lexicographic order, ... (multi-body, :94-108); column
+// `cconst` is the empty key (constant 1: the node's field).  Column Qp-1 is always a zero (padding) column.
 struct DevProblem {
     int64_t K, Kp, n;
     int64_t Qf, Qfp;  // statistic columns [0,Qf), zero padded to Qfp (multiple of 64)
     int64_t cconst;   // column of the constant statistic (= Qfp)
     int64_t Qp;       // row pitch of Xs / number of rows of Xt (= Qfp + 64)
+    unsigned *Sb;
+    unsigned *Xb, *Xtb;
+    int32_t *keys;
+    int ko;
     int8_t *Xs, *Xt;
-    unsigned *Xb, *Xtb; // bit images: sample-major (forward operand) and feature-major (backward operand)
     double *w;
     double wmax;      // max_k w_k
     double wuni;      // the common weight when all K samples weigh the same (counts all equal), else 0
@@ -30,7 +34,11 @@ struct DevProblem {
 // ---- packing -----------------------------------------------------------------------------
 void launch_transpose_i8(const int8_t *src, int64_t rows, int64_t cols, int64_t ld_src,
                          int8_t *dst, int64_t ld_dst, hipStream_t st);
-void launch_pack_bits(const DevProblem &d, hipStream_t st); // Xt -> Xb, Xtb
+// Sb from +-1 bytes: sample-major S [K][n] (ld ignored) or spin-major S [n][ld]
+void launch_spin_bits(const int8_t *S, bool spin_major, int64_t K, int64_t n, int64_t ld, int64_t Kp, unsigned *Sb, hipStream_t st);
+void launch_pack_bits(const DevProblem &d, hipStream_t st);      // Sb, keys -> Xb, Xtb
+void launch_unpack_spins(const DevProblem &d, int64_t k0, int64_t kk, int8_t *out /* [kk][n] */, hipStream_t st);
+void launch_expand_xt(const DevProblem &d, int8_t *Xt, hipStream_t st); // Sb, keys -> rows [0, Qf) of the byte image
 // *bad = smallest configuration index holding an entry that is not +-1 (unchanged if there is none; init -1)
 // Histogram matrix (K x (1+n), element type `dtype` of gml.h, leading dimension ld) -> counts [K] and +-1 int8 spins:
 // column-major input gives spin-major output [n][K], row-major input sample-major [K][n].  *bad as in launch_check_pm1.
@@ -38,19 +46,11 @@ void launch_convert_hist(const void *H, int dtype, int64_t K, int64_t n, int64_t
                          long long *bad, hipStream_t st);
 void launch_check_pm1(const int8_t *S, int64_t K, int64_t n, long long *bad, hipStream_t st);
 int64_t xtb_bytes(const DevProblem &d);
-void launch_expand_features(const int8_t *St, int64_t n, int64_t K, int64_t Kp,
-                            const int32_t *keys, int order, int64_t Q, int8_t *Xt,
-                            hipStream_t st);
 
-// Byte offset of limb l of V[r][k] in the int8 limb image Vq of the exact fixed-point pass:
-// images [node tile r/32][k/64] of [4 limbs x 32 rows][64 B], contiguous (8 KB each).  Within a row the
-// 64 samples of the step are PERMUTED: the forward epilogue's lane (node, half h) owns the samples
-// 32 i + 8 g + 4 h + j (i < 2, g < 4, j < 4) and stores them at byte 32 h + 16 i + 4 g + j, so that its
-// 32 bytes per limb are contiguous and go out as two 16-byte stores without an LDS transpose.  The
-// feature-major bit image (k_pack_bits_t) uses the same order, so the backward GEMM contracts
-// position against position.
-__host__ __device__ inline int vq_pos(int s) { return ((s >> 2) & 1) * 32 + (s >> 5) * 16 + ((s >> 3) & 3) * 4 + (s & 3); }
-__host__ __device__ inline int vq_sample(int p) { return ((p >> 4) & 1) * 32 + ((p >> 2) & 3) * 8 + (p >> 5) * 4 + (p & 3); }
+// Byte offset of limb l of V[r][k] in the int8 limb image Vq of the fixed-point pass: images [node tile r/32][k/64]
+// of [4 limbs x 32 rows][64 B], contiguous (8 KB each); within a row the 64 samples of the step are stored in the
+// order vq_pos() (gml_bits.h), which the feature-major bit image shares, so the backward GEMM contracts position
+// against position.
 __host__ __device__ inline int64_t vq_off(int64_t r, int l, int64_t k, int64_t Kp) {
     return ((((r >> 5) * (Kp >> 6) + (k >> 6)) * 4 + l) * 32 + (r & 31)) * 64 + vq_pos((int)(k & 63));
 }
@@ -70,10 +70,10 @@ void launch_bwd_f64(const DevProblem &P, const double *V, const int *groups, int
 // F [Rp][cap] column ids (padding = Qp-1), mt[r] = number of 32-tiles used by row r.
 void launch_hess_f64(const DevProblem &P, const double *V,
                      const int *rowcol, const int *F, const int *mt, const long long *hoff, int R, int cap, int form,
-                     int64_t Kh, double *H, hipStream_t st);
+                     int64_t Kh, int64_t kstride, double *H, hipStream_t st);
 // H is ragged: row r's block starts at hoff[r] and is (32 mt[r]) x (32 mt[r]) with that pitch.
-// Kh (multiple of 32, <= Kp): the Hessian is accumulated over the first Kh configurations only
-// (sub-sampled Newton: the gradient stays exact, so only the convergence rate is affected).
+// Kh (multiple of 512, <= Kp), kstride: the Hessian is accumulated over Kh configurations, every kstride-th block
+// of 512 (sub-sampled Newton: the gradient stays exact, so only the convergence rate is affected).
 
 // Exact sampling of one block (connected component) of a model given as terms (bit masks over the block's
 // spins + weights): energies of its 2^sb states, CDF, N draws written into S [N][n] (sample-major, +-1) at

@@ -153,7 +153,7 @@ struct gml_problem {
     std::vector<int32_t> gkeys; // [Q][ko] subsets of spins (feature keys), -1 padded
     int ko = 1;
     std::vector<int64_t> qoff; // qoff[q] = first column of the size-q subsets
-    std::vector<double> wprefix; // wprefix[j] = sum of w over the first 1024*j configurations
+    std::vector<double> wblk;    // wblk[j] = sum of w over the configurations [512 j, 512 j + 512)
     // workspace (sized for ws_rows rows)
     int64_t ws_rows = 0;
     double *dTheta = nullptr, *dV = nullptr, *dG = nullptr, *dF = nullptr;
@@ -272,16 +272,30 @@ static int upload_pageable(void *dst, const void *src, size_t bytes, hipStream_t
     return GML_OK;
 }
 
-static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /*K x n row-major, host*/,
-                     int8_t *dspins = nullptr /* the same on the device (then owned and freed here) */) {
+// Builds the device-resident problem from the +-1 configurations, given as host bytes `spins` (K x n row-major), or
+// as device bytes `dbytes` -- sample-major [K][n] or, with dev_spin_major, spin-major [n][ld] -- which this function
+// owns and frees on every path.  What stays resident is one bit per entry: the sign bits of the spins (Sb) and the two
+// MFMA operand images derived from them (Xb, Xtb): 2/8 byte per (configuration, statistic) + 1/8 per (configuration, spin).
+static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins, int8_t *dbytes = nullptr,
+                     bool dev_spin_major = false, int64_t ld = 0) {
+    struct Guard { // temporaries of this function: released on every return
+        int8_t *bytes = nullptr;
+        long long *bad = nullptr;
+        ~Guard() {
+            if (bytes) (void)hipFree(bytes);
+            if (bad) (void)hipFree(bad);
+        }
+    } tmp;
+    tmp.bytes = dbytes;
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipStreamCreate(&p->st));
     DevProblem &d = p->d;
-    const int fo = p->order - 1;
-    p->ko = fo > 0 ? fo : 1;
-    // internal columns: [0, Qf) = the non-empty subsets of spins (singles, then pairs (i<j)
-    // lexicographic, ...), zero padding up to Qfp, then the constant column `cconst` (the empty
-    // subset: the node's field) opening a final 64-byte block.
+    // Statistic columns: the non-empty subsets of spins up to size order-1 (singles, then pairs (i<j) lexicographic,
+    // ...), zero padding up to Qfp, then the constant column `cconst` (the empty subset: the node's field) opening a
+    // final 64-byte block.  Order 1 (fields only, :94-104 with interaction_order = 1) keeps the single-spin columns
+    // too -- the FP64 path reads the nodes' signs from them -- but gives them no parameter (node_cols).
+    const int fo = std::max(p->order - 1, 1);
+    p->ko = fo;
     p->qoff.assign(fo + 2, 0);
     int64_t Qf = 0;
     for (int q = 1; q <= fo; ++q) {
@@ -290,7 +304,7 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
     }
     p->qoff[fo + 1] = Qf;
     p->P = 0;
-    for (int q = 0; q <= fo; ++q) p->P += binom(p->n - 1, q);
+    for (int q = 0; q <= p->order - 1; ++q) p->P += binom(p->n - 1, q);
     d.K = p->K;
     d.n = p->n;
     d.Qf = Qf;
@@ -298,11 +312,17 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
     d.cconst = d.Qfp;
     d.Qp = d.Qfp + 64;
     d.Kp = round_up(p->K, 1024);
+    d.ko = p->ko;
     const int64_t Q = Qf;
-    // resident: Xt (bytes, feature-major) + the two bit images = 1.25 bytes per entry
-    if ((double)d.Kp * (double)d.Qp * 1.25 > 240e9)
-        return fail(GML_ENOMEM, "design matrix %lld x %lld does not fit in HBM", (long long)d.Kp, (long long)d.Qp);
     if (d.Qfp / 64 > 32000) return fail(GML_EUNSUPPORTED, "more than 2^21 statistics per node");
+    {
+        size_t freeb = 0, totalb = 0;
+        HIPCHK(hipMemGetInfo(&freeb, &totalb));
+        const double need = 2.0 * (double)d.Kp * (double)round_up(d.Qfp, 256) / 8.0 + (double)d.Kp * (double)p->n / 8.0 + 8.0 * (double)d.Kp;
+        if (need > 0.92 * (double)freeb)
+            return fail(GML_ENOMEM, "the bit images of the %lld x %lld design matrix (%.1f GB) do not fit in %.1f GB of free HBM",
+                        (long long)d.Kp, (long long)d.Qfp, need / 1e9, freeb / 1e9);
+    }
     // feature keys
     p->gkeys.assign((size_t)std::max<int64_t>(Q, 1) * p->ko, -1);
     {
@@ -316,12 +336,13 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
             } while (next_comb(idx, p->n));
         }
     }
-    d.Xs = nullptr; // FP64 path only, built on first use (ensure_f64)
-    HIPCHK(hipMalloc(&d.Xt, (size_t)d.Kp * d.Qp));
+    d.Xs = d.Xt = nullptr; // FP64 path only, built on first use (ensure_f64)
+    HIPCHK(hipMalloc(&d.Sb, (size_t)p->n * (d.Kp / 8)));
+    HIPCHK(hipMalloc(&d.keys, sizeof(int32_t) * p->gkeys.size()));
     HIPCHK(hipMalloc(&d.Xb, (size_t)d.Kp * (d.Qfp / 8)));
     HIPCHK(hipMalloc(&d.Xtb, (size_t)xtb_bytes(d)));
     HIPCHK(hipMalloc(&d.w, sizeof(double) * d.Kp));
-    HIPCHK(hipMemsetAsync(d.Xt, 0, (size_t)d.Kp * d.Qp, p->st));
+    HIPCHK(hipMemsetAsync(d.Sb, 0, (size_t)p->n * (d.Kp / 8), p->st));
     HIPCHK(hipMemsetAsync(d.w, 0, sizeof(double) * d.Kp, p->st));
     // weights w_k = counts[k]/M  (:170)
     std::vector<double> w((size_t)p->K);
@@ -336,57 +357,49 @@ static int alloc_dev(gml_problem *p, const double *counts, const int8_t *spins /
             d.wuni = 0.0;
             break;
         }
-    p->wprefix.assign((size_t)(d.Kp / 1024) + 1, 0.0);
-    {
-        double acc = 0;
-        for (int64_t k = 0; k < d.Kp; ++k) {
-            if ((k & 1023) == 0) p->wprefix[(size_t)(k >> 10)] = acc;
-            if (k < p->K) acc += w[k];
-        }
-        p->wprefix[(size_t)(d.Kp >> 10)] = acc;
-    }
+    p->wblk.assign((size_t)(d.Kp / 512), 0.0); // weight of every block of 512 configurations (sub-sampled Hessians)
+    for (int64_t k = 0; k < p->K; ++k) p->wblk[(size_t)(k >> 9)] += w[k];
     HIPCHK(hipMemcpyAsync(d.w, w.data(), sizeof(double) * p->K, hipMemcpyHostToDevice, p->st));
-    // spins: upload sample-major, transpose to spin-major St [n][Kp], expand, transpose back
-    int8_t *dS = dspins, *dSt = nullptr;
-    int32_t *dkeys = nullptr;
-    if (!dS) HIPCHK(hipMalloc(&dS, (size_t)p->K * p->n));
-    HIPCHK(hipMalloc(&dSt, (size_t)p->n * d.Kp));
-    HIPCHK(hipMalloc(&dkeys, sizeof(int32_t) * p->gkeys.size()));
-    if (!dspins) {
-        int urc = upload_pageable(dS, spins, (size_t)p->K * p->n, p->st);
+    HIPCHK(hipMemcpyAsync(d.keys, p->gkeys.data(), sizeof(int32_t) * p->gkeys.size(), hipMemcpyHostToDevice, p->st));
+    if (!tmp.bytes) {
+        HIPCHK(hipMalloc(&tmp.bytes, (size_t)p->K * p->n));
+        int urc = upload_pageable(tmp.bytes, spins, (size_t)p->K * p->n, p->st);
         if (urc) return urc;
         // validation of the +-1 alphabet (the reference validates nothing): first offending configuration
-        long long *dbad = nullptr, hbad = -1;
-        HIPCHK(hipMalloc(&dbad, sizeof(long long)));
-        HIPCHK(hipMemcpyAsync(dbad, &hbad, sizeof(long long), hipMemcpyHostToDevice, p->st));
-        launch_check_pm1(dS, p->K, p->n, dbad, p->st);
-        HIPCHK(hipMemcpyAsync(&hbad, dbad, sizeof(long long), hipMemcpyDeviceToHost, p->st));
+        long long hbad = -1;
+        HIPCHK(hipMalloc(&tmp.bad, sizeof(long long)));
+        HIPCHK(hipMemcpyAsync(tmp.bad, &hbad, sizeof(long long), hipMemcpyHostToDevice, p->st));
+        launch_check_pm1(tmp.bytes, p->K, p->n, tmp.bad, p->st);
+        HIPCHK(hipMemcpyAsync(&hbad, tmp.bad, sizeof(long long), hipMemcpyDeviceToHost, p->st));
         HIPCHK(hipStreamSynchronize(p->st));
-        (void)hipFree(dbad);
-        if (hbad >= 0) {
-            (void)hipFree(dS);
-            (void)hipFree(dSt);
-            (void)hipFree(dkeys);
-            return fail(GML_EINVAL, "configuration %lld holds a spin that is not +-1", hbad);
-        }
+        if (hbad >= 0) return fail(GML_EINVAL, "configuration %lld holds a spin that is not +-1", hbad);
+        dev_spin_major = false;
     }
-    HIPCHK(hipMemcpyAsync(dkeys, p->gkeys.data(), sizeof(int32_t) * p->gkeys.size(), hipMemcpyHostToDevice, p->st));
-    HIPCHK(hipMemsetAsync(dSt, 0, (size_t)p->n * d.Kp, p->st));
-    launch_transpose_i8(dS, p->K, p->n, p->n, dSt, d.Kp, p->st);
-    if (Q > 0) launch_expand_features(dSt, p->n, p->K, d.Kp, dkeys, p->ko, Q, d.Xt, p->st);
-    HIPCHK(hipMemsetAsync(d.Xt + d.cconst * d.Kp, 1, (size_t)p->K, p->st)); // the constant statistic
+    launch_spin_bits(tmp.bytes, dev_spin_major, p->K, p->n, ld, d.Kp, d.Sb, p->st);
     launch_pack_bits(d, p->st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(p->st));
-    HIPCHK(hipFree(dS));
-    HIPCHK(hipFree(dSt));
-    HIPCHK(hipFree(dkeys));
     return GML_OK;
 }
 
+static int create_common_impl(const double *counts, const int8_t *spins, int64_t K, int64_t n, int order, int64_t node0,
+                              int64_t node1, int device, gml_problem **out, int8_t *dspins, bool dev_spin_major, int64_t ld,
+                              bool *taken);
+
+// dspins: the configurations as validated +-1 bytes on the device (sample-major K x n, or spin-major n x ld with
+// dev_spin_major); owned from here on, whatever the outcome
 static int create_common(const double *counts, const int8_t *spins, int64_t K, int64_t n, int order,
                          int64_t node0, int64_t node1, int device, gml_problem **out,
-                         int8_t *dspins = nullptr /* K x n on the device, validated; owned from here on */) {
+                         int8_t *dspins = nullptr, bool dev_spin_major = false, int64_t ld = 0) {
+    bool taken = false;
+    const int rc = create_common_impl(counts, spins, K, n, order, node0, node1, device, out, dspins, dev_spin_major, ld, &taken);
+    if (!taken && dspins) (void)hipFree(dspins);
+    return rc;
+}
+
+static int create_common_impl(const double *counts, const int8_t *spins, int64_t K, int64_t n, int order, int64_t node0,
+                              int64_t node1, int device, gml_problem **out, int8_t *dspins, bool dev_spin_major, int64_t ld,
+                              bool *taken) {
     if (!out) return fail(GML_EINVAL, "out is NULL");
     *out = nullptr;
     if (K <= 0 || n <= 0) return fail(GML_EINVAL, "empty histogram (K=%lld, n=%lld)", (long long)K, (long long)n);
@@ -412,7 +425,8 @@ static int create_common(const double *counts, const int8_t *spins, int64_t K, i
     p->order = order;
     p->node0 = node0;
     p->node1 = node1;
-    int rc = alloc_dev(p, counts, spins, dspins);
+    *taken = true;
+    int rc = alloc_dev(p, counts, spins, dspins, dev_spin_major, ld);
     if (rc != GML_OK) {
         std::string keep = g_err;
         gml_problem_destroy(p);
@@ -455,12 +469,12 @@ extern "C" int gml_problem_create(const void *samples, int dtype, int64_t K, int
         const size_t esz = dtype == GML_I8 ? 1 : (dtype == GML_I32 ? 4 : 8);
         const size_t bytes = esz * (size_t)(col_major ? ld * (n + 1) - (ld - K) : (K - 1) * ld + (n + 1));
         void *dH = nullptr;
-        int8_t *dT = nullptr, *dS = nullptr;
+        int8_t *dS = nullptr;
         double *dC = nullptr;
         long long *dbad = nullptr, hbad = -1;
         hipStream_t st = nullptr;
         auto cleanup = [&](int rc) {
-            void *ptrs[] = {dH, dT, dC, dbad};
+            void *ptrs[] = {dH, dC, dbad};
             for (void *q : ptrs)
                 if (q) (void)hipFree(q);
             if (st) (void)hipStreamDestroy(st);
@@ -476,16 +490,14 @@ extern "C" int gml_problem_create(const void *samples, int dtype, int64_t K, int
     } while (0)
         CCHK(hipStreamCreate(&st));
         CCHK(hipMalloc(&dH, bytes));
-        CCHK(hipMalloc(&dT, (size_t)K * n));
         CCHK(hipMalloc(&dS, (size_t)K * n));
         CCHK(hipMalloc(&dC, sizeof(double) * K));
         CCHK(hipMalloc(&dbad, sizeof(long long)));
         CCHK(hipMemcpyAsync(dbad, &hbad, sizeof(long long), hipMemcpyHostToDevice, st));
         int urc = upload_pageable(dH, samples, bytes, st);
         if (urc) return cleanup(urc);
-        // column-major: spins land spin-major in dT and are transposed; row-major: straight into dS
-        launch_convert_hist(dH, dtype, K, n, ld, col_major, dC, col_major ? dT : dS, dbad, st);
-        if (col_major) launch_transpose_i8(dT, n, K, K, dS, n, st);
+        // column-major input gives spin-major bytes [n][K], row-major input sample-major [K][n]: the bit packer takes both
+        launch_convert_hist(dH, dtype, K, n, ld, col_major, dC, dS, dbad, st);
         std::vector<double> counts((size_t)K);
         CCHK(hipMemcpyAsync(counts.data(), dC, sizeof(double) * K, hipMemcpyDeviceToHost, st));
         CCHK(hipMemcpyAsync(&hbad, dbad, sizeof(long long), hipMemcpyDeviceToHost, st));
@@ -501,7 +513,7 @@ extern "C" int gml_problem_create(const void *samples, int dtype, int64_t K, int
         }
         if (!(Msum > 0)) return cleanup(fail(GML_EINVAL, "sum of counts is zero"));
         cleanup(GML_OK); // every check create_common repeats has passed: it takes ownership of dS
-        return create_common(counts.data(), nullptr, K, n, order, node0, node1, device, out, dS);
+        return create_common(counts.data(), nullptr, K, n, order, node0, node1, device, out, dS, col_major != 0, K);
     }
     auto at = [&](int64_t k, int64_t j) -> double {
         const int64_t off = col_major ? k + j * ld : k * ld + j;
@@ -736,11 +748,11 @@ extern "C" int gml_problem_create_mcmc_terms(const int32_t *keys, int key_stride
     p->node1 = node1;
     hipStream_t st = nullptr;
     const int64_t Np = round_up(N, 256);
-    int8_t *dS = nullptr, *dSt = nullptr;
+    int8_t *dSt = nullptr;
     int *dioff = nullptr, *dooff = nullptr, *doth = nullptr;
     double *diw = nullptr;
     auto cleanup = [&](int rc) {
-        void *ptrs[] = {dSt, dioff, dooff, doth, diw};
+        void *ptrs[] = {dioff, dooff, doth, diw};
         for (void *q : ptrs)
             if (q) (void)hipFree(q);
         if (st) (void)hipStreamDestroy(st);
@@ -750,14 +762,13 @@ extern "C" int gml_problem_create_mcmc_terms(const int32_t *keys, int key_stride
     do {                                                                                                        \
         hipError_t e_ = (expr);                                                                                 \
         if (e_ != hipSuccess) {                                                                                 \
-            if (dS) (void)hipFree(dS);                                                                          \
+            if (dSt) (void)hipFree(dSt);                                                                        \
             delete p;                                                                                           \
             return cleanup(fail(e_ == hipErrorOutOfMemory ? GML_ENOMEM : GML_EHIP, "%s failed: %s", #expr,      \
                                 hipGetErrorString(e_)));                                                        \
         }                                                                                                       \
     } while (0)
     SCHK(hipStreamCreate(&st));
-    SCHK(hipMalloc(&dS, (size_t)N * n));
     SCHK(hipMalloc(&dSt, (size_t)n * Np));
     SCHK(hipMalloc(&dioff, sizeof(int) * ioff.size()));
     SCHK(hipMalloc(&dooff, sizeof(int) * ooff.size()));
@@ -769,12 +780,11 @@ extern "C" int gml_problem_create_mcmc_terms(const int32_t *keys, int key_stride
     SCHK(hipMemcpyAsync(diw, iw.data(), sizeof(double) * iw.size(), hipMemcpyHostToDevice, st));
     SCHK(hipMemsetAsync(dSt, 0, (size_t)n * Np, st));
     launch_glauber(dioff, diw, dooff, doth, n, N, Np, sweeps, (unsigned long long)seed, dSt, st);
-    launch_transpose_i8(dSt, n, N, Np, dS, n, st); // spin-major -> the sample-major rows alloc_dev expects
     SCHK(hipGetLastError());
     SCHK(hipStreamSynchronize(st));
 #undef SCHK
     cleanup(0);
-    int rc = alloc_dev(p, nullptr, nullptr, dS);
+    int rc = alloc_dev(p, nullptr, nullptr, dSt, true, Np); // the chains' final states, spin-major
     if (rc != GML_OK) {
         std::string keep = g_err;
         gml_problem_destroy(p);
@@ -817,14 +827,14 @@ extern "C" int gml_problem_create_sampled(const double *model, int64_t n, int64_
 extern "C" int gml_problem_get_spins(gml_problem *p, int8_t *spins) {
     if (!p || !spins) return fail(GML_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(p->device));
-    // spin-major rows of Xt -> sample-major on the device (in slabs of <= 2^24 samples), one copy per slab
-    const int64_t slab = std::min<int64_t>(p->K, (int64_t)1 << 24);
+    // sign bits -> +-1 bytes, sample-major, on the device (in slabs of <= 2^22 samples), one copy per slab
+    const int64_t slab = std::min<int64_t>(p->K, (int64_t)1 << 22);
     int8_t *dT = nullptr;
     HIPCHK(hipMalloc(&dT, (size_t)slab * p->n));
     int rc = GML_OK;
     for (int64_t k0 = 0; k0 < p->K && rc == GML_OK; k0 += slab) {
         const int64_t kk = std::min(slab, p->K - k0);
-        launch_transpose_i8(p->d.Xt + k0, p->n, kk, p->d.Kp, dT, p->n, p->st);
+        launch_unpack_spins(p->d, k0, kk, dT, p->st);
         if (hipMemcpyAsync(spins + k0 * p->n, dT, (size_t)kk * p->n, hipMemcpyDeviceToHost, p->st) != hipSuccess ||
             hipStreamSynchronize(p->st) != hipSuccess)
             rc = fail(GML_EHIP, "download of the spins failed: %s", hipGetErrorString(hipGetLastError()));
@@ -839,15 +849,15 @@ void i8_get_v(void *ws, const int8_t **Vq, const double **tau);
 const unsigned *i8_get_mmax(void *ws);
 int64_t i8_hess_kmax(const DevProblem &d);
 int i8_hessian(void *ws, const DevProblem &d, const int *dRowcol, const int *dF, const int *dMt, const int *hMt,
-               const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh, double *dH, hipStream_t st,
-               std::string *err);
+               const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh, int64_t kstride, double *dH,
+               hipStream_t st, std::string *err);
 }
 
 extern "C" void gml_problem_destroy(gml_problem *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->st) (void)hipStreamSynchronize(p->st);
-    void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.Xb, p->d.Xtb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dFidx, p->dMt, p->dH};
+    void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.Sb, p->d.keys, p->d.Xb, p->d.Xtb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dFidx, p->dMt, p->dH};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     void *hptrs[] = {p->hTh, p->hG, p->hF, p->hCtl};
@@ -940,11 +950,15 @@ static int ensure_f64(gml_problem *p) {
     size_t freeb = 0, totalb = 0;
     if (!d.Xs) {
         HIPCHK(hipMemGetInfo(&freeb, &totalb));
-        if ((double)d.Kp * d.Qp > 0.9 * (double)freeb)
-            return fail(GML_EUNSUPPORTED, "the FP64 path needs a %.1f GB byte image of the design matrix: use precision i8x",
+        if (2.0 * (double)d.Kp * d.Qp > 0.9 * (double)freeb)
+            return fail(GML_EUNSUPPORTED, "the FP64 path needs two %.1f GB byte images of the design matrix: use precision i8x",
                         (double)d.Kp * d.Qp / 1e9);
+        HIPCHK(hipMalloc(&d.Xt, (size_t)d.Kp * d.Qp));
         HIPCHK(hipMalloc(&d.Xs, (size_t)d.Kp * d.Qp));
+        HIPCHK(hipMemsetAsync(d.Xt, 0, (size_t)d.Kp * d.Qp, p->st));
         HIPCHK(hipMemsetAsync(d.Xs, 0, (size_t)d.Kp * d.Qp, p->st));
+        launch_expand_xt(d, d.Xt, p->st);
+        HIPCHK(hipMemsetAsync(d.Xt + d.cconst * d.Kp, 1, (size_t)p->K, p->st)); // the constant statistic
         launch_transpose_i8(d.Xt, d.cconst + 1, p->K, d.Kp, d.Xs, d.Qp, p->st);
     }
     if (!p->dV) {
@@ -1103,7 +1117,7 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
 // (0 = skip).  The result is ragged: row r's block starts at hoff[r] in Hout and is mp x mp with
 // mp = 32*ceil(m[r]/32) (lower 32x32 tiles filled).
 static int device_newton(gml_problem *p, const RowSet &rs, const std::vector<int> &Fidx, const std::vector<int> &m,
-                         int cap, int form, int precision, int64_t Kh, const std::vector<double> &s1, double s2,
+                         int cap, int form, int precision, int64_t Kh, int64_t kstride, const std::vector<double> &s1, double s2,
                          const std::vector<double> &gF, const std::vector<double> &pgF, std::vector<double> &dout,
                          std::vector<double> &sdiag, gml_stats *stats) {
     std::vector<long long> hoff;
@@ -1143,14 +1157,14 @@ static int device_newton(gml_problem *p, const RowSet &rs, const std::vector<int
     if (precision == GML_PREC_I8X) {
         std::string err;
         int hrc = gml::i8_hessian(p->i8ws, p->d, p->dMt + R, p->dFidx, p->dMt, mt2.data(), p->dHoff, htotal, (int)R, cap, form,
-                                  Kh, p->dH, st, &err);
+                                  Kh, kstride, p->dH, st, &err);
         if (hrc == GML_OK) done = true;
         else if (hrc != GML_EUNSUPPORTED) return fail(hrc, "%s", err.c_str());
     }
     if (!done) {
         if (precision == GML_PREC_I8X)
             return fail(GML_EUNSUPPORTED, "a Newton block above 512 entries (the solver caps max_working at 512)");
-        launch_hess_f64(p->d, p->dV, p->dMt + R, p->dFidx, p->dMt, p->dHoff, (int)R, cap, form, Kh, p->dH, st);
+        launch_hess_f64(p->d, p->dV, p->dMt + R, p->dFidx, p->dMt, p->dHoff, (int)R, cap, form, Kh, kstride, p->dH, st);
     }
     HIPCHK(hipGetLastError());
     // Newton systems solved in place on the device; only the directions come back
@@ -1241,22 +1255,31 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     // (rows x configurations) is kept roughly constant: as nodes converge, the remaining ones get more
     // configurations, up to all of them -- an inexact Hessian only costs iterations, and it costs the
     // most on the few ill-conditioned nodes that are still active at the end.
-    int64_t Kh_max = o.precision == GML_PREC_I8X ? gml::i8_hess_kmax(p->d) : p->d.Kp;
+    // sub-sampled Newton: Hessians over Kh configurations -- every kstride-th block of 512, so that a sorted histogram
+    // is sampled evenly -- rescaled by the weight of the sub-sample.  The budget (rows x configurations) is kept
+    // roughly constant: as nodes converge, the remaining ones get more configurations, up to all of them -- an
+    // inexact Hessian only costs iterations, and it costs the most on the few ill-conditioned nodes that are still
+    // active at the end.
     const int64_t Kh_base = o.hess_samples == 0 ? 32768 : (o.hess_samples < 0 ? p->d.Kp : (int64_t)o.hess_samples);
-    int64_t Kh = p->d.Kp;
+    const int64_t nblk512 = p->d.Kp / 512;
+    int64_t Kh = p->d.Kp, kstride = 1;
     double hscale = 1.0;
     auto set_kh = [&](int64_t nactive) {
         int64_t want = Kh_base;
         if (o.hess_samples == 0 && nactive > 0) want = Kh_base * std::max<int64_t>(1, R / nactive);
-        want = round_up(std::max<int64_t>(want, 1024), 1024);
-        want = std::min(want, Kh_max);
-        if (want < p->K) {
-            Kh = want;
-            hscale = 1.0 / p->wprefix[(size_t)(Kh / 1024)];
-        } else {
-            Kh = std::min(p->d.Kp, Kh_max);
-            hscale = Kh < p->K ? 1.0 / p->wprefix[(size_t)(Kh / 1024)] : 1.0;
+        int64_t nb = std::min(nblk512, std::max<int64_t>(2, (want + 511) / 512));
+        if (nb * 512 >= p->K) nb = nblk512; // (nearly) everything: take it all
+        kstride = nblk512 / nb;
+        Kh = nb * 512;
+        double wsum = 0;
+        for (int64_t cb = 0; cb < nb; ++cb) wsum += p->wblk[(size_t)(cb * kstride)];
+        if (!(wsum > 0)) { // a sub-sample without weight (degenerate histogram): use every configuration
+            nb = nblk512;
+            kstride = 1;
+            Kh = p->d.Kp;
+            wsum = 1.0;
         }
+        hscale = nb == nblk512 ? 1.0 : 1.0 / wsum;
     };
     set_kh(R);
 
@@ -1450,7 +1473,6 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             prec = GML_PREC_F64;
             track_scale = false;
             stall_cap = 10;
-            Kh_max = p->d.Kp;
             std::fill(need.begin(), need.end(), 0);
             for (int64_t r = 0; r < R; ++r) {
                 if (!atfloor[r] || std::min(best[r], kkt[r]) <= o.tol) continue;
@@ -1511,7 +1533,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         });
         stats->t_host += now_s() - th1;
         std::vector<double> Dn, Sd;
-        rc = device_newton(p, rs, Fidx, msz, cap, formulation, prec, Kh, s1v, formulation == GML_LOGRISE ? 1.0 : 0.0,
+        rc = device_newton(p, rs, Fidx, msz, cap, formulation, prec, Kh, kstride, s1v, formulation == GML_LOGRISE ? 1.0 : 0.0,
                            gFm, pgFm, Dn, Sd, stats);
         if (rc) return rc;
         const double th1b = now_s();

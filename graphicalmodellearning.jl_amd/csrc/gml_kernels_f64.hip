@@ -101,29 +101,6 @@ void launch_transpose_i8(const int8_t *src, int64_t rows, int64_t cols, int64_t 
     hipLaunchKernelGGL(k_transpose_i8, grid, dim3(256), 0, st, src, rows, cols, ld_src, dst, ld_dst);
 }
 
-// Xt[c][k] = prod_{i in key_c} St[i][k]   (multi-body statistic, :107; the node's own spin is
-// applied later as the sign s_u).  key = -1 slots are unused; the empty key is the constant 1.
-__global__ __launch_bounds__(256) void k_expand_features(const int8_t *__restrict__ St, int64_t K,
-                                                         int64_t Kp, const int32_t *__restrict__ keys,
-                                                         int order, int64_t Q, int8_t *__restrict__ Xt) {
-    const int64_t c = blockIdx.x; // features on x: there can be more than 65535 of them
-    const int64_t k = (int64_t)blockIdx.y * 256 + threadIdx.x;
-    if (c >= Q || k >= K) return;
-    int v = 1;
-    for (int t = 0; t < order; ++t) {
-        int i = keys[c * order + t];
-        if (i >= 0) v *= (int)St[(int64_t)i * Kp + k];
-    }
-    Xt[c * Kp + k] = (int8_t)v;
-}
-
-void launch_expand_features(const int8_t *St, int64_t n, int64_t K, int64_t Kp, const int32_t *keys,
-                            int order, int64_t Q, int8_t *Xt, hipStream_t st) {
-    (void)n;
-    dim3 grid((unsigned)Q, (unsigned)((K + 255) / 256));
-    hipLaunchKernelGGL(k_expand_features, grid, dim3(256), 0, st, St, K, Kp, keys, order, Q, Xt);
-}
-
 // ------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------
@@ -319,7 +296,7 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
                                                   const int *__restrict__ rowcol,
                                                   const int *__restrict__ F, const int *__restrict__ mt,
                                                   const long long *__restrict__ hoff, int cap, int64_t Kp,
-                                                  int64_t Kh, int64_t kchunk, int nsplit, int form,
+                                                  int64_t Kh, int64_t kchunk, int64_t kstride, int nsplit, int form,
                                                   double *__restrict__ H) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, q = lane >> 4;
@@ -334,7 +311,8 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
     while (ti * (ti + 1) / 2 > pair) --ti;
     const int tj = pair - ti * (ti + 1) / 2;
     const int64_t kb = (int64_t)ks * kchunk;
-    const int64_t ke = (kb + kchunk < Kh) ? kb + kchunk : Kh; // only the first Kh configurations
+    // Kh configurations of a compact index whose block cb of 512 stands for the samples [512 cb kstride, +512)
+    const int64_t ke = (kb + kchunk < Kh) ? kb + kchunk : Kh;
     const int rc = rowcol[r];
     if (rc < 0) return;
 
@@ -354,7 +332,8 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (v4d){0, 0, 0, 0};
 
-    for (int64_t t0 = kb; t0 < ke; t0 += 32) {
+    for (int64_t tc = kb; tc < ke; tc += 32) {
+        const int64_t t0 = (tc >> 9) * kstride * 512 + (tc & 511);
         double h[8], sg[8], a[2][8], b[2][8];
         load8d(vrow + t0, h);
         load8b(srow + t0, sg);
@@ -394,7 +373,7 @@ __global__ __launch_bounds__(256) void k_hess_f64(const double *__restrict__ V,
 
 void launch_hess_f64(const DevProblem &P, const double *V,
                      const int *rowcol, const int *F, const int *mt, const long long *hoff, int R, int cap, int form,
-                     int64_t Kh, double *H, hipStream_t st) {
+                     int64_t Kh, int64_t kstride, double *H, hipStream_t st) {
     const int tiles = cap / 32;
     const int maxpairs = tiles * (tiles + 1) / 2;
     int64_t nsplit = (8192 + (int64_t)R * maxpairs - 1) / ((int64_t)R * maxpairs);
@@ -406,7 +385,7 @@ void launch_hess_f64(const DevProblem &P, const double *V,
     nsplit = (Kh + kchunk - 1) / kchunk;
     dim3 grid((unsigned)((nsplit + 3) / 4), (unsigned)maxpairs, (unsigned)R);
     hipLaunchKernelGGL(k_hess_f64, grid, dim3(256), 0, st, V, P.Xt, P.w, rowcol, F, mt, hoff, cap, P.Kp, Kh, kchunk,
-                       (int)nsplit, form, H);
+                       kstride, (int)nsplit, form, H);
 }
 
 

@@ -27,6 +27,7 @@
 // needs); with bits the loop loads 12 KB instead of 26.6 KB per 64-column step.
 #include "../../include/gml.h"
 #include "gml_dev.h"
+#include "gml_bits.h"
 #include <algorithm>
 #include <string>
 
@@ -47,9 +48,9 @@ struct I8Ws {
     unsigned *mmax = nullptr; // largest |V| / tau seen per row in the last pass (dynamic-range check)
     double *tauovr = nullptr; // per-row tau imposed by the caller (rescaled re-run), 0 = derive from the bound
     // working-set Hessian on the int8 cores
-    int64_t hKh = 0, hbuilt = 0, hcap_elems = 0;
-    int8_t *Mt = nullptr, *Hq = nullptr; // byte masks of Xt (0x00 / 0xFF) and limb planes of the Hessian weights
-    unsigned *Mb = nullptr;              // row-major bit image of Xt (blocked Hessian kernel), built on first use
+    int64_t hKh = 0, hcap_elems = 0;
+    int8_t *Hq = nullptr;   // limb planes of the Hessian weights over the compact (sub-sampled) index
+    unsigned *Mb = nullptr; // row-major twin of Xtb (gathered-row DMA of the Hessian kernel), built on first use
     long long *hS = nullptr, *H64 = nullptr;
 };
 
@@ -223,57 +224,135 @@ __device__ __forceinline__ void ring_wait(bool more) {
 }
 
 // ------------------------------------------------------------------------------------------
-// bit image of the design matrix for the forward GEMM.  One dword per (sample k, 64-column step kt,
-// half h): bit e + 8b  <->  column 64kt + 32(e>>2) + 16h + 4(e&3) + b  (e = 0..7, b = 0..3), set where
-// x = -1, so that dword e of the two MFMA fragments of the step is (v >> e) & 0x01010101.
-// Stored as 1-KB pieces [K/128][nk][128 rows][2 h]: one LDS-DMA instruction moves one piece.
+// Bit images.  The only stored form of the samples is Sb, the spin-major sign bits (gml_bits.h); the two MFMA
+// operand images are derived from it: a statistic of key S is the XOR of the rows of its spins.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack_bits(const int8_t *__restrict__ Xt, int64_t Kp, int nk,
-                                                   unsigned *__restrict__ Xb) {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int kt = blockIdx.y >> 1, h = blockIdx.y & 1;
+// Sb from sample-major bytes S [K][n]: thread <-> (spin i fastest, word w)
+__global__ __launch_bounds__(256) void k_bits_from_rows(const int8_t *__restrict__ S, int64_t K, int64_t n, int64_t wpr,
+                                                        unsigned *__restrict__ Sb) {
+    const int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x, w = blockIdx.x;
+    if (i >= n) return;
     unsigned v = 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int64_t c = 64 * (int64_t)kt + 32 * (e >> 2) + 16 * h + 4 * (e & 3) + b;
-            if (Xt[c * Kp + k] < 0) v |= 1u << (e + 8 * b);
-        }
-    Xb[((((k >> 7) * nk + kt) * 128) + (k & 127)) * 2 + h] = v;
+    for (int j = 0; j < 32; ++j) {
+        const int64_t k = w * 32 + j;
+        if (k < K && S[k * n + i] < 0) v |= 1u << j;
+    }
+    Sb[i * wpr + w] = v;
 }
 
-// The same for the backward GEMM (rows = columns c of the design matrix, depth = samples): dword
-// (c, kt, h): bit e + 8b <-> operand position 32(e>>2) + 16h + 4(e&3) + b of step kt, which holds sample
-// 64kt + vq_sample(position) -- the sample order of the Vq images (gml_dev.h); pieces [Qc/128][Kp/64][128][2 h],
-// Qc = Qfp rounded up to 256 (columns beyond Qfp: zero bits).
-__global__ __launch_bounds__(256) void k_pack_bits_t(const int8_t *__restrict__ Xt, int64_t Kp, int64_t Qfp, int64_t nkk,
-                                                     unsigned *__restrict__ Xtb) {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; // (kt, h)
-    const int64_t c = blockIdx.y;
-    if (j >= 2 * nkk) return;
-    const int64_t kt = j >> 1;
-    const int h = (int)(j & 1);
+// Sb from spin-major bytes St [n][ld]: thread <-> (word w fastest, spin i)
+__global__ __launch_bounds__(256) void k_bits_from_cols(const int8_t *__restrict__ St, int64_t K, int64_t ld, int64_t wpr,
+                                                        unsigned *__restrict__ Sb) {
+    const int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x, i = blockIdx.x;
+    if (w * 32 >= K) return;
+    const int8_t *row = St + i * ld + w * 32;
     unsigned v = 0;
-    if (c < Qfp) {
-        const int8_t *row = Xt + c * Kp + 64 * kt;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) // operand position 32(e>>2) + 16h + 4(e&3) + b holds sample vq_sample(position)
-                if (row[vq_sample(32 * (e >> 2) + 16 * h + 4 * (e & 3) + b)] < 0) v |= 1u << (e + 8 * b);
+    for (int j = 0; j < 32; ++j)
+        if (w * 32 + j < K && row[j] < 0) v |= 1u << j;
+    Sb[i * wpr + w] = v;
+}
+
+void launch_spin_bits(const int8_t *S, bool spin_major, int64_t K, int64_t n, int64_t ld, int64_t Kp, unsigned *Sb, hipStream_t st) {
+    const int64_t wpr = Kp / 32, nw = (K + 31) / 32;
+    if (spin_major)
+        hipLaunchKernelGGL(k_bits_from_cols, dim3((unsigned)n, (unsigned)((nw + 255) / 256)), dim3(256), 0, st, S, K, ld, wpr, Sb);
+    else
+        hipLaunchKernelGGL(k_bits_from_rows, dim3((unsigned)nw, (unsigned)((n + 255) / 256)), dim3(256), 0, st, S, K, n, wpr, Sb);
+}
+
+// natural-order word w of statistic column c: XOR of the rows of its spins (keys [Qf][ko], -1 = unused slot)
+__device__ __forceinline__ unsigned stat_word(const unsigned *__restrict__ Sb, int64_t wpr, const int32_t *__restrict__ keys, int ko,
+                                              int64_t Qf, int64_t c, int64_t w) {
+    if (c >= Qf) return 0u; // zero padding columns
+    unsigned v = 0;
+    for (int t = 0; t < ko; ++t) {
+        const int i = keys[c * ko + t];
+        if (i >= 0) v ^= Sb[(int64_t)i * wpr + w];
     }
-    Xtb[((((c >> 7) * nkk + kt) * 128) + (c & 127)) * 2 + h] = v;
+    return v;
+}
+
+// Forward operand Xb (sample-major): one thread builds the 32 dwords (k = 32w .. 32w+31, kt, h) from the 32 words
+// of the columns that dword covers (bit j <-> column 64kt + xb_col(j, h)) by a 32 x 32 bit transpose.
+// Pieces [K/128][nk][128 samples][2 h] dwords, one LDS-DMA instruction moves one 1-KB piece.
+__global__ __launch_bounds__(256) void k_build_xb(const unsigned *__restrict__ Sb, int64_t wpr, const int32_t *__restrict__ keys,
+                                                  int ko, int64_t Qf, int nk, unsigned *__restrict__ Xb) {
+    const int64_t w = (int64_t)blockIdx.x * 128 + (threadIdx.x >> 1);
+    const int h = threadIdx.x & 1, kt = blockIdx.y;
+    if (w >= wpr) return;
+    unsigned a[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) a[j] = stat_word(Sb, wpr, keys, ko, Qf, 64 * (int64_t)kt + xb_col(j, h), w);
+    transpose32(a);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int64_t k = w * 32 + s;
+        Xb[((((k >> 7) * nk + kt) * 128) + (k & 127)) * 2 + h] = a[s];
+    }
+}
+
+// Backward operand Xtb (feature-major): dword (c, kt, h) = xtb_from_natural(word 2kt + h of column c);
+// pieces [Qc/128][Kp/64][128 columns][2 h], Qc = Qfp rounded up to 256 (columns beyond Qf: zero bits).
+__global__ __launch_bounds__(256) void k_build_xtb(const unsigned *__restrict__ Sb, int64_t wpr, const int32_t *__restrict__ keys,
+                                                   int ko, int64_t Qf, int64_t nkk, unsigned *__restrict__ Xtb) {
+    const int64_t j = (int64_t)blockIdx.y * 256 + threadIdx.x; // (kt, h) = natural word index
+    const int64_t c = blockIdx.x;                              // columns on x: there can be more than 65535 of them
+    if (j >= 2 * nkk) return;
+    const unsigned v = xtb_from_natural(stat_word(Sb, wpr, keys, ko, Qf, c, j));
+    Xtb[((((c >> 7) * nkk + (j >> 1)) * 128) + (c & 127)) * 2 + (j & 1)] = v;
 }
 
 int64_t xtb_bytes(const DevProblem &d) { return (d.Qfp + 255) / 256 * 256 * (d.Kp / 8); }
 
 void launch_pack_bits(const DevProblem &d, hipStream_t st) {
     const int nk = (int)(d.Qfp / 64);
-    hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)(d.Kp / 256), (unsigned)(2 * nk)), dim3(256), 0, st, d.Xt, d.Kp, nk, d.Xb);
+    const int64_t wpr = d.Kp / 32;
+    hipLaunchKernelGGL(k_build_xb, dim3((unsigned)((wpr + 127) / 128), (unsigned)nk), dim3(256), 0, st, d.Sb, wpr, d.keys, d.ko, d.Qf, nk,
+                       d.Xb);
     const int64_t nkk = d.Kp / 64, Qc = (d.Qfp + 255) / 256 * 256;
-    hipLaunchKernelGGL(k_pack_bits_t, dim3((unsigned)((2 * nkk + 255) / 256), (unsigned)Qc), dim3(256), 0, st, d.Xt, d.Kp, d.Qfp, nkk,
-                       d.Xtb);
+    hipLaunchKernelGGL(k_build_xtb, dim3((unsigned)Qc, (unsigned)((2 * nkk + 255) / 256)), dim3(256), 0, st, d.Sb, wpr, d.keys, d.ko,
+                       d.Qf, nkk, d.Xtb);
+}
+
+// byte forms, on demand: the configurations back as +-1 bytes [kk][n] (gml_problem_get_spins), and the feature-major
+// byte image Xt [Qp][Kp] of the FP64 path (padding samples and columns zero; the constant column is set by the caller)
+__global__ __launch_bounds__(256) void k_unpack_spins(const unsigned *__restrict__ Sb, int64_t wpr, int64_t n, int64_t k0, int64_t kk,
+                                                      int8_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x, kl = blockIdx.x, k = k0 + kl;
+    if (i >= n || kl >= kk) return;
+    out[kl * n + i] = ((Sb[i * wpr + (k >> 5)] >> (k & 31)) & 1u) ? (int8_t)-1 : (int8_t)1;
+}
+
+void launch_unpack_spins(const DevProblem &d, int64_t k0, int64_t kk, int8_t *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_unpack_spins, dim3((unsigned)kk, (unsigned)((d.n + 255) / 256)), dim3(256), 0, st, d.Sb, d.Kp / 32, d.n, k0, kk, out);
+}
+
+__global__ __launch_bounds__(256) void k_expand_xt(const unsigned *__restrict__ Sb, int64_t wpr, const int32_t *__restrict__ keys, int ko,
+                                                   int64_t Qf, int64_t K, int64_t Kp, int8_t *__restrict__ Xt) {
+    const int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x, c = blockIdx.x;
+    if (w >= wpr) return;
+    const unsigned v = stat_word(Sb, wpr, keys, ko, Qf, c, w);
+    unsigned out[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        unsigned o = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t k = w * 32 + 4 * q + b;
+            const unsigned byte = k < K ? (((v >> (4 * q + b)) & 1u) ? 0xFFu : 0x01u) : 0u;
+            o |= byte << (8 * b);
+        }
+        out[q] = o;
+    }
+    v4i *dst = reinterpret_cast<v4i *>(Xt + c * Kp + w * 32);
+    dst[0] = (v4i){(int)out[0], (int)out[1], (int)out[2], (int)out[3]};
+    dst[1] = (v4i){(int)out[4], (int)out[5], (int)out[6], (int)out[7]};
+}
+
+void launch_expand_xt(const DevProblem &d, int8_t *Xt, hipStream_t st) {
+    if (d.Qf > 0)
+        hipLaunchKernelGGL(k_expand_xt, dim3((unsigned)d.Qf, (unsigned)((d.Kp / 32 + 255) / 256)), dim3(256), 0, st, d.Sb, d.Kp / 32, d.keys,
+                           d.ko, d.Qf, d.K, d.Kp, Xt);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -297,7 +376,7 @@ __device__ __forceinline__ void ring_wait_ahead(int ahead) {
 template <int LF, int FORM /* 0: exp forms (RISE, logRISE), 2: RPLE */, bool WANTF,
           bool WIDE /* more than 32768 statistics columns: |acc_l| <= 128 Qfp no longer leaves room for the int32 pairing */>
 __global__ __launch_bounds__(256, 2) void k_fwd_i8(
-    const unsigned *__restrict__ Xb, const int8_t *__restrict__ Xt, const int8_t *__restrict__ Tq,
+    const unsigned *__restrict__ Xb, const unsigned *__restrict__ Sb, const int8_t *__restrict__ Tq,
     const int *__restrict__ rowcol, const int *__restrict__ groups, int ngroups, const double *__restrict__ w,
     const double *__restrict__ sigma, const long long *__restrict__ qconst, const double *__restrict__ invtau,
     int64_t Kp, int ntiles_k, int nk /* 64-column steps */, double wuni /* > 0: every real sample has this weight */,
@@ -373,12 +452,15 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const int r = mytile * 32 + lr;
     const int rc = rowcol[r];
     const bool active = rc >= 0;
-    unsigned swp[WM][4];
+    // the node's sign bits for this wave's 64 samples (word i <-> MFMA tile i), shifted so that bit 8g + j is this
+    // lane's sample 8g + 4h + j of the tile
+    unsigned sgn[WM];
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            swp[i][g] = active ? *reinterpret_cast<const unsigned *>(Xt + (int64_t)rc * Kp + k0 + wave * 64 + i * 32 + 8 * g + 4 * h) : 0u;
+    for (int i = 0; i < WM; ++i) sgn[i] = active ? (Sb[(int64_t)rc * (Kp >> 5) + ((k0 + wave * 64) >> 5) + i] >> (4 * h)) : 0u;
+    // samples at or beyond Kreal are padding (they carry no weight): this lane's element (i, g, j) sits 32 i + 8 g + j
+    // samples after its first one, k0 + 64 wave + 4 h
+    const int64_t left = Kreal - (k0 + wave * 64 + 4 * h);
+    const int nreal = left > 64 ? 64 : (left < 0 ? 0 : (int)left);
     const double sg = active ? sigma[r] : 0.0;
     const double q0 = active ? (double)qconst[r] : 0.0;
     const double it = active ? invtau[r] : 0.0;
@@ -433,7 +515,6 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int64_t kk = kw + i * 32 + 8 * g + 4 * h;
-            const unsigned sw = swp[i][g];
             unsigned dj[4];
             if (FORM == 2) { // RPLE: gate each 4-sample group on the previous one (its longer arithmetic otherwise
                              // interleaves across groups and spills); pure arithmetic floats across sched_barriers
@@ -465,8 +546,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                 }
                 const double Ea = fma(a, sg2, sgq0);                // |E| pre-sign: sigma * (q0 + S - 2 A)
                 const double dith = (double)(int)(dh0 + (unsigned)(i * 32 + 8 * g + j) * 0x9E3779B9u) * 2.3283064365386963e-10; // [-1/2, 1/2)
-                const unsigned sbyte = sw >> (8 * j);               // s_u^k: 0x01, 0xFF, or 0 for a padding sample
-                const bool neg = (sbyte & 0x80u) != 0;
+                const bool neg = ((sgn[i] >> (8 * g + j)) & 1u) != 0; // s_u^k = -1
                 int vq;
                 if (FORM == 2) { // RPLE (:317): f = w log(1 + exp(-2E)), V = -2 w s / (1 + exp(2E)), E = s * Ea
                     const double wk0 = wuni > 0.0 ? (kk + j < Kreal ? wuni : 0.0) : w[kk + j];
@@ -493,10 +573,14 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     fp += wk0 * ((E2 < 0.0 ? -E2 : 0.0) + l1p);
                 } else { // RISE (:196,:204) / logRISE Z (:279): V = -w exp(-E) s
                     // x = -s E: flip the sign of Ea unless s = -1
-                    const double x = __hiloint2double(__double2hiint(Ea) ^ (int)(((sbyte & 0x80u) ^ 0x80u) << 24), __double2loint(Ea));
+                    const double x = __hiloint2double(__double2hiint(Ea) ^ (int)((~sgn[i] << (31 - (8 * g + j))) & 0x80000000u), __double2loint(Ea));
                     int mag;
-                    if (wuni > 0.0) mag = mag_exp(x, wkit, dith, etab) & -(int)(sbyte & 1u); // padding samples carry no weight
-                    else mag = mag_exp(x, w[kk + j] * it, dith, etab);
+                    if (wuni > 0.0) {
+                        mag = mag_exp(x, wkit, dith, etab);
+                        if (i * 32 + 8 * g + j >= nreal) mag = 0; // padding samples carry no weight
+                    } else {
+                        mag = mag_exp(x, w[kk + j] * it, dith, etab);
+                    }
                     vq = neg ? mag : -mag;
                     mx = mag > mx ? mag : mx;
                     if (WANTF) as += mag;
@@ -692,41 +776,44 @@ __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__
 // ------------------------------------------------------------------------------------------
 // Working-set Hessian on the int8 matrix cores.
 //   H_r[i][j] = sum_k h_rk x_ki x_kj,  x = +-1 = 1 - 2b  (b = 1 where x = -1)
-//             = S - 2 T_ii - 2 T_jj + 4 T_ij,   T_ij = sum_k h_rk b_ki b_kj,  S = sum_k h_rk.
-// With the masks m = -b (bytes 0x00 / 0xFF) the products become (h_l & m_i) * m_j = -h_l b_i b_j
-// for each base-256 digit plane h_l of the (non-negative, 31-bit) weight: exact integer GEMMs.
+//             = S - 2 T_ii - 2 T_jj + 4 T_ij,   T_ij = sum_k h_rk b_ki b_kj,  S = sum_k h_rk,
+// computed per base-256 digit plane h_l of the (non-negative, 31-bit) weight as (mask_i & h_l) * b_j with the byte
+// masks 0x00 / 0xFF expanded from bits in LDS: exact integer GEMMs.
+//
+// Sub-sampled Newton: the sum runs over `Kh` configurations taken as every `kstride`-th block of 512 (block cb of
+// the compact index <-> samples [512 cb kstride, +512)): spread over the whole histogram, whose rows are usually
+// sorted, instead of its first rows.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_make_masks(const int8_t *__restrict__ Xt, int64_t Kp, int64_t k0, int64_t k1,
-                                                    int64_t pitch, int8_t *__restrict__ Mt) {
-    const int64_t k = k0 + (int64_t)blockIdx.y * 256 + threadIdx.x, c = blockIdx.x;
-    if (k < k1) Mt[c * pitch + k] = Xt[c * Kp + k] < 0 ? (int8_t)-1 : (int8_t)0;
-}
-
-// Hessian weights of the active rows as limb planes: RISE / logRISE h = |V|; RPLE h = 2a(1 - a/(2w)), a = |V|
-__global__ __launch_bounds__(256) void k_make_hw(const int8_t *__restrict__ Vq, const int8_t *__restrict__ Xt,
+// Hessian weights of the active rows as limb planes over the compact index, in the sample order of the bit images
+// (vq_pos within each 64): RISE / logRISE h = |V|; RPLE h = 2a(1 - a/(2w)), a = |V|
+__global__ __launch_bounds__(256) void k_make_hw(const int8_t *__restrict__ Vq, const unsigned *__restrict__ Sb,
                                                  const double *__restrict__ w, const double *__restrict__ tau,
                                                  const int *__restrict__ rowcol, const int *__restrict__ mt, int64_t Kp,
-                                                 int64_t Kh /* pitch of Hq */, int form, int8_t *__restrict__ Hq,
+                                                 int64_t Hpitch, int64_t kstride, int form, int8_t *__restrict__ Hq,
                                                  long long *__restrict__ hS) {
     const int r = blockIdx.y;
     if (mt[r] == 0) return;
     const int u = rowcol[r];
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;        // compact index
+    const int64_t k = (j >> 9) * kstride * 512 + (j & 511);          // the configuration it stands for
     const int tile = r >> 5, rl = r & 31;
-    const int8_t *vq = Vq + vq_off(r, 0, k, Kp);
-    const int q = (int)vq[0] + 256 * ((int)vq[32 * 64] + 256 * ((int)vq[64 * 64] + 256 * (int)vq[96 * 64]));
-    const int s = (int)Xt[(int64_t)u * Kp + k];
-    int mag = -q * s; // >= 0
-    if (form == 2) {
-        const double t = tau[r], a = (double)mag * t, wk = w[k];
-        mag = wk > 0 ? (int)rint(2.0 * a * (1.0 - a / (2.0 * wk)) / t) : 0;
+    int mag = 0;
+    if (k < Kp) {
+        const int8_t *vq = Vq + vq_off(r, 0, k, Kp);
+        const int q = (int)vq[0] + 256 * ((int)vq[32 * 64] + 256 * ((int)vq[64 * 64] + 256 * (int)vq[96 * 64]));
+        const int sgn = (Sb[(int64_t)u * (Kp >> 5) + (k >> 5)] >> (k & 31)) & 1u; // s_u^k = 1 - 2 sgn
+        mag = sgn ? q : -q;                                           // V = -w exp(-E) s: |V| = -q s >= 0
+        if (form == 2) {
+            const double t = tau[r], a = (double)mag * t, wk = w[k];
+            mag = wk > 0 ? (int)rint(2.0 * a * (1.0 - a / (2.0 * wk)) / t) : 0;
+        }
     }
     const unsigned dg = ((unsigned)mag + 0x80808080u) ^ 0x80808080u;
-    int8_t *hq = Hq + ((int64_t)tile * 128 + rl) * Kh + k;
+    int8_t *hq = Hq + ((int64_t)tile * 128 + rl) * Hpitch + (j & ~(int64_t)63) + vq_pos((int)(j & 63));
     hq[0] = (int8_t)(dg & 0xff);
-    hq[32 * Kh] = (int8_t)((dg >> 8) & 0xff);
-    hq[64 * Kh] = (int8_t)((dg >> 16) & 0xff);
-    hq[96 * Kh] = (int8_t)((dg >> 24) & 0xff);
+    hq[32 * Hpitch] = (int8_t)((dg >> 8) & 0xff);
+    hq[64 * Hpitch] = (int8_t)((dg >> 16) & 0xff);
+    hq[96 * Hpitch] = (int8_t)((dg >> 24) & 0xff);
     // S = sum of the weights
     long long sm = mag;
     for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
@@ -736,147 +823,42 @@ __global__ __launch_bounds__(256) void k_make_hw(const int8_t *__restrict__ Vq, 
     if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&hS[r]), (unsigned long long)(red[0] + red[1] + red[2] + red[3]));
 }
 
-// One workgroup per (row, k-chunk); wave l handles digit plane l for ALL lower-triangular 32x32 tile
-// pairs of the row's working set (MT tiles per side).  LDS double buffer, register staged.
-template <int MT>
-__global__ __launch_bounds__(256) void k_hess_i8(const int8_t *__restrict__ Mt, const int8_t *__restrict__ Hq,
-                                                 const int *__restrict__ F, const int *__restrict__ mt,
-                                                 const long long *__restrict__ hoff, int cap, int64_t Kh, int64_t Kpitch,
-                                                 int64_t kchunk, long long *__restrict__ H64) {
-    constexpr int ROWS = MT * 32 + 4; // mask rows + the four weight planes
-    constexpr int NCH = (ROWS * 4 + 255) / 256;
-    constexpr int NPAIR = MT * (MT + 1) / 2;
-    __shared__ __attribute__((aligned(16))) int8_t lds[2][(MT * 32 + 16) * 64];
-    const int r = blockIdx.y;
-    const int m = mt[r];
-    if (m != MT) return; // one launch per working-set size class
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, h = lane >> 5;
-    const int64_t kb = (int64_t)blockIdx.x * kchunk;
-    if (kb >= Kh) return;
-    const int64_t ke = (kb + kchunk < Kh) ? kb + kchunk : Kh;
-    const int tile = r >> 5, rl = r & 31;
-    const int *Fr = F + (int64_t)r * cap;
-
-    const int8_t *src[NCH];
-    int dst[NCH];
-    bool have[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const int q = tid + 256 * j, row = q >> 2, slot = q & 3;
-        have[j] = row < ROWS;
-        if (row < MT * 32) src[j] = Mt + (int64_t)Fr[row < m * 32 ? row : 0] * Kpitch + slot * 16;
-        else src[j] = Hq + ((int64_t)tile * 128 + (row - MT * 32 < 4 ? row - MT * 32 : 0) * 32 + rl) * Kpitch + slot * 16;
-        dst[j] = lds_off(row, slot);
-    }
-    v16i acc[NPAIR];
-#pragma unroll
-    for (int p = 0; p < NPAIR; ++p)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[p][e] = 0;
-
-    v4i rg[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-        if (have[j]) rg[j] = *reinterpret_cast<const v4i *>(src[j] + kb);
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-        if (have[j]) *reinterpret_cast<v4i *>(&lds[0][dst[j]]) = rg[j];
-    __syncthreads();
-    int it = 0;
-    for (int64_t kk = kb; kk < ke; kk += 64, ++it) {
-        const int cur = it & 1;
-        const bool more = kk + 64 < ke;
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < NCH; ++j)
-                if (have[j]) rg[j] = *reinterpret_cast<const v4i *>(src[j] + kk + 64);
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int slot = 2 * t + h;
-            const v4i mg = *reinterpret_cast<const v4i *>(&lds[cur][lds_off(MT * 32 + wave, slot)]);
-            v4i mi[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) mi[i] = *reinterpret_cast<const v4i *>(&lds[cur][lds_off(i * 32 + lr, slot)]);
-            int p = 0;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const v4i a = mi[i] & mg;
-#pragma unroll
-                for (int j = 0; j <= i; ++j, ++p) acc[p] = MFMA_I8(a, mi[j], acc[p]);
-            }
-        }
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < NCH; ++j)
-                if (have[j]) *reinterpret_cast<v4i *>(&lds[cur ^ 1][dst[j]]) = rg[j];
-        }
-        __syncthreads();
-    }
-    // acc = -sum_k h_l b_i b_j : accumulate 256^l * acc into the int64 tile (integer atomics: deterministic)
-    long long *Hr = H64 + hoff[r];
-    constexpr int hp = 32 * MT;
-    int p = 0;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j, ++p) {
-            if (i < m) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int ii = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, jj = j * 32 + lr;
-                    const long long v = -((long long)acc[p][e]) * (1ll << (8 * wave));
-                    if (v != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&Hr[(int64_t)ii * hp + jj]), (unsigned long long)v);
-                }
-            }
-        }
+// Row-major twin of Xtb for the gathered-row DMA of the Hessian kernel: Mb [Qp][Kp/64][2 h] dwords, same dword format
+// and sample order as Xtb (rows at and beyond Qfp -- the constant column and the padding -- hold zero bits: x = +1).
+__global__ __launch_bounds__(256) void k_build_mb(const unsigned *__restrict__ Xtb, int64_t nkk, unsigned *__restrict__ Mb) {
+    const int64_t kt = (int64_t)blockIdx.y * 256 + threadIdx.x, c = blockIdx.x;
+    if (kt >= nkk) return;
+    const uint2 v = *reinterpret_cast<const uint2 *>(Xtb + ((((c >> 7) * nkk + kt) * 128) + (c & 127)) * 2);
+    *reinterpret_cast<uint2 *>(Mb + (c * nkk + kt) * 2) = v;
 }
 
-
-
-// H[i][j] = tau * (S - 2 T_ii - 2 T_jj + 4 T_ij) on the lower-triangular tiles
-// ------------------------------------------------------------------------------------------
-// Blocked working-set Hessian on the ROW-MAJOR bit image Mb ([Qp][Kp/64][2 h] dwords, same dword
-// format as Xtb): with byte masks (the form the single-block kernels above still use) it was L2 -> LDS bound (12.5 KB per 64-sample step
-// for a 64 x 128 block, 0.8 POP/s); as bits the same rows are 1.75 KB and the kernel runs twice as fast.  Per group of 8 steps (512 samples) the
-// workgroup DMAs 64 + 128 gathered rows x 64 B of bits and 4 x 512 B of weight limbs into a 3-stage ring.
-// Per step the four waves first expand the operands cooperatively into LDS, in MFMA fragment layout --
-// wave w expands B tile w (0/1 bytes, both K-halves) and A-mask fragment (i = w >> 1, t = w & 1)
-// (0x00/0xFF bytes) -- then every wave runs the 2 x 4 tile block for ITS weight limb l = wave:
+// Blocked kernel: a workgroup computes the tile block (rows 2a, 2a+1) x (columns BT b .. BT b + BT - 1) of one row's
+// working-set matrix (needed iff BT b <= 2a + 1: lower triangle) over one chunk of the compact index.  Per group of 8
+// steps (512 samples) it DMAs the 64 + 32 BT gathered rows x 64 B of bits and 4 x 512 B of weight limbs into a
+// 3-stage ring.  Per step the four waves first expand the operands cooperatively into LDS, in MFMA fragment layout --
+// wave w expands B tile w (0/1 bytes, both K-halves; w < BT) and A-mask fragment (i = w >> 1, t = w & 1) (0x00/0xFF
+// bytes) -- then every wave runs the 2 x BT tile block for ITS weight limb l = wave:
 //   acc[i][j] += (mask_i & h_l) * b_j  =  sum_k h_lk b_ik b_jk        (one barrier per step)
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack_bits_rows(const int8_t *__restrict__ Xt, int64_t Kp, int64_t nkk,
-                                                        unsigned *__restrict__ Mb) {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; // (kt, h)
-    const int64_t c = blockIdx.y;
-    if (j >= 2 * nkk) return;
-    const int8_t *row = Xt + c * Kp + 64 * (j >> 1) + 16 * (j & 1);
-    unsigned v = 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-            if (row[32 * (e >> 2) + 4 * (e & 3) + b] < 0) v |= 1u << (e + 8 * b);
-    Mb[c * 2 * nkk + j] = v;
-}
-
+// BT = 2 serves working sets of up to 4 tiles (128 entries), BT = 4 the larger ones (fewer, fatter blocks).
+template <int BT>
 __global__ __launch_bounds__(256, 2) void k_hess_bits_blk(const unsigned *__restrict__ Mb, const int8_t *__restrict__ Hq,
                                                           const int *__restrict__ F, const int *__restrict__ mt,
                                                           const long long *__restrict__ hoff, int cap, int64_t Kh,
                                                           int64_t Kp, int64_t Hpitch, int64_t kchunk /* multiple of 512 */,
-                                                          long long *__restrict__ H64) {
-    constexpr int AR = 64, BR = 128;
-    constexpr int STAGE = (AR + BR) * 64 + 4 * 512, NPIECE = STAGE / 1024, NSG = 3; // 14 pieces
-    constexpr int EBUF = (4 + 8) * 1024;                                              // expanded operands of one step
+                                                          int64_t kstride, long long *__restrict__ H64) {
+    constexpr int AR = 64, BR = 32 * BT, RP = (AR + BR) / 16; // row pieces
+    constexpr int STAGE = (AR + BR) * 64 + 4 * 512, NPIECE = STAGE / 1024, NSG = 3;
+    constexpr int NPJ = (NPIECE + 3) / 4;                     // pieces of the waves that carry one more
+    constexpr int EBUF = (4 + 2 * BT) * 1024;                 // expanded operands of one step
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     int8_t *eb = lds + NSG * STAGE;
     const int r = blockIdx.z;
     const int m = mt[r];
-    if (m <= 4) return; // handled by the single-block kernels
-    // decode the block index: a = tile-row pair, b = group of 4 tile columns, needed iff 4b <= 2a+1
+    if (m == 0 || (m <= 4) != (BT == 2)) return; // one launch per size class
+    // decode the block index: a = tile-row pair, b = group of BT tile columns, needed iff BT b <= 2a+1
     int a = 0, b = blockIdx.y;
     for (;;) {
-        const int nb = (2 * a + 1) / 4 + 1;
+        const int nb = (2 * a + 1) / BT + 1;
         if (b < nb) break;
         b -= nb;
         ++a;
@@ -884,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void k_hess_bits_blk(const unsigned *__rest
     }
     if (2 * a >= m) return;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 31, h = lane >> 5;
-    const int64_t kb = (int64_t)blockIdx.x * kchunk;
+    const int64_t kb = (int64_t)blockIdx.x * kchunk; // compact index
     if (kb >= Kh) return;
     const int64_t ke = (kb + kchunk < Kh) ? kb + kchunk : Kh;
     const int ngrp = (int)((ke - kb + 511) / 512);
@@ -893,23 +875,23 @@ __global__ __launch_bounds__(256, 2) void k_hess_bits_blk(const unsigned *__rest
     const int mrows = m * 32;
     const int64_t nkk = Kp >> 6;
 
-    // DMA sources of this wave's pieces (wave, wave + 4, wave + 8, and wave + 12 for waves 0, 1); per group: + 64 B
-    // (bits: 8 steps x 8 B) resp. + 512 B (limb bytes)
-    const bool four = wave < NPIECE - 12;
-    const int8_t *src[4];
-    int adv[4];
+    // DMA sources of this wave's pieces (wave + 4 j); per group: + 64 kstride B (bits: 8 steps x 8 B of every
+    // kstride-th block) resp. + 512 B (limb bytes, compact)
+    const bool extra = wave < NPIECE - 4 * (NPJ - 1);
+    const int8_t *src[NPJ];
+    int64_t adv[NPJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NPJ; ++j) {
         const int pc = wave + 4 * j;
-        if (pc < 12) {
-            const int row = pc * 16 + (lane >> 2); // 0..191: A rows then B rows
-            int fr = row < AR ? 2 * a * 32 + row : 4 * b * 32 + (row - AR);
+        if (pc < RP) {
+            const int row = pc * 16 + (lane >> 2); // A rows then B rows
+            int fr = row < AR ? 2 * a * 32 + row : BT * b * 32 + (row - AR);
             if (fr >= mrows) fr = 0;
             const int slot = (lane & 3) ^ ((row >> 2) & 3); // swizzle on the source (LDS side is linear)
-            src[j] = reinterpret_cast<const int8_t *>(Mb) + ((int64_t)Fr[fr] * nkk + (kb >> 6)) * 8 + slot * 16;
-            adv[j] = 64;
+            src[j] = reinterpret_cast<const int8_t *>(Mb) + ((int64_t)Fr[fr] * nkk + (kb >> 9) * kstride * 8) * 8 + slot * 16;
+            adv[j] = 64 * kstride;
         } else {
-            const int l = 2 * (pc < NPIECE ? pc - 12 : 0) + (lane >> 5);
+            const int l = 2 * (pc < NPIECE ? pc - RP : 0) + (lane >> 5);
             src[j] = Hq + ((int64_t)tile * 128 + l * 32 + rl) * Hpitch + kb + (lane & 31) * 16;
             adv[j] = 512;
         }
@@ -917,29 +899,29 @@ __global__ __launch_bounds__(256, 2) void k_hess_bits_blk(const unsigned *__rest
     auto issue = [&](int g) {
         int8_t *sb = lds + (g % NSG) * STAGE;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < NPJ - 1; ++j)
             __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (int64_t)g * adv[j]), (lptr_t)(sb + (wave + 4 * j) * 1024), 16, 0, 0);
-        if (four)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[3] + (int64_t)g * adv[3]), (lptr_t)(sb + (wave + 12) * 1024), 16, 0, 0);
+        if (extra)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[NPJ - 1] + (int64_t)g * adv[NPJ - 1]), (lptr_t)(sb + (wave + 4 * (NPJ - 1)) * 1024), 16, 0, 0);
     };
-    v16i acc[2][4];
+    v16i acc[2][BT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 4; ++jn)
+        for (int jn = 0; jn < BT; ++jn)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0;
 
     // LDS offsets (stage-relative) of the dwords this lane expands: its row of B tile `wave` and of A tile wave >> 1
-    const int rowB = AR + wave * 32 + lr, rowA = (wave >> 1) * 32 + lr;
+    const int rowB = AR + (wave < BT ? wave : 0) * 32 + lr, rowA = (wave >> 1) * 32 + lr;
     const int swB = (rowB >> 2) & 3, swA = (rowA >> 2) & 3;
     issue(0);
     if (ngrp > 1) issue(1);
     for (int g = 0; g < ngrp; ++g) {
         // this wave's pieces of stage g have landed (stage g + 1 may still be in flight), then every wave's
         if (g + 1 < ngrp) {
-            if (four) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPJ) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPJ - 1) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -947,37 +929,42 @@ __global__ __launch_bounds__(256, 2) void k_hess_bits_blk(const unsigned *__rest
         __builtin_amdgcn_sched_barrier(0);
         if (g + 2 < ngrp) issue(g + 2);
         const int8_t *st = lds + (g % NSG) * STAGE;
-        const int nsteps = (int)((ke - kb - (int64_t)g * 512 + 63) / 64) < 8 ? (int)((ke - kb - (int64_t)g * 512 + 63) / 64) : 8;
+        const int left = (int)((ke - kb - (int64_t)g * 512 + 63) / 64);
+        const int nsteps = left < 8 ? left : 8;
         for (int ks = 0; ks < nsteps; ++ks) {
             int8_t *e = eb + ((g * 8 + ks) & 1) * EBUF;
             // cooperative expansion of step ks: logical 16-byte slot ks >> 1 of the row, dword (ks & 1) * 2 + h
             {
-                const unsigned vB = *reinterpret_cast<const unsigned *>(st + rowB * 64 + ((((ks >> 1) ^ swB)) << 4) + (((ks & 1) * 2 + h) << 2));
                 const unsigned vA = *reinterpret_cast<const unsigned *>(st + rowA * 64 + ((((ks >> 1) ^ swA)) << 4) + (((ks & 1) * 2 + h) << 2));
-                v4i f0, f1, fm;
+                v4i fm;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    f0[d] = (int)((vB >> d) & 0x01010101u);
-                    f1[d] = (int)((vB >> (4 + d)) & 0x01010101u);
-                    fm[d] = (int)(((vA >> (4 * (wave & 1) + d)) & 0x01010101u) * 0xFFu);
-                }
-                *reinterpret_cast<v4i *>(e + 4096 + (wave * 2 + 0) * 1024 + lane * 16) = f0;
-                *reinterpret_cast<v4i *>(e + 4096 + (wave * 2 + 1) * 1024 + lane * 16) = f1;
+                for (int d = 0; d < 4; ++d) fm[d] = (int)(((vA >> (4 * (wave & 1) + d)) & 0x01010101u) * 0xFFu);
                 *reinterpret_cast<v4i *>(e + wave * 1024 + lane * 16) = fm; // fragment (i = wave >> 1, t = wave & 1)
+                if (wave < BT) {
+                    const unsigned vB = *reinterpret_cast<const unsigned *>(st + rowB * 64 + ((((ks >> 1) ^ swB)) << 4) + (((ks & 1) * 2 + h) << 2));
+                    v4i f0, f1;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        f0[d] = (int)((vB >> d) & 0x01010101u);
+                        f1[d] = (int)((vB >> (4 + d)) & 0x01010101u);
+                    }
+                    *reinterpret_cast<v4i *>(e + 4096 + (wave * 2 + 0) * 1024 + lane * 16) = f0;
+                    *reinterpret_cast<v4i *>(e + 4096 + (wave * 2 + 1) * 1024 + lane * 16) = f1;
+                }
             }
             __syncthreads();
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const v4i mg = *reinterpret_cast<const v4i *>(st + (AR + BR) * 64 + wave * 512 + ks * 64 + (2 * t + h) * 16);
-                v4i fa[2], fb[4];
+                v4i fa[2], fb[BT];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const v4i *>(e + (i * 2 + t) * 1024 + lane * 16) & mg;
 #pragma unroll
-                for (int jn = 0; jn < 4; ++jn) fb[jn] = *reinterpret_cast<const v4i *>(e + 4096 + (jn * 2 + t) * 1024 + lane * 16);
+                for (int jn = 0; jn < BT; ++jn) fb[jn] = *reinterpret_cast<const v4i *>(e + 4096 + (jn * 2 + t) * 1024 + lane * 16);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int jn = 0; jn < 4; ++jn) acc[i][jn] = MFMA_I8(fa[i], fb[jn], acc[i][jn]);
+                    for (int jn = 0; jn < BT; ++jn) acc[i][jn] = MFMA_I8(fa[i], fb[jn], acc[i][jn]);
             }
         }
     }
@@ -986,8 +973,8 @@ __global__ __launch_bounds__(256, 2) void k_hess_bits_blk(const unsigned *__rest
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 4; ++jn) {
-            const int ti = 2 * a + i, tj = 4 * b + jn;
+        for (int jn = 0; jn < BT; ++jn) {
+            const int ti = 2 * a + i, tj = BT * b + jn;
             if (ti < m && tj <= ti) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -1037,7 +1024,7 @@ void i8_free(void *p) {
     I8Ws *w = static_cast<I8Ws *>(p);
     if (!w) return;
     void *ptrs[] = {w->Tq, w->Vq, w->Gacc, w->sigma, w->tau, w->invtau, w->qconst, w->csum, w->asum, w->mmax, w->tauovr,
-                    w->Mt, w->Hq, w->hS, w->H64, w->Mb};
+                    w->Hq, w->hS, w->H64, w->Mb};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete w;
@@ -1069,47 +1056,61 @@ static int i8_ensure(void **wsp, const DevProblem &d, int Rp, int LF, std::strin
 }
 
 
-// Largest number of configurations the int8 Hessian can use (pitch of its mask / weight planes): all of
-// them unless the masks would exceed ~16 GB.
-int64_t i8_hess_kmax(const DevProblem &d) {
-    int64_t k = (int64_t)(16e9 / (double)d.Qp) / 1024 * 1024;
-    if (k < 131072) k = 131072;
-    return k < d.Kp ? k : d.Kp;
+// Largest number of configurations one int8 Hessian call can use (pitch of its weight planes): all of them.
+int64_t i8_hess_kmax(const DevProblem &d) { return d.Kp; }
+
+template <int BT>
+static void launch_hess_blk(const I8Ws *w, const DevProblem &d, const int *dF, const int *dMt, const long long *dHoff, int R, int cap,
+                            int maxm, int64_t Kh, int64_t kstride, hipStream_t st) {
+    // blocks (a, b) with BT b <= 2a + 1 for a < ceil(maxm / 2)
+    int nblk = 0;
+    for (int a = 0; 2 * a < maxm; ++a) nblk += (2 * a + 1) / BT + 1;
+    // k-split so that the grid fills the chip (~4096 workgroups), in chunks of whole 512-sample groups
+    const int maxsplit = (int)(Kh / 1024) > 0 ? (int)(Kh / 1024) : 1;
+    int ns = (int)((4096 + (int64_t)R * nblk - 1) / ((int64_t)R * nblk));
+    if (ns > maxsplit) ns = maxsplit;
+    if (ns < 1) ns = 1;
+    int64_t kc = (Kh + ns - 1) / ns;
+    kc = (kc + 511) / 512 * 512;
+    ns = (int)((Kh + kc - 1) / kc);
+    constexpr int shmem = 3 * ((64 + 32 * BT) * 64 + 4 * 512) + 2 * (4 + 2 * BT) * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hess_bits_blk<BT>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+    hipLaunchKernelGGL(k_hess_bits_blk<BT>, dim3((unsigned)ns, (unsigned)nblk, (unsigned)R), dim3(256), shmem, st, w->Mb, w->Hq, dF, dMt,
+                       dHoff, cap, Kh, d.Kp, w->hKh, kc, kstride, w->H64);
 }
 
-// Working-set Hessians from the int8 limb planes of the last pass.  Returns GML_EUNSUPPORTED when a
-// working set exceeds 128 entries (the caller then uses the FP64 kernel).
+// Working-set Hessians from the int8 limb planes of the last pass over Kh configurations (a multiple of 512; block cb
+// of the compact index = samples [512 cb kstride, +512)).  Returns GML_EUNSUPPORTED when a working set exceeds 512
+// entries (the solver caps its Newton blocks there).
 int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF, const int *dMt, const int *hMt,
-               const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh, double *dH, hipStream_t st,
-               std::string *err) {
+               const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh, int64_t kstride, double *dH,
+               hipStream_t st, std::string *err) {
     I8Ws *w = static_cast<I8Ws *>(wsp);
     if (!w) {
         if (err) *err = "no int8 pass has run on this handle";
         return GML_EINVAL;
     }
-    int maxm = 0;
-    for (int r = 0; r < R; ++r) maxm = hMt[r] > maxm ? hMt[r] : maxm;
-    if (maxm > 16) return GML_EUNSUPPORTED; // > 512 entries: not expected (the caller caps the Newton block)
-    // masks and weight planes are allocated once with the pitch i8_hess_kmax(d); mask columns are built on
-    // demand when a call asks for more configurations than any earlier one
-    const int64_t pitch = i8_hess_kmax(d);
+    int maxm = 0, maxsmall = 0;
+    for (int r = 0; r < R; ++r) {
+        maxm = hMt[r] > maxm ? hMt[r] : maxm;
+        if (hMt[r] <= 4) maxsmall = hMt[r] > maxsmall ? hMt[r] : maxsmall;
+    }
+    if (maxm > 16) return GML_EUNSUPPORTED;
+    const int64_t pitch = d.Kp;
     if (Kh > pitch) Kh = pitch;
     if (w->hKh != pitch) {
-        if (w->Mt) (void)hipFree(w->Mt);
         if (w->Hq) (void)hipFree(w->Hq);
         if (w->hS) (void)hipFree(w->hS);
-        w->Mt = w->Hq = nullptr;
+        w->Hq = nullptr;
         w->hS = nullptr;
-        w->hbuilt = 0;
-        I8CHK(hipMalloc(&w->Mt, (size_t)d.Qp * pitch));
         I8CHK(hipMalloc(&w->Hq, (size_t)w->rows * LB * pitch));
         I8CHK(hipMalloc(&w->hS, sizeof(long long) * w->rows));
         w->hKh = pitch;
     }
-    if (Kh > w->hbuilt) {
-        hipLaunchKernelGGL(k_make_masks, dim3((unsigned)d.Qp, (unsigned)((Kh - w->hbuilt + 255) / 256)), dim3(256), 0, st, d.Xt, d.Kp,
-                           w->hbuilt, Kh, pitch, w->Mt);
-        w->hbuilt = Kh;
+    if (!w->Mb) {
+        I8CHK(hipMalloc(&w->Mb, (size_t)d.Qp * (d.Kp / 8)));
+        I8CHK(hipMemsetAsync(w->Mb, 0, (size_t)d.Qp * (d.Kp / 8), st));
+        hipLaunchKernelGGL(k_build_mb, dim3((unsigned)d.Qfp, (unsigned)((d.Kp / 64 + 255) / 256)), dim3(256), 0, st, d.Xtb, d.Kp / 64, w->Mb);
     }
     const int64_t need = htotal;
     if (need > w->hcap_elems) {
@@ -1120,46 +1121,10 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF
     }
     I8CHK(hipMemsetAsync(w->H64, 0, sizeof(long long) * need, st));
     I8CHK(hipMemsetAsync(w->hS, 0, sizeof(long long) * w->rows, st));
-    hipLaunchKernelGGL(k_make_hw, dim3((unsigned)(Kh / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Xt, d.w, w->tau, dRowcol,
-                       dMt, d.Kp, pitch, form, w->Hq, w->hS);
-    // k-split so that the grid fills the chip: ~2048 workgroups
-    int nsplit = (int)((2048 + R - 1) / R);
-    const int maxsplit = (int)(Kh / 1024);
-    if (nsplit > maxsplit) nsplit = maxsplit;
-    if (nsplit < 1) nsplit = 1;
-    int64_t kchunk = (Kh + nsplit - 1) / nsplit;
-    kchunk = (kchunk + 63) / 64 * 64;
-    nsplit = (int)((Kh + kchunk - 1) / kchunk);
-    const dim3 grid((unsigned)nsplit, (unsigned)R);
-    // one launch per working-set size class (rows of other classes exit immediately)
-    bool cls[6] = {false, false, false, false, false, false};
-    for (int r = 0; r < R; ++r) cls[hMt[r] <= 4 ? hMt[r] : 5] = true;
-    if (cls[1]) hipLaunchKernelGGL((k_hess_i8<1>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, pitch, kchunk, w->H64);
-    if (cls[2]) hipLaunchKernelGGL((k_hess_i8<2>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, pitch, kchunk, w->H64);
-    if (cls[3]) hipLaunchKernelGGL((k_hess_i8<3>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, pitch, kchunk, w->H64);
-    if (cls[4]) hipLaunchKernelGGL((k_hess_i8<4>), grid, dim3(256), 0, st, w->Mt, w->Hq, dF, dMt, dHoff, cap, Kh, pitch, kchunk, w->H64);
-    if (cls[5]) {
-        // blocks (a, b) with 4b <= 2a+1 for a < ceil(maxm/2)
-        int nblk = 0;
-        for (int a = 0; 2 * a < maxm; ++a) nblk += (2 * a + 1) / 4 + 1;
-        int ns2 = (int)((4096 + (int64_t)R * nblk - 1) / ((int64_t)R * nblk));
-        if (ns2 > maxsplit) ns2 = maxsplit;
-        if (ns2 < 1) ns2 = 1;
-        int64_t kc2 = (Kh + ns2 - 1) / ns2;
-        kc2 = (kc2 + 63) / 64 * 64;
-        ns2 = (int)((Kh + kc2 - 1) / kc2);
-        if (!w->Mb) {
-            I8CHK(hipMalloc(&w->Mb, (size_t)d.Qp * (d.Kp / 8)));
-            hipLaunchKernelGGL(k_pack_bits_rows, dim3((unsigned)((2 * (d.Kp / 64) + 255) / 256), (unsigned)d.Qp), dim3(256), 0, st,
-                               d.Xt, d.Kp, d.Kp / 64, w->Mb);
-        }
-        kc2 = (kc2 + 511) / 512 * 512;
-        ns2 = (int)((Kh + kc2 - 1) / kc2);
-        constexpr int shmem = 3 * ((64 + 128) * 64 + 4 * 512) + 2 * 12 * 1024;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hess_bits_blk), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-        hipLaunchKernelGGL(k_hess_bits_blk, dim3((unsigned)ns2, (unsigned)nblk, (unsigned)R), dim3(256), shmem, st, w->Mb, w->Hq, dF,
-                           dMt, dHoff, cap, Kh, d.Kp, pitch, kc2, w->H64);
-    }
+    hipLaunchKernelGGL(k_make_hw, dim3((unsigned)(Kh / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Sb, d.w, w->tau, dRowcol, dMt, d.Kp,
+                       pitch, kstride, form, w->Hq, w->hS);
+    if (maxsmall > 0) launch_hess_blk<2>(w, d, dF, dMt, dHoff, R, cap, maxsmall, Kh, kstride, st);
+    if (maxm > 4) launch_hess_blk<4>(w, d, dF, dMt, dHoff, R, cap, maxm, Kh, kstride, st);
     hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64,
                        w->hS, w->tau, dMt, dHoff, dH);
     I8CHK(hipGetLastError());
@@ -1199,7 +1164,7 @@ static void launch_fwd3(const I8Ws *w, const DevProblem &d, const int *dRowcol, 
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
     const int ntk = (int)(d.Kp / 256);
     const int grid = ((ntk + 7) / 8) * 8 * ((ngroups + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE>), dim3(grid), dim3(256), shmem, st, d.Xb, d.Xt, w->Tq, dRowcol, dGroups,
+    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE>), dim3(grid), dim3(256), shmem, st, d.Xb, d.Sb, w->Tq, dRowcol, dGroups,
                        ngroups, d.w, w->sigma, w->qconst, w->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, w->Vq, w->csum,
                        w->asum, dF, w->mmax);
 }

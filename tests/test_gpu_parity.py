@@ -507,3 +507,44 @@ def test_wide_multibody_dense_constant_theta_no_int32_overflow():
     fo, go = O.objgrad_multi3_nodes(None, spins, nodes, theta)
     assert np.abs(f64 / fo - 1).max() <= 1e-11 and (np.abs(g64 - go) / fo[:, None]).max() <= 1e-11
     assert np.abs(f8 / fo - 1).max() <= 1e-7 and (np.abs(g8 - go) / fo[:, None]).max() <= 1e-7
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_interaction_order_one_fields_only(prec):
+    # multiRISE(c, sym, 1): the only key of node u is (u,) (:94-104 with interaction_order = 1), unpenalised (:118):
+    # min_theta sum_k w_k exp(-theta s_u^k)  =>  theta = 1/2 log(p(s_u = +1) / p(s_u = -1))
+    s = load_csv("c_samples.csv")
+    counts, spins = O.split_histogram(s)
+    n = spins.shape[1]
+    w = counts / counts.sum()
+    closed = np.array([0.5 * np.log(w[spins[:, u] > 0].sum() / w[spins[:, u] < 0].sum()) for u in range(n)])
+    fg = gml.learn(s, gml.multiRISE(0.4, True, 1), gml.HIP(tol=1e-11, precision=prec))
+    assert sorted(fg.keys()) == [(u + 1,) for u in range(n)]
+    assert max(abs(fg[(u + 1,)] - closed[u]) for u in range(n)) <= 1e-9
+    rec, _ = O.learn_multi(s, c=0.4, symmetrize=True, order=1)
+    assert max(abs(fg[k] - v) for k, v in rec.items()) <= 1e-9
+    with gml.Problem(s, order=1) as p:  # the operator at order 1: one parameter per node, any node id
+        assert p.P == 1 and p.multi_keys(2) == [(2,)]
+        th = np.array([[0.3], [-0.2], [0.0], [1.5]])
+        f, g = p.objgrad("RISE", np.arange(n), th, precision=prec)
+        assert np.array_equal(p.spins(), spins)
+    for u in range(n):
+        e = w * np.exp(-th[u, 0] * spins[:, u])
+        assert f[u] == pytest.approx(e.sum(), rel=1e-7) and g[u, 0] == pytest.approx(-(e * spins[:, u]).sum(), abs=1e-7)
+
+
+def test_sorted_histogram_above_the_hessian_subsample():
+    # a histogram as sample() returns it: unique configurations in SORTED order, with counts.  With more than 32768
+    # rows the Newton Hessians are sub-sampled; a prefix of the sorted rows would share constant leading spins
+    # (singular, biased curvature) -- the sub-sample is strided over the whole histogram instead.
+    n, N = 20, 300000
+    rng = np.random.default_rng(21)
+    J = np.triu(rng.uniform(0.1, 0.3, (n, n)) * rng.choice([-1.0, 1.0], (n, n)) * (rng.random((n, n)) < 0.25), 1)
+    J = J + J.T + np.diag(rng.uniform(-0.05, 0.05, n))
+    hist = synthetic.enumerate_sample(J, N, seed=3)
+    assert len(hist) > 40000 and (np.diff(hist[:, -1]) >= 0).all()  # sorted: the leading rows all have s_n = -1
+    for prec in PRECS:
+        with gml.Problem(hist) as p:
+            out, kkt, st = p.learn("RISE", 0.4, tol=1e-9, precision=prec)
+        assert st["not_converged"] == 0 and st["iterations"] <= 25
+        assert np.abs(0.5 * (out + out.T) - J).max() <= 0.02
