@@ -248,7 +248,7 @@ def main():
             sync()
             tg = time.perf_counter()
             buf = torch.from_numpy(out).to(cdev)
-            allb = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=cdev)
+            allb = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=cdev)
             dist.all_gather_into_tensor(allb, buf)
             torch.cuda.synchronize()
             extra["gather_s"] = time.perf_counter() - tg
@@ -267,7 +267,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import oracle as O
-        cores = os.cpu_count() or 1
+        hc = O.host_cpus()
+        cores = hc["threads"]
         try:
             cpu_model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
         except Exception:
@@ -289,9 +290,10 @@ def main():
         f_gpu, g_gpu = prob.objgrad("RISE", nodes, J[nodes], precision=args.precision)
         assert np.array_equal(g_gpu, g_res[nodes]) and np.array_equal(f_gpu, f_res[nodes]), "timed passes != operator output"
         cpu = {"value": nn / t_cpu, "unit": "node-evals/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
+               "cpus_visible": hc["visible"], "cgroup_cpu_quota": hc["quota"],
                "sample": f"{nn} node evaluations (nodes spread over 0..{n - 1}) at full K={K}, n={n}; oracle/gml_oracle_fast.c "
-                         f"gml_oracle_objgrad_nodes: FP64, 32-node blocks share one sweep over the spins, OpenMP over all "
-                         f"{cores} host threads",
+                         f"gml_oracle_objgrad_nodes: FP64, 32-node blocks share one sweep over the spins, OpenMP with {cores} threads "
+                         f"(the container's cgroup quota is {hc['quota']:g} CPUs of {hc['visible']} visible; thread count = 2 x quota)",
                "seconds": t_cpu, "gflops": 4.0 * K * n * nn / t_cpu / 1e9,
                "parity_max_abs_grad_diff": float(np.abs(g_gpu - g_cpu).max()),
                "parity_max_rel_f_diff": float(np.abs(f_gpu / f_cpu - 1).max())}

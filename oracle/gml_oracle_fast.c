@@ -36,6 +36,16 @@
 
 double gml_oracle_lambda(double c, int64_t n, double M);
 
+/* number of OpenMP threads of the calls below (0 = the runtime's default); the caller sizes it to the CPU time the
+ * process may actually use (a container's cgroup quota can be far below the visible core count) */
+void gml_oracle_set_threads(int t) {
+#ifdef _OPENMP
+    if (t > 0) omp_set_num_threads(t);
+#else
+    (void)t;
+#endif
+}
+
 static int nthreads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

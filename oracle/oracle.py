@@ -52,8 +52,32 @@ def lib():
         L.gml_oracle_objgrad_multi3_nodes.argtypes = [i64, i64, p, p, p, i64, p, p, p]
         L.gml_oracle_learn_pair_fast.restype = dbl
         L.gml_oracle_learn_pair_fast.argtypes = [C.c_int, i64, i64, p, p, i64, i64, dbl, dbl, C.c_int, p, p, p]
+        L.gml_oracle_set_threads.restype = None
+        L.gml_oracle_set_threads.argtypes = [C.c_int]
+        L.gml_oracle_set_threads(host_cpus()["threads"])
         _LIB = L
     return _LIB
+
+
+def host_cpus():
+    """CPU resources this process may use: visible logical CPUs, the cgroup CPU quota (a container is often limited to
+    far fewer CPUs' worth of time than it sees: 16 of 256 on the GPU box), and the OpenMP thread count the oracle
+    uses -- twice the quota (measured best on the GPU box: SMT siblings share the quota), capped by the visible CPUs."""
+    visible = os.cpu_count() or 1
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    quota = float(visible)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = min(quota, float(q) / float(per))
+    except Exception:
+        pass
+    env = os.environ.get("GML_ORACLE_THREADS")
+    threads = int(env) if env else int(min(visible, max(1, round(2 * quota)) if quota < visible else visible))
+    return {"visible": visible, "quota": quota, "threads": threads}
 
 
 def _ptr(a):
