@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string>
 #include "gml_bits.h"
 
 namespace gml {
@@ -54,6 +55,37 @@ int64_t xtb_bytes(const DevProblem &d);
 __host__ __device__ inline int64_t vq_off(int64_t r, int l, int64_t k, int64_t Kp) {
     return ((((r >> 5) * (Kp >> 6) + (k >> 6)) * 4 + l) * 32 + (r & 31)) * 64 + vq_pos((int)(k & 63));
 }
+
+// ---- int8-limb path --------------------------------------------------------------------------
+// One pass of the fixed-point operator (gml_kernels_i8.hip).  The rows to evaluate are listed in consecutive SLOTS
+// (32 slots = one MFMA node tile; slot0, slot1 multiples of 32), so the tiles that run are full whatever subset of the
+// caller's rows is active; all per-slot arrays (and the limb planes of V the Hessians are built from) live in the
+// workspace, indexed by slot.
+struct I8Pass {
+    const double *theta;  // device, [rows][Qp]: the parameter rows (internal column layout, masked slots zero)
+    const int *srow;      // device [slots]: slot -> row of theta / G (unused slots: anything)
+    const int *rowcol;    // device [slots]: slot -> node u (whose sign row is the node's spin), -1 = unused slot
+    const int *groups;    // device: the slot tiles to run (slot / 32), padded with -1 to a multiple of 4
+    int ngroups;          // tiles listed (without the padding)
+    int slot0, slot1;     // slot range the listed tiles lie in: its accumulators are zeroed, its rows quantised and finalised
+    int form;             // GML_RISE / GML_LOGRISE (Z) / GML_RPLE
+    bool want_grad;       // false: objective only (no backward GEMM)
+    double *F;            // device [slots]: f per slot (RISE f, logRISE Z, RPLE f)
+    double *G;            // device, [rows][Qp]: gradient rows (row srow[slot]); may be NULL when !want_grad
+    const double *tauovr; // device [slots] or NULL: per-slot scale of V imposed by the caller (0 = from the bound)
+    int hv;               // 1: Hessian-vector product -- theta rows are directions p, G receives sum_k h_k (x_k.p) x_k with the
+                          //    curvature weights h_k of the objective pass that last ran in slot vmap[slot]
+    const int *vmap;      // hv: device [slots]
+    int lf;               // forward limb planes (3, 4, 5; 0 = the default, 5): 8 lf - 2 significant bits of theta
+};
+int i8_pass(void **ws, const DevProblem &d, int64_t slot_capacity, const I8Pass &a, hipStream_t st, hipEvent_t *ev /* [3] or NULL */,
+            std::string *err);
+void i8_free(void *ws);
+// per-slot results of the last pass of the given kind (device pointers)
+void i8_slot_results(void *ws, int hv, const double **tau, const unsigned **mmax);
+int i8_hessian(void *ws, const DevProblem &d, const int *dRowcol, const int *dVslot, const int *dF, const int *dMt, const int *hMt,
+               const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh, int64_t kstride, double *dH,
+               hipStream_t st, std::string *err);
 
 // ---- FP64 path -----------------------------------------------------------------------------
 // Theta [Rp][Qp] (internal column layout, masked slots zero), rowcol[r] = u (row of Xt

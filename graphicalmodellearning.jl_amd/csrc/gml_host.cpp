@@ -5,8 +5,7 @@
 // replaces the reference's per-node Ipopt solve (:164-181), and the orchestration of the
 // device passes.  All arithmetic over the K configurations happens in HIP kernels
 // (gml_kernels_f64.hip, gml_kernels_i8.hip); there is no CPU fallback for it.
-#include "../../include/gml.h"
-#include "gml_dev.h"
+#include "gml_internal.h"
 
 #include <algorithm>
 #include <atomic>
@@ -17,11 +16,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
-#include <functional>
 #include <mutex>
-#include <string>
 #include <thread>
-#include <vector>
 
 using namespace gml;
 
@@ -29,7 +25,7 @@ using namespace gml;
 // errors
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
-static int fail(int code, const char *fmt, ...) {
+int gml_fail(int code, const char *fmt, ...) {
     char buf[1024];
     va_list ap;
     va_start(ap, fmt);
@@ -38,19 +34,13 @@ static int fail(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
-#define HIPCHK(expr)                                                                             \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return fail(e_ == hipErrorOutOfMemory ? GML_ENOMEM : GML_EHIP, "%s failed: %s (%s:%d)", \
-                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                       \
-    } while (0)
 
 extern "C" const char *gml_last_error(void) { return g_err.c_str(); }
 
-static double now_s() {
+double gml_now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+static double now_s() { return gml_now_s(); }
 
 // persistent worker pool for the host-side per-node loops (thread creation per call would cost
 // more than most of these loops)
@@ -136,38 +126,10 @@ Pool &pool() {
 }
 } // namespace
 
-static void parallel_for(int64_t n, const std::function<void(int64_t)> &fn) { pool().run(n, fn); }
+void gml_parallel_for(int64_t n, const std::function<void(int64_t)> &fn) { pool().run(n, fn); }
+static void parallel_for(int64_t n, const std::function<void(int64_t)> &fn) { gml_parallel_for(n, fn); }
 
-static int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
-
-// ------------------------------------------------------------------------------------------
-// problem handle
-// ------------------------------------------------------------------------------------------
-struct gml_problem {
-    int device = 0;
-    hipStream_t st = nullptr;
-    int64_t n = 0, K = 0, P = 0, node0 = 0, node1 = 0;
-    int order = 2;
-    double M = 0;
-    DevProblem d{};
-    std::vector<int32_t> gkeys; // [Q][ko] subsets of spins (feature keys), -1 padded
-    int ko = 1;
-    std::vector<int64_t> qoff; // qoff[q] = first column of the size-q subsets
-    std::vector<double> wblk;    // wblk[j] = sum of w over the configurations [512 j, 512 j + 512)
-    // workspace (sized for ws_rows rows)
-    int64_t ws_rows = 0;
-    double *dTheta = nullptr, *dV = nullptr, *dG = nullptr, *dF = nullptr;
-    int *hCtl = nullptr; // pinned twin of dRowcol | dGroups
-    int *dRowcol = nullptr, *dGroups = nullptr;
-    double *hTh = nullptr, *hG = nullptr, *hF = nullptr; // pinned staging (ws_rows x Qp, ws_rows)
-    // hessian workspace
-    int64_t hs_rows = 0, hs_cap = 0, hs_elems = 0;
-    int *dFidx = nullptr, *dMt = nullptr;
-    long long *dHoff = nullptr;
-    double *dH = nullptr, *dVec = nullptr;
-    // i8 path workspace lives in gml_i8 (allocated lazily)
-    void *i8ws = nullptr;
-};
+static int64_t round_up(int64_t a, int64_t b) { return gml_round_up(a, b); }
 
 static int64_t binom(int64_t n, int64_t k) {
     if (k < 0 || k > n) return 0;
@@ -843,28 +805,16 @@ extern "C" int gml_problem_get_spins(gml_problem *p, int8_t *spins) {
     return rc;
 }
 
-namespace gml {
-void i8_free(void *ws);
-void i8_get_v(void *ws, const int8_t **Vq, const double **tau);
-const unsigned *i8_get_mmax(void *ws);
-int64_t i8_hess_kmax(const DevProblem &d);
-int i8_hessian(void *ws, const DevProblem &d, const int *dRowcol, const int *dF, const int *dMt, const int *hMt,
-               const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh, int64_t kstride, double *dH,
-               hipStream_t st, std::string *err);
-}
-
 extern "C" void gml_problem_destroy(gml_problem *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->st) (void)hipStreamSynchronize(p->st);
-    void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.Sb, p->d.keys, p->d.Xb, p->d.Xtb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dRowcol, p->dFidx, p->dMt, p->dH};
+    void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.Sb, p->d.keys, p->d.Xb, p->d.Xtb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dSrow};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     void *hptrs[] = {p->hTh, p->hG, p->hF, p->hCtl};
     for (void *q : hptrs)
         if (q) (void)hipHostFree(q);
-    if (p->dHoff) (void)hipFree(p->dHoff);
-    if (p->dVec) (void)hipFree(p->dVec);
     if (p->i8ws) gml::i8_free(p->i8ws);
     if (p->st) (void)hipStreamDestroy(p->st);
     delete p;
@@ -900,19 +850,12 @@ extern "C" int gml_multi_keys(const gml_problem *p, int64_t u, int32_t *keys) {
 }
 
 // ------------------------------------------------------------------------------------------
-// device pass orchestration
+// device pass orchestration for the host-pointer operator calls (gml_objgrad_batch, gml_bench_pass*)
 // ------------------------------------------------------------------------------------------
-namespace gml {
-// implemented in gml_kernels_i8.hip: the exact int8-limb pass (same contract as the f64 one)
-int i8_pass(void **ws, const DevProblem &d, const double *dTheta, const int *dRowcol, const int *dGroups, int ngroups,
-            int Rp, int form, bool want_grad, double *dF, double *dG,
-            hipStream_t st, hipEvent_t *ev /* [3] or NULL */, const double *hTauOvr, std::string *err);
-}
-
-static int ensure_ws(gml_problem *p, int64_t rows) {
+int gml_ensure_ws(gml_problem *p, int64_t rows) {
     const int64_t Rp = round_up(rows, 32);
     if (Rp <= p->ws_rows) return GML_OK;
-    void *ptrs[] = {p->dTheta, p->dV, p->dG, p->dF, p->dRowcol};
+    void *ptrs[] = {p->dTheta, p->dV, p->dG, p->dF, p->dSrow};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     void *hptrs[] = {p->hTh, p->hG, p->hF, p->hCtl};
@@ -921,7 +864,7 @@ static int ensure_ws(gml_problem *p, int64_t rows) {
     p->hTh = p->hG = p->hF = nullptr;
     p->hCtl = nullptr;
     p->dTheta = p->dV = p->dG = p->dF = nullptr;
-    p->dRowcol = p->dGroups = nullptr;
+    p->dSrow = p->dRowcol = p->dGroups = nullptr;
     p->ws_rows = 0;
     size_t freeb = 0, totalb = 0;
     HIPCHK(hipMemGetInfo(&freeb, &totalb));
@@ -932,10 +875,12 @@ static int ensure_ws(gml_problem *p, int64_t rows) {
     HIPCHK(hipMalloc(&p->dTheta, sizeof(double) * Rp * p->d.Qp));
     HIPCHK(hipMalloc(&p->dG, sizeof(double) * Rp * p->d.Qp));
     HIPCHK(hipMalloc(&p->dF, sizeof(double) * Rp));
-    // control block: rowcol [Rp] | active tiles, padded with -1 [Rp/32 + 4]; one pinned twin, one upload per pass
-    HIPCHK(hipMalloc(&p->dRowcol, sizeof(int) * (Rp + Rp / 32 + 4)));
+    // control block: srow [Rp] | rowcol [Rp] | active tiles, padded with -1 [Rp/32 + 4]; one pinned twin, one upload per pass
+    const int64_t nctl = 2 * Rp + Rp / 32 + 4;
+    HIPCHK(hipMalloc(&p->dSrow, sizeof(int) * nctl));
+    p->dRowcol = p->dSrow + Rp;
     p->dGroups = p->dRowcol + Rp;
-    HIPCHK(hipHostMalloc(&p->hCtl, sizeof(int) * (Rp + Rp / 32 + 4)));
+    HIPCHK(hipHostMalloc(&p->hCtl, sizeof(int) * nctl));
     HIPCHK(hipHostMalloc(&p->hTh, sizeof(double) * Rp * p->d.Qp));
     HIPCHK(hipHostMalloc(&p->hG, sizeof(double) * Rp * p->d.Qp));
     HIPCHK(hipHostMalloc(&p->hF, sizeof(double) * Rp));
@@ -943,9 +888,10 @@ static int ensure_ws(gml_problem *p, int64_t rows) {
     p->ws_rows = Rp;
     return GML_OK;
 }
+static int ensure_ws(gml_problem *p, int64_t rows) { return gml_ensure_ws(p, rows); }
 
-// What only the FP64 path needs: the sample-major byte image Xs and V [ws_rows][Kp].
-static int ensure_f64(gml_problem *p) {
+// What only the FP64 path needs: the two byte images of the design matrix and V [vrows][Kp].
+int gml_ensure_f64(gml_problem *p, int64_t vrows) {
     DevProblem &d = p->d;
     size_t freeb = 0, totalb = 0;
     if (!d.Xs) {
@@ -961,12 +907,17 @@ static int ensure_f64(gml_problem *p) {
         HIPCHK(hipMemsetAsync(d.Xt + d.cconst * d.Kp, 1, (size_t)p->K, p->st)); // the constant statistic
         launch_transpose_i8(d.Xt, d.cconst + 1, p->K, d.Kp, d.Xs, d.Qp, p->st);
     }
-    if (!p->dV) {
+    vrows = round_up(vrows, 32);
+    if (!p->dV || p->dVrows < vrows) {
+        if (p->dV) (void)hipFree(p->dV);
+        p->dV = nullptr;
+        p->dVrows = 0;
         HIPCHK(hipMemGetInfo(&freeb, &totalb));
-        if ((double)p->ws_rows * d.Kp * 8.0 > 0.9 * (double)freeb)
-            return fail(GML_ENOMEM, "FP64 workspace of %.1f GB does not fit: use precision i8x", (double)p->ws_rows * d.Kp * 8.0 / 1e9);
-        HIPCHK(hipMalloc(&p->dV, sizeof(double) * p->ws_rows * d.Kp));
-        HIPCHK(hipMemsetAsync(p->dV, 0, sizeof(double) * p->ws_rows * d.Kp, p->st));
+        if ((double)vrows * d.Kp * 8.0 > 0.9 * (double)freeb)
+            return fail(GML_ENOMEM, "FP64 workspace of %.1f GB does not fit: use precision i8x", (double)vrows * d.Kp * 8.0 / 1e9);
+        HIPCHK(hipMalloc(&p->dV, sizeof(double) * vrows * d.Kp));
+        HIPCHK(hipMemsetAsync(p->dV, 0, sizeof(double) * vrows * d.Kp, p->st));
+        p->dVrows = vrows;
     }
     return GML_OK;
 }
@@ -981,10 +932,8 @@ struct RowSet {
 static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8_t> &act, const double *theta,
                        int form, int precision, bool want_grad, double *f, double *g, gml_stats *stats,
                        float *ms /* [2]: fwd, bwd or NULL */ = nullptr,
-                       double *fnoise /* R: absolute uncertainty of f[r] (before any log) or NULL */ = nullptr,
-                       const std::vector<double> *tau_ovr = nullptr /* Rp per-row tau (0 = from the bound): the solver's
-                       tracked scale, or the rescaled re-run below */,
-                       int depth = 0, double *vmax_out = nullptr /* R: rigorous bound on max_k |V_rk| of the evaluated rows */) {
+                       const std::vector<double> *tau_ovr = nullptr /* Rp per-row tau of the rescaled re-run below */,
+                       int depth = 0) {
     const int64_t R = rs.R, Qp = p->d.Qp;
     const int64_t Rp = round_up(R, 32);
     int rc = ensure_ws(p, R);
@@ -993,7 +942,7 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
     int64_t nact = 0;
     for (int64_t r = 0; r < R; ++r)
         if (act[r]) {
-            rowcol[r] = (int)rs.node[r]; // row of Xt holding s_u
+            rowcol[r] = (int)rs.node[r]; // the node whose sign bits the row uses
             ++nact;
         }
     if (nact == 0) return GML_OK;
@@ -1011,28 +960,47 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
         std::memcpy(p->hTh + r0 * Qp, theta + r0 * Qp, sizeof(double) * (r1 - r0) * Qp);
     });
     HIPCHK(hipMemcpyAsync(p->dTheta + ra * Qp, p->hTh + ra * Qp, sizeof(double) * (rb - ra) * Qp, hipMemcpyHostToDevice, st));
-    // control block (row -> node, active tiles) through its pinned twin: one asynchronous upload
+    // control block (slot = row here: identity map, row -> node, active tiles) through its pinned twin: one upload
     std::vector<int> gpad = groups;
     while (gpad.size() % 4) gpad.push_back(-1);
-    std::memcpy(p->hCtl, rowcol.data(), sizeof(int) * Rp);
-    std::memcpy(p->hCtl + p->ws_rows, gpad.data(), sizeof(int) * gpad.size());
-    HIPCHK(hipMemcpyAsync(p->dRowcol, p->hCtl, sizeof(int) * (p->ws_rows + gpad.size()), hipMemcpyHostToDevice, st));
-    if (precision != GML_PREC_I8X) { // the int8 pass zeroes its own accumulators (one kernel)
-        HIPCHK(hipMemsetAsync(p->dF, 0, sizeof(double) * Rp, st));
-        if (want_grad) HIPCHK(hipMemsetAsync(p->dG, 0, sizeof(double) * Rp * Qp, st));
-    }
+    const int64_t W = p->ws_rows;
+    for (int64_t r = 0; r < Rp; ++r) p->hCtl[r] = (int)r;
+    std::memcpy(p->hCtl + W, rowcol.data(), sizeof(int) * Rp);
+    std::memcpy(p->hCtl + 2 * W, gpad.data(), sizeof(int) * gpad.size());
+    HIPCHK(hipMemcpyAsync(p->dSrow, p->hCtl, sizeof(int) * (2 * W + gpad.size()), hipMemcpyHostToDevice, st));
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     if (ms)
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    double *dOvr = nullptr;
     if (precision == GML_PREC_I8X) {
+        if (tau_ovr) {
+            HIPCHK(hipMalloc(&dOvr, sizeof(double) * Rp));
+            HIPCHK(hipMemcpyAsync(dOvr, tau_ovr->data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
+        }
         std::string err;
-        rc = gml::i8_pass(&p->i8ws, p->d, p->dTheta, p->dRowcol, p->dGroups, (int)groups.size(),
-                          (int)Rp, form, want_grad, p->dF, p->dG, st, ms ? ev : nullptr, tau_ovr ? tau_ovr->data() : nullptr,
-                          &err);
-        if (rc) return fail(rc, "%s", err.c_str());
+        gml::I8Pass a{};
+        a.theta = p->dTheta;
+        a.srow = p->dSrow;
+        a.rowcol = p->dRowcol;
+        a.groups = p->dGroups;
+        a.ngroups = (int)groups.size();
+        a.slot0 = 0;
+        a.slot1 = (int)Rp;
+        a.form = form;
+        a.want_grad = want_grad;
+        a.F = p->dF;
+        a.G = p->dG;
+        a.tauovr = dOvr;
+        rc = gml::i8_pass(&p->i8ws, p->d, W, a, st, ms ? ev : nullptr, &err);
+        if (rc) {
+            if (dOvr) (void)hipFree(dOvr);
+            return fail(rc, "%s", err.c_str());
+        }
     } else {
-        rc = ensure_f64(p);
+        rc = gml_ensure_f64(p, p->ws_rows);
         if (rc) return rc;
+        HIPCHK(hipMemsetAsync(p->dF, 0, sizeof(double) * Rp, st));
+        if (want_grad) HIPCHK(hipMemsetAsync(p->dG, 0, sizeof(double) * Rp * Qp, st));
         if (ms) HIPCHK(hipEventRecord(ev[0], st));
         launch_fwd_f64(p->d, p->dTheta, p->dRowcol, p->dGroups, (int)gpad.size(), form, p->dV, p->dF, st);
         if (ms) HIPCHK(hipEventRecord(ev[1], st));
@@ -1047,27 +1015,17 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
     std::vector<double> tauh;
     std::vector<unsigned> mmaxh;
     const bool i8exp = precision == GML_PREC_I8X && form != GML_RPLE;
-    if (precision == GML_PREC_I8X) {
-        const int8_t *Vq = nullptr;
+    if (i8exp) {
         const double *tau = nullptr;
-        gml::i8_get_v(p->i8ws, &Vq, &tau);
+        const unsigned *mm = nullptr;
+        gml::i8_slot_results(p->i8ws, 0, &tau, &mm);
         tauh.resize((size_t)Rp);
+        mmaxh.resize((size_t)Rp);
         HIPCHK(hipMemcpyAsync(tauh.data(), tau, sizeof(double) * Rp, hipMemcpyDeviceToHost, st));
-        if (i8exp) {
-            mmaxh.resize((size_t)Rp);
-            HIPCHK(hipMemcpyAsync(mmaxh.data(), gml::i8_get_mmax(p->i8ws), sizeof(unsigned) * Rp, hipMemcpyDeviceToHost, st));
-        }
+        HIPCHK(hipMemcpyAsync(mmaxh.data(), mm, sizeof(unsigned) * Rp, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipStreamSynchronize(st));
-    if (fnoise)
-        for (int64_t r = 0; r < R; ++r) {
-            if (!act[r]) continue;
-            // f64: summation rounding.  int8 limbs: every V_rk is rounded to a multiple of tau_r with a dither
-            // that is equidistributed over the samples, so the errors (each within one unit, standard deviation
-            // 0.41 tau) add like a random walk: 8 sigma of sqrt(K) terms (the worst case K * tau is never approached).
-            fnoise[r] = 1e-13 * std::max(1.0, std::fabs(fh[r]));
-            if (precision == GML_PREC_I8X && form != GML_RPLE) fnoise[r] += 3.3 * std::sqrt((double)p->K) * tauh[r];
-        }
+    if (dOvr) (void)hipFree(dOvr);
     if (ms) {
         HIPCHK(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
         HIPCHK(hipEventElapsedTime(&ms[1], ev[1], ev[2]));
@@ -1101,88 +1059,10 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
                 ovr[r] = ((double)mmaxh[r] + 1.0) * tauh[r] * (1.0 + 1e-12) / 2130000000.0;
                 ++nagain;
             }
-        if (vmax_out)
-            for (int64_t r = 0; r < R; ++r)
-                if (act[r]) vmax_out[r] = ((double)mmaxh[r] + 1.0) * tauh[r];
         if (nagain > 0) {
             if (depth >= 6) return fail(GML_EUNSUPPORTED, "precision i8x: the weights exp(-E) of a row underflow its fixed-point range; use precision f64");
-            return device_pass(p, rs, again, theta, form, precision, want_grad, f, g, stats, nullptr, fnoise, &ovr, depth + 1, vmax_out);
+            return device_pass(p, rs, again, theta, form, precision, want_grad, f, g, stats, nullptr, &ovr, depth + 1);
         }
-    }
-    return GML_OK;
-}
-
-// Working-set Hessians of the active rows (int8 kernel over the limb planes of the last pass, or the
-// FP64 MFMA kernel over V).  Fidx: R x cap column ids (padding = Qp-1), m[r] = working-set size
-// (0 = skip).  The result is ragged: row r's block starts at hoff[r] in Hout and is mp x mp with
-// mp = 32*ceil(m[r]/32) (lower 32x32 tiles filled).
-static int device_newton(gml_problem *p, const RowSet &rs, const std::vector<int> &Fidx, const std::vector<int> &m,
-                         int cap, int form, int precision, int64_t Kh, int64_t kstride, const std::vector<double> &s1, double s2,
-                         const std::vector<double> &gF, const std::vector<double> &pgF, std::vector<double> &dout,
-                         std::vector<double> &sdiag, gml_stats *stats) {
-    std::vector<long long> hoff;
-    const int64_t R = rs.R;
-    const double t0 = now_s();
-    std::vector<int> mt2((size_t)3 * R);
-    hoff.assign((size_t)R + 1, 0);
-    for (int64_t r = 0; r < R; ++r) {
-        mt2[r] = (m[r] + 31) / 32;
-        mt2[R + r] = (int)rs.node[r];
-        mt2[2 * R + r] = m[r];
-        hoff[r + 1] = hoff[r] + (long long)mt2[r] * 32 * mt2[r] * 32;
-    }
-    const int64_t htotal = std::max<long long>(hoff[R], 1);
-    if (R > p->hs_rows || (int64_t)R * cap > p->hs_cap || htotal > p->hs_elems) {
-        void *ptrs[] = {p->dFidx, p->dMt, p->dH, p->dHoff, p->dVec};
-        for (void *q : ptrs)
-            if (q) (void)hipFree(q);
-        p->dFidx = p->dMt = nullptr;
-        p->dH = p->dVec = nullptr;
-        p->dHoff = nullptr;
-        p->hs_rows = std::max(R, p->hs_rows);
-        p->hs_cap = std::max<int64_t>((int64_t)R * cap, p->hs_cap);
-        p->hs_elems = std::max<int64_t>(htotal + htotal / 4, p->hs_elems);
-        HIPCHK(hipMalloc(&p->dFidx, sizeof(int) * p->hs_cap));
-        HIPCHK(hipMalloc(&p->dMt, sizeof(int) * 3 * p->hs_rows));
-        HIPCHK(hipMalloc(&p->dHoff, sizeof(long long) * (p->hs_rows + 1)));
-        HIPCHK(hipMalloc(&p->dH, sizeof(double) * p->hs_elems));
-        HIPCHK(hipMalloc(&p->dVec, sizeof(double) * (3 * p->hs_cap + 2 * p->hs_rows))); // gF | pgF | d | s1 | Sdiag
-    }
-    hipStream_t st = p->st;
-    HIPCHK(hipMemcpyAsync(p->dFidx, Fidx.data(), sizeof(int) * R * cap, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->dMt, mt2.data(), sizeof(int) * 3 * R, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->dHoff, hoff.data(), sizeof(long long) * (R + 1), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(p->dH, 0, sizeof(double) * htotal, st));
-    bool done = false;
-    if (precision == GML_PREC_I8X) {
-        std::string err;
-        int hrc = gml::i8_hessian(p->i8ws, p->d, p->dMt + R, p->dFidx, p->dMt, mt2.data(), p->dHoff, htotal, (int)R, cap, form,
-                                  Kh, kstride, p->dH, st, &err);
-        if (hrc == GML_OK) done = true;
-        else if (hrc != GML_EUNSUPPORTED) return fail(hrc, "%s", err.c_str());
-    }
-    if (!done) {
-        if (precision == GML_PREC_I8X)
-            return fail(GML_EUNSUPPORTED, "a Newton block above 512 entries (the solver caps max_working at 512)");
-        launch_hess_f64(p->d, p->dV, p->dMt + R, p->dFidx, p->dMt, p->dHoff, (int)R, cap, form, Kh, kstride, p->dH, st);
-    }
-    HIPCHK(hipGetLastError());
-    // Newton systems solved in place on the device; only the directions come back
-    double *dg = p->dVec, *dpg = dg + (int64_t)R * cap, *dd = dpg + (int64_t)R * cap, *ds1 = dd + (int64_t)R * cap,
-           *dsd = ds1 + R;
-    HIPCHK(hipMemcpyAsync(dg, gF.data(), sizeof(double) * R * cap, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(dpg, pgF.data(), sizeof(double) * R * cap, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(ds1, s1.data(), sizeof(double) * R, hipMemcpyHostToDevice, st));
-    launch_newton_solve(p->dH, p->dHoff, p->dMt, p->dMt + 2 * R, ds1, s2, dg, dpg, (int)R, cap, dd, dsd, st);
-    HIPCHK(hipGetLastError());
-    dout.resize((size_t)R * cap);
-    sdiag.resize((size_t)R);
-    HIPCHK(hipMemcpyAsync(dout.data(), dd, sizeof(double) * R * cap, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(sdiag.data(), dsd, sizeof(double) * R, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (stats) {
-        stats->t_hess += now_s() - t0;
-        ++stats->hessian_passes;
     }
     return GML_OK;
 }
@@ -1190,11 +1070,7 @@ static int device_newton(gml_problem *p, const RowSet &rs, const std::vector<int
 // ------------------------------------------------------------------------------------------
 // layouts: reference parameter vector <-> internal column layout
 // ------------------------------------------------------------------------------------------
-struct NodeLayout {
-    std::vector<int32_t> cols; // reference slot j -> internal column
-};
-
-static void build_layout(const gml_problem *p, int64_t u, NodeLayout &L) {
+void gml_build_layout(const gml_problem *p, int64_t u, NodeLayout &L) {
     if (p->order == 2) { // slot i <-> spin i, slot u = field (:162)
         L.cols.resize((size_t)p->n);
         for (int64_t i = 0; i < p->n; ++i) L.cols[i] = (int32_t)(i == u ? p->d.cconst : i);
@@ -1202,524 +1078,7 @@ static void build_layout(const gml_problem *p, int64_t u, NodeLayout &L) {
         node_cols(p, u, L.cols);
     }
 }
-
-static inline double pseudo_grad(double x, double g, double lam) {
-    if (lam == 0.0) return g;
-    if (x > 0) return g + lam;
-    if (x < 0) return g - lam;
-    if (g + lam < 0) return g + lam;
-    if (g - lam > 0) return g - lam;
-    return 0.0;
-}
-
-// ------------------------------------------------------------------------------------------
-// gml_learn: batched working-set orthant-wise Newton.
-//
-// Every local node u solves   min_x f_u(x) + lambda * sum_{j penalised} |x_j|   -- the problem
-// the reference builds for Ipopt with the z >= |x| epigraph (:166-177) -- in lock-step:
-//   1. one device pass gives f and the full gradient of every active node;
-//   2. pseudo-gradient / KKT residual per node; converged nodes drop out;
-//   3. working set = non-zeros + the largest violators; its Hessian comes from one device
-//      kernel over the same K configurations; Newton step by Cholesky on the host;
-//   4. projected (orthant) backtracking line search: first trial is a full pass (it usually
-//      succeeds), further trials are objective-only passes over the rows that need them.
-// ------------------------------------------------------------------------------------------
-extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, const gml_opts *opts_in,
-                         double *out, double *kkt_out, gml_stats *stats_out) {
-    if (!p || !out) return fail(GML_EINVAL, "NULL argument");
-    if (formulation < 0 || formulation > 2) return fail(GML_EINVAL, "unknown formulation %d", formulation);
-    if (formulation != GML_RISE && p->order != 2)
-        return fail(GML_EUNSUPPORTED, "multi-body statistics are defined for RISE only (multiRISE, :83-152)");
-    if (!(regularizer_c >= 0)) return fail(GML_EINVAL, "regularizer must be >= 0");
-    gml_opts o;
-    if (opts_in) o = *opts_in;
-    else gml_default_opts(&o);
-    if (!(o.tol > 0)) o.tol = 1e-9;
-    if (o.max_iter <= 0) o.max_iter = 100;
-    if (o.max_working < 32) o.max_working = 512;
-    if (o.max_working > 512) o.max_working = 512;
-    o.max_working = (int)round_up(o.max_working, 32);
-    if (o.max_add <= 0) o.max_add = 64;
-    HIPCHK(hipSetDevice(p->device));
-    const int64_t dbg_row = getenv("GML_DEBUG_ROW") ? atoll(getenv("GML_DEBUG_ROW")) : 0; // row traced at verbose >= 2
-    gml_stats stl;
-    std::memset(&stl, 0, sizeof stl);
-    gml_stats *stats = &stl;
-    const double t_start = now_s();
-
-    const int64_t R = p->node1 - p->node0, Qp = p->d.Qp, Q = p->d.Qp, P = p->P;
-    const int32_t cconst = (int32_t)p->d.cconst;
-    const double lambda = gml_lambda(regularizer_c, p->n, p->M);
-    stats->lambda = lambda;
-    // sub-sampled Newton: Hessians over the first Kh configurations, rescaled by M / M_h.  The budget
-    // (rows x configurations) is kept roughly constant: as nodes converge, the remaining ones get more
-    // configurations, up to all of them -- an inexact Hessian only costs iterations, and it costs the
-    // most on the few ill-conditioned nodes that are still active at the end.
-    // sub-sampled Newton: Hessians over Kh configurations -- every kstride-th block of 512, so that a sorted histogram
-    // is sampled evenly -- rescaled by the weight of the sub-sample.  The budget (rows x configurations) is kept
-    // roughly constant: as nodes converge, the remaining ones get more configurations, up to all of them -- an
-    // inexact Hessian only costs iterations, and it costs the most on the few ill-conditioned nodes that are still
-    // active at the end.
-    const int64_t Kh_base = o.hess_samples == 0 ? 32768 : (o.hess_samples < 0 ? p->d.Kp : (int64_t)o.hess_samples);
-    const int64_t nblk512 = p->d.Kp / 512;
-    int64_t Kh = p->d.Kp, kstride = 1;
-    double hscale = 1.0;
-    auto set_kh = [&](int64_t nactive) {
-        int64_t want = Kh_base;
-        if (o.hess_samples == 0 && nactive > 0) want = Kh_base * std::max<int64_t>(1, R / nactive);
-        int64_t nb = std::min(nblk512, std::max<int64_t>(2, (want + 511) / 512));
-        if (nb * 512 >= p->K) nb = nblk512; // (nearly) everything: take it all
-        kstride = nblk512 / nb;
-        Kh = nb * 512;
-        double wsum = 0;
-        for (int64_t cb = 0; cb < nb; ++cb) wsum += p->wblk[(size_t)(cb * kstride)];
-        if (!(wsum > 0)) { // a sub-sample without weight (degenerate histogram): use every configuration
-            nb = nblk512;
-            kstride = 1;
-            Kh = p->d.Kp;
-            wsum = 1.0;
-        }
-        hscale = nb == nblk512 ? 1.0 : 1.0 / wsum;
-    };
-    set_kh(R);
-
-    RowSet rs;
-    rs.R = R;
-    rs.node.resize((size_t)R);
-    for (int64_t r = 0; r < R; ++r) rs.node[r] = p->node0 + r;
-
-    // kind[r][c]: 0 = structurally absent (key contains u), 1 = free, 2 = l1-penalised
-    std::vector<uint8_t> kind((size_t)R * Qp, 0);
-    std::vector<NodeLayout> lay((size_t)R);
-    parallel_for(R, [&](int64_t r) {
-        build_layout(p, rs.node[r], lay[r]);
-        uint8_t *kr = kind.data() + r * Qp;
-        for (int32_t c : lay[r].cols) kr[c] = (c == cconst) ? 1 : 2; // length(inter) > 1 is penalised (:118,:171)
-    });
-
-    std::vector<double> X((size_t)R * Qp, 0.0), G((size_t)R * Qp, 0.0), Xt((size_t)R * Qp, 0.0),
-        Gt((size_t)R * Qp, 0.0), Xbest((size_t)R * Qp, 0.0);
-    std::vector<double> f((size_t)R, 0.0), ft((size_t)R, 0.0), Fobj((size_t)R, 0.0), kkt((size_t)R, INFINITY),
-        best((size_t)R, INFINITY), Z((size_t)R, 1.0), Zt((size_t)R, 1.0), alpha((size_t)R, 1.0), dd((size_t)R, 0.0),
-        fn((size_t)R, 0.0), fnt((size_t)R, 0.0);
-    std::vector<uint8_t> done((size_t)R, 0), act((size_t)R, 1), need((size_t)R, 0), vstale((size_t)R, 0), atfloor((size_t)R, 0);
-    // FP64 polish of the rows the int8-limb path leaves above tol: possible when the FP64 workspaces fit
-    bool can_polish = false;
-    if (o.precision == GML_PREC_I8X && o.polish >= 0) {
-        size_t freeb = 0, totalb = 0;
-        if (hipMemGetInfo(&freeb, &totalb) == hipSuccess) {
-            const double need_b = (p->d.Xs ? 0.0 : 2.0 * (double)p->d.Kp * (double)p->d.Qp) + (p->dV ? 0.0 : 8.0 * (double)round_up(R, 32) * (double)p->d.Kp);
-            can_polish = need_b < 0.8 * (double)freeb;
-        }
-    }
-    int stall_cap = can_polish ? 4 : 10;
-    std::vector<int> stall((size_t)R, 0), msz((size_t)R, 0), mtot((size_t)R, 0), blk((size_t)R, 0);
-    std::vector<std::vector<int>> Fset((size_t)R);
-    std::vector<std::vector<double>> Dset((size_t)R), PGset((size_t)R);
-    // Scale of the fixed-point V (int8 path): instead of the worst-case bound w_max exp(sum|theta|) every pass after
-    // a row's first uses vref = max_k |V_rk| measured by its previous pass, times exp(||theta - theta_ref||_1),
-    // which bounds the new weights rigorously (|E_k' - E_k| <= ||theta' - theta||_1).  Near the optimum the steps
-    // are tiny, so V keeps all 31 bits relative to its actual maximum and the noise floor of f and grad drops by the
-    // bits the bound would have wasted.
-    int prec = o.precision; // switches to FP64 for the rows the int8-limb path cannot bring below tol (see "polish" below)
-    bool track_scale = prec == GML_PREC_I8X && formulation != GML_RPLE;
-    std::vector<double> vref((size_t)R, 0.0), dref((size_t)R, 0.0), stepn((size_t)R, 0.0), vnew((size_t)R, 0.0),
-        ovr((size_t)round_up(R, 32), 0.0);
-    auto scale_for = [&](const std::vector<uint8_t> &rows, bool at_trial) -> const std::vector<double> * {
-        if (!track_scale) return nullptr;
-        for (int64_t r = 0; r < R; ++r)
-            ovr[r] = (rows[r] && vref[r] > 0.0) ? vref[r] * std::exp(dref[r] + (at_trial ? stepn[r] : 0.0)) * (1.0 + 1e-6) / 2130000000.0 : 0.0;
-        return &ovr;
-    };
-    auto scale_seen = [&](const std::vector<uint8_t> &rows, bool at_trial) {
-        if (!track_scale) return;
-        for (int64_t r = 0; r < R; ++r)
-            if (rows[r]) {
-                vref[r] = vnew[r];
-                dref[r] = at_trial ? stepn[r] : 0.0; // distance from the current iterate to the point just evaluated
-            }
-    };
-
-    // logRISE post-processing of a pass: f = log Z, g = grad Z / Z   (:279)
-    auto post = [&](const std::vector<uint8_t> &a, std::vector<double> &fv, std::vector<double> &gv,
-                    std::vector<double> &zv, std::vector<double> &nv, bool grad) {
-        if (formulation != GML_LOGRISE) return;
-        parallel_for(R, [&](int64_t r) {
-            if (!a[r]) return;
-            const double z = fv[r];
-            zv[r] = z;
-            fv[r] = std::log(z);
-            nv[r] = nv[r] / z; // uncertainty of log Z
-            if (grad) {
-                double *gr = gv.data() + r * Qp;
-                for (int64_t c = 0; c < Q; ++c) gr[c] /= z;
-            }
-        });
-    };
-
-    int rc = device_pass(p, rs, act, X.data(), formulation, prec, true, f.data(), G.data(), stats, nullptr,
-                         fn.data(), nullptr, 0, vnew.data());
-    if (rc) return rc;
-    scale_seen(act, false);
-    post(act, f, G, Z, fn, true);
-
-    int it = 0;
-    for (it = 0; it < o.max_iter; ++it) {
-        const double th0 = now_s();
-        // ---- KKT residuals, working sets ----------------------------------------------
-        parallel_for(R, [&](int64_t r) {
-            if (done[r]) return;
-            const double *x = X.data() + r * Qp, *g = G.data() + r * Qp;
-            const uint8_t *kr = kind.data() + r * Qp;
-            double F = f[r], worst = 0, worstW = 0;
-            std::vector<std::pair<double, int>> viol;
-            std::vector<int> &Fs = Fset[r];
-            Fs.clear();
-            for (int64_t c = 0; c < Q; ++c) {
-                if (!kr[c]) continue;
-                const double l = kr[c] == 2 ? lambda : 0.0;
-                F += l * std::fabs(x[c]);
-                const double pg = pseudo_grad(x[c], g[c], l);
-                if (std::fabs(pg) > worst) worst = std::fabs(pg);
-                if (x[c] != 0.0 || kr[c] == 1) {
-                    Fs.push_back((int)c);
-                    worstW = std::max(worstW, std::fabs(pg));
-                } else if (pg != 0.0) {
-                    viol.emplace_back(-std::fabs(pg), (int)c);
-                }
-            }
-            if (!std::isfinite(worst)) worst = INFINITY;
-            Fobj[r] = F;
-            kkt[r] = worst;
-            if (worst < best[r]) {
-                best[r] = worst;
-                std::memcpy(Xbest.data() + r * Qp, x, sizeof(double) * Qp);
-                stall[r] = 0;
-            } else {
-                ++stall[r];
-            }
-            if (worst <= o.tol) {
-                done[r] = 1;
-                return;
-            }
-            if (stall[r] >= stall_cap) { // no progress: at the noise floor of the pass arithmetic (or a failed line search)
-                done[r] = 1;
-                atfloor[r] = 1;
-                return;
-            }
-            // Only the max_add largest violators are admitted per iteration: at theta = 0 most
-            // coordinates violate |g| <= lambda merely through <s_u><s_c> (non-zero magnetisations), and
-            // stop doing so once the field and the strongest couplings have been fitted; and none at all
-            // while the residual on the current support still dominates (the violations outside are then
-            // largely an artefact of the unconverged support).
-            if (worstW > worst * 0.999999 && worstW > 0 && !viol.empty() && (int)Fs.size() > 1) viol.clear();
-            if ((int)viol.size() > o.max_add) {
-                std::nth_element(viol.begin(), viol.begin() + o.max_add, viol.end());
-                viol.resize(o.max_add);
-            }
-            // Newton block W: everything free if it fits the cap.  Otherwise (a denser optimum than the
-            // cap: lambda at or below the sampling noise) block Gauss-Seidel: the free coordinates are
-            // ranked by max(|pg|, |x| * f) and the iterations cycle through consecutive blocks of that
-            // ranking (the unpenalised slot is in every block); all other coordinates stay fixed, so the
-            // block Newton step cannot overshoot through couplings it ignores.
-            const int capW = o.max_working;
-            if ((int)(Fs.size() + viol.size()) <= capW) {
-                for (auto &v : viol) Fs.push_back(v.second);
-                blk[r] = 0;
-            } else {
-                std::vector<std::pair<double, int>> cand;
-                cand.reserve(Fs.size() + viol.size());
-                const double fs = std::max(std::fabs(formulation == GML_LOGRISE ? 1.0 : f[r]), 1e-300);
-                int cfree = -1;
-                for (int c : Fs) {
-                    if (kr[c] == 1) {
-                        cfree = c;
-                        continue;
-                    }
-                    cand.emplace_back(-std::max(std::fabs(pseudo_grad(x[c], g[c], lambda)), std::fabs(x[c]) * fs), c);
-                }
-                for (auto &v : viol) cand.emplace_back(v.first, v.second);
-                std::sort(cand.begin(), cand.end());
-                const int per = capW - 1, nblk = ((int)cand.size() + per - 1) / per;
-                const int b = blk[r] % nblk;
-                blk[r] = (blk[r] + 1) % nblk;
-                Fs.clear();
-                if (cfree >= 0) Fs.push_back(cfree);
-                for (int a = b * per; a < std::min<int>((b + 1) * per, (int)cand.size()); ++a) Fs.push_back(cand[a].second);
-            }
-            std::sort(Fs.begin(), Fs.end());
-        });
-        int64_t nactive = 0;
-        double worst_all = 0;
-        int maxm = 0;
-        for (int64_t r = 0; r < R; ++r) {
-            if (!done[r]) {
-                ++nactive;
-                maxm = std::max<int>(maxm, (int)Fset[r].size());
-            }
-            worst_all = std::max(worst_all, std::min(kkt[r], best[r]));
-        }
-        if (o.verbose)
-            fprintf(stderr, "[gml] it %3d active %6lld  max-kkt %.3e  max|F| %d  passes %d fwd %d\n", it,
-                    (long long)nactive, worst_all, maxm, stats->passes, stats->forward_passes);
-        if (nactive == 0) {
-            // Polish: rows that the int8-limb arithmetic could not bring below tol (its gradient carries ~sqrt(K) 2^-31
-            // of noise relative to the largest weight, which an ill-conditioned, weakly regularised problem amplifies)
-            // continue on the FP64 path from their best iterate, when that path fits in memory.
-            int64_t nfloor = 0;
-            for (int64_t r = 0; r < R; ++r) nfloor += (atfloor[r] && !(std::min(best[r], kkt[r]) <= o.tol));
-            if (!(prec == GML_PREC_I8X && can_polish && nfloor > 0)) break;
-            if (ensure_f64(p) != GML_OK) break; // does not fit after all: the rows stay as they are (reported not converged)
-            prec = GML_PREC_F64;
-            track_scale = false;
-            stall_cap = 10;
-            std::fill(need.begin(), need.end(), 0);
-            for (int64_t r = 0; r < R; ++r) {
-                if (!atfloor[r] || std::min(best[r], kkt[r]) <= o.tol) continue;
-                if (best[r] <= kkt[r]) std::memcpy(X.data() + r * Qp, Xbest.data() + r * Qp, sizeof(double) * Qp);
-                done[r] = 0;
-                atfloor[r] = 0;
-                stall[r] = 0;
-                best[r] = INFINITY;
-                blk[r] = 0;
-                need[r] = 1;
-            }
-            if (o.verbose) fprintf(stderr, "[gml] polish: %lld rows continue on the FP64 path\n", (long long)nfloor);
-            rc = device_pass(p, rs, need, X.data(), formulation, prec, true, f.data(), G.data(), stats, nullptr, fn.data(), nullptr, 0,
-                             nullptr);
-            if (rc) return rc;
-            post(need, f, G, Z, fn, true);
-            for (int64_t r = 0; r < R; ++r)
-                if (need[r]) vstale[r] = 0;
-            set_kh(nfloor);
-            ++stats->polished;
-            continue;
-        }
-        set_kh(nactive);
-
-        // rows whose V was overwritten by a rejected trial need a fresh pass before the Hessian
-        bool anystale = false;
-        for (int64_t r = 0; r < R; ++r) {
-            need[r] = (!done[r] && vstale[r]);
-            anystale |= need[r] != 0;
-        }
-        stats->t_host += now_s() - th0;
-        if (anystale) {
-            rc = device_pass(p, rs, need, X.data(), formulation, prec, true, f.data(), G.data(), stats, nullptr,
-                             fn.data(), scale_for(need, false), 0, vnew.data());
-            if (rc) return rc;
-            scale_seen(need, false);
-            post(need, f, G, Z, fn, true);
-            for (int64_t r = 0; r < R; ++r)
-                if (need[r]) vstale[r] = 0;
-        }
-
-        // ---- Newton directions on the working sets (Hessian + Cholesky solve on the device) ----
-        const double th1 = now_s();
-        const int cap = (int)round_up(std::max(maxm, 1), 32);
-        std::vector<int> Fidx((size_t)R * cap, (int)(Qp - 1));
-        std::vector<double> gFm((size_t)R * cap, 0.0), pgFm((size_t)R * cap, 0.0), s1v((size_t)R, 1.0);
-        parallel_for(R, [&](int64_t r) {
-            msz[r] = done[r] ? 0 : (int)Fset[r].size();
-            const double *x = X.data() + r * Qp, *g = G.data() + r * Qp;
-            const uint8_t *kr = kind.data() + r * Qp;
-            for (int a = 0; a < msz[r]; ++a) {
-                const int c = Fset[r][a];
-                Fidx[(size_t)r * cap + a] = c;
-                gFm[(size_t)r * cap + a] = g[c];
-                pgFm[(size_t)r * cap + a] = pseudo_grad(x[c], g[c], kr[c] == 2 ? lambda : 0.0);
-            }
-            s1v[r] = formulation == GML_LOGRISE ? hscale / Z[r] : hscale; // Hess log Z = Hess Z / Z - g g^T
-        });
-        stats->t_host += now_s() - th1;
-        std::vector<double> Dn, Sd;
-        rc = device_newton(p, rs, Fidx, msz, cap, formulation, prec, Kh, kstride, s1v, formulation == GML_LOGRISE ? 1.0 : 0.0,
-                           gFm, pgFm, Dn, Sd, stats);
-        if (rc) return rc;
-        const double th1b = now_s();
-        parallel_for(R, [&](int64_t r) {
-            if (done[r]) return;
-            const int m = msz[r];
-            std::vector<double> bw(Dn.begin() + (size_t)r * cap, Dn.begin() + (size_t)r * cap + m);
-            std::vector<double> pgv(pgFm.begin() + (size_t)r * cap, pgFm.begin() + (size_t)r * cap + m);
-            mtot[r] = (int)Fset[r].size();
-            Dset[r] = bw;
-            PGset[r] = pgv;
-        });
-        stats->t_host += now_s() - th1b;
-
-        // ---- projected backtracking line search ----------------------------------------
-        // Two acceptance regimes per row:
-        //  * the predicted decrease is well above the uncertainty of f  -> Armijo on F;
-        //  * otherwise ("noise regime": near the optimum, or a noisy int8-limb f) function values
-        //    cannot certify the step; the trial is then a full pass and is accepted iff it lowers
-        //    the KKT residual (max |pseudo-gradient|), which is what convergence is measured by.
-        std::vector<uint8_t> nreg((size_t)R, 0);
-        for (int64_t r = 0; r < R; ++r) {
-            need[r] = !done[r];
-            alpha[r] = 1.0;
-        }
-        std::vector<uint8_t> accepted_fwd((size_t)R, 0);
-        for (int ls = 0; ls < 30; ++ls) {
-            const double th2 = now_s();
-            bool any = false, anynoise = false;
-            parallel_for(R, [&](int64_t r) {
-                if (!need[r]) return;
-                const double *x = X.data() + r * Qp;
-                double *xt = Xt.data() + r * Qp;
-                const uint8_t *kr = kind.data() + r * Qp;
-                std::memcpy(xt, x, sizeof(double) * Qp);
-                const std::vector<int> &Fs = Fset[r];
-                double d_ = 0;
-                for (int a = 0; a < mtot[r]; ++a) {
-                    const int c = Fs[a];
-                    double v = x[c] + alpha[r] * Dset[r][a];
-                    if (kr[c] == 2 && lambda > 0) {
-                        const double pg = PGset[r][a];
-                        const double xi = x[c] != 0.0 ? (x[c] > 0 ? 1.0 : -1.0) : (pg < 0 ? 1.0 : -1.0);
-                        if (v * xi < 0) v = 0.0; // crossed zero: clip to the orthant face
-                    }
-                    xt[c] = v;
-                    d_ += PGset[r][a] * (v - x[c]);
-                }
-                if (!(d_ < 0)) {
-                    // The projected step is not a descent direction: some coordinate's Newton step crossed zero and
-                    // was clipped, while the other coordinates still carry the moves that were meant to accompany
-                    // it.  Take only the clipping (each such coordinate moves towards its 1-D minimiser, so F
-                    // decreases); the coordinate then leaves the working set and the next Newton system is right.
-                    std::memcpy(xt, x, sizeof(double) * Qp);
-                    d_ = 0;
-                    for (int a = 0; a < mtot[r]; ++a) {
-                        const int c = Fs[a];
-                        if (kr[c] != 2 || !(lambda > 0) || x[c] == 0.0) continue;
-                        const double v = x[c] + alpha[r] * Dset[r][a];
-                        if (v * x[c] < 0) {
-                            xt[c] = 0.0;
-                            d_ += PGset[r][a] * (0.0 - x[c]);
-                        }
-                    }
-                }
-                dd[r] = d_;
-                double sn = 0;
-                for (int a = 0; a < mtot[r]; ++a) sn += std::fabs(xt[Fs[a]] - x[Fs[a]]);
-                stepn[r] = sn; // ||trial - x||_1: bounds the change of every energy
-                nreg[r] = !(-0.1 * d_ > 8.0 * fn[r]); // the step's expected decrease (~|dd|/2) vs the uncertainty of f
-            });
-            for (int64_t r = 0; r < R; ++r) {
-                any |= need[r] != 0;
-                anynoise |= (need[r] && nreg[r]);
-            }
-            stats->t_host += now_s() - th2;
-            if (!any) break;
-            const bool full = (ls == 0) || anynoise;
-            rc = device_pass(p, rs, need, Xt.data(), formulation, prec, full, ft.data(), Gt.data(), stats, nullptr,
-                             fnt.data(), scale_for(need, true), 0, vnew.data());
-            if (rc) return rc;
-            scale_seen(need, true);
-            post(need, ft, Gt, Zt, fnt, full);
-            const double th3 = now_s();
-            parallel_for(R, [&](int64_t r) {
-                if (!need[r]) return;
-                vstale[r] = 1;
-                const double *xt = Xt.data() + r * Qp;
-                const uint8_t *kr = kind.data() + r * Qp;
-                bool ok;
-                if (nreg[r]) {
-                    // F is convex: F(x) >= F(xt) + F'(xt; x - xt).  So a trial whose directional derivative
-                    // BACK towards x is >= 0 cannot have increased F; a small negative value (overshoot of at
-                    // most ~1.5x the minimiser along the step) is tolerated.  Coordinates clipped to zero
-                    // contribute lambda|s_c| - g_c s_c >= 0 whenever they belong at zero.
-                    const double *gt = Gt.data() + r * Qp, *x0 = X.data() + r * Qp;
-                    double back = 0;
-                    for (int a = 0; a < mtot[r]; ++a) {
-                        const int c = Fset[r][a];
-                        const double sc = x0[c] - xt[c]; // direction back to x
-                        if (sc == 0.0) continue;
-                        double gl = gt[c] * sc;
-                        if (kr[c] == 2) gl += lambda * (xt[c] != 0.0 ? (xt[c] > 0 ? sc : -sc) : std::fabs(sc));
-                        back += gl;
-                    }
-                    ok = std::isfinite(ft[r]) && std::isfinite(back) && back >= -0.5 * std::fabs(dd[r]);
-                } else {
-                    double Fn = ft[r];
-                    for (int64_t c = 0; c < Q; ++c)
-                        if (kr[c] == 2 && xt[c] != 0.0) Fn += lambda * std::fabs(xt[c]);
-                    ok = std::isfinite(Fn) && Fn <= Fobj[r] + 1e-4 * dd[r] + fn[r] + fnt[r];
-                }
-                if (o.verbose >= 2 && r == dbg_row)
-                    fprintf(stderr, "[gml]   row %lld: ls %d alpha %.3g nreg %d ft %.12e Fobj %.12e dd %.3e fnt %.3e ok %d\n", (long long)r, ls, alpha[r],
-                            (int)nreg[r], ft[r], Fobj[r], dd[r], fnt[r], (int)ok);
-                if (ok) {
-                    dref[r] = 0.0; // the iterate moves onto the point the scale was measured at
-                    std::memcpy(X.data() + r * Qp, xt, sizeof(double) * Qp);
-                    f[r] = ft[r];
-                    fn[r] = fnt[r];
-                    Z[r] = Zt[r];
-                    if (full) {
-                        std::memcpy(G.data() + r * Qp, Gt.data() + r * Qp, sizeof(double) * Qp);
-                        vstale[r] = 0;
-                    } else {
-                        accepted_fwd[r] = 1;
-                    }
-                    need[r] = 0;
-                } else {
-                    alpha[r] *= 0.5;
-                    if (nreg[r] && alpha[r] < 1.0 / 64) {
-                        need[r] = 0; // cannot improve along this direction: the stall counter ends the row,
-                        stall[r] += 3; // after at most three such line searches (each costs ~7 passes)
-                    }
-                }
-            });
-            stats->t_host += now_s() - th3;
-        }
-        // rows accepted on an objective-only trial still need their gradient (and V)
-        bool anyf = false;
-        for (int64_t r = 0; r < R; ++r) anyf |= accepted_fwd[r] != 0;
-        if (anyf) {
-            rc = device_pass(p, rs, accepted_fwd, X.data(), formulation, prec, true, f.data(), G.data(), stats,
-                             nullptr, fn.data(), scale_for(accepted_fwd, false), 0, vnew.data());
-            if (rc) return rc;
-            scale_seen(accepted_fwd, false);
-            post(accepted_fwd, f, G, Z, fn, true);
-            for (int64_t r = 0; r < R; ++r)
-                if (accepted_fwd[r]) vstale[r] = 0;
-        }
-        // rows whose line search failed entirely: they stay where they are; the stall counter ends them
-    }
-
-    // ---- results in the reference layout --------------------------------------------------
-    int notconv = 0;
-    double maxk = 0;
-    for (int64_t r = 0; r < R; ++r) {
-        const double k = std::min(best[r], kkt[r]);
-        if (!(k <= o.tol)) ++notconv;
-        maxk = std::max(maxk, k);
-        if (kkt_out) kkt_out[r] = k;
-    }
-    std::vector<double> res((size_t)R * P);
-    parallel_for(R, [&](int64_t r) {
-        const double *x = (best[r] <= kkt[r] ? Xbest.data() : X.data()) + r * Qp;
-        for (int64_t j = 0; j < P; ++j) res[(size_t)r * P + j] = x[lay[r].cols[j]];
-    });
-    hipPointerAttribute_t attr;
-    bool dev_out = false;
-    if (hipPointerGetAttributes(&attr, out) == hipSuccess) dev_out = (attr.type == hipMemoryTypeDevice);
-    else (void)hipGetLastError();
-    if (dev_out) {
-        HIPCHK(hipMemcpy(out, res.data(), sizeof(double) * R * P, hipMemcpyHostToDevice));
-    } else {
-        std::memcpy(out, res.data(), sizeof(double) * R * P);
-    }
-    stats->iterations = it;
-    stats->max_kkt = maxk;
-    stats->not_converged = notconv;
-    stats->t_total = now_s() - t_start;
-    if (stats_out) *stats_out = *stats;
-    if (notconv)
-        return fail(GML_ENOTCONV, "%d of %lld nodes did not reach the KKT tolerance %.1e (worst %.3e)", notconv,
-                    (long long)R, o.tol, maxk);
-    return GML_OK;
-}
+static void build_layout(const gml_problem *p, int64_t u, NodeLayout &L) { gml_build_layout(p, u, L); }
 
 // ------------------------------------------------------------------------------------------
 // gml_objgrad_batch: the operator (:191-208, :221-233)
@@ -1787,13 +1146,17 @@ extern "C" int gml_bench_pass_resident(gml_problem *p, int formulation, int prec
         for (int64_t j = 0; j < P; ++j) p->hTh[(size_t)r * Qp + lay[r].cols[j]] = theta[r * P + j];
     });
     const int ngroups = (int)(Rp / 32);
-    for (int64_t r = 0; r < Rp; ++r) p->hCtl[r] = r < R ? (int)(p->node0 + r) : -1;
+    const int64_t W = p->ws_rows;
+    for (int64_t r = 0; r < Rp; ++r) {
+        p->hCtl[r] = (int)r; // slot = row
+        p->hCtl[W + r] = r < R ? (int)(p->node0 + r) : -1;
+    }
     int npad = 0;
-    for (int g = 0; g < ngroups || (npad % 4); ++g, ++npad) p->hCtl[p->ws_rows + g] = g < ngroups ? g : -1;
+    for (int g = 0; g < ngroups || (npad % 4); ++g, ++npad) p->hCtl[2 * W + g] = g < ngroups ? g : -1;
     HIPCHK(hipMemcpyAsync(p->dTheta, p->hTh, sizeof(double) * Rp * Qp, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->dRowcol, p->hCtl, sizeof(int) * (p->ws_rows + npad), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->dSrow, p->hCtl, sizeof(int) * (2 * W + npad), hipMemcpyHostToDevice, st));
     if (precision != GML_PREC_I8X) {
-        rc = ensure_f64(p);
+        rc = gml_ensure_f64(p, p->ws_rows);
         if (rc) return rc;
     }
     std::vector<hipEvent_t> ev((size_t)3 * steps, nullptr);
@@ -1802,8 +1165,19 @@ extern "C" int gml_bench_pass_resident(gml_problem *p, int formulation, int prec
         hipEvent_t *e3 = s >= warmup ? ev.data() + (size_t)3 * (s - warmup) : nullptr;
         if (precision == GML_PREC_I8X) {
             std::string err;
-            rc = gml::i8_pass(&p->i8ws, p->d, p->dTheta, p->dRowcol, p->dGroups, ngroups, (int)Rp, formulation, true, p->dF,
-                              p->dG, st, e3, nullptr, &err);
+            gml::I8Pass a{};
+            a.theta = p->dTheta;
+            a.srow = p->dSrow;
+            a.rowcol = p->dRowcol;
+            a.groups = p->dGroups;
+            a.ngroups = ngroups;
+            a.slot0 = 0;
+            a.slot1 = (int)Rp;
+            a.form = formulation;
+            a.want_grad = true;
+            a.F = p->dF;
+            a.G = p->dG;
+            rc = gml::i8_pass(&p->i8ws, p->d, W, a, st, e3, &err);
             if (rc) return fail(rc, "%s", err.c_str());
         } else {
             HIPCHK(hipMemsetAsync(p->dF, 0, sizeof(double) * Rp, st));
@@ -1823,7 +1197,10 @@ extern "C" int gml_bench_pass_resident(gml_problem *p, int formulation, int prec
     std::vector<unsigned> mm;
     if (precision == GML_PREC_I8X && formulation != GML_RPLE) {
         mm.resize((size_t)Rp);
-        HIPCHK(hipMemcpyAsync(mm.data(), gml::i8_get_mmax(p->i8ws), sizeof(unsigned) * Rp, hipMemcpyDeviceToHost, st));
+        const double *tau_ = nullptr;
+        const unsigned *mm_ = nullptr;
+        gml::i8_slot_results(p->i8ws, 0, &tau_, &mm_);
+        HIPCHK(hipMemcpyAsync(mm.data(), mm_, sizeof(unsigned) * Rp, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipStreamSynchronize(st));
     for (size_t r = 0; r < mm.size() && (int64_t)r < R; ++r)

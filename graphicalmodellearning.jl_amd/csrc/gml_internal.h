@@ -1,0 +1,58 @@
+// Internal host-side interface of libgml_hip shared by gml_host.cpp (handles, packing, operator) and gml_solver.cpp
+// (the l1 solver behind gml_learn).  Not part of the C ABI.
+#pragma once
+#include "../../include/gml.h"
+#include "gml_dev.h"
+
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+int gml_fail(int code, const char *fmt, ...);
+#define fail gml_fail
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? GML_ENOMEM : GML_EHIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                       \
+    } while (0)
+
+double gml_now_s();
+void gml_parallel_for(int64_t n, const std::function<void(int64_t)> &fn); // persistent host worker pool
+inline int64_t gml_round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// ------------------------------------------------------------------------------------------
+// problem handle
+// ------------------------------------------------------------------------------------------
+struct gml_problem {
+    int device = 0;
+    hipStream_t st = nullptr;
+    int64_t n = 0, K = 0, P = 0, node0 = 0, node1 = 0;
+    int order = 2;
+    double M = 0;
+    gml::DevProblem d{};
+    std::vector<int32_t> gkeys; // [Q][ko] subsets of spins (feature keys), -1 padded
+    int ko = 1;
+    std::vector<int64_t> qoff; // qoff[q] = first column of the size-q subsets
+    std::vector<double> wblk;    // wblk[j] = sum of w over the configurations [512 j, 512 j + 512)
+    // workspace of the host-pointer operator calls (sized for ws_rows rows)
+    int64_t ws_rows = 0;
+    double *dTheta = nullptr, *dV = nullptr, *dG = nullptr, *dF = nullptr;
+    int64_t dVrows = 0; // rows of the FP64 path's V (gml_ensure_f64)
+    int *hCtl = nullptr; // pinned twin of the control block: srow | rowcol | groups
+    int *dSrow = nullptr, *dRowcol = nullptr, *dGroups = nullptr;
+    double *hTh = nullptr, *hG = nullptr, *hF = nullptr; // pinned staging (ws_rows x Qp, ws_rows)
+    // int8-limb path workspace (gml_kernels_i8.hip, allocated lazily)
+    void *i8ws = nullptr;
+};
+
+// reference parameter vector of node u <-> internal column layout (pairwise :162, multi-body :94-104)
+struct NodeLayout {
+    std::vector<int32_t> cols; // reference slot j -> internal column
+};
+void gml_build_layout(const gml_problem *p, int64_t u, NodeLayout &L);
+
+int gml_ensure_ws(gml_problem *p, int64_t rows);
+int gml_ensure_f64(gml_problem *p, int64_t vrows); // byte images + V [vrows][Kp] of the FP64 path

@@ -38,17 +38,25 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int LB = 4; // limbs of V (30 significant bits relative to the per-node bound)
 
-struct I8Ws {
-    int64_t rows = 0; // capacity in node rows (multiple of 32)
-    int LF = 4;
-    int8_t *Tq = nullptr, *Vq = nullptr;
-    int32_t *Gacc = nullptr;
+// per-slot scalars of one kind of pass (objective/gradient passes, Hessian-vector passes)
+struct SlotScalars {
     double *sigma = nullptr, *tau = nullptr, *invtau = nullptr;
     long long *qconst = nullptr, *csum = nullptr, *asum = nullptr;
-    unsigned *mmax = nullptr; // largest |V| / tau seen per row in the last pass (dynamic-range check)
-    double *tauovr = nullptr; // per-row tau imposed by the caller (rescaled re-run), 0 = derive from the bound
-    // working-set Hessian on the int8 cores
-    int64_t hKh = 0, hcap_elems = 0;
+    unsigned *mmax = nullptr; // largest |V| / tau seen per slot in the last pass (dynamic-range check)
+};
+
+// Workspace of the int8-limb passes.  Everything is indexed by SLOT: a pass evaluates the node rows its caller lists
+// in consecutive slots (32 slots = one MFMA node tile), so that the tiles it runs are full whatever subset of the
+// rows is still active; `srow` maps a slot to the row of the caller's Theta / G arrays.
+struct I8Ws {
+    int64_t slots = 0; // capacity (multiple of 32)
+    int LF = 5;        // limb planes the Tq buffer is sized for
+    int8_t *Tq = nullptr, *Vq = nullptr, *Uq = nullptr; // Uq: the V-like limb planes of Hessian-vector passes (on first use)
+    int32_t *Gacc = nullptr;
+    SlotScalars sc[2]; // [0] objective/gradient passes, [1] Hessian-vector passes
+    double *tauovr = nullptr; // per-slot tau imposed by the caller (tracked scale, rescaled re-run), 0 = derive from the bound
+    // working-set Hessian on the int8 cores (indexed by ROW of the caller's arrays)
+    int64_t hKh = 0, hrows = 0, hcap_elems = 0;
     int8_t *Hq = nullptr;   // limb planes of the Hessian weights over the compact (sub-sampled) index
     unsigned *Mb = nullptr; // row-major twin of Xtb (gathered-row DMA of the Hessian kernel), built on first use
     long long *hS = nullptr, *H64 = nullptr;
@@ -58,15 +66,16 @@ struct I8Ws {
 // quantise Theta rows into limb planes.  One workgroup per node row.
 // ------------------------------------------------------------------------------------------
 template <int LF>
-__global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ Theta,
-                                                     const int *__restrict__ rowcol, int64_t Qp,
-                                                     int64_t Qfp, int64_t cconst, double wmax, int form,
+__global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ Theta, const int *__restrict__ srow,
+                                                     const int *__restrict__ rowcol, int slot0, int64_t Qp,
+                                                     int64_t Qfp, int64_t cconst, double wmax, int form, int hv,
+                                                     const int *__restrict__ vmap, const double *__restrict__ tauV,
                                                      int8_t *__restrict__ Tq, double *__restrict__ sigma,
                                                      double *__restrict__ tau, double *__restrict__ invtau,
                                                      long long *__restrict__ qconst, const double *__restrict__ tauovr) {
-    const int r = blockIdx.x;
+    const int r = slot0 + blockIdx.x; // slot
     if (rowcol[r] < 0) return;
-    const double *th = Theta + (int64_t)r * Qp;
+    const double *th = Theta + (int64_t)srow[r] * Qp;
     __shared__ double red[256];
     const int tid = threadIdx.x;
     double mx = 0.0;
@@ -119,20 +128,31 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
     }
     q0 += redl[0];
     if (tid == 0) {
-        // |E| <= sigma * sum|q|  (|X| <= 1)  =>  bound on |V|
+        // |E| <= sigma * sum|q|  (|X| <= 1)
         const double emax = red[0] * sg;
-        const double B = (form == 2) ? 2.0 * wmax : wmax * exp(emax);
-        // |V|/tau <= 2.13e9: the largest magnitude whose 4 balanced base-256 digits fit the packed
-        // (q + 0x80808080) ^ 0x80808080 form used by the forward epilogue
-        // The bound exp(sum|theta|) can exceed the largest actual |V| by many orders of magnitude (dense
-        // theta); the caller then re-runs the row with tau taken from the largest |V| the first pass saw, and
-        // the solver passes max|V| of its previous pass times exp(||step||_1), which bounds the new weights.
-        double t = B * (1.0 + 1e-12) / 2130000000.0;
-        if (tauovr && tauovr[r] > 0.0 && tauovr[r] < t) t = tauovr[r]; // a tighter rigorous scale from the caller
+        double t, it;
+        if (hv) {
+            // Hessian-vector pass: the row is a direction p, the forward epilogue forms u_k = h_k (x_k . p) with
+            // h_k = tau_V |q_V| the weights of the row's last objective pass (slot vmap[r]); |x_k . p| <= emax, so
+            // u_k / (tau_V emax) = |q_V| * (x_k . p) / emax is an integer of at most 31 bits.
+            const double pn = emax > 0.0 ? emax : 1.0;
+            t = tauV[vmap[r]] * pn;
+            it = 1.0 / pn;
+        } else {
+            const double B = (form == 2) ? 2.0 * wmax : wmax * exp(emax); // bound on |V|
+            // |V|/tau <= 2.13e9: the largest magnitude whose 4 balanced base-256 digits fit the packed
+            // (q + 0x80808080) ^ 0x80808080 form used by the forward epilogue.
+            // The bound exp(sum|theta|) can exceed the largest actual |V| by many orders of magnitude (dense
+            // theta); the caller then re-runs the row with tau taken from the largest |V| the first pass saw, and
+            // the solver passes max|V| of its previous pass times exp(||step||_1), which bounds the new weights.
+            t = B * (1.0 + 1e-12) / 2130000000.0;
+            if (tauovr && tauovr[r] > 0.0 && tauovr[r] < t) t = tauovr[r]; // a tighter rigorous scale from the caller
+            it = 1.0 / t;
+        }
         sigma[r] = sg;
         qconst[r] = q0;
         tau[r] = t;
-        invtau[r] = 1.0 / t;
+        invtau[r] = it;
     }
 }
 
@@ -373,7 +393,8 @@ __device__ __forceinline__ void ring_wait_ahead(int ahead) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int LF, int FORM /* 0: exp forms (RISE, logRISE), 2: RPLE */, bool WANTF,
+template <int LF, int FORM /* 0: exp forms (RISE, logRISE), 2: RPLE; Hessian-vector products: 3 (exp forms), 4 (RPLE) */,
+          bool WANTF,
           bool WIDE /* more than 32768 statistics columns: |acc_l| <= 128 Qfp no longer leaves room for the int32 pairing */>
 __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const unsigned *__restrict__ Xb, const unsigned *__restrict__ Sb, const int8_t *__restrict__ Tq,
@@ -381,8 +402,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const double *__restrict__ sigma, const long long *__restrict__ qconst, const double *__restrict__ invtau,
     int64_t Kp, int ntiles_k, int nk /* 64-column steps */, double wuni /* > 0: every real sample has this weight */,
     int64_t Kreal, int8_t *__restrict__ Vq, long long *__restrict__ csum, long long *__restrict__ asum,
-    double *__restrict__ fsum, unsigned *__restrict__ mmax) {
+    double *__restrict__ fsum, unsigned *__restrict__ mmax,
+    // Hessian-vector forms only: the limb planes of V written by the rows' last objective pass, the slot that holds
+    // them for each slot of this pass, and their scales
+    const int8_t *__restrict__ Vsrc, const int *__restrict__ vmap, const double *__restrict__ tauV) {
     constexpr int WM = 2;                 // 32-sample MFMA tiles per wave
+    constexpr bool HV = FORM >= 3;
     constexpr int BR = 32 * LF;           // rows of the Tq image
     constexpr int NPIECE = 2 + BR / 16, NP = (NPIECE + 3) / 4;
     constexpr int STAGE = NPIECE * 1024, NS = 4;
@@ -500,6 +525,13 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     // tile i are 16 contiguous bytes per limb: no LDS transpose, two 16-byte stores per limb.
     const int form = FORM;
     int8_t *vimg = Vq + vq_off(mytile * 32 + lr, 0, k0 + wave * 64, Kp) + h * 32; // row (limb 0, lr) of the wave's image
+    const int8_t *vsrc = nullptr; // Hessian-vector forms: the same bytes of the row's V image
+    double tvh = 0.0;
+    if (HV && active) {
+        const int vs = vmap[r];
+        vsrc = Vsrc + vq_off(vs, 0, k0 + wave * 64, Kp) + h * 32;
+        tvh = tauV[vs];
+    }
     long long cs = 0, as = 0;
     double fp = 0.0;
     int mx = 0;
@@ -511,11 +543,24 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const unsigned dh0 = (unsigned)rc * 0x85EBCA6Bu + (unsigned)(kw + 4 * h) * 0x9E3779B9u;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-        v4i pl[LB];
+        v4i pl[LB], pv[LB];
+        if (HV) {
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb) pv[lb] = active ? *reinterpret_cast<const v4i *>(vsrc + lb * 32 * 64 + i * 16) : (v4i){0, 0, 0, 0};
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int64_t kk = kw + i * 32 + 8 * g + 4 * h;
-            unsigned dj[4];
+            unsigned dj[4], dv[4];
+            if (HV) { // the 4 balanced digits of V of each of the group's 4 samples (inverse of the transpose below)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned sel = ((4u + j) << 8) | (unsigned)j;
+                    const unsigned t01 = __builtin_amdgcn_perm((unsigned)pv[1][g], (unsigned)pv[0][g], sel);
+                    const unsigned t23 = __builtin_amdgcn_perm((unsigned)pv[3][g], (unsigned)pv[2][g], sel);
+                    dv[j] = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+                }
+            }
             if (FORM == 2) { // RPLE: gate each 4-sample group on the previous one (its longer arithmetic otherwise
                              // interleaves across groups and spills); pure arithmetic floats across sched_barriers
                 asm volatile("" : "+v"(sg2), "+v"(fp));
@@ -548,7 +593,18 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                 const double dith = (double)(int)(dh0 + (unsigned)(i * 32 + 8 * g + j) * 0x9E3779B9u) * 2.3283064365386963e-10; // [-1/2, 1/2)
                 const bool neg = ((sgn[i] >> (8 * g + j)) & 1u) != 0; // s_u^k = -1
                 int vq;
-                if (FORM == 2) { // RPLE (:317): f = w log(1 + exp(-2E)), V = -2 w s / (1 + exp(2E)), E = s * Ea
+                if (HV) {
+                    // Hessian-vector product: u_k = h_k (x_k . p), h_k the curvature weight of the row's iterate:
+                    // |V_k| for the exp forms, 2a(1 - a/(2w)) with a = |V_k| for RPLE.  In units of tau_V * emax:
+                    // u = (h_k / tau_V) * (x_k . p) / emax, |.| <= 2^31 (Ea = x_k . p, it = 1 / emax)
+                    const int qv = (int)((dv[j] ^ 0x80808080u) - 0x80808080u);
+                    double hh = (double)(qv < 0 ? -qv : qv);
+                    if (FORM == 4) {
+                        const double wk0 = wuni > 0.0 ? (kk + j < Kreal ? wuni : 0.0) : w[kk + j];
+                        hh = wk0 > 0.0 ? 2.0 * hh * (1.0 - hh * tvh / (2.0 * wk0)) : 0.0;
+                    }
+                    vq = __double2loint(fma(hh, Ea * it, dith) + 6755399441055744.0);
+                } else if (FORM == 2) { // RPLE (:317): f = w log(1 + exp(-2E)), V = -2 w s / (1 + exp(2E)), E = s * Ea
                     const double wk0 = wuni > 0.0 ? (kk + j < Kreal ? wuni : 0.0) : w[kk + j];
                     const double E2 = neg ? -2.0 * Ea : 2.0 * Ea;
                     const double u = exp_tab(-fabs(E2), etab); // in (0, 1]
@@ -608,7 +664,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
         atomicAdd(reinterpret_cast<unsigned long long *>(&csum[r]), (unsigned long long)cs);
         if (WANTF) atomicAdd(reinterpret_cast<unsigned long long *>(&asum[r]), (unsigned long long)as);
     }
-    if (form != 2) {
+    if (form == 0) {
         const int mo = __shfl_xor(mx, 32);
         mx = mo > mx ? mo : mx;
         if (active && h == 0) atomicMax(&mmax[r], (unsigned)mx);
@@ -735,19 +791,19 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
         }
 }
 
-// G[r][c] = tau_r * (csum[r] - 2 sum_l 256^l Gacc[(t*4+l)*32+rl][c])  (x = 1 - 2b);  G[r][cconst] = tau_r * csum[r];
-// f[r] = tau_r * asum[r]  (= sum_k w_k exp(-E) for RISE / logRISE; RPLE keeps its FP64 sum)
+// G[row][c] = tau_r * (csum[r] - 2 sum_l 256^l Gacc[(t*4+l)*32+rl][c])  (x = 1 - 2b);  G[row][cconst] = tau_r * csum[r];
+// f[r] = tau_r * asum[r]  (= sum_k w_k exp(-E) for RISE / logRISE; RPLE keeps its FP64 sum).  r = slot, row = srow[r].
 __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__ Gacc, const double *__restrict__ tau,
                                                      const long long *__restrict__ csum,
-                                                     const long long *__restrict__ asum,
-                                                     const int *__restrict__ rowcol, int64_t Qp, int64_t Qfp, int64_t Qf,
-                                                     int64_t cconst, int form, int want_grad,
+                                                     const long long *__restrict__ asum, const int *__restrict__ srow,
+                                                     const int *__restrict__ rowcol, int slot0, int64_t Qp, int64_t Qfp, int64_t Qf,
+                                                     int64_t cconst, int form, int want_grad, int hv,
                                                      double *__restrict__ G, double *__restrict__ f) {
-    const int r = blockIdx.y;
+    const int r = slot0 + blockIdx.y;
     if (rowcol[r] < 0) return;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const double t = tau[r];
-    if (c == 0 && form != 2) {
+    if (c == 0 && form != 2 && !hv) {
         if (want_grad) { // f = sum_k w exp(-E) = -sum_k V_k s_k = -G[r][u] (u = the node's own, masked, column)
             const int tile = r >> 5, rl = r & 31, u = rowcol[r];
             long long s = 0;
@@ -769,7 +825,7 @@ __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__
     } else if (c == cconst) {
         v = t * (double)csum[r];
     }
-    G[(int64_t)r * Qp + c] = v;
+    G[(int64_t)srow[r] * Qp + c] = v;
 }
 
 
@@ -788,23 +844,25 @@ __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__
 // (vq_pos within each 64): RISE / logRISE h = |V|; RPLE h = 2a(1 - a/(2w)), a = |V|
 __global__ __launch_bounds__(256) void k_make_hw(const int8_t *__restrict__ Vq, const unsigned *__restrict__ Sb,
                                                  const double *__restrict__ w, const double *__restrict__ tau,
-                                                 const int *__restrict__ rowcol, const int *__restrict__ mt, int64_t Kp,
+                                                 const int *__restrict__ rowcol /* row -> node */,
+                                                 const int *__restrict__ vslot /* row -> slot of its V planes */,
+                                                 const int *__restrict__ mt, int64_t Kp,
                                                  int64_t Hpitch, int64_t kstride, int form, int8_t *__restrict__ Hq,
                                                  long long *__restrict__ hS) {
     const int r = blockIdx.y;
     if (mt[r] == 0) return;
-    const int u = rowcol[r];
+    const int u = rowcol[r], vs = vslot[r];
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;        // compact index
     const int64_t k = (j >> 9) * kstride * 512 + (j & 511);          // the configuration it stands for
     const int tile = r >> 5, rl = r & 31;
     int mag = 0;
     if (k < Kp) {
-        const int8_t *vq = Vq + vq_off(r, 0, k, Kp);
+        const int8_t *vq = Vq + vq_off(vs, 0, k, Kp);
         const int q = (int)vq[0] + 256 * ((int)vq[32 * 64] + 256 * ((int)vq[64 * 64] + 256 * (int)vq[96 * 64]));
         const int sgn = (Sb[(int64_t)u * (Kp >> 5) + (k >> 5)] >> (k & 31)) & 1u; // s_u^k = 1 - 2 sgn
         mag = sgn ? q : -q;                                           // V = -w exp(-E) s: |V| = -q s >= 0
         if (form == 2) {
-            const double t = tau[r], a = (double)mag * t, wk = w[k];
+            const double t = tau[vs], a = (double)mag * t, wk = w[k];
             mag = wk > 0 ? (int)rint(2.0 * a * (1.0 - a / (2.0 * wk)) / t) : 0;
         }
     }
@@ -987,7 +1045,8 @@ __global__ __launch_bounds__(256, 2) void k_hess_bits_blk(const unsigned *__rest
 }
 
 __global__ __launch_bounds__(256) void k_hess_i8_fin(const long long *__restrict__ H64, const long long *__restrict__ hS,
-                                                     const double *__restrict__ tau, const int *__restrict__ mt,
+                                                     const double *__restrict__ tau, const int *__restrict__ vslot,
+                                                     const int *__restrict__ mt,
                                                      const long long *__restrict__ hoff, double *__restrict__ H) {
     const int r = blockIdx.y;
     const int m = mt[r] * 32;
@@ -997,7 +1056,7 @@ __global__ __launch_bounds__(256) void k_hess_i8_fin(const long long *__restrict
     if ((j >> 5) > (i >> 5)) return;
     const long long *Hr = H64 + hoff[r];
     const long long T = Hr[(int64_t)i * m + j], Ti = Hr[(int64_t)i * m + i], Tj = Hr[(int64_t)j * m + j];
-    H[hoff[r] + (int64_t)i * m + j] = tau[r] * (double)(hS[r] - 2 * Ti - 2 * Tj + 4 * T);
+    H[hoff[r] + (int64_t)i * m + j] = tau[vslot[r]] * (double)(hS[r] - 2 * Ti - 2 * Tj + 4 * T);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1012,49 +1071,52 @@ __global__ __launch_bounds__(256) void k_hess_i8_fin(const long long *__restrict
         }                                                                                             \
     } while (0)
 
-void i8_get_v(void *p, const int8_t **Vq, const double **tau) {
+// per-slot results of the last pass of the given kind (device pointers): tau (scale of the V / u planes), mmax
+void i8_slot_results(void *p, int hv, const double **tau, const unsigned **mmax) {
     I8Ws *w = static_cast<I8Ws *>(p);
-    *Vq = w ? w->Vq : nullptr;
-    *tau = w ? w->tau : nullptr;
+    *tau = w ? w->sc[hv ? 1 : 0].tau : nullptr;
+    *mmax = w ? w->sc[hv ? 1 : 0].mmax : nullptr;
 }
-
-const unsigned *i8_get_mmax(void *p) { return p ? static_cast<I8Ws *>(p)->mmax : nullptr; }
 
 void i8_free(void *p) {
     I8Ws *w = static_cast<I8Ws *>(p);
     if (!w) return;
-    void *ptrs[] = {w->Tq, w->Vq, w->Gacc, w->sigma, w->tau, w->invtau, w->qconst, w->csum, w->asum, w->mmax, w->tauovr,
-                    w->Hq, w->hS, w->H64, w->Mb};
+    void *ptrs[] = {w->Tq, w->Vq, w->Uq, w->Gacc, w->tauovr, w->Hq, w->hS, w->H64, w->Mb};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    for (auto &sc : w->sc) {
+        void *qs[] = {sc.sigma, sc.tau, sc.invtau, sc.qconst, sc.csum, sc.asum, sc.mmax};
+        for (void *q : qs)
+            if (q) (void)hipFree(q);
+    }
     delete w;
 }
 
-static int i8_ensure(void **wsp, const DevProblem &d, int Rp, int LF, std::string *err) {
+static int i8_ensure(void **wsp, const DevProblem &d, int64_t slots, std::string *err) {
     I8Ws *w = static_cast<I8Ws *>(*wsp);
-    if (w && w->rows >= Rp && w->LF == LF) return GML_OK;
+    if (w && w->slots >= slots) return GML_OK;
     if (w) i8_free(w);
     *wsp = nullptr;
     w = new I8Ws();
-    w->LF = LF;
     *wsp = w; // owned by the handle from here on: a failed allocation below is released by i8_free
-    I8CHK(hipMalloc(&w->Tq, (size_t)Rp * LF * d.Qfp));
-    I8CHK(hipMalloc(&w->Vq, (size_t)Rp * LB * d.Kp));
-    I8CHK(hipMalloc(&w->Gacc, sizeof(int32_t) * (size_t)Rp * LB * d.Qfp));
-    I8CHK(hipMalloc(&w->sigma, sizeof(double) * Rp));
-    I8CHK(hipMalloc(&w->tau, sizeof(double) * Rp));
-    I8CHK(hipMalloc(&w->invtau, sizeof(double) * Rp));
-    I8CHK(hipMalloc(&w->qconst, sizeof(long long) * Rp));
-    I8CHK(hipMalloc(&w->csum, sizeof(long long) * Rp));
-    I8CHK(hipMalloc(&w->asum, sizeof(long long) * Rp));
-    I8CHK(hipMalloc(&w->mmax, sizeof(unsigned) * Rp));
-    I8CHK(hipMalloc(&w->tauovr, sizeof(double) * Rp));
-    I8CHK(hipMemset(w->Tq, 0, (size_t)Rp * LF * d.Qfp));
-    I8CHK(hipMemset(w->Vq, 0, (size_t)Rp * LB * d.Kp));
-    w->rows = Rp;
+    I8CHK(hipMalloc(&w->Tq, (size_t)slots * w->LF * d.Qfp));
+    I8CHK(hipMalloc(&w->Vq, (size_t)slots * LB * d.Kp));
+    I8CHK(hipMalloc(&w->Gacc, sizeof(int32_t) * (size_t)slots * LB * d.Qfp));
+    for (auto &sc : w->sc) {
+        I8CHK(hipMalloc(&sc.sigma, sizeof(double) * slots));
+        I8CHK(hipMalloc(&sc.tau, sizeof(double) * slots));
+        I8CHK(hipMalloc(&sc.invtau, sizeof(double) * slots));
+        I8CHK(hipMalloc(&sc.qconst, sizeof(long long) * slots));
+        I8CHK(hipMalloc(&sc.csum, sizeof(long long) * slots));
+        I8CHK(hipMalloc(&sc.asum, sizeof(long long) * slots));
+        I8CHK(hipMalloc(&sc.mmax, sizeof(unsigned) * slots));
+    }
+    I8CHK(hipMalloc(&w->tauovr, sizeof(double) * slots));
+    I8CHK(hipMemset(w->Tq, 0, (size_t)slots * w->LF * d.Qfp));
+    I8CHK(hipMemset(w->Vq, 0, (size_t)slots * LB * d.Kp));
+    w->slots = slots;
     return GML_OK;
 }
-
 
 // Largest number of configurations one int8 Hessian call can use (pitch of its weight planes): all of them.
 int64_t i8_hess_kmax(const DevProblem &d) { return d.Kp; }
@@ -1079,12 +1141,13 @@ static void launch_hess_blk(const I8Ws *w, const DevProblem &d, const int *dF, c
                        dHoff, cap, Kh, d.Kp, w->hKh, kc, kstride, w->H64);
 }
 
-// Working-set Hessians from the int8 limb planes of the last pass over Kh configurations (a multiple of 512; block cb
-// of the compact index = samples [512 cb kstride, +512)).  Returns GML_EUNSUPPORTED when a working set exceeds 512
-// entries (the solver caps its Newton blocks there).
-int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF, const int *dMt, const int *hMt,
-               const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh, int64_t kstride, double *dH,
-               hipStream_t st, std::string *err) {
+// Working-set Hessians of the rows 0..R-1 of the caller's arrays (mt[r] = 0: skip) from the int8 limb planes their
+// last objective passes left in the slots vslot[r], over Kh configurations (a multiple of 512; block cb of the
+// compact index = samples [512 cb kstride, +512)).  Returns GML_EUNSUPPORTED when a working set exceeds 512 entries
+// (the solver handles larger ones matrix-free).
+int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node */, const int *dVslot /* row -> slot */, const int *dF,
+               const int *dMt, const int *hMt, const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh,
+               int64_t kstride, double *dH, hipStream_t st, std::string *err) {
     I8Ws *w = static_cast<I8Ws *>(wsp);
     if (!w) {
         if (err) *err = "no int8 pass has run on this handle";
@@ -1096,16 +1159,17 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF
         if (hMt[r] <= 4) maxsmall = hMt[r] > maxsmall ? hMt[r] : maxsmall;
     }
     if (maxm > 16) return GML_EUNSUPPORTED;
-    const int64_t pitch = d.Kp;
+    const int64_t pitch = d.Kp, Rp = (R + 31) / 32 * 32;
     if (Kh > pitch) Kh = pitch;
-    if (w->hKh != pitch) {
+    if (w->hKh != pitch || w->hrows < Rp) {
         if (w->Hq) (void)hipFree(w->Hq);
         if (w->hS) (void)hipFree(w->hS);
         w->Hq = nullptr;
         w->hS = nullptr;
-        I8CHK(hipMalloc(&w->Hq, (size_t)w->rows * LB * pitch));
-        I8CHK(hipMalloc(&w->hS, sizeof(long long) * w->rows));
+        I8CHK(hipMalloc(&w->Hq, (size_t)Rp * LB * pitch));
+        I8CHK(hipMalloc(&w->hS, sizeof(long long) * Rp));
         w->hKh = pitch;
+        w->hrows = Rp;
     }
     if (!w->Mb) {
         I8CHK(hipMalloc(&w->Mb, (size_t)d.Qp * (d.Kp / 8)));
@@ -1120,30 +1184,31 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol, const int *dF
         w->hcap_elems = need;
     }
     I8CHK(hipMemsetAsync(w->H64, 0, sizeof(long long) * need, st));
-    I8CHK(hipMemsetAsync(w->hS, 0, sizeof(long long) * w->rows, st));
-    hipLaunchKernelGGL(k_make_hw, dim3((unsigned)(Kh / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Sb, d.w, w->tau, dRowcol, dMt, d.Kp,
-                       pitch, kstride, form, w->Hq, w->hS);
+    I8CHK(hipMemsetAsync(w->hS, 0, sizeof(long long) * Rp, st));
+    hipLaunchKernelGGL(k_make_hw, dim3((unsigned)(Kh / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Sb, d.w, w->sc[0].tau, dRowcol, dVslot,
+                       dMt, d.Kp, pitch, kstride, form, w->Hq, w->hS);
     if (maxsmall > 0) launch_hess_blk<2>(w, d, dF, dMt, dHoff, R, cap, maxsmall, Kh, kstride, st);
     if (maxm > 4) launch_hess_blk<4>(w, d, dF, dMt, dHoff, R, cap, maxm, Kh, kstride, st);
     hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64,
-                       w->hS, w->tau, dMt, dHoff, dH);
+                       w->hS, w->sc[0].tau, dVslot, dMt, dHoff, dH);
     I8CHK(hipGetLastError());
     return GML_OK;
 }
 
+// one launch zeroes every accumulator of a pass over the slots [slot0, slot0 + ns): slot sums, maxima, f, and the i32
+// gradient planes of those slots' tiles
 __global__ __launch_bounds__(256) void k_zero_pass(long long *__restrict__ csum, long long *__restrict__ asum,
-                                                   unsigned *__restrict__ mmax, double *__restrict__ f, int Rp,
-                                                   v4i *__restrict__ gacc, int64_t ngacc, v4i *__restrict__ g, int64_t ng) {
+                                                   unsigned *__restrict__ mmax, double *__restrict__ f, int slot0, int ns,
+                                                   v4i *__restrict__ gacc, int64_t ngacc) {
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
-    if (i0 < Rp) {
-        csum[i0] = 0;
-        asum[i0] = 0;
-        mmax[i0] = 0;
-        f[i0] = 0.0;
+    if (i0 < ns) {
+        csum[slot0 + i0] = 0;
+        asum[slot0 + i0] = 0;
+        mmax[slot0 + i0] = 0;
+        if (f) f[slot0 + i0] = 0.0;
     }
     const v4i z = {0, 0, 0, 0};
     for (int64_t i = i0; i < ngacc; i += stride) gacc[i] = z;
-    for (int64_t i = i0; i < ng; i += stride) g[i] = z;
 }
 
 int i8_limbs_forward() {
@@ -1155,85 +1220,95 @@ int i8_limbs_forward() {
     return lf;
 }
 
+struct FwdLaunch {
+    const I8Ws *w;
+    const DevProblem *d;
+    const SlotScalars *sc;
+    const int *rowcol, *groups, *vmap;
+    int ngroups;
+    double *F;
+    int8_t *Vout;
+    hipStream_t st;
+};
+
 template <int LF, int FORM, bool WANTF, bool WIDE>
-static void launch_fwd3(const I8Ws *w, const DevProblem &d, const int *dRowcol, const int *dGroups, int ngroups, double *dF,
-                        hipStream_t st) {
+static void launch_fwd3(const FwdLaunch &a) {
     constexpr int STAGE = (2 + 2 * LF) * 1024;
     constexpr int shmem = 4 * STAGE + 512 + 1024; // ring + exp, log tables
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF, WIDE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
+    const DevProblem &d = *a.d;
     const int ntk = (int)(d.Kp / 256);
-    const int grid = ((ntk + 7) / 8) * 8 * ((ngroups + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE>), dim3(grid), dim3(256), shmem, st, d.Xb, d.Sb, w->Tq, dRowcol, dGroups,
-                       ngroups, d.w, w->sigma, w->qconst, w->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, w->Vq, w->csum,
-                       w->asum, dF, w->mmax);
+    const int grid = ((ntk + 7) / 8) * 8 * ((a.ngroups + 7) / 8) * 8;
+    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.w->Tq, a.rowcol, a.groups,
+                       a.ngroups, d.w, a.sc->sigma, a.sc->qconst, a.sc->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, a.Vout,
+                       a.sc->csum, a.sc->asum, a.F, a.sc->mmax, a.w->Vq, a.vmap, a.w->sc[0].tau);
 }
 
 template <int LF, int FORM, bool WANTF>
-static void launch_fwd2(const I8Ws *w, const DevProblem &d, const int *dRowcol, const int *dGroups, int ngroups, double *dF,
-                        hipStream_t st) {
-    if (d.Qfp > 32768) launch_fwd3<LF, FORM, WANTF, true>(w, d, dRowcol, dGroups, ngroups, dF, st);
-    else launch_fwd3<LF, FORM, WANTF, false>(w, d, dRowcol, dGroups, ngroups, dF, st);
+static void launch_fwd2(const FwdLaunch &a) {
+    if (a.d->Qfp > 32768) launch_fwd3<LF, FORM, WANTF, true>(a);
+    else launch_fwd3<LF, FORM, WANTF, false>(a);
 }
 
 template <int LF>
-static void launch_fwd(const I8Ws *w, const DevProblem &d, const int *dRowcol, const int *dGroups, int ngroups, int form, bool wantf,
-                       double *dF, hipStream_t st) {
-    if (form == 2) launch_fwd2<LF, 2, true>(w, d, dRowcol, dGroups, ngroups, dF, st);
-    else if (wantf) launch_fwd2<LF, 0, true>(w, d, dRowcol, dGroups, ngroups, dF, st);
-    else launch_fwd2<LF, 0, false>(w, d, dRowcol, dGroups, ngroups, dF, st);
+static void launch_fwd(const FwdLaunch &a, int form, bool wantf, int hv) {
+    if (hv) {
+        if (form == 2) launch_fwd2<LF, 4, false>(a);
+        else launch_fwd2<LF, 3, false>(a);
+    } else if (form == 2) launch_fwd2<LF, 2, true>(a);
+    else if (wantf) launch_fwd2<LF, 0, true>(a);
+    else launch_fwd2<LF, 0, false>(a);
 }
 
-int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dRowcol, const int *dGroups /* active 32-node
-            tiles, padded with -1 to a multiple of 4 */, int ngroups, int Rp, int form, bool want_grad, double *dF, double *dG, hipStream_t st,
-            hipEvent_t *ev, const double *hTauOvr /* Rp per-row tau overrides (0 = none) or NULL */, std::string *err) {
+// One pass of the int8-limb operator over the slots the caller lists (I8Pass, gml_dev.h).
+int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass &a, hipStream_t st, hipEvent_t *ev, std::string *err) {
     if (d.Kp > (int64_t)1 << 24) {
         if (err) *err = "GML_PREC_I8X supports up to 2^24 configurations per handle (i32 accumulators)";
         return GML_EUNSUPPORTED;
     }
-    const int LF = i8_limbs_forward();
-    int rc = i8_ensure(wsp, d, Rp, LF, err);
+    int rc = i8_ensure(wsp, d, slot_capacity, err);
     if (rc) return rc;
     I8Ws *w = static_cast<I8Ws *>(*wsp);
-    if (ngroups + 1 > 4096) {
-        if (err) *err = "too many node tiles";
-        return GML_EUNSUPPORTED;
+    int LF = a.lf ? a.lf : i8_limbs_forward();
+    if (LF > w->LF) LF = w->LF;
+    if (a.ngroups + 1 > 65536 || a.slot1 > w->slots || a.slot0 % 32 || a.slot1 % 32) {
+        if (err) *err = "bad slot range";
+        return GML_EINVAL;
     }
-    // one launch zeroes every accumulator of the pass (row sums, maxima, the i32 gradient planes, f and G)
-    hipLaunchKernelGGL(k_zero_pass, dim3(1024), dim3(256), 0, st, w->csum, w->asum, w->mmax, dF, Rp,
-                       reinterpret_cast<v4i *>(w->Gacc), want_grad ? (int64_t)Rp * LB * d.Qfp / 4 : 0, reinterpret_cast<v4i *>(dG),
-                       want_grad ? (int64_t)Rp * d.Qp / 2 : 0);
-    const double *dOvr = nullptr;
-    if (hTauOvr) {
-        // (pageable source: the runtime stages it before returning, the caller keeps it alive until its final sync)
-        I8CHK(hipMemcpyAsync(w->tauovr, hTauOvr, sizeof(double) * Rp, hipMemcpyHostToDevice, st));
-        dOvr = w->tauovr;
+    const int hv = a.hv ? 1 : 0;
+    if (hv && !w->Uq) {
+        I8CHK(hipMalloc(&w->Uq, (size_t)w->slots * LB * d.Kp));
+        I8CHK(hipMemsetAsync(w->Uq, 0, (size_t)w->slots * LB * d.Kp, st));
     }
+    const SlotScalars &sc = w->sc[hv];
+    const int ns = a.slot1 - a.slot0;
+    const bool grad = a.want_grad || hv;
+    int32_t *gacc0 = w->Gacc + (int64_t)a.slot0 * LB * d.Qfp;
+    hipLaunchKernelGGL(k_zero_pass, dim3(1024), dim3(256), 0, st, sc.csum, sc.asum, sc.mmax, a.F, a.slot0, ns, reinterpret_cast<v4i *>(gacc0),
+                       grad ? (int64_t)ns * LB * d.Qfp / 4 : 0);
+#define QUANT(LFV)                                                                                                                    \
+    hipLaunchKernelGGL((k_quant_theta<LFV>), dim3(ns), dim3(256), 0, st, a.theta, a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.cconst,   \
+                       d.wmax, a.form, hv, a.vmap, w->sc[0].tau, w->Tq, sc.sigma, sc.tau, sc.invtau, sc.qconst, a.tauovr)
     switch (LF) {
-    case 3:
-        hipLaunchKernelGGL((k_quant_theta<3>), dim3(Rp), dim3(256), 0, st, dTheta, dRowcol, d.Qp, d.Qfp, d.cconst, d.wmax,
-                           form, w->Tq, w->sigma, w->tau, w->invtau, w->qconst, dOvr);
-        break;
-    case 5:
-        hipLaunchKernelGGL((k_quant_theta<5>), dim3(Rp), dim3(256), 0, st, dTheta, dRowcol, d.Qp, d.Qfp, d.cconst, d.wmax,
-                           form, w->Tq, w->sigma, w->tau, w->invtau, w->qconst, dOvr);
-        break;
-    default:
-        hipLaunchKernelGGL((k_quant_theta<4>), dim3(Rp), dim3(256), 0, st, dTheta, dRowcol, d.Qp, d.Qfp, d.cconst, d.wmax,
-                           form, w->Tq, w->sigma, w->tau, w->invtau, w->qconst, dOvr);
+    case 3: QUANT(3); break;
+    case 4: QUANT(4); break;
+    default: QUANT(5);
     }
+#undef QUANT
     if (ev) I8CHK(hipEventRecord(ev[0], st));
+    FwdLaunch fl{w, &d, &sc, a.rowcol, a.groups, a.vmap, a.ngroups, a.F, hv ? w->Uq : w->Vq, st};
     switch (LF) {
     // with the gradient requested, f comes out of the backward GEMM for free (column u of row u)
-    case 3: launch_fwd<3>(w, d, dRowcol, dGroups, ngroups, form, !want_grad, dF, st); break;
-    case 5: launch_fwd<5>(w, d, dRowcol, dGroups, ngroups, form, !want_grad, dF, st); break;
-    default: launch_fwd<4>(w, d, dRowcol, dGroups, ngroups, form, !want_grad, dF, st);
+    case 3: launch_fwd<3>(fl, a.form, !a.want_grad, hv); break;
+    case 4: launch_fwd<4>(fl, a.form, !a.want_grad, hv); break;
+    default: launch_fwd<5>(fl, a.form, !a.want_grad, hv);
     }
     if (ev) I8CHK(hipEventRecord(ev[1], st));
-    if (want_grad) {
+    if (grad) {
         const int nNt = (int)((d.Qfp + 255) / 256);
         static const int TM = [] { const char *e = getenv("GML_BWD_TM"); return e && atoi(e) == 2 ? 2 : 1; }();
-        const int ngt = (ngroups + TM - 1) / TM;
+        const int ngt = (a.ngroups + TM - 1) / TM;
         const int T = ngt * nNt;
         // split-K: a multiple of 8 chunks (one XCD each), at least 16, and enough workgroups (~1024 x 2/TM) to
         // fill the chip when few node tiles are active (node-sharded ranks, late solver iterations)
@@ -1245,20 +1320,21 @@ int i8_pass(void **wsp, const DevProblem &d, const double *dTheta, const int *dR
         nsplit = (int)((d.Kp + kchunk - 1) / kchunk);
         const int grid = ((nsplit + 7) / 8) * 8 * T;
         const int shmem = 4 * (8 * TM + 2) * 1024;
-        // dGroups holds the active tile list padded with -1 to an even count
+        const int8_t *Vin = hv ? w->Uq : w->Vq;
+        // the tile list is padded with -1 to an even count
         if (TM == 2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-            hipLaunchKernelGGL(k_bwd_i8<2>, dim3(grid), dim3(512), shmem, st, w->Vq, d.Xtb, dGroups, ngt, nNt, d.Qfp, d.Kp, kchunk,
+            hipLaunchKernelGGL(k_bwd_i8<2>, dim3(grid), dim3(512), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
                                nsplit, w->Gacc);
         } else {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-            hipLaunchKernelGGL(k_bwd_i8<1>, dim3(grid), dim3(256), shmem, st, w->Vq, d.Xtb, dGroups, ngt, nNt, d.Qfp, d.Kp, kchunk,
+            hipLaunchKernelGGL(k_bwd_i8<1>, dim3(grid), dim3(256), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
                                nsplit, w->Gacc);
         }
     }
     if (ev) I8CHK(hipEventRecord(ev[2], st));
-    hipLaunchKernelGGL(k_finalize_i8, dim3((unsigned)((d.Qp + 255) / 256), (unsigned)Rp), dim3(256), 0, st, w->Gacc, w->tau,
-                       w->csum, w->asum, dRowcol, d.Qp, d.Qfp, d.Qf, d.cconst, form, want_grad ? 1 : 0, dG, dF);
+    hipLaunchKernelGGL(k_finalize_i8, dim3((unsigned)((d.Qp + 255) / 256), (unsigned)ns), dim3(256), 0, st, w->Gacc, sc.tau, sc.csum, sc.asum,
+                       a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.Qf, d.cconst, a.form, grad ? 1 : 0, hv, a.G, a.F);
     I8CHK(hipGetLastError());
     return GML_OK;
 }

@@ -1,0 +1,729 @@
+// gml_learn: the batched l1 solver of libgml_hip, device-resident.
+//
+// Every local node u solves   min_x f_u(x) + lambda * sum_{j penalised} |x_j|   -- the problem the reference builds
+// for Ipopt with the z >= |x| epigraph (GraphicalModelLearning.jl:166-177, one model per node in the loop :161) -- and
+// all nodes advance in lock-step:
+//   1. one device pass gives f and the full gradient of every active node (int8-limb or FP64 MFMA kernels);
+//   2. pseudo-gradient / KKT residual and working set per node (k_select); converged nodes drop out;
+//   3. Newton direction on the working set: Hessian by one device kernel over a sub-sample of the configurations +
+//      batched Cholesky (working sets up to max_working entries), or matrix-free conjugate gradients with
+//      Hessian-vector products from the same GEMM kernels (larger working sets: dense optima);
+//   4. projected (orthant-wise) backtracking line search: the first trial is a full pass (it usually succeeds), further
+//      trials are objective-only passes over the rows that need them.
+// The iterates X, gradients G, trial points, directions and pseudo-gradients are [rows][Qp] arrays that stay in HBM;
+// per iteration only per-row scalars (a few dozen bytes per node) and the small control blocks of the passes cross PCIe.
+// A pass evaluates exactly the active rows, packed into consecutive slots of the int8-limb workspace (full MFMA tiles
+// whatever subset is still active).
+#include "gml_internal.h"
+#include "gml_solver.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace gml;
+
+#define RCCHK(expr)             \
+    do {                        \
+        const int rc__ = (expr); \
+        if (rc__) return rc__;  \
+    } while (0)
+
+namespace {
+
+// device allocations of one gml_learn call, released together
+struct Arena {
+    std::vector<void *> ptrs;
+    ~Arena() {
+        for (void *q : ptrs)
+            if (q) (void)hipFree(q);
+    }
+    template <typename T> hipError_t get(T **out, size_t count) {
+        *out = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(out), sizeof(T) * std::max<size_t>(count, 1));
+        if (e == hipSuccess) ptrs.push_back(*out);
+        return e;
+    }
+};
+
+} // namespace
+
+extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, const gml_opts *opts_in, double *out,
+                         double *kkt_out, gml_stats *stats_out) {
+    if (!p || !out) return fail(GML_EINVAL, "NULL argument");
+    if (formulation < 0 || formulation > 2) return fail(GML_EINVAL, "unknown formulation %d", formulation);
+    if (formulation != GML_RISE && p->order != 2)
+        return fail(GML_EUNSUPPORTED, "multi-body statistics are defined for RISE only (multiRISE, :83-152)");
+    if (!(regularizer_c >= 0)) return fail(GML_EINVAL, "regularizer must be >= 0");
+    gml_opts o;
+    if (opts_in) o = *opts_in;
+    else gml_default_opts(&o);
+    if (!(o.tol > 0)) o.tol = 1e-9;
+    if (o.max_iter <= 0) o.max_iter = 100;
+    if (o.max_working < 32) o.max_working = 512;
+    if (o.max_working > 512) o.max_working = 512;
+    o.max_working = (int)gml_round_up(o.max_working, 32);
+    if (o.max_add <= 0) o.max_add = 64;
+    if (o.precision != GML_PREC_F64 && o.precision != GML_PREC_I8X) return fail(GML_EINVAL, "unknown precision %d", o.precision);
+    HIPCHK(hipSetDevice(p->device));
+    const int64_t dbg_row = getenv("GML_DEBUG_ROW") ? atoll(getenv("GML_DEBUG_ROW")) : 0; // row traced at verbose >= 2
+    gml_stats stl;
+    std::memset(&stl, 0, sizeof stl);
+    gml_stats *stats = &stl;
+    const double t_start = gml_now_s();
+    hipStream_t st = p->st;
+    const DevProblem &d = p->d;
+
+    const int64_t R = p->node1 - p->node0, Rp = gml_round_up(R, 32), Qp = d.Qp, P = p->P;
+    const int capW = o.max_working, capP = capW;
+    const double lambda = gml_lambda(regularizer_c, p->n, p->M);
+    stats->lambda = lambda;
+
+    // ---- device state -------------------------------------------------------------------------------------------------
+    Arena A;
+    double *X, *G, *Xt, *Gt, *Xb, *D, *PG, *Gs = nullptr, *Rv = nullptr, *Pv = nullptr, *Hp = nullptr;
+    uint8_t *kind;
+    int *dNode, *dRows, *dRows2, *dRowsP, *dCtl, *dFidx, *dMt, *dVslot, *dHv = nullptr;
+    long long *dHoff;
+    double *dBest, *dAlpha, *dScale, *dS1, *dFs, *dOvr, *dgF, *dpgF, *dsol, *dSdiag, *dH = nullptr;
+    SelectOut *dSel;
+    TrialOut *dTrial;
+    CgState *dCg;
+    int64_t dH_elems = 0;
+    const size_t nd = (size_t)Rp * Qp;
+    // slots of the int8-limb workspace: every active row of a pass in its own slot, the passes of one iteration in
+    // disjoint ranges (their V planes feed the next Hessians)
+    const int64_t Scap = o.precision == GML_PREC_I8X ? Rp + gml_round_up(R / 2, 32) + 64 : Rp;
+    {
+        size_t freeb = 0, totalb = 0;
+        HIPCHK(hipMemGetInfo(&freeb, &totalb));
+        const double need = 7.0 * 8.0 * (double)nd + (double)nd;
+        if (need > 0.9 * (double)freeb)
+            return fail(GML_ENOMEM, "solver state of %.1f GB for %lld rows does not fit in %.1f GB free HBM", need / 1e9, (long long)R,
+                        freeb / 1e9);
+    }
+    HIPCHK(A.get(&X, nd));
+    HIPCHK(A.get(&G, nd));
+    HIPCHK(A.get(&Xt, nd));
+    HIPCHK(A.get(&Gt, nd));
+    HIPCHK(A.get(&Xb, nd));
+    HIPCHK(A.get(&D, nd));
+    HIPCHK(A.get(&PG, nd));
+    HIPCHK(A.get(&kind, nd));
+    HIPCHK(A.get(&dNode, (size_t)Rp));
+    HIPCHK(A.get(&dRows, (size_t)Rp));
+    HIPCHK(A.get(&dRows2, (size_t)Rp));
+    HIPCHK(A.get(&dRowsP, (size_t)Rp));
+    HIPCHK(A.get(&dCtl, (size_t)(2 * Scap + Scap / 32 + 8)));
+    HIPCHK(A.get(&dFidx, (size_t)Rp * capP));
+    HIPCHK(A.get(&dMt, (size_t)3 * Rp));
+    HIPCHK(A.get(&dVslot, (size_t)Rp));
+    HIPCHK(A.get(&dHoff, (size_t)Rp + 1));
+    HIPCHK(A.get(&dBest, (size_t)Rp));
+    HIPCHK(A.get(&dAlpha, (size_t)Rp));
+    HIPCHK(A.get(&dScale, (size_t)Rp));
+    HIPCHK(A.get(&dS1, (size_t)Rp));
+    HIPCHK(A.get(&dFs, (size_t)Scap));
+    HIPCHK(A.get(&dOvr, (size_t)Scap));
+    HIPCHK(A.get(&dgF, (size_t)Rp * capP));
+    HIPCHK(A.get(&dpgF, (size_t)Rp * capP));
+    HIPCHK(A.get(&dsol, (size_t)Rp * capP));
+    HIPCHK(A.get(&dSdiag, (size_t)Rp));
+    HIPCHK(A.get(&dSel, (size_t)Rp));
+    HIPCHK(A.get(&dTrial, (size_t)Rp));
+    HIPCHK(A.get(&dCg, (size_t)Rp));
+    HIPCHK(hipMemsetAsync(X, 0, sizeof(double) * nd, st));
+    HIPCHK(hipMemsetAsync(Xb, 0, sizeof(double) * nd, st));
+    HIPCHK(hipMemsetAsync(G, 0, sizeof(double) * nd, st));
+    HIPCHK(hipMemsetAsync(D, 0, sizeof(double) * nd, st));
+    {
+        std::vector<int> node((size_t)Rp, -1);
+        for (int64_t r = 0; r < R; ++r) node[r] = (int)(p->node0 + r);
+        std::vector<double> inf((size_t)Rp, INFINITY);
+        HIPCHK(hipMemcpyAsync(dNode, node.data(), sizeof(int) * Rp, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dBest, inf.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    launch_kind(d, p->order, dNode, (int)Rp, kind, st);
+
+    // ---- host state (scalars per row) -----------------------------------------------------------------------------------
+    std::vector<double> f((size_t)R, 0.0), ft((size_t)R, 0.0), Fobj((size_t)R, 0.0), kkt((size_t)R, INFINITY), best((size_t)R, INFINITY),
+        Z((size_t)R, 1.0), Zt((size_t)R, 1.0), alpha((size_t)R, 1.0), dd((size_t)R, 0.0), fn((size_t)R, 0.0), fnt((size_t)R, 0.0),
+        l1t((size_t)R, 0.0), backv((size_t)R, 0.0);
+    std::vector<uint8_t> done((size_t)R, 0), vstale((size_t)R, 0), atfloor((size_t)R, 0), nreg((size_t)R, 0), accepted_fwd((size_t)R, 0),
+        need((size_t)R, 0), iscg((size_t)R, 0);
+    std::vector<int> stall((size_t)R, 0), msz((size_t)R, 0), vslot((size_t)R, -1), owner((size_t)Scap, -1);
+    std::vector<SelectOut> sel((size_t)Rp);
+    std::vector<TrialOut> trial((size_t)Rp);
+    int64_t slot_next = 0;
+    // Scale of the fixed-point V (int8 path): instead of the worst-case bound w_max exp(sum|theta|) every pass after a row's
+    // first uses vref = max_k |V_rk| measured by its previous pass, times exp(||theta - theta_ref||_1), which bounds the new
+    // weights rigorously (|E_k' - E_k| <= ||theta' - theta||_1).  Near the optimum the steps are tiny, so V keeps all 31 bits
+    // relative to its actual maximum and the noise floor of f and grad drops by the bits the bound would have wasted.
+    std::vector<double> vref((size_t)R, 0.0), dref((size_t)R, 0.0), stepn((size_t)R, 0.0);
+
+    int prec = o.precision; // switches to FP64 for the rows the int8-limb path cannot bring below tol ("polish")
+    bool can_polish = false;
+    if (o.precision == GML_PREC_I8X && o.polish >= 0) {
+        size_t freeb = 0, totalb = 0;
+        if (hipMemGetInfo(&freeb, &totalb) == hipSuccess) {
+            const double need_b = (d.Xs ? 0.0 : 2.0 * (double)d.Kp * (double)Qp) + (p->dV && p->dVrows >= Rp ? 0.0 : 8.0 * (double)Rp * (double)d.Kp) +
+                                  8.0 * (double)nd + 4.0 * (double)Scap * d.Kp /* the i8 workspace still to come */;
+            can_polish = need_b < 0.8 * (double)freeb;
+        }
+    }
+    int stall_cap = can_polish ? 4 : 10;
+
+    auto upload_rows = [&](const std::vector<int> &rows, int *dst) -> int {
+        if (!rows.empty()) HIPCHK(hipMemcpyAsync(dst, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice, st));
+        return GML_OK;
+    };
+
+    // ---- one objective(/gradient) pass over the listed rows ---------------------------------------------------------------
+    //   src: X or Xt; dst: G or Gt (want_grad); results per row: fo (f, or log Z), zo (Z, logRISE), no (noise of f)
+    //   pp: the arithmetic of this pass (the solver's current precision; the FP64 phase borrows int8 passes for the V
+    //   planes its matrix-free rows need)
+    std::function<int(const std::vector<int> &, const double *, double *, bool, bool, std::vector<double> &, std::vector<double> &,
+                      std::vector<double> &, const std::vector<double> *, int, int)>
+        run_pass = [&](const std::vector<int> &rows, const double *src, double *dst, bool want_grad, bool at_trial,
+                       std::vector<double> &fo, std::vector<double> &zo, std::vector<double> &no, const std::vector<double> *ovr_in,
+                       int depth, int pp) -> int {
+        const int64_t n = (int64_t)rows.size();
+        if (n == 0) return GML_OK;
+        const double t0 = gml_now_s();
+        const int64_t np = gml_round_up(n, 32);
+        std::vector<double> fh, tauh;
+        std::vector<unsigned> mmh;
+        int64_t base = 0;
+        const bool track = pp == GML_PREC_I8X && formulation != GML_RPLE;
+        if (pp == GML_PREC_I8X) {
+            base = gml_round_up(slot_next, 32);
+            if (base + np > Scap) base = 0; // wrap: the rows whose V planes are overwritten become stale below
+            slot_next = base + np;
+            std::vector<int> ctl((size_t)(2 * np + np / 32 + 4), -1);
+            std::vector<double> ovr((size_t)np, 0.0);
+            for (int64_t a = 0; a < np; ++a) {
+                const int64_t s = base + a;
+                const int prev = owner[s];
+                if (prev >= 0 && vslot[prev] == s) {
+                    vslot[prev] = -1;
+                    vstale[prev] = 1;
+                }
+                owner[s] = a < n ? rows[a] : -1;
+                ctl[a] = a < n ? rows[a] : 0;                                  // srow
+                ctl[np + a] = a < n ? (int)(p->node0 + rows[a]) : -1;         // rowcol
+                if (a < n) {
+                    vslot[rows[a]] = (int)s;
+                    vstale[rows[a]] = 0;
+                    if (ovr_in) ovr[a] = (*ovr_in)[rows[a]];
+                    else if (track && vref[rows[a]] > 0.0)
+                        ovr[a] = vref[rows[a]] * std::exp(dref[rows[a]] + (at_trial ? stepn[rows[a]] : 0.0)) * (1.0 + 1e-6) / 2130000000.0;
+                }
+            }
+            for (int64_t g = 0; g < np / 32; ++g) ctl[2 * np + g] = (int)(base / 32 + g);
+            // device control block: srow | rowcol are indexed by slot, so they are placed at the slot range
+            HIPCHK(hipMemcpyAsync(dCtl + base, ctl.data(), sizeof(int) * np, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dCtl + Scap + base, ctl.data() + np, sizeof(int) * np, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dCtl + 2 * Scap, ctl.data() + 2 * np, sizeof(int) * (np / 32 + 4), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dOvr + base, ovr.data(), sizeof(double) * np, hipMemcpyHostToDevice, st));
+            I8Pass a{};
+            a.theta = src;
+            a.srow = dCtl;
+            a.rowcol = dCtl + Scap;
+            a.groups = dCtl + 2 * Scap;
+            a.ngroups = (int)(np / 32);
+            a.slot0 = (int)base;
+            a.slot1 = (int)(base + np);
+            a.form = formulation;
+            a.want_grad = want_grad;
+            a.F = dFs;
+            a.G = dst;
+            a.tauovr = dOvr;
+            std::string err;
+            int rc = i8_pass(&p->i8ws, d, Scap, a, st, nullptr, &err);
+            if (rc) return fail(rc, "%s", err.c_str());
+            fh.resize((size_t)np);
+            tauh.resize((size_t)np);
+            mmh.resize((size_t)np);
+            const double *dtau = nullptr;
+            const unsigned *dmm = nullptr;
+            i8_slot_results(p->i8ws, 0, &dtau, &dmm);
+            HIPCHK(hipMemcpyAsync(fh.data(), dFs + base, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(tauh.data(), dtau + base, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(mmh.data(), dmm + base, sizeof(unsigned) * np, hipMemcpyDeviceToHost, st));
+        } else {
+            // FP64 path: slot = row; a tile's backward GEMM writes every row of the tile, so the gradient goes to a
+            // scratch array first and only the listed rows are copied out
+            int rc = gml_ensure_f64(p, Rp);
+            if (rc) return rc;
+            if (!Gs) HIPCHK(A.get(&Gs, nd));
+            std::vector<int> ctl((size_t)(Rp + Rp / 32 + 8), -1);
+            std::vector<uint8_t> tile((size_t)(Rp / 32), 0);
+            for (int64_t a = 0; a < n; ++a) {
+                ctl[rows[a]] = (int)(p->node0 + rows[a]);
+                tile[rows[a] >> 5] = 1;
+            }
+            int ng = 0;
+            for (int64_t g = 0; g < Rp / 32; ++g)
+                if (tile[g]) ctl[Rp + ng++] = (int)g;
+            const int ng4 = (int)gml_round_up(ng, 4);
+            HIPCHK(hipMemcpyAsync(dCtl, ctl.data(), sizeof(int) * (Rp + ng4), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemsetAsync(dFs, 0, sizeof(double) * Rp, st));
+            launch_fwd_f64(d, src, dCtl, dCtl + Rp, ng4, formulation, p->dV, dFs, st);
+            if (want_grad) {
+                HIPCHK(hipMemsetAsync(Gs, 0, sizeof(double) * nd, st));
+                launch_bwd_f64(d, p->dV, dCtl + Rp, ng, Gs, st);
+                RCCHK(upload_rows(rows, dRowsP));
+                launch_copy_rows(dRowsP, (int)n, Qp, Gs, dst, nullptr, nullptr, st);
+            }
+            fh.resize((size_t)Rp);
+            HIPCHK(hipMemcpyAsync(fh.data(), dFs, sizeof(double) * Rp, hipMemcpyDeviceToHost, st));
+            for (int64_t a = 0; a < n; ++a) vstale[rows[a]] = 0; // (V [row][Kp] of the FP64 path is indexed by row)
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<int> again;
+        std::vector<double> ovr2;
+        std::vector<double> scale;
+        for (int64_t a = 0; a < n; ++a) {
+            const int r = rows[a];
+            const double fv = pp == GML_PREC_I8X ? fh[a] : fh[r];
+            // f64: summation rounding.  int8 limbs: every V_rk is rounded to a multiple of tau_r with a dither that is
+            // equidistributed over the samples, so the errors (each within one unit, standard deviation 0.41 tau) add like a
+            // random walk: 8 sigma of sqrt(K) terms (the worst case K * tau is never approached).
+            double noise = 1e-13 * std::max(1.0, std::fabs(fv));
+            if (track) {
+                noise += 3.3 * std::sqrt((double)p->K) * tauh[a];
+                const double vmax = ((double)mmh[a] + 1.0) * tauh[a]; // rigorous bound on max_k |V_rk|
+                vref[r] = vmax;
+                dref[r] = at_trial ? stepn[r] : 0.0; // distance from the current iterate to the point just evaluated
+                // Dynamic range: tau_r was derived from a bound; when the largest |V_rk| actually seen is more than 8 bits
+                // below it (dense theta), the row is re-run with tau_r taken from that maximum
+                if (mmh[a] < (1u << 23)) {
+                    if (ovr2.empty()) ovr2.assign((size_t)R, 0.0);
+                    again.push_back(r);
+                    ovr2[r] = vmax * (1.0 + 1e-12) / 2130000000.0;
+                }
+            }
+            if (formulation == GML_LOGRISE) { // f = log Z, g = grad Z / Z   (:279)
+                zo[r] = fv;
+                fo[r] = std::log(fv);
+                no[r] = noise / fv;
+            } else {
+                fo[r] = fv;
+                no[r] = noise;
+            }
+        }
+        stats->node_evals += n;
+        if (want_grad) ++stats->passes;
+        else ++stats->forward_passes;
+        if (!again.empty()) {
+            stats->t_pass += gml_now_s() - t0;
+            if (depth >= 6) return fail(GML_EUNSUPPORTED, "precision i8x: the weights exp(-E) of a row underflow its fixed-point range; use precision f64");
+            int rc = run_pass(again, src, dst, want_grad, at_trial, fo, zo, no, &ovr2, depth + 1, pp);
+            if (rc) return rc;
+            // rows of this call that were not re-run still need their logRISE scaling: fall through with them only
+        }
+        if (formulation == GML_LOGRISE && want_grad) {
+            std::vector<int> keep;
+            std::vector<double> sc((size_t)Rp, 1.0);
+            for (int64_t a = 0; a < n; ++a) {
+                const int r = rows[a];
+                if (std::find(again.begin(), again.end(), r) != again.end()) continue; // scaled by the re-run
+                keep.push_back(r);
+                sc[r] = 1.0 / zo[r];
+            }
+            if (!keep.empty()) {
+                HIPCHK(hipMemcpyAsync(dScale, sc.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
+                RCCHK(upload_rows(keep, dRowsP));
+                launch_scale_rows(dRowsP, (int)keep.size(), dScale, Qp, dst, st);
+                HIPCHK(hipStreamSynchronize(st)); // sc, keep are locals
+            }
+        }
+        if (again.empty()) stats->t_pass += gml_now_s() - t0;
+        return GML_OK;
+    };
+
+    // sub-sampled Newton: Hessians over Kh configurations -- every kstride-th block of 512, so that a sorted histogram is
+    // sampled evenly -- rescaled by the weight of the sub-sample.  The budget (rows x configurations) is kept roughly
+    // constant: as nodes converge, the remaining ones get more configurations, up to all of them -- an inexact Hessian only
+    // costs iterations, and it costs the most on the few ill-conditioned nodes that are still active at the end.
+    const int64_t Kh_base = o.hess_samples == 0 ? 32768 : (o.hess_samples < 0 ? d.Kp : (int64_t)o.hess_samples);
+    const int64_t nblk512 = d.Kp / 512;
+    int64_t Kh = d.Kp, kstride = 1;
+    double hscale = 1.0;
+    auto set_kh = [&](int64_t nactive) {
+        int64_t want = Kh_base;
+        if (o.hess_samples == 0 && nactive > 0) want = Kh_base * std::max<int64_t>(1, R / nactive);
+        int64_t nb = std::min(nblk512, std::max<int64_t>(2, (want + 511) / 512));
+        if (nb * 512 >= p->K) nb = nblk512; // (nearly) everything: take it all
+        kstride = nblk512 / nb;
+        Kh = nb * 512;
+        double wsum = 0;
+        for (int64_t cb = 0; cb < nb; ++cb) wsum += p->wblk[(size_t)(cb * kstride)];
+        if (!(wsum > 0)) { // a sub-sample without weight (degenerate histogram): use every configuration
+            nb = nblk512;
+            kstride = 1;
+            Kh = d.Kp;
+            wsum = 1.0;
+        }
+        hscale = nb == nblk512 ? 1.0 : 1.0 / wsum;
+    };
+    set_kh(R);
+
+    // ---- first pass at X = 0 ------------------------------------------------------------------------------------------------
+    std::vector<int> rows_all((size_t)R);
+    for (int64_t r = 0; r < R; ++r) rows_all[r] = (int)r;
+    int rc = run_pass(rows_all, X, G, true, false, f, Z, fn, nullptr, 0, prec);
+    if (rc) return rc;
+
+    int it = 0;
+    for (it = 0; it < o.max_iter; ++it) {
+        const double th0 = gml_now_s();
+        // ---- KKT residuals, working sets (device) -----------------------------------------------------------------------------
+        std::vector<int> act;
+        for (int64_t r = 0; r < R; ++r)
+            if (!done[r]) act.push_back((int)r);
+        RCCHK(upload_rows(act, dRows));
+        launch_select(dRows, (int)act.size(), X, G, kind, Qp, lambda, o.max_add, capW, capP, PG, dFidx, dgF, dpgF, dSel, dBest, Xb, st);
+        HIPCHK(hipMemcpyAsync(sel.data(), dSel, sizeof(SelectOut) * Rp, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        int64_t nactive = 0, ncg = 0;
+        double worst_all = 0;
+        int maxm = 0;
+        for (int r : act) {
+            const SelectOut &s = sel[r];
+            Fobj[r] = f[r] + s.l1;
+            kkt[r] = std::isfinite(s.worst) && std::isfinite(f[r]) ? s.worst : INFINITY;
+            if (kkt[r] < best[r]) { // (the device made the same comparison and saved the iterate)
+                best[r] = kkt[r];
+                stall[r] = 0;
+            } else {
+                ++stall[r];
+            }
+            if (kkt[r] <= o.tol) {
+                done[r] = 1;
+                continue;
+            }
+            if (stall[r] >= stall_cap) { // no progress: at the noise floor of the pass arithmetic (or a failed line search)
+                done[r] = 1;
+                atfloor[r] = 1;
+                continue;
+            }
+            ++nactive;
+            iscg[r] = s.m < 0;
+            msz[r] = s.m < 0 ? 0 : s.m;
+            if (iscg[r]) ++ncg;
+            maxm = std::max(maxm, msz[r]);
+        }
+        for (int64_t r = 0; r < R; ++r) {
+            if (done[r]) msz[r] = 0;
+            worst_all = std::max(worst_all, std::min(kkt[r], best[r]));
+        }
+        if (o.verbose)
+            fprintf(stderr, "[gml] it %3d active %6lld (cg %lld)  max-kkt %.3e  max|W| %d  passes %d fwd %d%s\n", it, (long long)nactive,
+                    (long long)ncg, worst_all, maxm, stats->passes, stats->forward_passes, prec == GML_PREC_F64 && o.precision != prec ? "  [fp64 polish]" : "");
+        if (o.verbose >= 2 && dbg_row < R)
+            fprintf(stderr, "[gml]   row %lld: kkt %.3e best %.3e F %.15e m %d nsupp %d nviol %d stall %d\n", (long long)dbg_row, kkt[dbg_row],
+                    best[dbg_row], Fobj[dbg_row], sel[dbg_row].m, sel[dbg_row].nsupp, sel[dbg_row].nviol, stall[dbg_row]);
+        stats->t_host += gml_now_s() - th0;
+        if (nactive == 0) {
+            // Polish: rows that the int8-limb arithmetic could not bring below tol (its gradient carries ~sqrt(K) 2^-31 of noise
+            // relative to the largest weight, which an ill-conditioned, weakly regularised problem amplifies) continue on the
+            // FP64 path from their best iterate, when that path fits in memory.
+            std::vector<int> fl;
+            for (int64_t r = 0; r < R; ++r)
+                if (atfloor[r] && !(std::min(best[r], kkt[r]) <= o.tol)) fl.push_back((int)r);
+            if (!(prec == GML_PREC_I8X && can_polish && !fl.empty())) break;
+            if (gml_ensure_f64(p, Rp) != GML_OK) break; // does not fit after all: the rows stay as they are (reported not converged)
+            prec = GML_PREC_F64;
+            stall_cap = 10;
+            RCCHK(upload_rows(fl, dRows));
+            launch_copy_rows(dRows, (int)fl.size(), Qp, Xb, X, nullptr, nullptr, st); // back to the best iterate
+            std::vector<double> inf((size_t)Rp, INFINITY);
+            HIPCHK(hipMemcpyAsync(dBest, inf.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int r : fl) {
+                done[r] = 0;
+                atfloor[r] = 0;
+                stall[r] = 0;
+                best[r] = INFINITY;
+            }
+            if (o.verbose) fprintf(stderr, "[gml] polish: %zu rows continue on the FP64 path\n", fl.size());
+            rc = run_pass(fl, X, G, true, false, f, Z, fn, nullptr, 0, prec);
+            if (rc) return rc;
+            set_kh((int64_t)fl.size());
+            stats->polished = 1;
+            continue;
+        }
+        set_kh(nactive);
+
+        // rows whose V planes were overwritten (a rejected trial, a wrapped slot range) need a fresh pass before the curvature
+        {
+            std::vector<int> stale;
+            for (int64_t r = 0; r < R; ++r)
+                if (!done[r] && (vstale[r] || (prec == GML_PREC_I8X && vslot[r] < 0))) stale.push_back((int)r);
+            if (!stale.empty()) {
+                rc = run_pass(stale, X, G, true, false, f, Z, fn, nullptr, 0, prec);
+                if (rc) return rc;
+            }
+        }
+
+        // ---- Newton directions -----------------------------------------------------------------------------------------------------
+        const double th1 = gml_now_s();
+        std::vector<int> chol_rows, cg_rows;
+        for (int64_t r = 0; r < R; ++r)
+            if (!done[r]) (iscg[r] ? cg_rows : chol_rows).push_back((int)r);
+        {
+            std::vector<double> s1((size_t)Rp, 1.0);
+            for (int64_t r = 0; r < R; ++r) // Hess log Z = Hess Z / Z - g g^T; the matrix-free rows use every configuration
+                s1[r] = (iscg[r] ? 1.0 : hscale) / (formulation == GML_LOGRISE ? Z[r] : 1.0);
+            HIPCHK(hipMemcpyAsync(dS1, s1.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dVslot, vslot.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        if (!chol_rows.empty()) {
+            // Hessian on the working sets (int8 kernel over the limb planes of the rows' last passes, or the FP64 MFMA kernel over
+            // V) and batched Cholesky, both on the device; the directions are scattered into D
+            std::vector<int> mt2((size_t)3 * R);
+            std::vector<long long> hoff((size_t)R + 1, 0);
+            for (int64_t r = 0; r < R; ++r) {
+                const int m = iscg[r] ? 0 : msz[r];
+                mt2[r] = (m + 31) / 32;
+                mt2[R + r] = (int)(p->node0 + r);
+                mt2[2 * R + r] = m;
+                hoff[r + 1] = hoff[r] + (long long)mt2[r] * 32 * mt2[r] * 32;
+            }
+            const int64_t htotal = std::max<long long>(hoff[R], 1);
+            if (htotal > dH_elems) {
+                dH_elems = htotal + htotal / 4;
+                HIPCHK(A.get(&dH, (size_t)dH_elems));
+            }
+            HIPCHK(hipMemcpyAsync(dMt, mt2.data(), sizeof(int) * 3 * R, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dHoff, hoff.data(), sizeof(long long) * (R + 1), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemsetAsync(dH, 0, sizeof(double) * htotal, st));
+            if (prec == GML_PREC_I8X) {
+                std::string err;
+                int hrc = i8_hessian(p->i8ws, d, dMt + R, dVslot, dFidx, dMt, mt2.data(), dHoff, htotal, (int)R, capP, formulation, Kh, kstride,
+                                     dH, st, &err);
+                if (hrc) return fail(hrc, "%s", err.empty() ? "int8 Hessian: working set above 512 entries" : err.c_str());
+            } else {
+                launch_hess_f64(d, p->dV, dMt + R, dFidx, dMt, dHoff, (int)R, capP, formulation, Kh, kstride, dH, st);
+            }
+            launch_newton_solve(dH, dHoff, dMt, dMt + 2 * R, dS1, formulation == GML_LOGRISE ? 1.0 : 0.0, dgF, dpgF, (int)R, capP, dsol,
+                                dSdiag, st);
+            RCCHK(upload_rows(chol_rows, dRows));
+            launch_scatter_dir(dRows, (int)chol_rows.size(), dFidx, dsol, dMt + 2 * R, capP, Qp, D, st);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st)); // mt2, hoff are locals
+            ++stats->hessian_passes;
+        }
+        if (!cg_rows.empty()) {
+            // Matrix-free Newton-CG: H_WW d = -pg_W by conjugate gradients, Hessian-vector products from the device operator
+            // (forward GEMM of the direction, weights of the rows' last objective pass, backward GEMM).  Inexact Newton:
+            // the residual is reduced by eta = min(0.1, sqrt(kkt)) -- superlinear in the end, cheap far from the optimum.
+            if (!Rv) {
+                HIPCHK(A.get(&Rv, nd));
+                HIPCHK(A.get(&Pv, nd));
+                HIPCHK(A.get(&Hp, nd));
+                HIPCHK(A.get(&dHv, (size_t)(3 * Rp + Rp / 32 + 8)));
+            }
+            if (prec != GML_PREC_I8X) {
+                // FP64 phase: the curvature weights of these rows come from an int8-limb objective pass at the same iterate
+                // (the Hessian-vector products run on the int8 cores either way; only the curvature is approximate)
+                std::vector<double> tf((size_t)R), tz((size_t)R, 1.0), tn((size_t)R);
+                rc = run_pass(cg_rows, X, nullptr, false, false, tf, tz, tn, nullptr, 0, GML_PREC_I8X);
+                if (rc) return rc;
+            }
+            RCCHK(upload_rows(cg_rows, dRows));
+            launch_cg_init(dRows, (int)cg_rows.size(), X, PG, kind, Qp, D, Rv, Pv, dCg, st);
+            std::vector<CgState> cgs((size_t)Rp);
+            std::vector<int> live = cg_rows;
+            const int maxcg = 60;
+            for (int ci = 0; ci < maxcg && !live.empty(); ++ci) {
+                // Hp = H p for the live rows: an hv pass over slots [0, n) of the u-plane workspace
+                const int64_t n = (int64_t)live.size(), np = gml_round_up(n, 32);
+                std::vector<int> ctl((size_t)(3 * np + np / 32 + 4), -1);
+                for (int64_t a = 0; a < np; ++a) {
+                    ctl[a] = a < n ? live[a] : 0;
+                    ctl[np + a] = a < n ? (int)(p->node0 + live[a]) : -1;
+                    ctl[2 * np + a] = a < n ? vslot[live[a]] : 0;
+                }
+                for (int64_t g = 0; g < np / 32; ++g) ctl[3 * np + g] = (int)g;
+                HIPCHK(hipMemcpyAsync(dHv, ctl.data(), sizeof(int) * ctl.size(), hipMemcpyHostToDevice, st));
+                I8Pass a{};
+                a.theta = Pv;
+                a.srow = dHv;
+                a.rowcol = dHv + np;
+                a.vmap = dHv + 2 * np;
+                a.groups = dHv + 3 * np;
+                a.ngroups = (int)(np / 32);
+                a.slot0 = 0;
+                a.slot1 = (int)np;
+                a.form = formulation;
+                a.want_grad = true;
+                a.F = nullptr;
+                a.G = Hp;
+                a.hv = 1;
+                a.lf = 4;
+                std::string err;
+                rc = i8_pass(&p->i8ws, d, Scap, a, st, nullptr, &err);
+                if (rc) return fail(rc, "%s", err.c_str());
+                RCCHK(upload_rows(live, dRows));
+                launch_cg_step(dRows, (int)live.size(), X, PG, G, kind, Qp, dS1, formulation == GML_LOGRISE ? 1.0 : 0.0, Hp, D, Rv, Pv, dCg, st);
+                HIPCHK(hipMemcpyAsync(cgs.data(), dCg, sizeof(CgState) * Rp, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(st));
+                ++stats->hessian_passes;
+                stats->node_evals += n;
+                std::vector<int> nxt;
+                for (int r : live) {
+                    const double eta = std::min(0.1, std::sqrt(std::max(kkt[r], 1e-300)));
+                    if (cgs[r].pHp > 0 && cgs[r].rs > eta * eta * cgs[r].rs0) nxt.push_back(r);
+                }
+                if (o.verbose >= 2) fprintf(stderr, "[gml]   cg %2d: %zu rows live\n", ci, nxt.size());
+                live.swap(nxt);
+            }
+        }
+        stats->t_hess += gml_now_s() - th1;
+
+        // ---- projected backtracking line search ----------------------------------------------------------------------------------------
+        // Two acceptance regimes per row:
+        //  * the predicted decrease is well above the uncertainty of f  -> Armijo on F;
+        //  * otherwise ("noise regime": near the optimum, or a noisy int8-limb f) function values cannot certify the step; the trial
+        //    is then a full pass and is accepted iff the directional derivative of F at the trial point back towards x is >= 0 (up
+        //    to an overshoot allowance): F is convex, so such a trial cannot have increased F.
+        // The passes of this iteration use fresh slot ranges: the V planes of the previous ones are no longer needed.
+        slot_next = 0;
+        for (int64_t r = 0; r < R; ++r) {
+            need[r] = !done[r];
+            alpha[r] = 1.0;
+            accepted_fwd[r] = 0;
+        }
+        for (int ls = 0; ls < 30; ++ls) {
+            const double th2 = gml_now_s();
+            std::vector<int> rows;
+            for (int64_t r = 0; r < R; ++r)
+                if (need[r]) rows.push_back((int)r);
+            if (rows.empty()) break;
+            RCCHK(upload_rows(rows, dRows));
+            HIPCHK(hipMemcpyAsync(dAlpha, alpha.data(), sizeof(double) * R, hipMemcpyHostToDevice, st));
+            launch_trial(dRows, (int)rows.size(), X, D, PG, kind, Qp, lambda, dAlpha, Xt, dTrial, st);
+            HIPCHK(hipMemcpyAsync(trial.data(), dTrial, sizeof(TrialOut) * Rp, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+            bool anynoise = false;
+            for (int r : rows) {
+                dd[r] = trial[r].dd;
+                stepn[r] = trial[r].stepn; // ||trial - x||_1: bounds the change of every energy
+                l1t[r] = trial[r].l1t;
+                nreg[r] = !(-0.1 * dd[r] > 8.0 * fn[r]); // the step's expected decrease (~|dd|/2) vs the uncertainty of f
+                anynoise |= nreg[r] != 0;
+            }
+            stats->t_host += gml_now_s() - th2;
+            const bool full = (ls == 0) || anynoise;
+            rc = run_pass(rows, Xt, Gt, full, true, ft, Zt, fnt, nullptr, 0, prec);
+            if (rc) return rc;
+            const double th3 = gml_now_s();
+            if (full) {
+                launch_back(dRows, (int)rows.size(), X, Xt, Gt, kind, Qp, lambda, dTrial, st);
+                HIPCHK(hipMemcpyAsync(trial.data(), dTrial, sizeof(TrialOut) * Rp, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+            }
+            std::vector<int> acc;
+            for (int r : rows) {
+                vstale[r] = 1; // V now belongs to the trial point
+                bool ok;
+                if (nreg[r]) {
+                    const double back = trial[r].back;
+                    ok = std::isfinite(ft[r]) && std::isfinite(back) && back >= -0.5 * std::fabs(dd[r]);
+                } else {
+                    const double Fn = ft[r] + l1t[r];
+                    ok = std::isfinite(Fn) && Fn <= Fobj[r] + 1e-4 * dd[r] + fn[r] + fnt[r];
+                }
+                if (o.verbose >= 2 && r == dbg_row)
+                    fprintf(stderr, "[gml]   row %d: ls %d alpha %.3g nreg %d ft %.12e Fobj %.12e dd %.3e fnt %.3e back %.3e ok %d\n", r, ls, alpha[r],
+                            (int)nreg[r], ft[r], Fobj[r], dd[r], fnt[r], trial[r].back, (int)ok);
+                if (ok) {
+                    dref[r] = 0.0; // the iterate moves onto the point the scale was measured at
+                    f[r] = ft[r];
+                    fn[r] = fnt[r];
+                    Z[r] = Zt[r];
+                    acc.push_back(r);
+                    if (full) vstale[r] = 0;
+                    else accepted_fwd[r] = 1;
+                    need[r] = 0;
+                } else {
+                    alpha[r] *= 0.5;
+                    if (nreg[r] && alpha[r] < 1.0 / 64) {
+                        need[r] = 0;   // cannot improve along this direction: the stall counter ends the row,
+                        stall[r] += 3; // after at most three such line searches (each costs ~7 passes)
+                    }
+                }
+            }
+            RCCHK(upload_rows(acc, dRows2));
+            launch_copy_rows(dRows2, (int)acc.size(), Qp, Xt, X, full ? Gt : nullptr, G, st);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+            stats->t_host += gml_now_s() - th3;
+        }
+        // rows accepted on an objective-only trial still need their gradient (and V)
+        {
+            std::vector<int> rows;
+            for (int64_t r = 0; r < R; ++r)
+                if (accepted_fwd[r]) rows.push_back((int)r);
+            if (!rows.empty()) {
+                rc = run_pass(rows, X, G, true, false, f, Z, fn, nullptr, 0, prec);
+                if (rc) return rc;
+            }
+        }
+        // rows whose line search failed entirely stay where they are; the stall counter ends them
+    }
+
+    // ---- results in the reference layout -----------------------------------------------------------------------------------------------
+    int notconv = 0;
+    double maxk = 0;
+    std::vector<int> frombest, fromx;
+    for (int64_t r = 0; r < R; ++r) {
+        const double k = std::min(best[r], kkt[r]);
+        if (!(k <= o.tol)) ++notconv;
+        maxk = std::max(maxk, k);
+        if (kkt_out) kkt_out[r] = k;
+        (best[r] <= kkt[r] ? frombest : fromx).push_back((int)r);
+    }
+    // best iterate per row -> Xt (free now), one download
+    RCCHK(upload_rows(frombest, dRows));
+    launch_copy_rows(dRows, (int)frombest.size(), Qp, Xb, Xt, nullptr, nullptr, st);
+    RCCHK(upload_rows(fromx, dRows2));
+    launch_copy_rows(dRows2, (int)fromx.size(), Qp, X, Xt, nullptr, nullptr, st);
+    std::vector<double> xh((size_t)R * Qp);
+    HIPCHK(hipMemcpyAsync(xh.data(), Xt, sizeof(double) * R * Qp, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<double> res((size_t)R * P);
+    gml_parallel_for(R, [&](int64_t r) {
+        NodeLayout L;
+        gml_build_layout(p, p->node0 + r, L);
+        const double *x = xh.data() + r * Qp;
+        for (int64_t j = 0; j < P; ++j) res[(size_t)r * P + j] = x[L.cols[j]];
+    });
+    hipPointerAttribute_t attr;
+    bool dev_out = false;
+    if (hipPointerGetAttributes(&attr, out) == hipSuccess) dev_out = (attr.type == hipMemoryTypeDevice);
+    else (void)hipGetLastError();
+    if (dev_out) {
+        HIPCHK(hipMemcpy(out, res.data(), sizeof(double) * R * P, hipMemcpyHostToDevice));
+    } else {
+        std::memcpy(out, res.data(), sizeof(double) * R * P);
+    }
+    stats->iterations = it;
+    stats->max_kkt = maxk;
+    stats->not_converged = notconv;
+    stats->t_total = gml_now_s() - t_start;
+    if (stats_out) *stats_out = *stats;
+    if (notconv)
+        return fail(GML_ENOTCONV, "%d of %lld nodes did not reach the KKT tolerance %.1e (worst %.3e)", notconv, (long long)R, o.tol, maxk);
+    return GML_OK;
+}

@@ -1,0 +1,41 @@
+// Interface between the host solver (gml_solver.cpp) and its device kernels (gml_solver.hip).
+#pragma once
+#include "gml_dev.h"
+
+namespace gml {
+
+struct SelectOut {
+    double l1;     // lambda * sum |x_c| over the penalised columns
+    double worst;  // KKT residual: max |pseudo-gradient|
+    double worstW; // the same over the current support
+    int m;         // working-set size (Cholesky row), or -|W| for a matrix-free (Newton-CG) row
+    int nsupp, nviol, pad;
+};
+struct TrialOut {
+    double dd;    // pg . (xt - x)
+    double stepn; // |xt - x|_1
+    double l1t;   // lambda * sum |xt_c|
+    double back;  // F'(xt; x - xt) (k_back)
+};
+struct CgState {
+    double rs, rs0, pHp;
+};
+
+void launch_kind(const DevProblem &d, int order, const int *dnode, int R, uint8_t *kind, hipStream_t st);
+void launch_scale_rows(const int *drows, int nrows, const double *dscale, int64_t Qp, double *G, hipStream_t st);
+void launch_copy_rows(const int *drows, int nrows, int64_t Qp, const double *s0, double *d0, const double *s1, double *d1, hipStream_t st);
+void launch_select(const int *drows, int nrows, const double *X, const double *G, const uint8_t *kind, int64_t Qp, double lambda,
+                   int max_add, int capW, int capP, double *PG, int *F, double *gF, double *pgF, SelectOut *out, double *best,
+                   double *Xbest, hipStream_t st);
+void launch_scatter_dir(const int *drows, int nrows, const int *F, const double *dsol, const int *msz, int capP, int64_t Qp, double *D,
+                        hipStream_t st);
+void launch_trial(const int *drows, int nrows, const double *X, const double *D, const double *PG, const uint8_t *kind, int64_t Qp,
+                  double lambda, const double *alpha, double *Xt, TrialOut *out, hipStream_t st);
+void launch_back(const int *drows, int nrows, const double *X, const double *Xt, const double *Gt, const uint8_t *kind, int64_t Qp,
+                 double lambda, TrialOut *out, hipStream_t st);
+void launch_cg_init(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, double *D, double *Rv,
+                    double *Pv, CgState *cg, hipStream_t st);
+void launch_cg_step(const int *drows, int nrows, const double *X, const double *PG, const double *G, const uint8_t *kind, int64_t Qp,
+                    const double *s1, double s2, double *Hp, double *D, double *Rv, double *Pv, CgState *cg, hipStream_t st);
+
+} // namespace gml

@@ -1,0 +1,426 @@
+// Device side of the batched l1 solver (gml_solver.cpp): everything the iteration does with the dense per-row arrays
+// -- pseudo-gradient / KKT residual, working-set selection, trial points of the projected line search, acceptance
+// tests, the vector operations of the matrix-free Newton-CG -- runs here, on [rows][Qp] FP64 arrays that never leave
+// HBM.  Only a few scalars per row cross PCIe per iteration.
+//
+// The problem of row r (node u = node[r]) is   min_x f_u(x) + lambda * sum_{c penalised} |x_c|   -- what the
+// reference hands to Ipopt through the z >= |x| epigraph (GraphicalModelLearning.jl:166-177); kind[r][c] says which
+// columns are parameters of the row: 0 = none (the key contains u, or padding), 1 = free (the field), 2 = penalised.
+#include "../../include/gml.h"
+#include "gml_dev.h"
+#include "gml_solver.h"
+
+namespace gml {
+
+__device__ __forceinline__ double pseudo_grad(double x, double g, double lam) {
+    if (lam == 0.0) return g;
+    if (x > 0) return g + lam;
+    if (x < 0) return g - lam;
+    if (g + lam < 0) return g + lam;
+    if (g - lam > 0) return g - lam;
+    return 0.0;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ double block_max(double v, double *red) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+__device__ __forceinline__ int block_sum_i(int v, int *red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// kind[r][c] from the statistic keys: column c is a parameter of node u iff its key does not contain u and its size
+// is at most order - 1 (:94-104); the constant column is the field (free), every other parameter is penalised (:118, :171)
+__global__ __launch_bounds__(256) void k_kind(const int32_t *__restrict__ keys, int ko, int64_t Qf, int64_t Qp, int64_t cconst,
+                                              int order, const int *__restrict__ node, uint8_t *__restrict__ kind) {
+    const int r = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= Qp) return;
+    const int u = node[r];
+    uint8_t k = 0;
+    if (u >= 0) {
+        if (c == cconst) k = 1;
+        else if (c < Qf) {
+            int sz = 0;
+            bool has = false;
+            for (int t = 0; t < ko; ++t) {
+                const int i = keys[c * ko + t];
+                if (i >= 0) {
+                    ++sz;
+                    has |= (i == u);
+                }
+            }
+            if (!has && sz <= order - 1) k = 2;
+        }
+    }
+    kind[(int64_t)r * Qp + c] = k;
+}
+
+void launch_kind(const DevProblem &d, int order, const int *dnode, int R, uint8_t *kind, hipStream_t st) {
+    hipLaunchKernelGGL(k_kind, dim3((unsigned)((d.Qp + 255) / 256), (unsigned)R), dim3(256), 0, st, d.keys, d.ko, d.Qf, d.Qp, d.cconst, order,
+                       dnode, kind);
+}
+
+// G[r][:] *= scale[r] for the listed rows (logRISE: grad log Z = grad Z / Z, :279)
+__global__ __launch_bounds__(256) void k_scale_rows(const int *__restrict__ rows, const double *__restrict__ scale, int64_t Qp,
+                                                    double *__restrict__ G) {
+    const int r = rows[blockIdx.y];
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < Qp) G[(int64_t)r * Qp + c] *= scale[r];
+}
+void launch_scale_rows(const int *drows, int nrows, const double *dscale, int64_t Qp, double *G, hipStream_t st) {
+    if (nrows > 0)
+        hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((Qp + 255) / 256), (unsigned)nrows), dim3(256), 0, st, drows, dscale, Qp, G);
+}
+
+// dst[r][:] = src[r][:] for the listed rows (up to two pairs of arrays)
+__global__ __launch_bounds__(256) void k_copy_rows(const int *__restrict__ rows, int64_t Qp, const double *__restrict__ s0,
+                                                   double *__restrict__ d0, const double *__restrict__ s1, double *__restrict__ d1) {
+    const int r = rows[blockIdx.y];
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= Qp) return;
+    d0[(int64_t)r * Qp + c] = s0[(int64_t)r * Qp + c];
+    if (s1) d1[(int64_t)r * Qp + c] = s1[(int64_t)r * Qp + c];
+}
+void launch_copy_rows(const int *drows, int nrows, int64_t Qp, const double *s0, double *d0, const double *s1, double *d1, hipStream_t st) {
+    if (nrows > 0)
+        hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((Qp + 255) / 256), (unsigned)nrows), dim3(256), 0, st, drows, Qp, s0, d0, s1, d1);
+}
+
+// ------------------------------------------------------------------------------------------
+// KKT residual and working set of one row (one workgroup per listed row).
+//   PG[r][c]  pseudo-gradient (minimum-norm subgradient of F = f + lambda |x|_1 on the penalised columns)
+//   out[r]    {l1 = lambda sum |x_c|, worst = max |pg|, worstW = max |pg| on the current support, m, nsupp, nviol}
+//   working set W = support (x != 0, or the free column) + the at most max_add largest violators (x = 0, pg != 0) --
+//   none while the residual on the support still dominates (worstW ~ worst: the violations outside are then largely
+//   an artefact of the unconverged support) -- written in ascending column order to F[r][0..m), with g and pg
+//   gathered next to it; when W exceeds capW the row is flagged for the matrix-free Newton-CG instead (m = -|W|,
+//   W = every column with x != 0 or pg != 0; nothing is gathered).
+// Also keeps the best iterate: if worst < best[r], best[r] = worst and Xbest[r] = X[r].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ G,
+                                                const uint8_t *__restrict__ kind, int64_t Qp, double lambda, int max_add, int capW,
+                                                int capP, double *__restrict__ PG, int *__restrict__ F, double *__restrict__ gF,
+                                                double *__restrict__ pgF, SelectOut *__restrict__ out, double *__restrict__ best,
+                                                double *__restrict__ Xbest) {
+    const int r = rows[blockIdx.x];
+    const int tid = threadIdx.x;
+    const double *x = X + (int64_t)r * Qp, *g = G + (int64_t)r * Qp;
+    const uint8_t *kr = kind + (int64_t)r * Qp;
+    double *pgr = PG + (int64_t)r * Qp;
+    __shared__ double red[4];
+    __shared__ int redi[4];
+    __shared__ int scan[257];
+    double l1 = 0, worst = 0, worstW = 0;
+    int nsupp = 0, nviol = 0;
+    for (int64_t c = tid; c < Qp; c += 256) {
+        const uint8_t k = kr[c];
+        double pg = 0.0;
+        if (k) {
+            const double l = k == 2 ? lambda : 0.0, xc = x[c];
+            l1 += l * fabs(xc);
+            pg = pseudo_grad(xc, g[c], l);
+            const double a = fabs(pg);
+            worst = fmax(worst, a);
+            if (xc != 0.0 || k == 1) {
+                ++nsupp;
+                worstW = fmax(worstW, a);
+            } else if (pg != 0.0) {
+                ++nviol;
+            }
+        }
+        pgr[c] = pg;
+    }
+    l1 = block_sum(l1, red);
+    worst = block_max(worst, red);
+    worstW = block_max(worstW, red);
+    nsupp = block_sum_i(nsupp, redi);
+    nviol = block_sum_i(nviol, redi);
+    if (!(worst == worst)) worst = INFINITY; // NaN
+    const bool addv = !(worstW > worst * 0.999999 && worstW > 0 && nsupp > 1);
+    // threshold of the max_add largest violators: bisection on the float pattern of |pg| (monotone as unsigned)
+    unsigned thr = 0;
+    if (addv && nviol > max_add) {
+        unsigned lo = 0, hi = 0x7f800000u; // invariant: count(v >= lo) > max_add >= count(v >= hi)
+        while (hi - lo > 1) {
+            const unsigned mid = lo + (hi - lo) / 2;
+            int cnt = 0;
+            for (int64_t c = tid; c < Qp; c += 256)
+                if (kr[c] == 2 && x[c] == 0.0 && pgr[c] != 0.0 && __float_as_uint((float)fabs(pgr[c])) >= mid) ++cnt;
+            cnt = block_sum_i(cnt, redi);
+            if (cnt > max_add) lo = mid;
+            else hi = mid;
+        }
+        int cnt = 0;
+        for (int64_t c = tid; c < Qp; c += 256)
+            if (kr[c] == 2 && x[c] == 0.0 && pgr[c] != 0.0 && __float_as_uint((float)fabs(pgr[c])) >= hi) ++cnt;
+        cnt = block_sum_i(cnt, redi);
+        thr = cnt > 0 ? hi : lo; // nothing above the tie class at `lo`: take that class (a large one sends the row to CG)
+    }
+    SelectOut o;
+    o.l1 = l1;
+    o.worst = worst;
+    o.worstW = worstW;
+    o.nsupp = nsupp;
+    o.nviol = nviol;
+    // ordered compaction: thread t owns the columns [t*chunk, (t+1)*chunk)
+    const int64_t chunk = (Qp + 255) / 256, c0 = tid * chunk, c1 = c0 + chunk < Qp ? c0 + chunk : Qp;
+    int cnt = 0;
+    for (int64_t c = c0; c < c1; ++c) {
+        const uint8_t k = kr[c];
+        if (!k) continue;
+        cnt += (x[c] != 0.0 || k == 1) || (addv && pgr[c] != 0.0 && __float_as_uint((float)fabs(pgr[c])) >= thr);
+    }
+    scan[tid + 1] = cnt;
+    if (tid == 0) scan[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int t = 1; t <= 256; ++t) scan[t] += scan[t - 1];
+    __syncthreads();
+    const int m = scan[256];
+    if (m > capW) {
+        o.m = -(nsupp + (addv ? nviol : 0)); // matrix-free row: W = the support + every violator
+    } else {
+        int pos = scan[tid];
+        for (int64_t c = c0; c < c1; ++c) {
+            const uint8_t k = kr[c];
+            if (!k) continue;
+            if ((x[c] != 0.0 || k == 1) || (addv && pgr[c] != 0.0 && __float_as_uint((float)fabs(pgr[c])) >= thr)) {
+                F[(int64_t)r * capP + pos] = (int)c;
+                gF[(int64_t)r * capP + pos] = g[c];
+                pgF[(int64_t)r * capP + pos] = pgr[c];
+                ++pos;
+            }
+        }
+        for (int a = m + tid; a < capP; a += 256) { // padding
+            F[(int64_t)r * capP + a] = (int)(Qp - 1);
+            gF[(int64_t)r * capP + a] = 0.0;
+            pgF[(int64_t)r * capP + a] = 0.0;
+        }
+        o.m = m;
+    }
+    const bool better = worst < best[r];
+    if (tid == 0) {
+        out[r] = o;
+        if (better) best[r] = worst;
+    }
+    if (better)
+        for (int64_t c = tid; c < Qp; c += 256) Xbest[(int64_t)r * Qp + c] = x[c];
+}
+
+void launch_select(const int *drows, int nrows, const double *X, const double *G, const uint8_t *kind, int64_t Qp, double lambda,
+                   int max_add, int capW, int capP, double *PG, int *F, double *gF, double *pgF, SelectOut *out, double *best,
+                   double *Xbest, hipStream_t st) {
+    if (nrows > 0)
+        hipLaunchKernelGGL(k_select, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, G, kind, Qp, lambda, max_add, capW, capP, PG, F, gF,
+                           pgF, out, best, Xbest);
+}
+
+// D[r][:] = 0, D[r][F[r][a]] = dsol[r][a] (a < m[r]) for the listed rows: the Newton direction of the Cholesky rows
+__global__ __launch_bounds__(256) void k_scatter_dir(const int *__restrict__ rows, const int *__restrict__ F, const double *__restrict__ dsol,
+                                                     const int *__restrict__ msz, int capP, int64_t Qp, double *__restrict__ D) {
+    const int r = rows[blockIdx.x];
+    double *d = D + (int64_t)r * Qp;
+    for (int64_t c = threadIdx.x; c < Qp; c += 256) d[c] = 0.0;
+    __syncthreads();
+    const int m = msz[r];
+    for (int a = threadIdx.x; a < m; a += 256) d[F[(int64_t)r * capP + a]] = dsol[(int64_t)r * capP + a];
+}
+void launch_scatter_dir(const int *drows, int nrows, const int *F, const double *dsol, const int *msz, int capP, int64_t Qp, double *D,
+                        hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_scatter_dir, dim3((unsigned)nrows), dim3(256), 0, st, drows, F, dsol, msz, capP, Qp, D);
+}
+
+// ------------------------------------------------------------------------------------------
+// Trial point of the projected (orthant-wise) line search: xt = P(x + alpha d), where a penalised coordinate that
+// would cross zero is clipped to it (orthant face: the sign of x, or of -pg at zero).  out: dd = pg . (xt - x) (the
+// directional derivative of F along the projected step), stepn = |xt - x|_1, l1t = lambda sum |xt_c|.
+// When the projected step is not a descent direction (dd >= 0: a coordinate's step crossed zero and was clipped while
+// the others still carry the moves that were meant to accompany it) only the clipping is taken.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trial(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ D,
+                                               const double *__restrict__ PG, const uint8_t *__restrict__ kind, int64_t Qp, double lambda,
+                                               const double *__restrict__ alpha, double *__restrict__ Xt, TrialOut *__restrict__ out) {
+    const int r = rows[blockIdx.x];
+    const int tid = threadIdx.x;
+    const double *x = X + (int64_t)r * Qp, *d = D + (int64_t)r * Qp, *pg = PG + (int64_t)r * Qp;
+    const uint8_t *kr = kind + (int64_t)r * Qp;
+    double *xt = Xt + (int64_t)r * Qp;
+    const double al = alpha[r];
+    __shared__ double red[4];
+    double dd = 0, sn = 0, l1 = 0;
+    for (int64_t c = tid; c < Qp; c += 256) {
+        const double xc = x[c];
+        double v = xc;
+        const uint8_t k = kr[c];
+        if (k && d[c] != 0.0) {
+            v = xc + al * d[c];
+            if (k == 2 && lambda > 0) {
+                const double xi = xc != 0.0 ? (xc > 0 ? 1.0 : -1.0) : (pg[c] < 0 ? 1.0 : -1.0);
+                if (v * xi < 0) v = 0.0;
+            }
+            dd += pg[c] * (v - xc);
+            sn += fabs(v - xc);
+        }
+        if (k == 2) l1 += lambda * fabs(v);
+        xt[c] = v;
+    }
+    dd = block_sum(dd, red);
+    if (!(dd < 0)) { // uniform over the workgroup
+        dd = 0;
+        sn = 0;
+        l1 = 0;
+        for (int64_t c = tid; c < Qp; c += 256) {
+            const double xc = x[c];
+            double v = xc;
+            const uint8_t k = kr[c];
+            if (k == 2 && lambda > 0 && xc != 0.0 && d[c] != 0.0 && (xc + al * d[c]) * xc < 0) {
+                v = 0.0;
+                dd += pg[c] * (0.0 - xc);
+                sn += fabs(xc);
+            }
+            if (k == 2) l1 += lambda * fabs(v);
+            xt[c] = v;
+        }
+        dd = block_sum(dd, red);
+    }
+    sn = block_sum(sn, red);
+    l1 = block_sum(l1, red);
+    if (tid == 0) {
+        TrialOut o;
+        o.dd = dd;
+        o.stepn = sn;
+        o.l1t = l1;
+        o.back = 0.0;
+        out[r] = o;
+    }
+}
+void launch_trial(const int *drows, int nrows, const double *X, const double *D, const double *PG, const uint8_t *kind, int64_t Qp,
+                  double lambda, const double *alpha, double *Xt, TrialOut *out, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_trial, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, D, PG, kind, Qp, lambda, alpha, Xt, out);
+}
+
+// back[r] = F'(xt; x - xt): directional derivative of F at the trial point back towards x (gradient Gt at xt).  F is
+// convex, so back >= 0 implies F(xt) <= F(x): the acceptance test when function values are below their noise.
+__global__ __launch_bounds__(256) void k_back(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ Xt,
+                                              const double *__restrict__ Gt, const uint8_t *__restrict__ kind, int64_t Qp, double lambda,
+                                              TrialOut *__restrict__ out) {
+    const int r = rows[blockIdx.x];
+    const double *x = X + (int64_t)r * Qp, *xt = Xt + (int64_t)r * Qp, *gt = Gt + (int64_t)r * Qp;
+    const uint8_t *kr = kind + (int64_t)r * Qp;
+    __shared__ double red[4];
+    double back = 0;
+    for (int64_t c = threadIdx.x; c < Qp; c += 256) {
+        const double sc = x[c] - xt[c]; // direction back to x
+        if (sc == 0.0 || !kr[c]) continue;
+        double gl = gt[c] * sc;
+        if (kr[c] == 2) gl += lambda * (xt[c] != 0.0 ? (xt[c] > 0 ? sc : -sc) : fabs(sc));
+        back += gl;
+    }
+    back = block_sum(back, red);
+    if (threadIdx.x == 0) out[r].back = back;
+}
+void launch_back(const int *drows, int nrows, const double *X, const double *Xt, const double *Gt, const uint8_t *kind, int64_t Qp,
+                 double lambda, TrialOut *out, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_back, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, Xt, Gt, kind, Qp, lambda, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// Matrix-free Newton-CG on the rows whose working set is too large for a Cholesky block: solve H_WW d = -pg_W by
+// conjugate gradients, W = {c : x_c != 0 or pg_c != 0}, with H p from the device operator (two GEMM passes, i8_pass
+// with hv = 1).  Vectors live in [rows][Qp] arrays; the per-row scalars in CgState.
+// ------------------------------------------------------------------------------------------
+// r = -pg on W, p = r, d = 0; rs = r.r
+__global__ __launch_bounds__(256) void k_cg_init(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ PG,
+                                                 const uint8_t *__restrict__ kind, int64_t Qp, double *__restrict__ D,
+                                                 double *__restrict__ Rv, double *__restrict__ Pv, CgState *__restrict__ cg) {
+    const int r = rows[blockIdx.x];
+    __shared__ double red[4];
+    double rs = 0;
+    for (int64_t c = threadIdx.x; c < Qp; c += 256) {
+        const int64_t i = (int64_t)r * Qp + c;
+        const bool inW = kind[i] && (X[i] != 0.0 || PG[i] != 0.0);
+        const double v = inW ? -PG[i] : 0.0;
+        Rv[i] = v;
+        Pv[i] = v;
+        D[i] = 0.0;
+        rs += v * v;
+    }
+    rs = block_sum(rs, red);
+    if (threadIdx.x == 0) {
+        cg[r].rs = rs;
+        cg[r].rs0 = rs;
+        cg[r].pHp = 0.0;
+    }
+}
+void launch_cg_init(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, double *D, double *Rv,
+                    double *Pv, CgState *cg, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_cg_init, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, PG, kind, Qp, D, Rv, Pv, cg);
+}
+
+// One CG update given Hp = (sum_k h_k x_k x_k^T) p from the device:
+//   Hp <- s1[r] * Hp - s2 * g (g . p), restricted to W   (logRISE: Hess log Z = Hess Z / Z - g g^T, s1 = 1/Z, s2 = 1)
+//   alpha = rs / p.Hp;  d += alpha p;  r -= alpha Hp;  beta = rs' / rs;  p = r + beta p
+__global__ __launch_bounds__(256) void k_cg_step(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ PG,
+                                                 const double *__restrict__ G, const uint8_t *__restrict__ kind, int64_t Qp,
+                                                 const double *__restrict__ s1, double s2, double *__restrict__ Hp, double *__restrict__ D,
+                                                 double *__restrict__ Rv, double *__restrict__ Pv, CgState *__restrict__ cg) {
+    const int r = rows[blockIdx.x];
+    const int64_t base = (int64_t)r * Qp;
+    __shared__ double red[4];
+    double gp = 0;
+    if (s2 != 0.0) {
+        for (int64_t c = threadIdx.x; c < Qp; c += 256) gp += G[base + c] * Pv[base + c];
+        gp = block_sum(gp, red);
+    }
+    const double sc = s1[r];
+    double pHp = 0;
+    for (int64_t c = threadIdx.x; c < Qp; c += 256) {
+        const int64_t i = base + c;
+        const bool inW = kind[i] && (X[i] != 0.0 || PG[i] != 0.0);
+        const double h = inW ? sc * Hp[i] - s2 * G[i] * gp : 0.0;
+        Hp[i] = h;
+        pHp += Pv[i] * h;
+    }
+    pHp = block_sum(pHp, red);
+    const double rs = cg[r].rs;
+    const double al = pHp > 0 ? rs / pHp : 0.0;
+    double rsn = 0;
+    for (int64_t c = threadIdx.x; c < Qp; c += 256) {
+        const int64_t i = base + c;
+        D[i] += al * Pv[i];
+        const double rv = Rv[i] - al * Hp[i];
+        Rv[i] = rv;
+        rsn += rv * rv;
+    }
+    rsn = block_sum(rsn, red);
+    const double be = rs > 0 ? rsn / rs : 0.0;
+    for (int64_t c = threadIdx.x; c < Qp; c += 256) {
+        const int64_t i = base + c;
+        Pv[i] = Rv[i] + be * Pv[i];
+    }
+    if (threadIdx.x == 0) {
+        cg[r].rs = rsn;
+        cg[r].pHp = pHp;
+    }
+}
+void launch_cg_step(const int *drows, int nrows, const double *X, const double *PG, const double *G, const uint8_t *kind, int64_t Qp,
+                    const double *s1, double s2, double *Hp, double *D, double *Rv, double *Pv, CgState *cg, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_cg_step, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, PG, G, kind, Qp, s1, s2, Hp, D, Rv, Pv, cg);
+}
+
+} // namespace gml
