@@ -79,6 +79,7 @@ def lib():
     L.gml_problem_info.argtypes = [p] + [p] * 6
     L.gml_multi_keys.argtypes = [p, i64, p]
     L.gml_objgrad_batch.argtypes = [p, i32, i32, i64, p, p, i64, p, p]
+    L.gml_hessvec_batch.argtypes = [p, i32, i64, p, p, p, i64, p]
     L.gml_learn.argtypes = [p, i32, dbl, C.POINTER(Opts), p, p, C.POINTER(Stats)]
     L.gml_bench_pass.argtypes = [p, i32, i32, p, i32, i32, p]
     L.gml_bench_pass_resident.argtypes = [p, i32, i32, p, i32, i32, p, p, p]
@@ -192,6 +193,16 @@ class Problem:
         check(lib().gml_objgrad_batch(self._h, FORMULATION_IDS[formulation], PRECISIONS[precision], len(nodes),
                                       _ptr(nodes), _ptr(theta), theta.shape[1], _ptr(f), _ptr(g)))
         return f, g
+
+    def hessvec(self, formulation, nodes, theta, vec):
+        """Hess f_u(theta) @ vec for the listed nodes (gml_hessvec_batch; int8-limb passes)."""
+        nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(len(nodes), -1)
+        vec = np.ascontiguousarray(vec, dtype=np.float64).reshape(len(nodes), -1)
+        out = np.zeros_like(theta)
+        check(lib().gml_hessvec_batch(self._h, FORMULATION_IDS[formulation], len(nodes), _ptr(nodes), _ptr(theta), _ptr(vec),
+                                      theta.shape[1], _ptr(out)))
+        return out
 
     def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="i8x", max_working=512, max_add=64,
               verbose=0, hess_samples=0, polish=True, out_ptr=None, raise_on_fail=True):

@@ -1127,6 +1127,79 @@ extern "C" int gml_objgrad_batch(gml_problem *p, int formulation, int precision,
     return GML_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// gml_hessvec_batch: curvature operator, H_u(theta) v for many nodes at once
+// ------------------------------------------------------------------------------------------
+extern "C" int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows, const int64_t *nodes, const double *theta,
+                                 const double *vec, int64_t ld, double *hv) {
+    if (!p || !nodes || !theta || !vec || !hv) return fail(GML_EINVAL, "NULL argument");
+    if (formulation < 0 || formulation > 2) return fail(GML_EINVAL, "unknown formulation %d", formulation);
+    if (nrows <= 0) return fail(GML_EINVAL, "nrows must be positive");
+    if (ld < p->P) return fail(GML_EINVAL, "ld %lld smaller than the %lld parameters per node", (long long)ld, (long long)p->P);
+    for (int64_t r = 0; r < nrows; ++r)
+        if (nodes[r] < 0 || nodes[r] >= p->n) return fail(GML_EINVAL, "node id %lld out of range", (long long)nodes[r]);
+    HIPCHK(hipSetDevice(p->device));
+    const int64_t Qp = p->d.Qp, P = p->P, Rp = round_up(nrows, 32);
+    // 1. objective + gradient pass at theta: leaves the curvature weights (limb planes of V) in the slots 0..nrows-1
+    RowSet rs;
+    rs.R = nrows;
+    rs.node.assign(nodes, nodes + nrows);
+    std::vector<NodeLayout> lay((size_t)nrows);
+    std::vector<double> Th((size_t)nrows * Qp, 0.0), Vc((size_t)nrows * Qp, 0.0), Gi((size_t)nrows * Qp), Hv((size_t)nrows * Qp);
+    std::vector<uint8_t> badrow((size_t)nrows, 0);
+    parallel_for(nrows, [&](int64_t r) {
+        build_layout(p, nodes[r], lay[r]);
+        for (int64_t j = 0; j < P; ++j) {
+            const double a = theta[r * ld + j], b = vec[r * ld + j];
+            if (!std::isfinite(a) || !std::isfinite(b)) badrow[r] = 1;
+            Th[(size_t)r * Qp + lay[r].cols[j]] = a;
+            Vc[(size_t)r * Qp + lay[r].cols[j]] = b;
+        }
+    });
+    for (int64_t r = 0; r < nrows; ++r)
+        if (badrow[r]) return fail(GML_EINVAL, "row %lld contains a non-finite value", (long long)r);
+    std::vector<uint8_t> act((size_t)nrows, 1);
+    std::vector<double> fv((size_t)nrows);
+    int rc = device_pass(p, rs, act, Th.data(), formulation, GML_PREC_I8X, true, fv.data(), Gi.data(), nullptr);
+    if (rc) return rc;
+    // 2. Hessian-vector pass: the rows of the direction through the same slots (vmap = identity)
+    hipStream_t st = p->st;
+    const int64_t W = p->ws_rows;
+    std::memcpy(p->hTh, Vc.data(), sizeof(double) * nrows * Qp);
+    HIPCHK(hipMemcpyAsync(p->dTheta, p->hTh, sizeof(double) * nrows * Qp, hipMemcpyHostToDevice, st));
+    gml::I8Pass a{};
+    a.theta = p->dTheta;
+    a.srow = p->dSrow; // identity, rowcol and groups as device_pass left them
+    a.rowcol = p->dRowcol;
+    a.groups = p->dGroups;
+    a.ngroups = (int)(Rp / 32);
+    a.slot0 = 0;
+    a.slot1 = (int)Rp;
+    a.form = formulation;
+    a.want_grad = true;
+    a.F = nullptr;
+    a.G = p->dG;
+    a.hv = 1;
+    a.vmap = p->dSrow;
+    std::string err;
+    rc = gml::i8_pass(&p->i8ws, p->d, W, a, st, nullptr, &err);
+    if (rc) return fail(rc, "%s", err.c_str());
+    HIPCHK(hipMemcpyAsync(p->hG, p->dG, sizeof(double) * nrows * Qp, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    parallel_for(nrows, [&](int64_t r) {
+        const double z = fv[r];
+        double gv = 0.0;
+        if (formulation == GML_LOGRISE) // Hess log Z = Hess Z / Z - g g^T with g = grad Z / Z (:279)
+            for (int64_t j = 0; j < P; ++j) gv += Gi[(size_t)r * Qp + lay[r].cols[j]] / z * vec[r * ld + j];
+        for (int64_t j = 0; j < P; ++j) {
+            double v = p->hG[(size_t)r * Qp + lay[r].cols[j]];
+            if (formulation == GML_LOGRISE) v = v / z - Gi[(size_t)r * Qp + lay[r].cols[j]] / z * gv;
+            hv[r * ld + j] = v;
+        }
+    });
+    return GML_OK;
+}
+
 // Timing hook with the parameters RESIDENT in HBM: Theta is uploaded once, then `warmup + steps` passes run back
 // to back on the handle's stream with no host round trip (a device-side optimiser would call the operator this
 // way); f and the gradient of the last pass are downloaded once at the end.  kernel_ms[3] = device time per pass.

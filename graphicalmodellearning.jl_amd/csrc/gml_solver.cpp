@@ -95,7 +95,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     const size_t nd = (size_t)Rp * Qp;
     // slots of the int8-limb workspace: every active row of a pass in its own slot, the passes of one iteration in
     // disjoint ranges (their V planes feed the next Hessians)
-    const int64_t Scap = o.precision == GML_PREC_I8X ? Rp + gml_round_up(R / 2, 32) + 64 : Rp;
+    const int64_t Scap = o.precision == GML_PREC_I8X ? Rp + gml_round_up(std::max<int64_t>(R / 2, 96), 32) + 64 : Rp + 64;
     {
         size_t freeb = 0, totalb = 0;
         HIPCHK(hipMemGetInfo(&freeb, &totalb));
@@ -280,7 +280,10 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             }
             fh.resize((size_t)Rp);
             HIPCHK(hipMemcpyAsync(fh.data(), dFs, sizeof(double) * Rp, hipMemcpyDeviceToHost, st));
-            for (int64_t a = 0; a < n; ++a) vstale[rows[a]] = 0; // (V [row][Kp] of the FP64 path is indexed by row)
+            for (int64_t a = 0; a < n; ++a) { // (V [row][Kp] of the FP64 path is indexed by row)
+                vstale[rows[a]] = 0;
+                if (vslot[rows[a]] < 0) vslot[rows[a]] = 0;
+            }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
@@ -321,7 +324,16 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         else ++stats->forward_passes;
         if (!again.empty()) {
             stats->t_pass += gml_now_s() - t0;
-            if (depth >= 6) return fail(GML_EUNSUPPORTED, "precision i8x: the weights exp(-E) of a row underflow its fixed-point range; use precision f64");
+            if (depth >= 6) {
+                // the weights exp(-E) of these rows underflow the fixed-point range even after six rescalings (|theta|_1 in the
+                // hundreds): a trial point that far out is simply rejected; at the iterate itself it is an error
+                if (!at_trial) return fail(GML_EUNSUPPORTED, "precision i8x: the weights exp(-E) of a row underflow its fixed-point range; use precision f64");
+                for (int r : again) {
+                    fo[r] = INFINITY;
+                    no[r] = 0.0;
+                }
+                return GML_OK;
+            }
             int rc = run_pass(again, src, dst, want_grad, at_trial, fo, zo, no, &ovr2, depth + 1, pp);
             if (rc) return rc;
             // rows of this call that were not re-run still need their logRISE scaling: fall through with them only
@@ -465,7 +477,15 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         {
             std::vector<int> stale;
             for (int64_t r = 0; r < R; ++r)
-                if (!done[r] && (vstale[r] || (prec == GML_PREC_I8X && vslot[r] < 0))) stale.push_back((int)r);
+                if (!done[r] && (vstale[r] || vslot[r] < 0)) stale.push_back((int)r);
+            if (!stale.empty() && gml_round_up(slot_next, 32) + gml_round_up((int64_t)stale.size(), 32) > Scap) {
+                // the refresh would wrap around the slot range and overwrite planes that are still needed: re-evaluate every
+                // active row from slot 0 instead (they always fit)
+                stale.clear();
+                for (int64_t r = 0; r < R; ++r)
+                    if (!done[r]) stale.push_back((int)r);
+                slot_next = 0;
+            }
             if (!stale.empty()) {
                 rc = run_pass(stale, X, G, true, false, f, Z, fn, nullptr, 0, prec);
                 if (rc) return rc;

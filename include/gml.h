@@ -166,6 +166,16 @@ int gml_objgrad_batch(gml_problem *p, int formulation, int precision, int64_t nr
                       double *g);
 
 /*
+ * gml_hessvec_batch -- beyond the reference (whose registered operator is first-order, :221-233, so Ipopt falls back
+ * to a limited-memory Hessian there): the curvature operator  hv[r] = Hess f_{nodes[r]}(theta[r]) * vec[r]  for
+ * second-order / Newton-CG external solvers, same layouts as gml_objgrad_batch.  Two GEMM passes on the int8 matrix
+ * cores with the curvature weights of an objective pass at theta (precision i8x; ~1e-8 relative).  This is the
+ * operator gml_learn's matrix-free Newton-CG uses for working sets above max_working.
+ */
+int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows, const int64_t *nodes, const double *theta,
+                      const double *vec, int64_t ld, double *hv);
+
+/*
  * gml_learn -- replaces learn(samples, formulation, method) for the handle's node range
  * (:154-189 RISE, :263-298 logRISE, :301-336 RPLE, :210-260 RISEA, :83-133 multiRISE up to
  * the per-node solve).  For every local node it minimises

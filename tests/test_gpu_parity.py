@@ -385,22 +385,46 @@ def test_headline_config_full_size_properties():
 
 @pytest.mark.parametrize("prec", PRECS)
 def test_dense_solutions_large_working_sets(prec):
-    # small regulariser -> hundreds of non-zeros per node: exercises the blocked int8 Hessian (> 128
-    # entries), the device Cholesky solve and, with a small Newton-block cap, the cyclic block
-    # Gauss-Seidel Newton iteration.  All variants must reach the same optimum.
+    # small regulariser -> hundreds of non-zeros per node: exercises the blocked int8 Hessian (> 128 entries), the device
+    # Cholesky solve and, with a Newton-block cap below the support size, the matrix-free Newton-CG (Hessian-vector
+    # products on the int8 cores).  Both must reach the same optimum, certified by the oracle's KKT residual.
     n, K = 192, 30000
     spins, J = synthetic.block_ising(n, K, block=16, seed=7)
     lam = O.lam(0.05, n, K)
     with gml.Problem(spins=spins) as p:
         full, kkt_f, st_f = p.learn("RISE", 0.05, tol=1e-9, precision=prec, max_working=512, max_iter=200)
-        # a cap below the support size: cyclic block Gauss-Seidel (linear convergence, looser tolerance)
-        capped, kkt_c, st_c = p.learn("RISE", 0.05, tol=1e-6, precision=prec, max_working=128, max_iter=400,
-                                      raise_on_fail=False)
-    assert st_f["not_converged"] == 0
+        capped, kkt_c, st_c = p.learn("RISE", 0.05, tol=1e-9, precision=prec, max_working=128, max_iter=200)
+    assert st_f["not_converged"] == 0 and st_c["not_converged"] == 0
     nnz = (full != 0).sum(1)
-    assert nnz.max() > 128  # the large-block path really ran
-    assert kkt_c.max() <= 1e-4 and np.abs(full - capped).max() <= 1e-3
+    assert nnz.max() > 128  # the large-block path / the matrix-free path really ran
+    assert np.abs(full - capped).max() <= 1e-7
     assert _kkt_from_oracle(spins, full, [0, 50, 191], lam) <= 5e-9
+    assert _kkt_from_oracle(spins, capped, [0, 50, 191], lam) <= 5e-9
+
+
+def test_multibody_dense_optimum_matrix_free_newton_cg():
+    # multiRISE at the reference's default regulariser on a multi-body problem: lambda comes from n^2, not from the number of
+    # parameters (:86), so the optimum is dense (a sizeable share of the P noise coefficients exceed lambda).  Reduced n;
+    # with the Newton blocks capped below the support the solver runs matrix-free Newton-CG.  The optimum is certified by the
+    # oracle's order-3 gradient (KKT residual) on every node checked.
+    n, K = 36, 40000
+    spins, terms = synthetic.block_multibody(n, K, block=12, seed=3)
+    with gml.Problem(spins=spins, order=3) as p:
+        P = p.P
+        out, kkt, st = p.learn("RISE", 0.4, tol=1e-9, precision="i8x", max_working=64, max_iter=100)
+        lam = st["lambda_"]
+        assert st["not_converged"] == 0 and kkt.max() <= 1e-9
+        out2, kkt2, st2 = p.learn("RISE", 0.4, tol=1e-9, precision="i8x", max_working=512, max_iter=100)
+    nnz = (out != 0).sum(1)
+    assert nnz.max() > 64 and P == 1 + 35 + 35 * 34 // 2
+    assert np.abs(out - out2).max() <= 1e-7  # Cholesky blocks (up to 512) and Newton-CG agree
+    nodes = np.array([0, 17, 35])
+    fo, go = O.objgrad_multi3_nodes(None, spins, nodes, out[nodes])
+    for a in range(len(nodes)):
+        x, g = out[nodes[a]], go[a]
+        pg = np.where(x > 0, g + lam, np.where(x < 0, g - lam, np.sign(g) * np.maximum(np.abs(g) - lam, 0)))
+        pg[0] = g[0]  # the field (key (u,)) is not penalised (:118)
+        assert np.abs(pg).max() <= 5e-9
 
 
 def test_subsampled_hessian_does_not_change_the_optimum():
@@ -548,3 +572,40 @@ def test_sorted_histogram_above_the_hessian_subsample():
             out, kkt, st = p.learn("RISE", 0.4, tol=1e-9, precision=prec)
         assert st["not_converged"] == 0 and st["iterations"] <= 25
         assert np.abs(0.5 * (out + out.T) - J).max() <= 0.02
+
+
+@pytest.mark.parametrize("form", FORMS)
+def test_hessvec_matches_finite_differences_of_the_gradient(form):
+    # the curvature operator (Hessian-vector product on the int8 cores) against central differences of the FP64 gradient
+    n, K = 48, 20000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=13)
+    rng = np.random.default_rng(2)
+    nodes = np.array([0, 17, 47, 17])
+    theta = J[nodes] + rng.normal(scale=0.05, size=(4, n)) * (rng.random((4, n)) < 0.3)
+    vec = rng.normal(size=(4, n)) * (rng.random((4, n)) < 0.5)
+    eps = 1e-5
+    with gml.Problem(spins=spins) as p:
+        hv = p.hessvec(form, nodes, theta, vec)
+        _, gp = p.objgrad(form, nodes, theta + eps * vec, precision="f64")
+        _, gm = p.objgrad(form, nodes, theta - eps * vec, precision="f64")
+    fd = (gp - gm) / (2 * eps)
+    assert np.abs(hv - fd).max() <= 2e-7 * max(1.0, np.abs(fd).max())
+
+
+def test_hessvec_multibody_wide():
+    # order 3 with more than 32768 statistics columns (the wide recombination path of the forward kernel)
+    n, K = 260, 4096
+    rng = np.random.default_rng(5)
+    spins = np.where(rng.random((K, n)) < 0.6, 1, -1).astype(np.int8)
+    with gml.Problem(spins=spins, order=3) as p:
+        P = p.P
+        assert P > 32768
+        nodes = np.array([3, 259])
+        theta = rng.normal(scale=2e-3, size=(2, P)) * (rng.random((2, P)) < 0.2)
+        vec = rng.normal(size=(2, P)) * (rng.random((2, P)) < 0.1)
+        hv = p.hessvec("RISE", nodes, theta, vec)
+        eps = 1e-5  # |eps x.vec| ~ 6e-4: the O(eps^2) truncation of the central difference is ~1e-7 relative
+        _, gp = p.objgrad("RISE", nodes, theta + eps * vec, precision="f64")
+        _, gm = p.objgrad("RISE", nodes, theta - eps * vec, precision="f64")
+    fd = (gp - gm) / (2 * eps)
+    assert np.abs(hv - fd).max() <= 2e-6 * max(1.0, np.abs(fd).max())
