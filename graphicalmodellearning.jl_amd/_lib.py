@@ -31,7 +31,7 @@ class GMLConvergenceError(AssertionError):
 class Opts(C.Structure):
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("precision", C.c_int32),
                 ("max_working", C.c_int32), ("max_add", C.c_int32), ("verbose", C.c_int32),
-                ("hess_samples", C.c_int32), ("polish", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("hess_samples", C.c_int32), ("polish", C.c_int32), ("max_cg", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -205,7 +205,7 @@ class Problem:
         return out
 
     def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="i8x", max_working=512, max_add=64,
-              verbose=0, hess_samples=0, polish=True, out_ptr=None, raise_on_fail=True):
+              verbose=0, hess_samples=0, polish=True, max_cg=0, out_ptr=None, raise_on_fail=True):
         L = lib()
         o = Opts()
         L.gml_default_opts(C.byref(o))
@@ -213,6 +213,7 @@ class Problem:
         o.max_working, o.max_add, o.verbose = int(max_working), int(max_add), int(verbose)
         o.hess_samples = int(hess_samples)
         o.polish = 0 if polish else -1
+        o.max_cg = int(max_cg)
         R = self.node1 - self.node0
         out = None
         if out_ptr is None:

@@ -83,19 +83,21 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
 
     // ---- device state -------------------------------------------------------------------------------------------------
     Arena A;
-    double *X, *G, *Xt, *Gt, *Xb, *D, *PG, *Gs = nullptr, *Rv = nullptr, *Pv = nullptr, *Hp = nullptr;
+    double *X, *G, *Xt, *Gt, *Xb, *D, *PG, *Gs = nullptr, *Rv = nullptr, *Pv = nullptr, *Hp = nullptr, *Zv = nullptr;
     uint8_t *kind;
-    int *dNode, *dRows, *dRows2, *dRowsP, *dCtl, *dFidx, *dMt, *dVslot, *dHv = nullptr;
+    int *dNode, *dRows, *dRows2, *dRowsP, *dCtl, *dFidx, *dMt, *dMsCg, *dVslot, *dHv = nullptr;
+    CgState *dCg;
     long long *dHoff;
-    double *dBest, *dAlpha, *dScale, *dS1, *dFs, *dOvr, *dgF, *dpgF, *dsol, *dSdiag, *dH = nullptr;
+    double *dBest, *dAlpha, *dScale, *dS1, *dS1cg, *dDinv, *dFs, *dOvr, *dgF, *dpgF, *dsol, *dSdiag, *dH = nullptr;
     SelectOut *dSel;
     TrialOut *dTrial;
-    CgState *dCg;
     int64_t dH_elems = 0;
     const size_t nd = (size_t)Rp * Qp;
     // slots of the int8-limb workspace: every active row of a pass in its own slot, the passes of one iteration in
     // disjoint ranges (their V planes feed the next Hessians)
-    const int64_t Scap = o.precision == GML_PREC_I8X ? Rp + gml_round_up(std::max<int64_t>(R / 2, 96), 32) + 64 : Rp + 64;
+    // Objective-only passes (line-search trials whose V planes nobody reads) run in a scratch range above the main one.
+    const int64_t Smain = o.precision == GML_PREC_I8X ? Rp + gml_round_up(std::max<int64_t>(R / 2, 96), 32) + 64 : Rp + 64;
+    const int64_t Scap = Smain + Rp;
     {
         size_t freeb = 0, totalb = 0;
         HIPCHK(hipMemGetInfo(&freeb, &totalb));
@@ -119,6 +121,10 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     HIPCHK(A.get(&dCtl, (size_t)(2 * Scap + Scap / 32 + 8)));
     HIPCHK(A.get(&dFidx, (size_t)Rp * capP));
     HIPCHK(A.get(&dMt, (size_t)3 * Rp));
+    HIPCHK(A.get(&dMsCg, (size_t)Rp));
+    HIPCHK(A.get(&dDinv, (size_t)Rp));
+    HIPCHK(A.get(&dS1cg, (size_t)Rp));
+    HIPCHK(A.get(&dCg, (size_t)Rp));
     HIPCHK(A.get(&dVslot, (size_t)Rp));
     HIPCHK(A.get(&dHoff, (size_t)Rp + 1));
     HIPCHK(A.get(&dBest, (size_t)Rp));
@@ -133,7 +139,6 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     HIPCHK(A.get(&dSdiag, (size_t)Rp));
     HIPCHK(A.get(&dSel, (size_t)Rp));
     HIPCHK(A.get(&dTrial, (size_t)Rp));
-    HIPCHK(A.get(&dCg, (size_t)Rp));
     HIPCHK(hipMemsetAsync(X, 0, sizeof(double) * nd, st));
     HIPCHK(hipMemsetAsync(Xb, 0, sizeof(double) * nd, st));
     HIPCHK(hipMemsetAsync(G, 0, sizeof(double) * nd, st));
@@ -154,7 +159,8 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         l1t((size_t)R, 0.0), backv((size_t)R, 0.0);
     std::vector<uint8_t> done((size_t)R, 0), vstale((size_t)R, 0), atfloor((size_t)R, 0), nreg((size_t)R, 0), accepted_fwd((size_t)R, 0),
         need((size_t)R, 0), iscg((size_t)R, 0);
-    std::vector<int> stall((size_t)R, 0), msz((size_t)R, 0), vslot((size_t)R, -1), owner((size_t)Scap, -1);
+    std::vector<int> stall((size_t)R, 0), msz((size_t)R, 0), vslot((size_t)R, -1), vprev((size_t)R, -1), owner((size_t)Scap, -1);
+    std::vector<double> Fbest((size_t)R, INFINITY);
     std::vector<SelectOut> sel((size_t)Rp);
     std::vector<TrialOut> trial((size_t)Rp);
     int64_t slot_next = 0;
@@ -176,6 +182,13 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     }
     int stall_cap = can_polish ? 4 : 10;
 
+    auto stage = [&](const char *name) {
+        if (o.verbose >= 3) {
+            (void)hipStreamSynchronize(st);
+            fprintf(stderr, "[gml]     stage %s (last error: %s)\n", name, hipGetErrorString(hipGetLastError()));
+            fflush(stderr);
+        }
+    };
     auto upload_rows = [&](const std::vector<int> &rows, int *dst) -> int {
         if (!rows.empty()) HIPCHK(hipMemcpyAsync(dst, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice, st));
         return GML_OK;
@@ -185,6 +198,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     //   src: X or Xt; dst: G or Gt (want_grad); results per row: fo (f, or log Z), zo (Z, logRISE), no (noise of f)
     //   pp: the arithmetic of this pass (the solver's current precision; the FP64 phase borrows int8 passes for the V
     //   planes its matrix-free rows need)
+    std::vector<int> pslot((size_t)R, -1); // slot each row occupied in the pass being re-run (scale re-runs happen in place)
     std::function<int(const std::vector<int> &, const double *, double *, bool, bool, std::vector<double> &, std::vector<double> &,
                       std::vector<double> &, const std::vector<double> *, int, int)>
         run_pass = [&](const std::vector<int> &rows, const double *src, double *dst, bool want_grad, bool at_trial,
@@ -193,49 +207,86 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         const int64_t n = (int64_t)rows.size();
         if (n == 0) return GML_OK;
         const double t0 = gml_now_s();
+        stage(want_grad ? "pass" : "fwd pass");
         const int64_t np = gml_round_up(n, 32);
         std::vector<double> fh, tauh;
         std::vector<unsigned> mmh;
         int64_t base = 0;
         const bool track = pp == GML_PREC_I8X && formulation != GML_RPLE;
         if (pp == GML_PREC_I8X) {
-            base = gml_round_up(slot_next, 32);
-            if (base + np > Scap) base = 0; // wrap: the rows whose V planes are overwritten become stale below
-            slot_next = base + np;
-            std::vector<int> ctl((size_t)(2 * np + np / 32 + 4), -1);
-            std::vector<double> ovr((size_t)np, 0.0);
-            for (int64_t a = 0; a < np; ++a) {
-                const int64_t s = base + a;
-                const int prev = owner[s];
-                if (prev >= 0 && vslot[prev] == s) {
-                    vslot[prev] = -1;
-                    vstale[prev] = 1;
+            // slots of this pass: a fresh consecutive range, or (re-run of some rows of a pass with a tighter scale: ovr_in)
+            // the slots those rows already hold -- a re-run must not claim new slots, it could wrap around and overwrite
+            // planes of its own pass
+            std::vector<int64_t> slot((size_t)n);
+            int64_t lo, hi;
+            if (ovr_in) {
+                lo = Scap;
+                hi = 0;
+                for (int64_t a = 0; a < n; ++a) {
+                    slot[a] = pslot[rows[a]];
+                    lo = std::min(lo, slot[a] / 32 * 32);
+                    hi = std::max(hi, slot[a] / 32 * 32 + 32);
                 }
-                owner[s] = a < n ? rows[a] : -1;
-                ctl[a] = a < n ? rows[a] : 0;                                  // srow
-                ctl[np + a] = a < n ? (int)(p->node0 + rows[a]) : -1;         // rowcol
-                if (a < n) {
-                    vslot[rows[a]] = (int)s;
-                    vstale[rows[a]] = 0;
-                    if (ovr_in) ovr[a] = (*ovr_in)[rows[a]];
-                    else if (track && vref[rows[a]] > 0.0)
-                        ovr[a] = vref[rows[a]] * std::exp(dref[rows[a]] + (at_trial ? stepn[rows[a]] : 0.0)) * (1.0 + 1e-6) / 2130000000.0;
+            } else if (!want_grad && at_trial) {
+                // objective-only trial: scratch slots, the rows keep the V planes of their iterates
+                lo = Smain;
+                hi = Smain + np;
+                for (int64_t a = 0; a < n; ++a) slot[a] = Smain + a;
+            } else {
+                base = gml_round_up(slot_next, 32);
+                if (base + np > Smain) base = 0; // wrap: the rows whose V planes are overwritten become stale below
+                slot_next = base + np;
+                lo = base;
+                hi = base + np;
+                for (int64_t a = 0; a < np; ++a) {
+                    const int64_t s = base + a;
+                    const int prev = owner[s];
+                    if (prev >= 0 && vslot[prev] == s) {
+                        vslot[prev] = -1;
+                        vstale[prev] = 1;
+                    }
+                    owner[s] = a < n ? rows[a] : -1;
+                }
+                for (int64_t a = 0; a < n; ++a) {
+                    const int r = rows[a];
+                    slot[a] = base + a;
+                    vprev[r] = at_trial ? vslot[r] : -1; // a rejected trial goes back to the planes of the iterate, if they survive
+                    vslot[r] = (int)(base + a);
+                    vstale[r] = 0;
                 }
             }
-            for (int64_t g = 0; g < np / 32; ++g) ctl[2 * np + g] = (int)(base / 32 + g);
+            for (int64_t a = 0; a < n; ++a) pslot[rows[a]] = (int)slot[a];
+            const int64_t ns = hi - lo;
+            std::vector<int> srow((size_t)ns, 0), rowcol((size_t)ns, -1), groups;
+            std::vector<double> ovr((size_t)ns, 0.0);
+            std::vector<uint8_t> tile((size_t)(ns / 32), 0);
+            for (int64_t a = 0; a < n; ++a) {
+                const int64_t q = slot[a] - lo;
+                const int r = rows[a];
+                srow[q] = r;
+                rowcol[q] = (int)(p->node0 + r);
+                tile[q / 32] = 1;
+                if (ovr_in) ovr[q] = (*ovr_in)[r];
+                else if (track && vref[r] > 0.0)
+                    ovr[q] = vref[r] * std::exp(dref[r] + (at_trial ? stepn[r] : 0.0)) * (1.0 + 1e-6) / 2130000000.0;
+            }
+            for (int64_t g = 0; g < ns / 32; ++g)
+                if (tile[g]) groups.push_back((int)(lo / 32 + g));
+            const int ng = (int)groups.size();
+            while (groups.size() % 4) groups.push_back(-1);
             // device control block: srow | rowcol are indexed by slot, so they are placed at the slot range
-            HIPCHK(hipMemcpyAsync(dCtl + base, ctl.data(), sizeof(int) * np, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dCtl + Scap + base, ctl.data() + np, sizeof(int) * np, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dCtl + 2 * Scap, ctl.data() + 2 * np, sizeof(int) * (np / 32 + 4), hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dOvr + base, ovr.data(), sizeof(double) * np, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dCtl + lo, srow.data(), sizeof(int) * ns, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dCtl + Scap + lo, rowcol.data(), sizeof(int) * ns, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dCtl + 2 * Scap, groups.data(), sizeof(int) * groups.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dOvr + lo, ovr.data(), sizeof(double) * ns, hipMemcpyHostToDevice, st));
             I8Pass a{};
             a.theta = src;
             a.srow = dCtl;
             a.rowcol = dCtl + Scap;
             a.groups = dCtl + 2 * Scap;
-            a.ngroups = (int)(np / 32);
-            a.slot0 = (int)base;
-            a.slot1 = (int)(base + np);
+            a.ngroups = ng;
+            a.slot0 = (int)lo;
+            a.slot1 = (int)hi;
             a.form = formulation;
             a.want_grad = want_grad;
             a.F = dFs;
@@ -244,15 +295,24 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             std::string err;
             int rc = i8_pass(&p->i8ws, d, Scap, a, st, nullptr, &err);
             if (rc) return fail(rc, "%s", err.c_str());
-            fh.resize((size_t)np);
-            tauh.resize((size_t)np);
-            mmh.resize((size_t)np);
+            std::vector<double> fr((size_t)ns), taur((size_t)ns);
+            std::vector<unsigned> mmr((size_t)ns);
             const double *dtau = nullptr;
             const unsigned *dmm = nullptr;
             i8_slot_results(p->i8ws, 0, &dtau, &dmm);
-            HIPCHK(hipMemcpyAsync(fh.data(), dFs + base, sizeof(double) * np, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(tauh.data(), dtau + base, sizeof(double) * np, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(mmh.data(), dmm + base, sizeof(unsigned) * np, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(fr.data(), dFs + lo, sizeof(double) * ns, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(taur.data(), dtau + lo, sizeof(double) * ns, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(mmr.data(), dmm + lo, sizeof(unsigned) * ns, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+            fh.resize((size_t)n);
+            tauh.resize((size_t)n);
+            mmh.resize((size_t)n);
+            for (int64_t a2 = 0; a2 < n; ++a2) {
+                fh[a2] = fr[slot[a2] - lo];
+                tauh[a2] = taur[slot[a2] - lo];
+                mmh[a2] = mmr[slot[a2] - lo];
+            }
         } else {
             // FP64 path: slot = row; a tile's backward GEMM writes every row of the tile, so the gradient goes to a
             // scratch array first and only the listed rows are copied out
@@ -399,6 +459,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         for (int64_t r = 0; r < R; ++r)
             if (!done[r]) act.push_back((int)r);
         RCCHK(upload_rows(act, dRows));
+        stage("select");
         launch_select(dRows, (int)act.size(), X, G, kind, Qp, lambda, o.max_add, capW, capP, PG, dFidx, dgF, dpgF, dSel, dBest, Xb, st);
         HIPCHK(hipMemcpyAsync(sel.data(), dSel, sizeof(SelectOut) * Rp, hipMemcpyDeviceToHost, st));
         HIPCHK(hipGetLastError());
@@ -410,8 +471,15 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             const SelectOut &s = sel[r];
             Fobj[r] = f[r] + s.l1;
             kkt[r] = std::isfinite(s.worst) && std::isfinite(f[r]) ? s.worst : INFINITY;
-            if (kkt[r] < best[r]) { // (the device made the same comparison and saved the iterate)
+            // progress = a smaller KKT residual (the device made the same comparison and saved the iterate) or a smaller
+            // objective beyond its noise: with thousands of coordinates entering at once (dense optima) the residual is
+            // not monotone along a converging sequence, the objective is
+            const bool fdown = Fobj[r] < Fbest[r] - std::max(10.0 * fn[r], 1e-13 * std::fabs(Fobj[r]));
+            if (Fobj[r] < Fbest[r]) Fbest[r] = Fobj[r];
+            if (kkt[r] < best[r]) {
                 best[r] = kkt[r];
+                stall[r] = 0;
+            } else if (fdown) {
                 stall[r] = 0;
             } else {
                 ++stall[r];
@@ -427,7 +495,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             }
             ++nactive;
             iscg[r] = s.m < 0;
-            msz[r] = s.m < 0 ? 0 : s.m;
+            msz[r] = s.m < 0 ? s.pad : s.m; // working set of the Cholesky step, or the preconditioner block of a matrix-free row
             if (iscg[r]) ++ncg;
             maxm = std::max(maxm, msz[r]);
         }
@@ -463,6 +531,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 atfloor[r] = 0;
                 stall[r] = 0;
                 best[r] = INFINITY;
+                Fbest[r] = INFINITY;
             }
             if (o.verbose) fprintf(stderr, "[gml] polish: %zu rows continue on the FP64 path\n", fl.size());
             rc = run_pass(fl, X, G, true, false, f, Z, fn, nullptr, 0, prec);
@@ -473,23 +542,22 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         }
         set_kh(nactive);
 
-        // rows whose V planes were overwritten (a rejected trial, a wrapped slot range) need a fresh pass before the curvature
-        {
+        // rows whose V planes were overwritten (a wrapped slot range) need a fresh pass before the curvature; such a pass can
+        // itself overwrite planes that are still needed, hence the loop: its last round re-evaluates every active row from
+        // slot 0 (they always fit)
+        for (int round = 0; round < 3; ++round) {
             std::vector<int> stale;
             for (int64_t r = 0; r < R; ++r)
                 if (!done[r] && (vstale[r] || vslot[r] < 0)) stale.push_back((int)r);
-            if (!stale.empty() && gml_round_up(slot_next, 32) + gml_round_up((int64_t)stale.size(), 32) > Scap) {
-                // the refresh would wrap around the slot range and overwrite planes that are still needed: re-evaluate every
-                // active row from slot 0 instead (they always fit)
+            if (stale.empty()) break;
+            if (round == 2) {
                 stale.clear();
                 for (int64_t r = 0; r < R; ++r)
                     if (!done[r]) stale.push_back((int)r);
                 slot_next = 0;
             }
-            if (!stale.empty()) {
-                rc = run_pass(stale, X, G, true, false, f, Z, fn, nullptr, 0, prec);
-                if (rc) return rc;
-            }
+            rc = run_pass(stale, X, G, true, false, f, Z, fn, nullptr, 0, prec);
+            if (rc) return rc;
         }
 
         // ---- Newton directions -----------------------------------------------------------------------------------------------------
@@ -497,25 +565,31 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         std::vector<int> chol_rows, cg_rows;
         for (int64_t r = 0; r < R; ++r)
             if (!done[r]) (iscg[r] ? cg_rows : chol_rows).push_back((int)r);
-        {
-            std::vector<double> s1((size_t)Rp, 1.0);
-            for (int64_t r = 0; r < R; ++r) // Hess log Z = Hess Z / Z - g g^T; the matrix-free rows use every configuration
-                s1[r] = (iscg[r] ? 1.0 : hscale) / (formulation == GML_LOGRISE ? Z[r] : 1.0);
-            HIPCHK(hipMemcpyAsync(dS1, s1.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dVslot, vslot.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
-            HIPCHK(hipStreamSynchronize(st));
+        if (!cg_rows.empty() && prec != GML_PREC_I8X) {
+            // FP64 phase: the curvature weights of the matrix-free rows' Hessian-vector products come from an int8-limb objective
+            // pass at the same iterate (those products run on the int8 cores either way; only the curvature is approximate)
+            std::vector<double> tf((size_t)R), tz((size_t)R, 1.0), tn((size_t)R);
+            rc = run_pass(cg_rows, X, nullptr, false, false, tf, tz, tn, nullptr, 0, GML_PREC_I8X);
+            if (rc) return rc;
         }
-        if (!chol_rows.empty()) {
-            // Hessian on the working sets (int8 kernel over the limb planes of the rows' last passes, or the FP64 MFMA kernel over
-            // V) and batched Cholesky, both on the device; the directions are scattered into D
-            std::vector<int> mt2((size_t)3 * R);
+        {
+            // Hessian blocks (int8 kernel over the limb planes of the rows' last passes, or the FP64 MFMA kernel over V): the
+            // working set of a Cholesky row, the preconditioner block of a matrix-free row
+            std::vector<int> mt2((size_t)3 * R), mscg((size_t)R, 0);
             std::vector<long long> hoff((size_t)R + 1, 0);
+            std::vector<double> s1((size_t)Rp, 1.0), s1cg((size_t)Rp, 1.0), dinv((size_t)Rp, 1.0);
             for (int64_t r = 0; r < R; ++r) {
-                const int m = iscg[r] ? 0 : msz[r];
+                const int m = done[r] ? 0 : msz[r];
                 mt2[r] = (m + 31) / 32;
                 mt2[R + r] = (int)(p->node0 + r);
-                mt2[2 * R + r] = m;
+                mt2[2 * R + r] = iscg[r] ? 0 : m; // the Cholesky step solves these
+                mscg[r] = iscg[r] ? m : 0;        // the preconditioner solves of the matrix-free rows
                 hoff[r + 1] = hoff[r] + (long long)mt2[r] * 32 * mt2[r] * 32;
+                const double zi = formulation == GML_LOGRISE ? 1.0 / Z[r] : 1.0; // Hess log Z = Hess Z / Z - g g^T
+                s1[r] = hscale * zi; // sub-sampled blocks
+                s1cg[r] = zi;        // the Hessian-vector products use every configuration
+                // the common diagonal of the operator: sum_k h_k (RISE: f; logRISE: Z / Z = 1; RPLE: at most 1)
+                dinv[r] = formulation == GML_RISE ? 1.0 / std::max(f[r], 1e-300) : 1.0;
             }
             const int64_t htotal = std::max<long long>(hoff[R], 1);
             if (htotal > dH_elems) {
@@ -523,8 +597,19 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 HIPCHK(A.get(&dH, (size_t)dH_elems));
             }
             HIPCHK(hipMemcpyAsync(dMt, mt2.data(), sizeof(int) * 3 * R, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dMsCg, mscg.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(dHoff, hoff.data(), sizeof(long long) * (R + 1), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dS1, s1.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dDinv, dinv.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dS1cg, s1cg.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dVslot, vslot.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemsetAsync(dH, 0, sizeof(double) * htotal, st));
+            stage("hessian");
+            if (prec == GML_PREC_I8X)
+                for (int64_t r = 0; r < R; ++r)
+                    if (mt2[r] > 0 && (vslot[r] < 0 || vslot[r] >= Scap || owner[vslot[r]] != r || vstale[r]))
+                        return fail(GML_EHIP, "internal: row %lld enters the Hessian without valid V planes (slot %d, owner %d, stale %d)",
+                                    (long long)r, vslot[r], vslot[r] >= 0 && vslot[r] < Scap ? owner[vslot[r]] : -2, (int)vstale[r]);
             if (prec == GML_PREC_I8X) {
                 std::string err;
                 int hrc = i8_hessian(p->i8ws, d, dMt + R, dVslot, dFidx, dMt, mt2.data(), dHoff, htotal, (int)R, capP, formulation, Kh, kstride,
@@ -533,36 +618,39 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             } else {
                 launch_hess_f64(d, p->dV, dMt + R, dFidx, dMt, dHoff, (int)R, capP, formulation, Kh, kstride, dH, st);
             }
-            launch_newton_solve(dH, dHoff, dMt, dMt + 2 * R, dS1, formulation == GML_LOGRISE ? 1.0 : 0.0, dgF, dpgF, (int)R, capP, dsol,
-                                dSdiag, st);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st)); // the vectors above are locals
+            ++stats->hessian_passes;
+        }
+        const double s2 = formulation == GML_LOGRISE ? 1.0 : 0.0;
+        if (!chol_rows.empty()) {
+            // batched Cholesky on the device; the directions are scattered into D
+            stage("cholesky");
+            launch_newton_solve(dH, dHoff, dMt, dMt + 2 * R, dS1, s2, dgF, dpgF, (int)R, capP, dsol, dSdiag, st);
             RCCHK(upload_rows(chol_rows, dRows));
             launch_scatter_dir(dRows, (int)chol_rows.size(), dFidx, dsol, dMt + 2 * R, capP, Qp, D, st);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(st)); // mt2, hoff are locals
-            ++stats->hessian_passes;
         }
         if (!cg_rows.empty()) {
-            // Matrix-free Newton-CG: H_WW d = -pg_W by conjugate gradients, Hessian-vector products from the device operator
-            // (forward GEMM of the direction, weights of the rows' last objective pass, backward GEMM).  Inexact Newton:
-            // the residual is reduced by eta = min(0.1, sqrt(kkt)) -- superlinear in the end, cheap far from the optimum.
+            // Matrix-free Newton-CG: H_WW d = -pg_W by preconditioned conjugate gradients, Hessian-vector products from the device
+            // operator (forward GEMM of the direction, weights of the rows' last objective pass, backward GEMM), preconditioner =
+            // the Cholesky-factored Hessian block of the row's strongest entries + the common diagonal elsewhere.  Inexact Newton:
+            // the residual is reduced by eta = min(0.05, sqrt(kkt)) -- superlinear in the end, cheap far from the optimum.
+            stage("pcg");
             if (!Rv) {
                 HIPCHK(A.get(&Rv, nd));
                 HIPCHK(A.get(&Pv, nd));
                 HIPCHK(A.get(&Hp, nd));
+                HIPCHK(A.get(&Zv, nd));
                 HIPCHK(A.get(&dHv, (size_t)(3 * Rp + Rp / 32 + 8)));
             }
-            if (prec != GML_PREC_I8X) {
-                // FP64 phase: the curvature weights of these rows come from an int8-limb objective pass at the same iterate
-                // (the Hessian-vector products run on the int8 cores either way; only the curvature is approximate)
-                std::vector<double> tf((size_t)R), tz((size_t)R, 1.0), tn((size_t)R);
-                rc = run_pass(cg_rows, X, nullptr, false, false, tf, tz, tn, nullptr, 0, GML_PREC_I8X);
-                if (rc) return rc;
-            }
             RCCHK(upload_rows(cg_rows, dRows));
-            launch_cg_init(dRows, (int)cg_rows.size(), X, PG, kind, Qp, D, Rv, Pv, dCg, st);
+            launch_pcg_init(dRows, (int)cg_rows.size(), X, PG, kind, Qp, dFidx, dMsCg, capP, D, Rv, dpgF, dCg, st);
+            launch_newton_solve(dH, dHoff, dMt, dMsCg, dS1, s2, dgF, dpgF, (int)R, capP, dsol, dSdiag, st);
+            launch_pcg_dir(dRows, (int)cg_rows.size(), Qp, dFidx, dMsCg, capP, dsol, dDinv, Rv, Zv, Pv, 1, dCg, st);
             std::vector<CgState> cgs((size_t)Rp);
             std::vector<int> live = cg_rows;
-            const int maxcg = 60;
+            const int maxcg = o.max_cg > 0 ? o.max_cg : 40;
             for (int ci = 0; ci < maxcg && !live.empty(); ++ci) {
                 // Hp = H p for the live rows: an hv pass over slots [0, n) of the u-plane workspace
                 const int64_t n = (int64_t)live.size(), np = gml_round_up(n, 32);
@@ -593,7 +681,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 rc = i8_pass(&p->i8ws, d, Scap, a, st, nullptr, &err);
                 if (rc) return fail(rc, "%s", err.c_str());
                 RCCHK(upload_rows(live, dRows));
-                launch_cg_step(dRows, (int)live.size(), X, PG, G, kind, Qp, dS1, formulation == GML_LOGRISE ? 1.0 : 0.0, Hp, D, Rv, Pv, dCg, st);
+                launch_pcg_step(dRows, (int)live.size(), X, PG, G, kind, Qp, dS1cg, s2, dFidx, dMsCg, capP, Hp, D, Rv, Pv, dpgF, dCg, st);
                 HIPCHK(hipMemcpyAsync(cgs.data(), dCg, sizeof(CgState) * Rp, hipMemcpyDeviceToHost, st));
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipStreamSynchronize(st));
@@ -601,13 +689,18 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 stats->node_evals += n;
                 std::vector<int> nxt;
                 for (int r : live) {
-                    const double eta = std::min(0.1, std::sqrt(std::max(kkt[r], 1e-300)));
+                    const double eta = std::min(0.05, std::sqrt(std::max(kkt[r], 1e-300)));
                     if (cgs[r].pHp > 0 && cgs[r].rs > eta * eta * cgs[r].rs0) nxt.push_back(r);
                 }
                 if (o.verbose >= 2) fprintf(stderr, "[gml]   cg %2d: %zu rows live\n", ci, nxt.size());
                 live.swap(nxt);
+                if (live.empty()) break;
+                RCCHK(upload_rows(live, dRows));
+                launch_newton_solve(dH, dHoff, dMt, dMsCg, dS1, s2, dgF, dpgF, (int)R, capP, dsol, dSdiag, st);
+                launch_pcg_dir(dRows, (int)live.size(), Qp, dFidx, dMsCg, capP, dsol, dDinv, Rv, Zv, Pv, 0, dCg, st);
             }
         }
+        HIPCHK(hipStreamSynchronize(st));
         stats->t_hess += gml_now_s() - th1;
 
         // ---- projected backtracking line search ----------------------------------------------------------------------------------------
@@ -631,6 +724,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             if (rows.empty()) break;
             RCCHK(upload_rows(rows, dRows));
             HIPCHK(hipMemcpyAsync(dAlpha, alpha.data(), sizeof(double) * R, hipMemcpyHostToDevice, st));
+            stage("trial");
             launch_trial(dRows, (int)rows.size(), X, D, PG, kind, Qp, lambda, dAlpha, Xt, dTrial, st);
             HIPCHK(hipMemcpyAsync(trial.data(), dTrial, sizeof(TrialOut) * Rp, hipMemcpyDeviceToHost, st));
             HIPCHK(hipGetLastError());
@@ -655,7 +749,6 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             }
             std::vector<int> acc;
             for (int r : rows) {
-                vstale[r] = 1; // V now belongs to the trial point
                 bool ok;
                 if (nreg[r]) {
                     const double back = trial[r].back;
@@ -673,10 +766,16 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                     fn[r] = fnt[r];
                     Z[r] = Zt[r];
                     acc.push_back(r);
-                    if (full) vstale[r] = 0;
-                    else accepted_fwd[r] = 1;
+                    if (!full) accepted_fwd[r] = 1; // (its V planes still belong to the old iterate)
                     need[r] = 0;
                 } else {
+                    if (prec != GML_PREC_I8X) {
+                        vstale[r] = 1; // the FP64 path's V is indexed by row: every trial overwrites it
+                    } else if (full) { // the planes just written belong to the rejected point: back to those of the iterate, if they survive
+                        const int pv = vprev[r];
+                        if (pv >= 0 && owner[pv] == r) vslot[r] = pv;
+                        else vstale[r] = 1;
+                    }
                     alpha[r] *= 0.5;
                     if (nreg[r] && alpha[r] < 1.0 / 64) {
                         need[r] = 0;   // cannot improve along this direction: the stall counter ends the row,

@@ -9,16 +9,17 @@ struct SelectOut {
     double worst;  // KKT residual: max |pseudo-gradient|
     double worstW; // the same over the current support
     int m;         // working-set size (Cholesky row), or -|W| for a matrix-free (Newton-CG) row
-    int nsupp, nviol, pad;
+    int nsupp, nviol;
+    int pad;       // matrix-free rows: size of the preconditioner block S gathered in F (0 otherwise)
+};
+struct CgState {
+    double rs, rs0, pHp, rz;
 };
 struct TrialOut {
     double dd;    // pg . (xt - x)
     double stepn; // |xt - x|_1
     double l1t;   // lambda * sum |xt_c|
     double back;  // F'(xt; x - xt) (k_back)
-};
-struct CgState {
-    double rs, rs0, pHp;
 };
 
 void launch_kind(const DevProblem &d, int order, const int *dnode, int R, uint8_t *kind, hipStream_t st);
@@ -33,9 +34,12 @@ void launch_trial(const int *drows, int nrows, const double *X, const double *D,
                   double lambda, const double *alpha, double *Xt, TrialOut *out, hipStream_t st);
 void launch_back(const int *drows, int nrows, const double *X, const double *Xt, const double *Gt, const uint8_t *kind, int64_t Qp,
                  double lambda, TrialOut *out, hipStream_t st);
-void launch_cg_init(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, double *D, double *Rv,
-                    double *Pv, CgState *cg, hipStream_t st);
-void launch_cg_step(const int *drows, int nrows, const double *X, const double *PG, const double *G, const uint8_t *kind, int64_t Qp,
-                    const double *s1, double s2, double *Hp, double *D, double *Rv, double *Pv, CgState *cg, hipStream_t st);
+void launch_pcg_init(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, const int *F,
+                     const int *ms, int capP, double *D, double *Rv, double *nrS, CgState *cg, hipStream_t st);
+void launch_pcg_dir(const int *drows, int nrows, int64_t Qp, const int *F, const int *ms, int capP, const double *zS, const double *dinv,
+                    const double *Rv, double *Zv, double *Pv, int first, CgState *cg, hipStream_t st);
+void launch_pcg_step(const int *drows, int nrows, const double *X, const double *PG, const double *G, const uint8_t *kind, int64_t Qp,
+                     const double *s1, double s2, const int *F, const int *ms, int capP, double *Hp, double *D, double *Rv, const double *Pv,
+                     double *nrS, CgState *cg, hipStream_t st);
 
 } // namespace gml

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, co
     const double *x = X + (int64_t)r * Qp, *g = G + (int64_t)r * Qp;
     const uint8_t *kr = kind + (int64_t)r * Qp;
     double *pgr = PG + (int64_t)r * Qp;
+    const double bprev = best[r]; // read by every thread before thread 0 updates it (barriers in between)
     __shared__ double red[4];
     __shared__ int redi[4];
     __shared__ int scan[257];
@@ -193,7 +194,50 @@ __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, co
     __syncthreads();
     const int m = scan[256];
     if (m > capW) {
-        o.m = -(nsupp + (addv ? nviol : 0)); // matrix-free row: W = the support + every violator
+        // Matrix-free row: W = the support + every violator (dense vectors, nothing gathered).  For the block
+        // preconditioner of its CG the strongest capW entries of W are gathered instead: the free column plus the
+        // largest |x_c| + |pg_c| -- the strongly coupled statistics sit there, the remainder of W (coefficients at the
+        // noise level) has a Hessian close to a multiple of the identity.
+        unsigned lo = 0, hi = 0x7f800000u; // invariant: count(score >= lo) > capW - 1 >= count(score >= hi)
+        while (hi - lo > 1) {
+            const unsigned mid = lo + (hi - lo) / 2;
+            int c2 = 0;
+            for (int64_t c = tid; c < Qp; c += 256)
+                if (kr[c] == 2 && (x[c] != 0.0 || pgr[c] != 0.0) && __float_as_uint((float)(fabs(x[c]) + fabs(pgr[c]))) >= mid) ++c2;
+            c2 = block_sum_i(c2, redi);
+            if (c2 > capW - 1) lo = mid;
+            else hi = mid;
+        }
+        int c3 = 0;
+        for (int64_t c = c0; c < c1; ++c) {
+            const uint8_t k = kr[c];
+            c3 += k == 1 || (k == 2 && (x[c] != 0.0 || pgr[c] != 0.0) && __float_as_uint((float)(fabs(x[c]) + fabs(pgr[c]))) >= hi);
+        }
+        __syncthreads();
+        scan[tid + 1] = c3;
+        if (tid == 0) scan[0] = 0;
+        __syncthreads();
+        if (tid == 0)
+            for (int t = 1; t <= 256; ++t) scan[t] += scan[t - 1];
+        __syncthreads();
+        const int ms = scan[256]; // <= capW
+        int pos = scan[tid];
+        for (int64_t c = c0; c < c1; ++c) {
+            const uint8_t k = kr[c];
+            if (k == 1 || (k == 2 && (x[c] != 0.0 || pgr[c] != 0.0) && __float_as_uint((float)(fabs(x[c]) + fabs(pgr[c]))) >= hi)) {
+                F[(int64_t)r * capP + pos] = (int)c;
+                gF[(int64_t)r * capP + pos] = g[c];
+                pgF[(int64_t)r * capP + pos] = pgr[c];
+                ++pos;
+            }
+        }
+        for (int a = ms + tid; a < capP; a += 256) {
+            F[(int64_t)r * capP + a] = (int)(Qp - 1);
+            gF[(int64_t)r * capP + a] = 0.0;
+            pgF[(int64_t)r * capP + a] = 0.0;
+        }
+        o.m = -(nsupp + (addv ? nviol : 0));
+        o.pad = ms;
     } else {
         int pos = scan[tid];
         for (int64_t c = c0; c < c1; ++c) {
@@ -212,8 +256,9 @@ __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, co
             pgF[(int64_t)r * capP + a] = 0.0;
         }
         o.m = m;
+        o.pad = 0;
     }
-    const bool better = worst < best[r];
+    const bool better = worst < bprev;
     if (tid == 0) {
         out[r] = o;
         if (better) best[r] = worst;
@@ -340,14 +385,19 @@ void launch_back(const int *drows, int nrows, const double *X, const double *Xt,
 }
 
 // ------------------------------------------------------------------------------------------
-// Matrix-free Newton-CG on the rows whose working set is too large for a Cholesky block: solve H_WW d = -pg_W by
-// conjugate gradients, W = {c : x_c != 0 or pg_c != 0}, with H p from the device operator (two GEMM passes, i8_pass
-// with hv = 1).  Vectors live in [rows][Qp] arrays; the per-row scalars in CgState.
+// Matrix-free Newton-CG on the rows whose working set is too large for a Cholesky block (dense optima: lambda at the
+// level of the sampling noise): solve H_WW d = -pg_W by preconditioned conjugate gradients, W = {c : x_c != 0 or
+// pg_c != 0}, with H p from the device operator (two GEMM passes, i8_pass with hv = 1).  Preconditioner
+// M = blockdiag(A_SS, a I): the (sub-sampled) Hessian block of the row's strongest capW entries S (k_select), solved by
+// the batched Cholesky kernel, and the common diagonal a of the rest (the statistics are +-1: every diagonal entry of
+// sum_k h_k x_k x_k^T is sum_k h_k).  Vectors live in [rows][Qp] arrays; the per-row scalars in CgState; the S parts
+// travel through the gathered arrays nrS / zS.
 // ------------------------------------------------------------------------------------------
-// r = -pg on W, p = r, d = 0; rs = r.r
-__global__ __launch_bounds__(256) void k_cg_init(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ PG,
-                                                 const uint8_t *__restrict__ kind, int64_t Qp, double *__restrict__ D,
-                                                 double *__restrict__ Rv, double *__restrict__ Pv, CgState *__restrict__ cg) {
+// r = -pg on W, d = 0; nrS = -r gathered at S (the Cholesky kernel solves A z = -rhs)
+__global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ PG,
+                                                  const uint8_t *__restrict__ kind, int64_t Qp, const int *__restrict__ F,
+                                                  const int *__restrict__ ms, int capP, double *__restrict__ D, double *__restrict__ Rv,
+                                                  double *__restrict__ nrS, CgState *__restrict__ cg) {
     const int r = rows[blockIdx.x];
     __shared__ double red[4];
     double rs = 0;
@@ -356,32 +406,62 @@ __global__ __launch_bounds__(256) void k_cg_init(const int *__restrict__ rows, c
         const bool inW = kind[i] && (X[i] != 0.0 || PG[i] != 0.0);
         const double v = inW ? -PG[i] : 0.0;
         Rv[i] = v;
-        Pv[i] = v;
         D[i] = 0.0;
         rs += v * v;
     }
     rs = block_sum(rs, red);
+    for (int a = threadIdx.x; a < ms[r]; a += 256) nrS[(int64_t)r * capP + a] = -Rv[(int64_t)r * Qp + F[(int64_t)r * capP + a]];
     if (threadIdx.x == 0) {
         cg[r].rs = rs;
         cg[r].rs0 = rs;
         cg[r].pHp = 0.0;
+        cg[r].rz = 0.0;
     }
 }
-void launch_cg_init(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, double *D, double *Rv,
-                    double *Pv, CgState *cg, hipStream_t st) {
-    if (nrows > 0) hipLaunchKernelGGL(k_cg_init, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, PG, kind, Qp, D, Rv, Pv, cg);
+void launch_pcg_init(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, const int *F,
+                     const int *ms, int capP, double *D, double *Rv, double *nrS, CgState *cg, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_pcg_init, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, PG, kind, Qp, F, ms, capP, D, Rv, nrS, cg);
 }
 
-// One CG update given Hp = (sum_k h_k x_k x_k^T) p from the device:
-//   Hp <- s1[r] * Hp - s2 * g (g . p), restricted to W   (logRISE: Hess log Z = Hess Z / Z - g g^T, s1 = 1/Z, s2 = 1)
-//   alpha = rs / p.Hp;  d += alpha p;  r -= alpha Hp;  beta = rs' / rs;  p = r + beta p
-__global__ __launch_bounds__(256) void k_cg_step(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ PG,
-                                                 const double *__restrict__ G, const uint8_t *__restrict__ kind, int64_t Qp,
-                                                 const double *__restrict__ s1, double s2, double *__restrict__ Hp, double *__restrict__ D,
-                                                 double *__restrict__ Rv, double *__restrict__ Pv, CgState *__restrict__ cg) {
+// z = M^-1 r: z_S = zS (from the Cholesky solve), z_c = dinv[r] * r_c elsewhere on W;  beta = r.z / (r.z)_old (0 on the first
+// call);  p = z + beta p.  Zv is scratch for z.
+__global__ __launch_bounds__(256) void k_pcg_dir(const int *__restrict__ rows, int64_t Qp, const int *__restrict__ F,
+                                                 const int *__restrict__ ms, int capP, const double *__restrict__ zS,
+                                                 const double *__restrict__ dinv, const double *__restrict__ Rv, double *__restrict__ Zv,
+                                                 double *__restrict__ Pv, int first, CgState *__restrict__ cg) {
     const int r = rows[blockIdx.x];
     const int64_t base = (int64_t)r * Qp;
     __shared__ double red[4];
+    const double di = dinv[r], rzo = cg[r].rz;
+    for (int64_t c = threadIdx.x; c < Qp; c += 256) Zv[base + c] = di * Rv[base + c];
+    __syncthreads();
+    for (int a = threadIdx.x; a < ms[r]; a += 256) Zv[base + F[(int64_t)r * capP + a]] = zS[(int64_t)r * capP + a];
+    __syncthreads();
+    double rz = 0;
+    for (int64_t c = threadIdx.x; c < Qp; c += 256) rz += Rv[base + c] * Zv[base + c];
+    rz = block_sum(rz, red);
+    const double be = (!first && rzo > 0) ? rz / rzo : 0.0;
+    for (int64_t c = threadIdx.x; c < Qp; c += 256) Pv[base + c] = Zv[base + c] + (first ? 0.0 : be * Pv[base + c]);
+    if (threadIdx.x == 0) cg[r].rz = rz;
+}
+void launch_pcg_dir(const int *drows, int nrows, int64_t Qp, const int *F, const int *ms, int capP, const double *zS, const double *dinv,
+                    const double *Rv, double *Zv, double *Pv, int first, CgState *cg, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_pcg_dir, dim3((unsigned)nrows), dim3(256), 0, st, drows, Qp, F, ms, capP, zS, dinv, Rv, Zv, Pv, first, cg);
+}
+
+// Given Hp = (sum_k h_k x_k x_k^T) p from the device:
+//   Hp <- s1[r] * Hp - s2 * g (g . p), restricted to W   (logRISE: Hess log Z = Hess Z / Z - g g^T, s1 = 1/Z, s2 = 1)
+//   alpha = r.z / p.Hp;  d += alpha p;  r -= alpha Hp;  rs = r.r;  -r_S gathered for the next preconditioner solve
+__global__ __launch_bounds__(256) void k_pcg_step(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ PG,
+                                                  const double *__restrict__ G, const uint8_t *__restrict__ kind, int64_t Qp,
+                                                  const double *__restrict__ s1, double s2, const int *__restrict__ F,
+                                                  const int *__restrict__ ms, int capP, double *__restrict__ Hp, double *__restrict__ D,
+                                                  double *__restrict__ Rv, const double *__restrict__ Pv, double *__restrict__ nrS,
+                                                  CgState *__restrict__ cg) {
+    const int r = rows[blockIdx.x];
+    const int64_t base = (int64_t)r * Qp;
+    __shared__ double red[4];
+    const double rzo = cg[r].rz;
     double gp = 0;
     if (s2 != 0.0) {
         for (int64_t c = threadIdx.x; c < Qp; c += 256) gp += G[base + c] * Pv[base + c];
@@ -397,8 +477,7 @@ __global__ __launch_bounds__(256) void k_cg_step(const int *__restrict__ rows, c
         pHp += Pv[i] * h;
     }
     pHp = block_sum(pHp, red);
-    const double rs = cg[r].rs;
-    const double al = pHp > 0 ? rs / pHp : 0.0;
+    const double al = pHp > 0 ? rzo / pHp : 0.0;
     double rsn = 0;
     for (int64_t c = threadIdx.x; c < Qp; c += 256) {
         const int64_t i = base + c;
@@ -408,19 +487,17 @@ __global__ __launch_bounds__(256) void k_cg_step(const int *__restrict__ rows, c
         rsn += rv * rv;
     }
     rsn = block_sum(rsn, red);
-    const double be = rs > 0 ? rsn / rs : 0.0;
-    for (int64_t c = threadIdx.x; c < Qp; c += 256) {
-        const int64_t i = base + c;
-        Pv[i] = Rv[i] + be * Pv[i];
-    }
+    for (int a = threadIdx.x; a < ms[r]; a += 256) nrS[(int64_t)r * capP + a] = -Rv[base + F[(int64_t)r * capP + a]];
     if (threadIdx.x == 0) {
         cg[r].rs = rsn;
         cg[r].pHp = pHp;
     }
 }
-void launch_cg_step(const int *drows, int nrows, const double *X, const double *PG, const double *G, const uint8_t *kind, int64_t Qp,
-                    const double *s1, double s2, double *Hp, double *D, double *Rv, double *Pv, CgState *cg, hipStream_t st) {
-    if (nrows > 0) hipLaunchKernelGGL(k_cg_step, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, PG, G, kind, Qp, s1, s2, Hp, D, Rv, Pv, cg);
+void launch_pcg_step(const int *drows, int nrows, const double *X, const double *PG, const double *G, const uint8_t *kind, int64_t Qp,
+                     const double *s1, double s2, const int *F, const int *ms, int capP, double *Hp, double *D, double *Rv, const double *Pv,
+                     double *nrS, CgState *cg, hipStream_t st) {
+    if (nrows > 0)
+        hipLaunchKernelGGL(k_pcg_step, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, PG, G, kind, Qp, s1, s2, F, ms, capP, Hp, D, Rv, Pv, nrS, cg);
 }
 
 } // namespace gml

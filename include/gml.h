@@ -59,7 +59,8 @@ typedef struct gml_opts {
                             last few nodes get all of them); the gradient always uses all     */
     int32_t polish;      /* precision i8x only: 0 = rows that stall above tol at the noise floor of the int8-limb
                             arithmetic continue on the FP64 path when its workspaces fit (default); -1 = never */
-    int32_t reserved[1];
+    int32_t max_cg;      /* conjugate-gradient iterations per Newton step of the matrix-free rows (working sets above
+                            max_working); each costs one Hessian-vector pass (default 40) */
 } gml_opts;
 
 typedef struct gml_stats {
