@@ -170,6 +170,12 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     // relative to its actual maximum and the noise floor of f and grad drops by the bits the bound would have wasted.
     std::vector<double> vref((size_t)R, 0.0), dref((size_t)R, 0.0), stepn((size_t)R, 0.0);
 
+    // Matrix-free rows admit, per iteration, only the violators within this fraction of the largest violation (measured on
+    // the order-3 config at the reference's default regulariser: with every violator at once -- 0 -- or a quarter of the
+    // largest -- 0.25 -- the projected Newton steps are damped to nothing by the line search; 0.5 takes full steps throughout;
+    // 0.7 converges too, in 1.6x the iterations)
+    const double viol_frac = getenv("GML_CG_VIOL_FRAC") ? atof(getenv("GML_CG_VIOL_FRAC")) : 0.5;
+    const double cg_eta = getenv("GML_CG_ETA") ? atof(getenv("GML_CG_ETA")) : 0.05;
     int prec = o.precision; // switches to FP64 for the rows the int8-limb path cannot bring below tol ("polish")
     bool can_polish = false;
     if (o.precision == GML_PREC_I8X && o.polish >= 0) {
@@ -460,7 +466,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             if (!done[r]) act.push_back((int)r);
         RCCHK(upload_rows(act, dRows));
         stage("select");
-        launch_select(dRows, (int)act.size(), X, G, kind, Qp, lambda, o.max_add, capW, capP, PG, dFidx, dgF, dpgF, dSel, dBest, Xb, st);
+        launch_select(dRows, (int)act.size(), X, G, kind, Qp, lambda, o.max_add, capW, capP, viol_frac, PG, dFidx, dgF, dpgF, dSel, dBest, Xb, st);
         HIPCHK(hipMemcpyAsync(sel.data(), dSel, sizeof(SelectOut) * Rp, hipMemcpyDeviceToHost, st));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
@@ -689,7 +695,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 stats->node_evals += n;
                 std::vector<int> nxt;
                 for (int r : live) {
-                    const double eta = std::min(0.05, std::sqrt(std::max(kkt[r], 1e-300)));
+                    const double eta = std::min(cg_eta, std::sqrt(std::max(kkt[r], 1e-300)));
                     if (cgs[r].pHp > 0 && cgs[r].rs > eta * eta * cgs[r].rs0) nxt.push_back(r);
                 }
                 if (o.verbose >= 2) fprintf(stderr, "[gml]   cg %2d: %zu rows live\n", ci, nxt.size());

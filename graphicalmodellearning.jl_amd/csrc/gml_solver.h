@@ -26,7 +26,7 @@ void launch_kind(const DevProblem &d, int order, const int *dnode, int R, uint8_
 void launch_scale_rows(const int *drows, int nrows, const double *dscale, int64_t Qp, double *G, hipStream_t st);
 void launch_copy_rows(const int *drows, int nrows, int64_t Qp, const double *s0, double *d0, const double *s1, double *d1, hipStream_t st);
 void launch_select(const int *drows, int nrows, const double *X, const double *G, const uint8_t *kind, int64_t Qp, double lambda,
-                   int max_add, int capW, int capP, double *PG, int *F, double *gF, double *pgF, SelectOut *out, double *best,
+                   int max_add, int capW, int capP, double viol_frac, double *PG, int *F, double *gF, double *pgF, SelectOut *out, double *best,
                    double *Xbest, hipStream_t st);
 void launch_scatter_dir(const int *drows, int nrows, const int *F, const double *dsol, const int *msz, int capP, int64_t Qp, double *D,
                         hipStream_t st);

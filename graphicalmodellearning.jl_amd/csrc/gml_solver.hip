@@ -114,7 +114,7 @@ void launch_copy_rows(const int *drows, int nrows, int64_t Qp, const double *s0,
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ G,
                                                 const uint8_t *__restrict__ kind, int64_t Qp, double lambda, int max_add, int capW,
-                                                int capP, double *__restrict__ PG, int *__restrict__ F, double *__restrict__ gF,
+                                                int capP, double viol_frac, double *__restrict__ PG, int *__restrict__ F, double *__restrict__ gF,
                                                 double *__restrict__ pgF, SelectOut *__restrict__ out, double *__restrict__ best,
                                                 double *__restrict__ Xbest) {
     const int r = rows[blockIdx.x];
@@ -198,6 +198,19 @@ __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, co
         // preconditioner of its CG the strongest capW entries of W are gathered instead: the free column plus the
         // largest |x_c| + |pg_c| -- the strongly coupled statistics sit there, the remainder of W (coefficients at the
         // noise level) has a Hessian close to a multiple of the identity.
+        // Only the violators within viol_frac of the largest one enter W in this iteration (the others keep pg = 0 in the
+        // dense array, which defines W for the CG and the line search): thousands of coordinates leaving zero at once, most
+        // of them to come back, make the projected Newton step a poor one.
+        if (viol_frac > 0.0) {
+            double mv = 0.0;
+            for (int64_t c = tid; c < Qp; c += 256)
+                if (kr[c] == 2 && x[c] == 0.0) mv = fmax(mv, fabs(pgr[c]));
+            mv = block_max(mv, red);
+            const double cut = viol_frac * mv;
+            for (int64_t c = tid; c < Qp; c += 256)
+                if (kr[c] == 2 && x[c] == 0.0 && fabs(pgr[c]) < cut) pgr[c] = 0.0;
+            __syncthreads();
+        }
         unsigned lo = 0, hi = 0x7f800000u; // invariant: count(score >= lo) > capW - 1 >= count(score >= hi)
         while (hi - lo > 1) {
             const unsigned mid = lo + (hi - lo) / 2;
@@ -268,10 +281,10 @@ __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, co
 }
 
 void launch_select(const int *drows, int nrows, const double *X, const double *G, const uint8_t *kind, int64_t Qp, double lambda,
-                   int max_add, int capW, int capP, double *PG, int *F, double *gF, double *pgF, SelectOut *out, double *best,
+                   int max_add, int capW, int capP, double viol_frac, double *PG, int *F, double *gF, double *pgF, SelectOut *out, double *best,
                    double *Xbest, hipStream_t st) {
     if (nrows > 0)
-        hipLaunchKernelGGL(k_select, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, G, kind, Qp, lambda, max_add, capW, capP, PG, F, gF,
+        hipLaunchKernelGGL(k_select, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, G, kind, Qp, lambda, max_add, capW, capP, viol_frac, PG, F, gF,
                            pgF, out, best, Xbest);
 }
 

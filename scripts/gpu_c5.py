@@ -17,7 +17,7 @@ with gml.Problem(spins=spins, order=3) as p:
     print('objgrad all nodes: first %.2fs, second %.2fs; f[0]=%.6f' % (t_pass0, t_pass, f[0]), flush=True)
     t1 = time.time()
     creg = float(sys.argv[3]) if len(sys.argv) > 3 else 0.4
-    out, kkt, st = p.learn('RISE', creg, tol=1e-8, precision='i8x', raise_on_fail=False, verbose=1, max_iter=60)
+    out, kkt, st = p.learn('RISE', creg, tol=1e-8, precision='i8x', raise_on_fail=False, verbose=1, max_iter=int(sys.argv[4]) if len(sys.argv) > 4 else 100)
     t_learn = time.time() - t1
     keys0 = p.multi_keys(0)
 rec = {'n': n, 'K': K, 'c': creg, 'nnz_per_node_max': int((out != 0).sum(1).max()), 'P': int(out.shape[1]), 'pass_s': t_pass, 'learn_s': t_learn, **{k: st[k] for k in ['iterations', 'passes', 'forward_passes', 'hessian_passes', 'max_kkt', 'not_converged', 't_pass', 't_hess', 't_host']}}
@@ -28,4 +28,4 @@ for key, v in zip(keys0, out[0]):
     err = max(err, abs(v - terms.get(k1, 0.0)))
 rec['max_err_node0_vs_truth'] = err
 print(json.dumps(rec), flush=True)
-json.dump(rec, open('gpurun_out/c5.json', 'w'))
+json.dump(rec, open('gpurun_out/c5_c%g.json' % creg, 'w'))
