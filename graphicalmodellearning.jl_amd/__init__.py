@@ -4,7 +4,7 @@ Same surface as the reference module (GraphicalModelLearning.jl:3-6, models.jl:3
 the GMLFormulation types, the GMLMethod types (NLP plus the new HIP), FactorGraph.  The compute
 path is libgml_hip.so (hand-written HIP kernels for gfx950 behind the C ABI in include/gml.h).
 """
-from ._lib import GMLConvergenceError, GMLError, Problem, lib  # noqa: F401
+from ._lib import GMLConvergenceError, GMLError, MultiProblem, Problem, lib  # noqa: F401
 from .factor_graph import FactorGraph, matrix_to_terms, permutations, check_model_data  # noqa: F401
 from .formulations import (HIP, ISODUS, NLP, RISE, RISEA, RPLE, GMLFormulation, GMLMethod,  # noqa: F401
                            logRISE, multiRISE)
@@ -12,4 +12,4 @@ from .learn import learn  # noqa: F401
 from .sampling import GMSampler, Gibbs, Glauber, sample  # noqa: F401
 
 __all__ = ["learn", "GMLFormulation", "RISE", "logRISE", "RPLE", "RISEA", "multiRISE", "ISODUS", "GMLMethod",
-           "NLP", "HIP", "FactorGraph", "Problem", "GMLError", "GMLConvergenceError", "sample", "GMSampler", "Gibbs"]
+           "NLP", "HIP", "FactorGraph", "Problem", "MultiProblem", "GMLError", "GMLConvergenceError", "sample", "GMSampler", "Gibbs"]

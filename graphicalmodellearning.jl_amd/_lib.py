@@ -80,6 +80,11 @@ def lib():
     L.gml_multi_keys.argtypes = [p, i64, p]
     L.gml_objgrad_batch.argtypes = [p, i32, i32, i64, p, p, i64, p, p]
     L.gml_hessvec_batch.argtypes = [p, i32, i64, p, p, p, i64, p]
+    L.gml_multi_create.argtypes = [p, i32, i64, i64, i64, i32, i32, p, i32, C.POINTER(p)]
+    L.gml_multi_info.argtypes = [p] + [p] * 6
+    L.gml_multi_learn.argtypes = [p, i32, dbl, C.POINTER(Opts), p, p, C.POINTER(Stats), p]
+    L.gml_multi_destroy.argtypes = [p]
+    L.gml_multi_destroy.restype = None
     L.gml_learn.argtypes = [p, i32, dbl, C.POINTER(Opts), p, p, C.POINTER(Stats)]
     L.gml_bench_pass.argtypes = [p, i32, i32, p, i32, i32, p]
     L.gml_bench_pass_resident.argtypes = [p, i32, i32, p, i32, i32, p, p, p]
@@ -250,3 +255,78 @@ class Problem:
                                             int(warmup), _ptr(ms), _ptr(f), _ptr(g)))
         out = {"fwd_ms": ms[0], "bwd_ms": ms[1], "pass_ms": ms[2], "device_ms_per_pass": ms[3]}
         return (out, f, g) if want_output else out
+
+
+class MultiProblem:
+    """One problem on several GPUs of this node from one process (gml_multi_*): GPU g owns the nodes [g n/G, (g+1) n/G),
+    one host thread per device inside the library; what the Julia wrapper's HIP(devices = ...) binds."""
+
+    def __init__(self, samples, devices, order=2):
+        L = lib()
+        s = np.asarray(samples)
+        if s.ndim != 2 or s.shape[1] < 2:
+            raise GMLError(GML_EINVAL, "samples must be a K x (1+n) histogram matrix")
+        if s.dtype not in DTYPES:
+            s = s.astype(np.float64)
+        col_major = bool(s.flags.f_contiguous and not s.flags.c_contiguous)
+        if not (s.flags.c_contiguous or s.flags.f_contiguous):
+            s = np.ascontiguousarray(s)
+        K, n = s.shape[0], s.shape[1] - 1
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        check(L.gml_multi_create(_ptr(s), DTYPES[s.dtype], K, n, K if col_major else n + 1, int(col_major), int(order), _ptr(dev),
+                                 len(dev), C.byref(h)))
+        self._h = h
+        nn, KK, PP, nd = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+        M = C.c_double()
+        check(L.gml_multi_info(h, C.byref(nn), C.byref(KK), C.byref(M), C.byref(PP), C.byref(nd), None))
+        self.n, self.K, self.M, self.P, self.ndev = nn.value, KK.value, M.value, PP.value, nd.value
+        self.devices = [int(v) for v in dev]
+
+    def gather_kind(self):
+        buf = C.create_string_buffer(32)
+        check(lib().gml_multi_info(self._h, None, None, None, None, None, buf))
+        return buf.value.decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gml_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="i8x", max_working=512, max_add=64, verbose=0,
+              hess_samples=0, polish=True, dev_out=None, raise_on_fail=True):
+        """dev_out: optional list of device pointers (ints), one per part, each an n x P float64 buffer on that part's GPU;
+        the gathered matrix is left in all of them (RCCL all-gather)."""
+        L = lib()
+        o = Opts()
+        L.gml_default_opts(C.byref(o))
+        o.tol, o.max_iter, o.precision = float(tol), int(max_iter), PRECISIONS[precision]
+        o.max_working, o.max_add, o.verbose, o.hess_samples = int(max_working), int(max_add), int(verbose), int(hess_samples)
+        o.polish = 0 if polish else -1
+        out = np.zeros((self.n, self.P))
+        kkt = np.zeros(self.n)
+        st = Stats()
+        dptr = None
+        if dev_out is not None:
+            dptr = (C.c_void_p * self.ndev)(*[C.c_void_p(int(v)) for v in dev_out])
+        rc = L.gml_multi_learn(self._h, FORMULATION_IDS[formulation], float(c), C.byref(o), _ptr(out), _ptr(kkt), C.byref(st), dptr)
+        if rc == GML_ENOTCONV:
+            if raise_on_fail:
+                err = GMLConvergenceError(L.gml_last_error().decode())
+                err.stats, err.kkt = st.asdict(), kkt
+                raise err
+        else:
+            check(rc)
+        return out, kkt, st.asdict()

@@ -1,0 +1,209 @@
+// gml_multi_*: one problem on several GPUs of a node from ONE caller (the reference's host language has no
+// torch.distributed: a Julia `learn(samples, RISE(), HIP(devices = 0:7))` lands here).
+//
+// The node-wise problems are independent (the loop GraphicalModelLearning.jl:161 touches only row u, :181), so GPU g
+// owns the contiguous node range [g n / G, (g+1) n / G): its own gml_problem handle (the sample bits are replicated,
+// 1/8 byte per entry), its own host thread, no communication while solving.  The learned row blocks are gathered
+//   * into the caller's host matrix directly (every thread writes its rows), and/or
+//   * into a device-resident copy of the full matrix on EVERY GPU by one RCCL all-gather over xGMI (gml_multi_learn's
+//     dev_out), for callers that keep working on the devices.  librccl is loaded at run time (dlopen): the library has no
+//     link-time dependency on it, and falls back to peer copies when it is absent or the device list repeats a GPU.
+#include "gml_internal.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+#include <thread>
+
+namespace {
+
+// the few RCCL entry points used, resolved at run time
+struct Rccl {
+    typedef void *comm_t;
+    int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int /*ncclDataType_t*/, comm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    Rccl() {
+        void *h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD); // the copy a host framework has already loaded, if any
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(h, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(h, "ncclAllGather"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather;
+    }
+};
+Rccl &rccl() {
+    static Rccl r;
+    return r;
+}
+constexpr int kNcclFloat64 = 8; // ncclDouble / ncclFloat64 (nccl.h)
+
+} // namespace
+
+struct gml_multi {
+    std::vector<gml_problem *> part;
+    std::vector<int> device;
+    int64_t n = 0, K = 0, P = 0;
+    double M = 0;
+    std::vector<Rccl::comm_t> comm; // one per part when RCCL is usable for this device list
+    char gather_kind[32] = "host";
+};
+
+extern "C" void gml_multi_destroy(gml_multi *m) {
+    if (!m) return;
+    for (size_t g = 0; g < m->comm.size(); ++g)
+        if (m->comm[g]) {
+            (void)hipSetDevice(m->device[g]);
+            (void)rccl().CommDestroy(m->comm[g]);
+        }
+    for (gml_problem *p : m->part) gml_problem_destroy(p);
+    delete m;
+}
+
+extern "C" int gml_multi_create(const void *samples, int dtype, int64_t K, int64_t n, int64_t ld, int col_major, int order,
+                                const int *devices, int ndev, gml_multi **out) {
+    if (!out) return fail(GML_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!devices || ndev < 1) return fail(GML_EINVAL, "empty device list");
+    if (n < ndev) return fail(GML_EINVAL, "more devices (%d) than nodes (%lld)", ndev, (long long)n);
+    gml_multi *m = new gml_multi();
+    m->part.assign((size_t)ndev, nullptr);
+    m->device.assign(devices, devices + ndev);
+    std::vector<int> rc((size_t)ndev, GML_OK);
+    std::vector<std::string> msg((size_t)ndev);
+    std::vector<std::thread> th;
+    for (int g = 0; g < ndev; ++g)
+        th.emplace_back([&, g] {
+            const int64_t n0 = (int64_t)g * n / ndev, n1 = (int64_t)(g + 1) * n / ndev; // contiguous node ranges
+            rc[g] = gml_problem_create(samples, dtype, K, n, ld, col_major, order, n0, n1, devices[g], &m->part[g]);
+            if (rc[g]) msg[g] = gml_last_error();
+        });
+    for (auto &t : th) t.join();
+    for (int g = 0; g < ndev; ++g)
+        if (rc[g]) {
+            const int code = rc[g];
+            const std::string keep = msg[g];
+            gml_multi_destroy(m);
+            return fail(code, "device %d: %s", devices[g], keep.c_str());
+        }
+    (void)gml_problem_info(m->part[0], &m->n, &m->K, &m->M, &m->P, nullptr, nullptr);
+    // RCCL communicators, when every part sits on its own GPU
+    std::vector<int> uniq(m->device);
+    std::sort(uniq.begin(), uniq.end());
+    const bool distinct = std::adjacent_find(uniq.begin(), uniq.end()) == uniq.end();
+    if (distinct && rccl().ok) {
+        m->comm.assign((size_t)ndev, nullptr);
+        if (rccl().CommInitAll(m->comm.data(), ndev, devices) != 0) m->comm.clear(); // fall back to peer copies
+    }
+    *out = m;
+    return GML_OK;
+}
+
+extern "C" int gml_multi_info(const gml_multi *m, int64_t *n, int64_t *K, double *M, int64_t *P, int *ndev, char *gather_kind /* >= 32 bytes or NULL */) {
+    if (!m) return fail(GML_EINVAL, "handle is NULL");
+    if (n) *n = m->n;
+    if (K) *K = m->K;
+    if (M) *M = m->M;
+    if (P) *P = m->P;
+    if (ndev) *ndev = (int)m->part.size();
+    if (gather_kind) std::strcpy(gather_kind, m->gather_kind);
+    return GML_OK;
+}
+
+extern "C" int gml_multi_learn(gml_multi *m, int formulation, double regularizer_c, const gml_opts *opts, double *out, double *kkt,
+                               gml_stats *stats, double **dev_out) {
+    if (!m || (!out && !dev_out)) return fail(GML_EINVAL, "NULL argument");
+    const int G = (int)m->part.size();
+    const int64_t n = m->n, P = m->P;
+    std::vector<int> rc((size_t)G, GML_OK);
+    std::vector<std::string> msg((size_t)G);
+    std::vector<gml_stats> st((size_t)G);
+    std::vector<std::vector<double>> rows((size_t)G);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g)
+        th.emplace_back([&, g] {
+            const int64_t n0 = (int64_t)g * n / G, n1 = (int64_t)(g + 1) * n / G;
+            double *dst = out ? out + n0 * P : nullptr; // disjoint row blocks of the caller's matrix: the host-side gather
+            if (!dst) {
+                rows[g].resize((size_t)((n1 - n0) * P));
+                dst = rows[g].data();
+            }
+            rc[g] = gml_learn(m->part[g], formulation, regularizer_c, opts, dst, kkt ? kkt + n0 : nullptr, &st[g]);
+            if (rc[g]) msg[g] = gml_last_error();
+        });
+    for (auto &t : th) t.join();
+    if (stats) { // totals over the parts, the wall-clock entries of the slowest part
+        std::memset(stats, 0, sizeof *stats);
+        for (int g = 0; g < G; ++g) {
+            stats->iterations = std::max(stats->iterations, st[g].iterations);
+            stats->passes += st[g].passes;
+            stats->forward_passes += st[g].forward_passes;
+            stats->hessian_passes += st[g].hessian_passes;
+            stats->node_evals += st[g].node_evals;
+            stats->max_kkt = std::max(stats->max_kkt, st[g].max_kkt);
+            stats->lambda = st[g].lambda;
+            stats->t_pass = std::max(stats->t_pass, st[g].t_pass);
+            stats->t_hess = std::max(stats->t_hess, st[g].t_hess);
+            stats->t_host = std::max(stats->t_host, st[g].t_host);
+            stats->t_total = std::max(stats->t_total, st[g].t_total);
+            stats->not_converged += st[g].not_converged;
+            stats->polished |= st[g].polished;
+        }
+    }
+    int worst = GML_OK;
+    std::string wmsg;
+    for (int g = 0; g < G; ++g)
+        if (rc[g] && (worst == GML_OK || rc[g] != GML_ENOTCONV)) {
+            worst = rc[g];
+            wmsg = msg[g];
+        }
+    if (worst != GML_OK && worst != GML_ENOTCONV) return fail(worst, "%s", wmsg.c_str());
+    if (dev_out) {
+        // the full matrix on every GPU: one all-gather of the row blocks over xGMI (RCCL), or peer copies
+        const bool even = n % G == 0;
+        std::vector<double *> send((size_t)G, nullptr);
+        std::vector<hipStream_t> sts((size_t)G, nullptr);
+        for (int g = 0; g < G; ++g) {
+            const int64_t n0 = (int64_t)g * n / G, n1 = (int64_t)(g + 1) * n / G;
+            HIPCHK(hipSetDevice(m->device[g]));
+            HIPCHK(hipStreamCreate(&sts[g]));
+            const double *src = out ? out + n0 * P : rows[g].data();
+            send[g] = dev_out[g] + n0 * P; // in place: the block sits where the all-gather expects it
+            HIPCHK(hipMemcpyAsync(send[g], src, sizeof(double) * (n1 - n0) * P, hipMemcpyHostToDevice, sts[g]));
+        }
+        if (!m->comm.empty() && even) {
+            std::strcpy(m->gather_kind, "rccl-allgather");
+            int e = rccl().GroupStart();
+            for (int g = 0; g < G && e == 0; ++g) e = rccl().AllGather(send[g], dev_out[g], (size_t)(n / G * P), kNcclFloat64, m->comm[g], sts[g]);
+            if (e == 0) e = rccl().GroupEnd();
+            if (e != 0) return fail(GML_EHIP, "RCCL all-gather failed: %s", rccl().GetErrorString ? rccl().GetErrorString(e) : "?");
+        } else {
+            std::strcpy(m->gather_kind, "peer-copy");
+            for (int g = 0; g < G; ++g) HIPCHK(hipStreamSynchronize(sts[g]));
+            for (int g = 0; g < G; ++g)
+                for (int h = 0; h < G; ++h) {
+                    if (h == g || dev_out[h] == dev_out[g]) continue;
+                    const int64_t n0 = (int64_t)h * n / G, n1 = (int64_t)(h + 1) * n / G;
+                    HIPCHK(hipMemcpyPeerAsync(dev_out[g] + n0 * P, m->device[g], dev_out[h] + n0 * P, m->device[h], sizeof(double) * (n1 - n0) * P, sts[g]));
+                }
+        }
+        for (int g = 0; g < G; ++g) {
+            HIPCHK(hipSetDevice(m->device[g]));
+            HIPCHK(hipStreamSynchronize(sts[g]));
+            (void)hipStreamDestroy(sts[g]);
+        }
+    }
+    if (worst == GML_ENOTCONV) return fail(GML_ENOTCONV, "%s", wmsg.c_str());
+    return GML_OK;
+}

@@ -1,7 +1,7 @@
 """The reference's formulation / method types (GraphicalModelLearning.jl:20-65), same names,
 same field order, same defaults -- plus the one new GMLMethod subtype, HIP."""
 from dataclasses import dataclass, field
-from typing import Any, Optional, Tuple
+from typing import Any, Optional, Sequence, Tuple
 
 
 class GMLFormulation:  # :20
@@ -55,11 +55,14 @@ class HIP(GMLMethod):
     precision  "i8x" (int8-limb fixed point on the i8 MFMA: the fast path, the default; rows it cannot bring
                below tol are finished on the FP64 path unless polish=False) or "f64" (FP64 MFMA throughout)
     device     HIP device ordinal; with distributed=True the local rank's device
-    distributed  shard the nodes over torch.distributed ranks and gather the rows (RCCL)
+    devices    several GPUs of this node from this one process: the library shards the nodes over them (one host thread
+               per GPU, gml_multi_*); what the Julia wrapper's HIP(devices = 0:7) binds
+    distributed  shard the nodes over torch.distributed ranks (one process per GPU) and gather the rows (RCCL)
     """
     tol: float = 1e-9
     precision: str = "i8x"
     device: Optional[int] = None
+    devices: Optional[Sequence[int]] = None
     max_iter: int = 100
     max_working: int = 512
     max_add: int = 64

@@ -30,30 +30,47 @@ const GML_PREC_F64, GML_PREC_I8X = Cint(0), Cint(1)
 
 struct GmlOpts                      # struct gml_opts
     tol::Cdouble; max_iter::Int32; precision::Int32; max_working::Int32; max_add::Int32
-    verbose::Int32; hess_samples::Int32; reserved1::Int32; reserved2::Int32
+    verbose::Int32; hess_samples::Int32; polish::Int32; max_cg::Int32
 end
 
 struct GmlStats                     # struct gml_stats
     iterations::Int32; passes::Int32; forward_passes::Int32; hessian_passes::Int32
     node_evals::Int64; max_kkt::Cdouble; lambda::Cdouble
     t_pack::Cdouble; t_pass::Cdouble; t_hess::Cdouble; t_host::Cdouble; t_total::Cdouble
-    not_converged::Int32; reserved::Int32
+    not_converged::Int32; polished::Int32
 end
 
 """
-    HIP(; tol=1e-9, precision=:f64, device=0, max_iter=100, node_range=nothing)
+    HIP(; tol=1e-9, precision=:i8x, device=0, devices=nothing, max_iter=100, max_working=512, max_add=64,
+        hess_samples=0, polish=true, verbose=0, node_range=nothing)
 
-GMLMethod that solves every node-wise problem on an MI355X through libgml_hip.
-`precision = :i8x` selects the exact int8-limb fixed-point pass.
+GMLMethod that solves every node-wise problem on MI355X through libgml_hip (same fields and defaults as the Python
+twin, graphicalmodellearning.jl_amd/formulations.py).
+`precision = :i8x` (default) is the int8-limb fixed-point pass; rows it cannot bring below `tol` are finished on the
+FP64 path unless `polish = false`; `:f64` runs FP64 MFMA throughout.  `devices = 0:7` shards the nodes over several
+GPUs of this node from this one process (gml_multi_*: one handle and one host thread per GPU inside the library, the
+row blocks are written straight into the result matrix).
 """
 mutable struct HIP <: GMLMethod
     tol::Float64
     precision::Symbol
     device::Int
+    devices::Union{Nothing,Vector{Int}}
     max_iter::Int
+    max_working::Int
+    max_add::Int
+    hess_samples::Int
+    polish::Bool
+    verbose::Int
     node_range::Union{Nothing,Tuple{Int,Int}}   # 1-based inclusive, for one-process-per-GPU sharding
 end
-HIP(; tol=1e-9, precision=:f64, device=0, max_iter=100, node_range=nothing) = HIP(tol, precision, device, max_iter, node_range)
+HIP(; tol=1e-9, precision=:i8x, device=0, devices=nothing, max_iter=100, max_working=512, max_add=64, hess_samples=0,
+    polish=true, verbose=0, node_range=nothing) =
+    HIP(tol, precision, device, devices === nothing ? nothing : collect(Int, devices), max_iter, max_working, max_add,
+        hess_samples, polish, verbose, node_range)
+
+gmlopts(m::HIP) = Ref(GmlOpts(m.tol, m.max_iter, m.precision == :i8x ? GML_PREC_I8X : GML_PREC_F64, m.max_working, m.max_add,
+                              m.verbose, m.hess_samples, m.polish ? 0 : -1, 0))
 
 lasterr() = unsafe_string(ccall((:gml_last_error, libgml), Cstring, ()))
 
@@ -66,6 +83,7 @@ function solve_rows(samples::Array{T,2}, formulation, method::HIP, order::Int) w
     s = T <: AbstractFloat ? convert(Array{Float64,2}, samples) : convert(Array{Int64,2}, samples)
     dtype = eltype(s) == Float64 ? GML_F64 : GML_I64
     K, n = size(s, 1), size(s, 2) - 1
+    method.devices === nothing || return solve_rows_multi(s, dtype, formulation, method, order)
     n0, n1 = method.node_range === nothing ? (0, n) : (method.node_range[1] - 1, method.node_range[2])
     handle = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:gml_problem_create, libgml), Cint,
@@ -79,8 +97,7 @@ function solve_rows(samples::Array{T,2}, formulation, method::HIP, order::Int) w
               handle[], C_NULL, C_NULL, C_NULL, P, C_NULL, C_NULL)
         R = n1 - n0
         out = Array{Float64}(undef, P[], R)          # C row-major (R x P) == Julia (P x R)
-        opts = Ref(GmlOpts(method.tol, method.max_iter, method.precision == :i8x ? GML_PREC_I8X : GML_PREC_F64,
-                           512, 64, 0, 0, 0, 0))
+        opts = gmlopts(method)
         stats = Ref{GmlStats}()
         rc = ccall((:gml_learn, libgml), Cint,
                    (Ptr{Cvoid}, Cint, Cdouble, Ref{GmlOpts}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{GmlStats}),
@@ -100,6 +117,47 @@ function solve_rows(samples::Array{T,2}, formulation, method::HIP, order::Int) w
         return permutedims(out), keys, n0                # R x P
     finally
         ccall((:gml_problem_destroy, libgml), Cvoid, (Ptr{Cvoid},), handle[])
+    end
+end
+
+# all nodes over method.devices: gml_multi_* (one handle + one host thread per GPU inside the library)
+function solve_rows_multi(s, dtype, formulation, method::HIP, order::Int)
+    K, n = size(s, 1), size(s, 2) - 1
+    devs = convert(Vector{Cint}, method.devices)
+    handle = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:gml_multi_create, libgml), Cint,
+               (Ptr{Cvoid}, Cint, Int64, Int64, Int64, Cint, Cint, Ptr{Cint}, Cint, Ref{Ptr{Cvoid}}),
+               s, dtype, K, n, K, 1, order, devs, length(devs), handle)
+    rc == GML_OK || error("gml_multi_create: $(lasterr())")
+    try
+        P = Ref{Int64}(0)
+        ccall((:gml_multi_info, libgml), Cint,
+              (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}, Ptr{Cint}, Ptr{UInt8}),
+              handle[], C_NULL, C_NULL, C_NULL, P, C_NULL, C_NULL)
+        out = Array{Float64}(undef, P[], n)               # C row-major (n x P) == Julia (P x n)
+        stats = Ref{GmlStats}()
+        rc = ccall((:gml_multi_learn, libgml), Cint,
+                   (Ptr{Cvoid}, Cint, Cdouble, Ref{GmlOpts}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{GmlStats}, Ptr{Ptr{Cdouble}}),
+                   handle[], formulation_id(formulation), Float64(formulation.regularizer), gmlopts(method), out, C_NULL, stats, C_NULL)
+        rc == GML_ENOTCONV && throw(AssertionError(lasterr()))   # @assert ... LOCALLY_SOLVED (:180)
+        rc == GML_OK || error("gml_multi_learn: $(lasterr())")
+        keys = nothing
+        if order != 2   # keys of node u in the reference's order (:94-104): (u), (u,i) ascending, (u,i,j) lexicographic, ...
+            keys = Vector{Matrix{Int32}}()
+            for u in 0:(n - 1)
+                others = [i for i in 0:(n - 1) if i != u]
+                cols = Vector{Vector{Int32}}()
+                for p in 1:order
+                    for c in GraphicalModelLearning.permutations(others, p - 1, asymmetric=false)
+                        k = fill(Int32(-1), order); k[1] = u; k[2:p] .= collect(c); push!(cols, k)
+                    end
+                end
+                push!(keys, reduce(hcat, cols))
+            end
+        end
+        return permutedims(out), keys, 0
+    finally
+        ccall((:gml_multi_destroy, libgml), Cvoid, (Ptr{Cvoid},), handle[])
     end
 end
 

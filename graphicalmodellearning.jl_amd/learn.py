@@ -36,6 +36,16 @@ def _local_solve_hip(samples, formulation, method, order, node_range, device):
     return out, kkt, st, keys
 
 
+def _local_solve_multi(samples, formulation, method, order):
+    """all nodes on method.devices from this process (gml_multi_*: one handle + one host thread per GPU in the library)"""
+    with _lib.MultiProblem(samples, method.devices, order=order) as prob:
+        out, kkt, st = prob.learn(_form_name(formulation), formulation.regularizer, tol=method.tol, max_iter=method.max_iter,
+                                  precision=method.precision, max_working=method.max_working, max_add=method.max_add,
+                                  verbose=method.verbose, hess_samples=method.hess_samples, polish=method.polish)
+        st["n_gpus"] = prob.ndev
+    return out, kkt, st, None
+
+
 def _gather_rows(local, n, P, method):
     """all-gather of the per-rank row blocks (RCCL over xGMI when the backend is nccl)."""
     import torch
@@ -90,7 +100,11 @@ def learn(samples, formulation=None, method=None, *, _local_solve=None):
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
     solve = _local_solve or _local_solve_hip
     try:
-        out, kkt, st, keys = solve(samples, formulation, method, order, node_range, device)
+        if method.devices is not None and _local_solve is None and not method.distributed:
+            out, kkt, st, keys = _local_solve_multi(samples, formulation, method, order)
+            node_range = (0, n)
+        else:
+            out, kkt, st, keys = solve(samples, formulation, method, order, node_range, device)
     except _lib.GMLConvergenceError as e:  # the reference's @assert (:180): keep what the solver reached
         method.stats.clear()
         method.stats.update(getattr(e, "stats", {}) or {})

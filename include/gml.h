@@ -194,6 +194,29 @@ int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows, const int6
 int gml_learn(gml_problem *p, int formulation, double regularizer_c, const gml_opts *opts,
               double *out, double *kkt, gml_stats *stats);
 
+/*
+ * gml_multi_* -- the node loop of `learn` (:161: `for current_spin = 1:num_spins`, rows stored at :181) over several
+ * GPUs of one node from a single caller (the reference's host language has no process group: Julia's
+ * `learn(samples, RISE(), HIP(devices = 0:7))` binds these).  GPU g owns the nodes [g n / G, (g+1) n / G): one handle and
+ * one host thread per device, the sample bits replicated, no communication while solving.
+ *
+ *   gml_multi_create   as gml_problem_create, for the devices listed (a device may be listed more than once)
+ *   gml_multi_learn    out: n x P row-major host matrix (may be NULL), rows written by the part that owns them; kkt: n.
+ *                      dev_out: NULL, or one device pointer per part (n x P doubles on that part's GPU): the full
+ *                      matrix is left on EVERY GPU by one RCCL all-gather over xGMI (librccl is loaded at run time;
+ *                      peer copies when it is absent, the device list repeats a GPU, or n is not a multiple of G).
+ *                      stats: totals over the parts, times of the slowest part.
+ *   gml_multi_info     gather_kind (>= 32 bytes or NULL): how the last dev_out gather was done
+ *                      ("rccl-allgather", "peer-copy", "host" when none was asked for)
+ */
+typedef struct gml_multi gml_multi;
+int gml_multi_create(const void *samples, int dtype, int64_t K, int64_t n, int64_t ld, int col_major, int order,
+                     const int *devices, int ndev, gml_multi **out);
+int gml_multi_info(const gml_multi *m, int64_t *n, int64_t *K, double *M, int64_t *P, int *ndev, char *gather_kind);
+int gml_multi_learn(gml_multi *m, int formulation, double regularizer_c, const gml_opts *opts, double *out, double *kkt,
+                    gml_stats *stats, double **dev_out);
+void gml_multi_destroy(gml_multi *m);
+
 /* Timing hook for the benchmark: runs `steps` full objective+gradient passes over the local
  * nodes at the given theta ((node1-node0) x P, reference layout, host) on the handle's
  * stream and returns the average device time of the dominant kernels measured with HIP
