@@ -261,6 +261,9 @@ def main():
                       "learn_forward_passes": st["forward_passes"], "learn_node_evals": st["node_evals"],
                       "learn_max_kkt": st["max_kkt"], "learn_not_converged": st["not_converged"],
                       "learn_t_pass": st["t_pass"], "learn_t_hess": st["t_hess"], "learn_t_host": st["t_host"],
+                      # what the passes cost INSIDE learn() (control uploads, scalar downloads and the per-pass sync included):
+                      # the solver drives the same resident pass function the timed region above calls
+                      "learn_pass_node_evals_per_s": st["node_evals"] / max(st["t_pass"], 1e-9) * world,
                       "max_err_vs_true_model": sym_err})
 
     # ---- CPU baseline (rank 0 of a 1-GPU run only) -----------------------------------------------------------------

@@ -104,7 +104,7 @@ def pairwise(name, desc, J, K, form, c, seed, node_range=None, sample_nodes=4, c
     return name, rec
 
 
-def c5(name, K=1000000, n=512, c=1.2, seed=5, tol=1e-8):
+def c5(name, K=1000000, n=512, c=1.2, seed=5, tol=1e-8, max_iter=100):
     terms = syn.block_multibody_terms(n, block=16, seed=0)
     rec = {"config": "multi-body (3-spin) model, multiRISE/ISODUS order 3", "n": n, "K": K, "formulation": f"multiRISE({c}, true, 3)",
            "seed": seed, "precision": "i8x", "tol": tol, "n_gpus": 1, **cpu_info()}
@@ -113,12 +113,13 @@ def c5(name, K=1000000, n=512, c=1.2, seed=5, tol=1e-8):
         rec["create_s"] = time.time() - t0
         rec["P_per_node"] = P = p.P
         t0 = time.time()
-        out, kkt, st = p.learn("RISE", c, tol=tol, precision="i8x", max_iter=80, raise_on_fail=False)
+        out, kkt, st = p.learn("RISE", c, tol=tol, precision="i8x", max_iter=max_iter, raise_on_fail=False)
         rec["learn_s"] = time.time() - t0
         rec.update({"lambda": st["lambda_"], "iterations": st["iterations"], "passes": st["passes"], "forward_passes": st["forward_passes"],
+                    "hessian_and_hv_passes": st["hessian_passes"],
                     "node_evals": st["node_evals"], "max_kkt": st["max_kkt"], "not_converged": st["not_converged"],
                     "t_pass": st["t_pass"], "t_hess": st["t_hess"], "t_host": st["t_host"],
-                    "nnz_per_node_max": int((out != 0).sum(1).max())})
+                    "nnz_per_node_max": int((out != 0).sum(1).max()), "nnz_per_node_mean": float((out != 0).sum(1).mean())})
         km = p.bench_pass_resident("RISE", out, steps=2, warmup=1, precision="i8x")
         rec["pass"] = {**km, **roof(K, P, n, km["device_ms_per_pass"])}
         rec["node_evals_per_s"] = n / (km["device_ms_per_pass"] * 1e-3)
@@ -152,7 +153,7 @@ def main():
     if "--round" in sys.argv:
         rnd = sys.argv[sys.argv.index("--round") + 1]
         args = [a for a in args if a != rnd]
-    which = args or ["c1", "c2", "c3", "c4", "c5"]
+    which = args or ["c1", "c2", "c3", "c4", "c5", "c5d"]
     out_dir = os.path.join(ROOT, "gpurun_out", "configs")
     os.makedirs(out_dir, exist_ok=True)
     jobs = []
@@ -174,6 +175,8 @@ def main():
                                      syn.block_ising_model(4096, 8, 1), 1000000, "RISE", 0.4, 4, node_range=(0, 512), cpu_learn="extrapolate"))
     if "c5" in which:
         jobs.append(lambda: c5("C5"))
+    if "c5d" in which:  # the reference's default regulariser (multiRISE(0.4, true, 3) / ISODUS()): dense optimum, matrix-free Newton-CG
+        jobs.append(lambda: c5("C5_default_c0.4", c=0.4))
     for job in jobs:
         name, rec = job()
         if name == "C1":

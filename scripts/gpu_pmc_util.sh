@@ -16,7 +16,7 @@ for f in glob.glob('gpurun_out/prof_util/**/*counter_collection.csv', recursive=
         per[(row['Kernel_Name'], row['Dispatch_Id'], row['Counter_Name'])] += float(row['Counter_Value'])
     for (k, _, c), v in per.items():
         name = k.split('(')[0].replace('void ', '')
-        if 'fwd_i8' in name or 'bwd_i8' in name:
+        if 'fwd_i8' in name or 'bwd_i8' in name or 'hess_bits' in name:
             res[name][c] = max(res[name].get(c, 0.0), v)
 json.dump(res, open('gpurun_out/prof_util/summary.json', 'w'), indent=1)
 print(json.dumps(res, indent=1))

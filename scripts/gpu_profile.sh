@@ -2,7 +2,7 @@
 # Round profile: bench line, rocprofv3 kernel stats, PMC HBM traffic (separate passes).  Run on the GPU box
 # from the repo root: bash scripts/gpu_profile.sh r1   (writes under gpurun_out/prof_r1/)
 set -u
-tag=${1:-r1}
+tag=${1:-r2}
 o=gpurun_out/prof_$tag
 mkdir -p $o
 export TMPDIR=/tmp

@@ -147,3 +147,23 @@ def test_glauber_chains_match_exact_distribution_and_feed_the_learner():
         out, kkt, st = p.learn("RISE", 0.4, tol=1e-9, precision="i8x")
     assert st["not_converged"] == 0
     assert np.abs(0.5 * (out + out.T) - J).max() <= 0.05
+
+
+def test_multibody_learn_sample_relearn_round_trip():
+    # runtests.jl:161-181: learn an order-4 multiRISE model (lambda = 0, un-symmetrised) from 10000 samples, sample from the
+    # LEARNED FactorGraph, learn again.  The un-symmetrised result holds every coupling once per member spin -- keys (1,2) and
+    # (2,1) -- and the general sampler sums all terms (sampling.jl:60-65), so the second model's couplings come back twice as
+    # large; the reference's test documents exactly that ("this is a bug ...") and checks value / 2 -- so does this one.
+    from conftest import MODELS
+    for name, mtx in MODELS.items():
+        gm_tmp = gml.FactorGraph(mtx)
+        order = min(4, mtx.shape[0])
+        hist = gml.sample(gm_tmp, 10000, seed=0)
+        learned_gm = gml.learn(hist, gml.multiRISE(0.0, False, order), gml.HIP(tol=1e-10))
+        for key, value in gm_tmp:
+            assert learned_gm[key] == pytest.approx(value, abs=0.15)
+        assert learned_gm.order == order and len(learned_gm) > len(gm_tmp)
+        hist2 = gml.sample(learned_gm, 10000, seed=1)
+        learned_gm2 = gml.learn(hist2, gml.multiRISE(0.0, False, order), gml.HIP(tol=1e-10))
+        for key, value in gm_tmp:
+            assert learned_gm2[key] / 2.0 == pytest.approx(value, abs=0.16)
