@@ -42,14 +42,15 @@ extern "C" {
 
 /* ---- arithmetic of the device objective/gradient pass ------------------------------- */
 #define GML_PREC_F64 0   /* FP64 MFMA (v_mfma_f64_16x16x4_f64)                             */
-#define GML_PREC_I8X 1   /* exact fixed-point: int8 limbs on v_mfma_i32_*_i8                */
+#define GML_PREC_I8X 1   /* fixed point on v_mfma_i32_*_i8: Theta in 38-bit and V in 31-bit int8 limbs (V rounded
+                            with a dither), integer GEMMs without further rounding: f, grad to ~1e-9 relative      */
 
 typedef struct gml_problem gml_problem; /* opaque: packed spins + weights resident in HBM  */
 
 typedef struct gml_opts {
     double tol;          /* KKT tolerance: max |pseudo-gradient| per node (default 1e-9)    */
     int32_t max_iter;    /* outer (Newton) iterations (default 100)                         */
-    int32_t precision;   /* GML_PREC_*                                                      */
+    int32_t precision;   /* GML_PREC_* (default GML_PREC_I8X)                                */
     int32_t max_working; /* cap on a node's Newton block (default = max = 512, multiple of 32); a
                             denser optimum is solved by cycling blocks (block Gauss-Seidel)    */
     int32_t max_add;     /* new (violating) coordinates admitted per node per iteration (default 64) */
