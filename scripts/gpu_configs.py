@@ -120,7 +120,12 @@ def c5(name, K=1000000, n=512, c=1.2, seed=5, tol=1e-8, max_iter=100):
                     "node_evals": st["node_evals"], "max_kkt": st["max_kkt"], "not_converged": st["not_converged"],
                     "t_pass": st["t_pass"], "t_hess": st["t_hess"], "t_host": st["t_host"],
                     "nnz_per_node_max": int((out != 0).sum(1).max()), "nnz_per_node_mean": float((out != 0).sum(1).mean())})
-        km = p.bench_pass_resident("RISE", out, steps=2, warmup=1, precision="i8x")
+        try:
+            km = p.bench_pass_resident("RISE", out, steps=2, warmup=1, precision="i8x")
+        except gml.GMLError:  # dense theta: some rows need the rescaled re-run, which the host-pointer pass performs
+            km = p.bench_pass("RISE", out, steps=2, warmup=1, precision="i8x")
+            km["device_ms_per_pass"] = km["pass_ms"]
+            km["note"] = "kernel times of the first (bound-scaled) pass of gml_bench_pass; the rescaled re-run of some rows is extra"
         rec["pass"] = {**km, **roof(K, P, n, km["device_ms_per_pass"])}
         rec["node_evals_per_s"] = n / (km["device_ms_per_pass"] * 1e-3)
         some = np.array([0, n - 1])
