@@ -641,7 +641,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             // Matrix-free Newton-CG: H_WW d = -pg_W by preconditioned conjugate gradients, Hessian-vector products from the device
             // operator (forward GEMM of the direction, weights of the rows' last objective pass, backward GEMM), preconditioner =
             // the Cholesky-factored Hessian block of the row's strongest entries + the common diagonal elsewhere.  Inexact Newton:
-            // the residual is reduced by eta = min(0.05, sqrt(kkt)) -- superlinear in the end, cheap far from the optimum.
+            // the residual is reduced by eta = min(0.05, sqrt(kkt)), in at most max_cg steps.
             stage("pcg");
             if (!Rv) {
                 HIPCHK(A.get(&Rv, nd));
@@ -656,7 +656,10 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             launch_pcg_dir(dRows, (int)cg_rows.size(), Qp, dFidx, dMsCg, capP, dsol, dDinv, Rv, Zv, Pv, 1, dCg, st);
             std::vector<CgState> cgs((size_t)Rp);
             std::vector<int> live = cg_rows;
-            const int maxcg = o.max_cg > 0 ? o.max_cg : 40;
+            // at most 16 CG steps per Newton step: the number of Newton iterations is set by the admission of the violators, not by
+            // the accuracy of the directions (order-3 probe: 32 iterations with a cap of 40, 16 or 15 -- 545 / 349 / 333
+            // Hessian-vector passes; 40 iterations, 279 passes with a cap of 8)
+            const int maxcg = o.max_cg > 0 ? o.max_cg : (getenv("GML_CG_MAX") ? atoi(getenv("GML_CG_MAX")) : 16);
             for (int ci = 0; ci < maxcg && !live.empty(); ++ci) {
                 // Hp = H p for the live rows: an hv pass over slots [0, n) of the u-plane workspace
                 const int64_t n = (int64_t)live.size(), np = gml_round_up(n, 32);

@@ -61,7 +61,7 @@ typedef struct gml_opts {
     int32_t polish;      /* precision i8x only: 0 = rows that stall above tol at the noise floor of the int8-limb
                             arithmetic continue on the FP64 path when its workspaces fit (default); -1 = never */
     int32_t max_cg;      /* conjugate-gradient iterations per Newton step of the matrix-free rows (working sets above
-                            max_working); each costs one Hessian-vector pass (default 40) */
+                            max_working); each costs one Hessian-vector pass (default 16) */
 } gml_opts;
 
 typedef struct gml_stats {
