@@ -1,3 +1,6 @@
+"""64-node probe of BASELINE config 5 at the reference's default regulariser (order-3 statistics, n spins, K samples, nodes 0..63):
+the dense-optimum path of the solver (matrix-free Newton-CG), cheap enough for parameter studies (GML_CG_VIOL_FRAC, GML_CG_ETA,
+GML_CG_MAX).  usage: gpu_c5_probe.py n K [max_working] [max_iter] [verbose]"""
 import sys, numpy as np
 sys.path.insert(0, '.')
 import gml_amd as gml
