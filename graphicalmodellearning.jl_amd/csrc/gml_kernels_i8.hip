@@ -395,7 +395,10 @@ __device__ __forceinline__ void ring_wait_ahead(int ahead) {
 
 template <int LF, int FORM /* 0: exp forms (RISE, logRISE), 2: RPLE; Hessian-vector products: 3 (exp forms), 4 (RPLE) */,
           bool WANTF,
-          bool WIDE /* more than 32768 statistics columns: |acc_l| <= 128 Qfp no longer leaves room for the int32 pairing */>
+          bool WIDE /* more than 32768 statistics columns: |acc_l| <= 128 Qfp no longer leaves room for the int32 pairing */,
+          bool UNIW /* every real sample has the weight wuni (all counts equal): no weight loads.  A template parameter, not
+                       a run-time test: a branch per element would put each of the epilogue's 32 dependent chains (range
+                       reduction -> table read -> polynomial -> rounding) into its own basic block and serialise them */>
 __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const unsigned *__restrict__ Xb, const unsigned *__restrict__ Sb, const int8_t *__restrict__ Tq,
     const int *__restrict__ rowcol, const int *__restrict__ groups, int ngroups, const double *__restrict__ w,
@@ -600,12 +603,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     const int qv = (int)((dv[j] ^ 0x80808080u) - 0x80808080u);
                     double hh = (double)(qv < 0 ? -qv : qv);
                     if (FORM == 4) {
-                        const double wk0 = wuni > 0.0 ? (kk + j < Kreal ? wuni : 0.0) : w[kk + j];
+                        const double wk0 = UNIW ? (i * 32 + 8 * g + j < nreal ? wuni : 0.0) : w[kk + j];
                         hh = wk0 > 0.0 ? 2.0 * hh * (1.0 - hh * tvh / (2.0 * wk0)) : 0.0;
                     }
                     vq = __double2loint(fma(hh, Ea * it, dith) + 6755399441055744.0);
                 } else if (FORM == 2) { // RPLE (:317): f = w log(1 + exp(-2E)), V = -2 w s / (1 + exp(2E)), E = s * Ea
-                    const double wk0 = wuni > 0.0 ? (kk + j < Kreal ? wuni : 0.0) : w[kk + j];
+                    const double wk0 = UNIW ? (i * 32 + 8 * g + j < nreal ? wuni : 0.0) : w[kk + j];
                     const double E2 = neg ? -2.0 * Ea : 2.0 * Ea;
                     const double u = exp_tab(-fabs(E2), etab); // in (0, 1]
                     const double opu = 1.0 + u;
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     // x = -s E: flip the sign of Ea unless s = -1
                     const double x = __hiloint2double(__double2hiint(Ea) ^ (int)((~sgn[i] << (31 - (8 * g + j))) & 0x80000000u), __double2loint(Ea));
                     int mag;
-                    if (wuni > 0.0) {
+                    if (UNIW) {
                         mag = mag_exp(x, wkit, dith, etab);
                         if (i * 32 + 8 * g + j >= nreal) mag = 0; // padding samples carry no weight
                     } else {
@@ -1231,18 +1234,24 @@ struct FwdLaunch {
     hipStream_t st;
 };
 
-template <int LF, int FORM, bool WANTF, bool WIDE>
-static void launch_fwd3(const FwdLaunch &a) {
+template <int LF, int FORM, bool WANTF, bool WIDE, bool UNIW>
+static void launch_fwd4(const FwdLaunch &a) {
     constexpr int STAGE = (2 + 2 * LF) * 1024;
     constexpr int shmem = 4 * STAGE + 512 + 1024; // ring + exp, log tables
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF, WIDE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF, WIDE, UNIW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
     const DevProblem &d = *a.d;
     const int ntk = (int)(d.Kp / 256);
     const int grid = ((ntk + 7) / 8) * 8 * ((a.ngroups + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.w->Tq, a.rowcol, a.groups,
+    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE, UNIW>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.w->Tq, a.rowcol, a.groups,
                        a.ngroups, d.w, a.sc->sigma, a.sc->qconst, a.sc->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, a.Vout,
                        a.sc->csum, a.sc->asum, a.F, a.sc->mmax, a.w->Vq, a.vmap, a.w->sc[0].tau);
+}
+
+template <int LF, int FORM, bool WANTF, bool WIDE>
+static void launch_fwd3(const FwdLaunch &a) {
+    if (a.d->wuni > 0.0) launch_fwd4<LF, FORM, WANTF, WIDE, true>(a);
+    else launch_fwd4<LF, FORM, WANTF, WIDE, false>(a);
 }
 
 template <int LF, int FORM, bool WANTF>

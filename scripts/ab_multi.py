@@ -2,11 +2,11 @@
 import subprocess, sys, json, os
 libs = [a.split("=", 1) for a in sys.argv[1:]]
 res = {t: [] for t, _ in libs}
-for rnd in range(2):
+for rnd in range(3):
     for tag, path in libs:
         env = dict(os.environ)
         if path: env["GML_LIB_OVERRIDE"] = path
-        out = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "1", "--no-cpu", "--no-learn"], env=env,
+        out = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "3", "--no-cpu", "--no-learn", "--no-f64"], env=env,
                              capture_output=True, text=True).stdout.strip().splitlines()[-1]
         d = json.loads(out)
         res[tag].append((round(d["ms_per_step"], 3), round(d["roofline"]["fwd_ms"], 3), round(d["roofline"]["bwd_ms"], 3)))
