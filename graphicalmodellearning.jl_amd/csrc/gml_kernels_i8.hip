@@ -180,17 +180,27 @@ __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ t
     return ldexp(tab[n & 63] * p, n >> 6);
 }
 
-// |V| / tau of one element: rint(wkit * exp(x)) for x = -s E, to 3e-10 relative before the rounding.
-// FP64 range reduction with one FMA (the product t * ln2/64 is not rounded inside an FMA), FP32
-// polynomial for expm1 of the reduced argument, table of 2^(j/64), exponent added as an integer, and
-// the final rounding to an integer through the 1.5 * 2^52 trick, after adding a dither in [-1/2, 1/2) that is a
-// fixed function of (node, sample): the rounding is then "stochastic" -- still
-// deterministic and within one unit, but uncorrelated across samples.  Round-to-nearest is coherent whenever a
-// sparse theta row leaves only a few distinct energies (thousands of samples share each rounding error), which
-// made the realised error of f and grad approach the K * tau / 2 worst case instead of ~ sqrt(K) * tau.
-__device__ __forceinline__ int mag_exp(double x, double wkit, double dith, const double *__restrict__ tab) {
-    const double MAGIC = 6755399441055744.0;
-    const double tm = fma(x, 92.33248261689366, MAGIC); // 64/ln2
+// V / tau of one element of the exp forms: -s rint(w/tau exp(-s E) + dither), E = s Ea.  Ea to 3e-10 relative before
+// the rounding.  FP64 range reduction with one FMA (the product t * ln2/64 is not rounded inside an FMA), FP32
+// polynomial for expm1 of the reduced argument, table of 2^(j/64), exponent added as an integer, and the final rounding
+// to an integer through the 1.5 * 2^52 trick, after adding a dither in [-1/2, 1/2) that is a fixed function of
+// (node, sample): the rounding is then "stochastic" -- still deterministic and within one unit, but uncorrelated across
+// samples.  Round-to-nearest is coherent whenever a sparse theta row leaves only a few distinct energies (thousands of
+// samples share each rounding error), which made the realised error of f and grad approach the K * tau / 2 worst case
+// instead of ~ sqrt(K) * tau.
+// The epilogue is bound by the number of vector instructions, so this is written for few of them:
+//   * sb (bit 0: s = +1) flips the sign of Ea going in (x = -s E) and of the result coming out by adding sb << 31 to
+//     the high word -- round-half-even is symmetric, so rounding -y gives minus the rounding of y;
+//   * everything from the weight on is scaled by 2^32 (wk32 = 2^32 w / tau; exact): the dither is then the hash itself,
+//     converted int -> double, and the integer is read off below 1.5 * 2^84;
+//   * the table holds 2^(j/64) with j << 14 taken off the high word: the exponent of 2^(n >> 6), n = 64 q + j, goes on
+//     as n << 14 (= (q << 20) + (j << 14)) in one shift-add.
+__device__ __forceinline__ int vq_exp(double Ea, unsigned sb, double wk32, unsigned dh, const double *__restrict__ tabb) {
+    const double MAGIC = 6755399441055744.0;                  // 1.5 * 2^52
+    const double MAGIC32 = 6755399441055744.0 * 4294967296.0; // 1.5 * 2^84: rounds to multiples of 2^32
+    const int flip = (int)(sb << 31);
+    const double x = __hiloint2double(__double2hiint(Ea) + flip, __double2loint(Ea)); // -s E
+    const double tm = fma(x, 92.33248261689366, MAGIC);                               // 64/ln2
     const int n = __double2loint(tm);
     const double t = tm - MAGIC;
     const double r = fma(t, -0.010830424696249145, x); // ln2/64
@@ -199,10 +209,12 @@ __device__ __forceinline__ int mag_exp(double x, double wkit, double dith, const
     d = fmaf(d, rf, 0.5f);
     d = fmaf(d, rf, 1.0f);
     d = d * rf; // expm1(r)
-    const double tj0 = tab[n & 63];
-    const double tj = __hiloint2double(__double2hiint(tj0) + ((n >> 6) << 20), __double2loint(tj0)); // * 2^(n>>6)
+    const double tj0 = tabb[n & 63];
+    const double tj = __hiloint2double((int)((unsigned)__double2hiint(tj0) + ((unsigned)n << 14)), __double2loint(tj0)); // 2^(n/64)
     const double res = fma(tj, (double)d, tj);
-    return __double2loint(fma(wkit, res, dith) + MAGIC);
+    const double y = fma(wk32, res, (double)(int)dh); // 2^32 (|V| / tau + dither)
+    const double ys = __hiloint2double(__double2hiint(y) + flip, __double2loint(y));
+    return __double2loint(ys + MAGIC32);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -420,7 +432,11 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lr = lane & 31, h = lane >> 5;
-    if (tid < 64) etab[tid] = exp2((double)tid / 64.0);
+    if (tid < 64) {
+        const double v = exp2((double)tid / 64.0);
+        // exp forms: the table of vq_exp(), j << 14 taken off the high word
+        etab[tid] = FORM == 0 ? __hiloint2double(__double2hiint(v) - (tid << 14), __double2loint(v)) : v;
+    }
     if (FORM == 2 && tid < 64) { // log table for RPLE: c_j = 1 + (j + 1/2)/64 -> 1/c_j, log c_j
         const double cj = 1.0 + ((double)tid + 0.5) / 64.0;
         etab[64 + tid] = 1.0 / cj;
@@ -493,6 +509,9 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const double q0 = active ? (double)qconst[r] : 0.0;
     const double it = active ? invtau[r] : 0.0;
 
+    // Two workgroups share a CU, one wave of each per SIMD.  The wave that is in its GEMM gets the issue priority over
+    // the one that is in its epilogue: the matrix pipe is the scarcer resource (-3 % forward time, interleaved A/B).
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s);
@@ -522,6 +541,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                 for (int l = 0; l < LF; ++l) acc[i][l] = MFMA_I8(fa[i], fb[l], acc[i][l]);
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- epilogue ----------------------------------------------------------------------------
     // lane <-> node row (lr), register e <-> sample (e&3) + 8*(e>>2) + 4*h within the 32-sample tile.  The
     // Vq image stores a step's samples in the order vq_pos() (gml_dev.h), in which this lane's 16 samples of
@@ -539,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     double fp = 0.0;
     int mx = 0;
     const int64_t kw = k0 + wave * 64; // first sample of this wave
-    const double sgq0 = sg * q0, wkit = wuni * it;
+    const double sgq0 = sg * q0, wk32 = 4294967296.0 * (wuni * it); // 2^32 w / tau (vq_exp)
     double sg2 = -2.0 * sg;
     // dither of the V rounding: golden-ratio (Weyl) sequence in the global sample index, offset per node --
     // independent of tiling, node sharding and compaction, so results stay bit-identical across GPU counts
@@ -631,16 +651,15 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     const double l1p = fma(lp, r1, etab[128 + jt]);
                     fp += wk0 * ((E2 < 0.0 ? -E2 : 0.0) + l1p);
                 } else { // RISE (:196,:204) / logRISE Z (:279): V = -w exp(-E) s
-                    // x = -s E: flip the sign of Ea unless s = -1
-                    const double x = __hiloint2double(__double2hiint(Ea) ^ (int)((~sgn[i] << (31 - (8 * g + j))) & 0x80000000u), __double2loint(Ea));
-                    int mag;
+                    const unsigned sb = ~sgn[i] >> (8 * g + j); // bit 0: s = +1
+                    const unsigned dh = dh0 + (unsigned)(i * 32 + 8 * g + j) * 0x9E3779B9u;
                     if (UNIW) {
-                        mag = mag_exp(x, wkit, dith, etab);
-                        if (i * 32 + 8 * g + j >= nreal) mag = 0; // padding samples carry no weight
+                        vq = vq_exp(Ea, sb, wk32, dh, etab);
+                        if (i * 32 + 8 * g + j >= nreal) vq = 0; // padding samples carry no weight
                     } else {
-                        mag = mag_exp(x, w[kk + j] * it, dith, etab);
+                        vq = vq_exp(Ea, sb, 4294967296.0 * (w[kk + j] * it), dh, etab);
                     }
-                    vq = neg ? mag : -mag;
+                    const int nvq = -vq, mag = vq > nvq ? vq : nvq;
                     mx = mag > mx ? mag : mx;
                     if (WANTF) as += mag;
                 }
@@ -658,7 +677,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
         }
         if (active) {
 #pragma unroll
-            for (int lb = 0; lb < LB; ++lb) *reinterpret_cast<v4i *>(vimg + lb * 32 * 64 + i * 16) = pl[lb];
+            for (int lb = 0; lb < LB; ++lb) // streamed: V is read next by the backward kernel, from HBM (it is far larger than the caches)
+                __builtin_nontemporal_store(pl[lb], reinterpret_cast<v4i *>(vimg + lb * 32 * 64 + i * 16));
         }
     }
     cs += __shfl_xor(cs, 32);

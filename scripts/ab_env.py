@@ -1,10 +1,17 @@
-"""Interleaved A/B of an environment switch on the same GPU: python scripts/ab_env.py VAR valA valB [rounds]"""
+"""Interleaved timing of one build of libgml_hip under different environments (argv: tag=VAR=value[,VAR=value] ...)."""
 import subprocess, sys, json, os
-var, a, b = sys.argv[1:4]
-rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-for rnd in range(rounds):
-    for val in (a, b):
-        env = dict(os.environ); env[var] = val
-        out = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "1", "--no-cpu", "--no-learn"], env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
-        d = json.loads(out)
-        print(var, val, "ms/step %.3f fwd %.3f bwd %.3f" % (d["ms_per_step"], d["roofline"]["fwd_ms"], d["roofline"]["bwd_ms"]), flush=True)
+cases = []
+for a in sys.argv[1:]:
+    tag, rest = a.split("=", 1)
+    cases.append((tag, dict(kv.split("=", 1) for kv in rest.split(",") if kv)))
+for rnd in range(3):
+    for tag, extra in cases:
+        env = dict(os.environ)
+        env.update(extra)
+        out = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "3", "--no-cpu", "--no-learn", "--no-f64"], env=env,
+                             capture_output=True, text=True)
+        try:
+            d = json.loads(out.stdout.strip().splitlines()[-1])
+            print(tag, (round(d["ms_per_step"], 3), round(d["roofline"]["fwd_ms"], 3), round(d["roofline"]["bwd_ms"], 3)), flush=True)
+        except Exception:
+            print(tag, "FAILED", out.stdout[-500:], out.stderr[-1500:], flush=True)
