@@ -238,11 +238,18 @@ def main():
     # ---- learn() wall-clock of this config ---------------------------------------------------------------------
     out = None
     if not args.no_learn:
-        sync()
-        t0 = time.perf_counter()
-        out, kkt, st = prob.learn("RISE", 0.4, tol=1e-9, precision=args.precision, raise_on_fail=False)
-        sync()
-        t_learn, learn_per_rank = max_over_ranks(time.perf_counter() - t0)
+        # three runs, the median reported (every run listed): a run now and then carries a one-off stall of the
+        # allocator or of a lazily loaded code object that has nothing to do with the path
+        runs = []
+        for _ in range(3):
+            sync()
+            t0 = time.perf_counter()
+            out, kkt, st = prob.learn("RISE", 0.4, tol=1e-9, precision=args.precision, raise_on_fail=False)
+            sync()
+            runs.append((max_over_ranks(time.perf_counter() - t0), st))
+        runs_s = [r[0][0] for r in runs]
+        (t_learn, learn_per_rank), st = sorted(runs, key=lambda r: r[0][0])[1]
+        extra["learn_wall_runs_s"] = runs_s
         if world > 1:
             # final gather of the row blocks over RCCL/xGMI (the only collective of the path)
             sync()

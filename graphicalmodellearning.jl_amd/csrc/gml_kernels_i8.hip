@@ -677,8 +677,9 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
         }
         if (active) {
 #pragma unroll
-            for (int lb = 0; lb < LB; ++lb) // streamed: V is read next by the backward kernel, from HBM (it is far larger than the caches)
-                __builtin_nontemporal_store(pl[lb], reinterpret_cast<v4i *>(vimg + lb * 32 * 64 + i * 16));
+            // (plain stores: the two 16-byte halves of a 64-byte row come from two instructions and merge in L2; as
+            // non-temporal stores they reach HBM separately -- 8.2 GB written instead of 5.1 -- for 2 % less time)
+            for (int lb = 0; lb < LB; ++lb) *reinterpret_cast<v4i *>(vimg + lb * 32 * 64 + i * 16) = pl[lb];
         }
     }
     cs += __shfl_xor(cs, 32);
