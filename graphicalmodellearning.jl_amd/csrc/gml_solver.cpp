@@ -660,6 +660,11 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             // the accuracy of the directions (order-3 probe: 32 iterations with a cap of 40, 16 or 15 -- 545 / 349 / 333
             // Hessian-vector passes; 40 iterations, 279 passes with a cap of 8)
             const int maxcg = o.max_cg > 0 ? o.max_cg : (getenv("GML_CG_MAX") ? atoi(getenv("GML_CG_MAX")) : 16);
+            // limbs of the CG direction p in the Hessian-vector passes: 3 (22 bits of max|p|) are plenty for an inexact Newton
+            // step that stops at a residual of 5 % -- same iteration counts as with 4, 18 % less time per H.v (64-node
+            // probe of config 5)
+            int hv_lf = getenv("GML_HV_LF") ? atoi(getenv("GML_HV_LF")) : 3;
+            hv_lf = hv_lf < 3 ? 3 : (hv_lf > 5 ? 5 : hv_lf);
             for (int ci = 0; ci < maxcg && !live.empty(); ++ci) {
                 // Hp = H p for the live rows: an hv pass over slots [0, n) of the u-plane workspace
                 const int64_t n = (int64_t)live.size(), np = gml_round_up(n, 32);
@@ -685,7 +690,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 a.F = nullptr;
                 a.G = Hp;
                 a.hv = 1;
-                a.lf = 4;
+                a.lf = hv_lf;
                 std::string err;
                 rc = i8_pass(&p->i8ws, d, Scap, a, st, nullptr, &err);
                 if (rc) return fail(rc, "%s", err.c_str());
