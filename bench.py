@@ -215,6 +215,12 @@ def main():
                 roofline["traffic_note"] = ("bytes per launch from profiles/%s (2*FETCH_SIZE + WRITE_SIZE, KB; a separate rocprofv3 "
                                             "--pmc run of this command, not this run); algorithmic bytes per launch: %.3g (bit image "
                                             "K*n/8 + the 4 int8 limb planes of V, 4*K*n_loc)" % (fn, K * n / 8.0 + 4.0 * K * nloc))
+                # were the counters taken on the kernels that ran just now?
+                import hashlib
+                ksrc = os.path.join(ROOT, "graphicalmodellearning.jl_amd", "csrc", "gml_kernels_i8.hip")
+                sha = pm.get("_kernel_source_sha256")
+                roofline["traffic_kernels_match"] = (None if sha is None else
+                                                     sha == hashlib.sha256(open(ksrc, "rb").read()).hexdigest())
                 break
             except Exception:
                 continue

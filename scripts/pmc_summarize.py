@@ -13,5 +13,11 @@ for d in dirs:
         for (k, _, c), v in per.items():
             name = k.split("(")[0].replace("void ", "")
             res[name][c + "_KB"] = max(res[name].get(c + "_KB", 0.0), v)
-json.dump({k: v for k, v in res.items() if k.startswith("gml::")}, open(out, "w"), indent=1)
+# the kernels the counters belong to: bench.py compares this with the source it runs and says so when they differ
+import hashlib
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "graphicalmodellearning.jl_amd", "csrc", "gml_kernels_i8.hip")
+summary = {k: v for k, v in res.items() if k.startswith("gml::")}
+summary["_kernel_source_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
+json.dump(summary, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if "fwd_i8" in k or "bwd_i8" in k}, indent=1))
