@@ -447,13 +447,24 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     // XCD-aware L2 blocking.  Blocks b and b+8 share an XCD (round-robin dispatch); XCD x owns the
     // sample tiles st = 8*i + x.  Within an XCD: groups of TG node tiles (outer), sample tiles
     // (middle), the TG node tiles (inner): Tq of the group stays resident in the XCD's L2 over the
-    // sweep and each bit piece is fetched once per node-tile group.
+    // sweep and each bit piece is fetched once per node-tile group.  The last group holds ngroups % TG tiles; the grid
+    // has no idle workgroups beyond the sample tiles that pad ntiles_k to a multiple of 8 (a node-sharded rank runs few
+    // node tiles: half of its launch would otherwise be workgroups that start only to exit).
     constexpr int TG = 8;
     const int b = blockIdx.x, xcd = b & 7, bi = b >> 3;
     const int ntk8 = (ntiles_k + 7) >> 3;
-    const int tgi = bi / (ntk8 * TG), rem = bi % (ntk8 * TG);
-    const int st = (rem / TG) * 8 + xcd, gi = tgi * TG + rem % TG;
-    if (st >= ntiles_k || gi >= ngroups) return;
+    const int nfull = ngroups / TG, per_full = ntk8 * TG;
+    int st, gi;
+    if (bi < nfull * per_full) {
+        const int rem = bi % per_full;
+        st = (rem / TG) * 8 + xcd;
+        gi = (bi / per_full) * TG + rem % TG;
+    } else {
+        const int lastn = ngroups - nfull * TG, rem = bi - nfull * per_full;
+        st = (rem / lastn) * 8 + xcd;
+        gi = nfull * TG + rem % lastn;
+    }
+    if (st >= ntiles_k) return;
     const int64_t k0 = (int64_t)st * 256;
     const int mytile = groups[gi];
 
@@ -1263,7 +1274,7 @@ static void launch_fwd4(const FwdLaunch &a) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
     const DevProblem &d = *a.d;
     const int ntk = (int)(d.Kp / 256);
-    const int grid = ((ntk + 7) / 8) * 8 * ((a.ngroups + 7) / 8) * 8;
+    const int grid = ((ntk + 7) / 8) * 8 * a.ngroups; // one workgroup per (sample tile, node tile); see the kernel's block mapping
     hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE, UNIW>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.w->Tq, a.rowcol, a.groups,
                        a.ngroups, d.w, a.sc->sigma, a.sc->qconst, a.sc->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, a.Vout,
                        a.sc->csum, a.sc->asum, a.F, a.sc->mmax, a.w->Vq, a.vmap, a.w->sc[0].tau);
@@ -1340,10 +1351,14 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
         static const int TM = [] { const char *e = getenv("GML_BWD_TM"); return e && atoi(e) == 2 ? 2 : 1; }();
         const int ngt = (a.ngroups + TM - 1) / TM;
         const int T = ngt * nNt;
-        // split-K: a multiple of 8 chunks (one XCD each), at least 16, and enough workgroups (~1024 x 2/TM) to
-        // fill the chip when few node tiles are active (node-sharded ranks, late solver iterations)
-        int nsplit = ((2048 / TM + T - 1) / T + 7) / 8 * 8;
-        if (nsplit < 16) nsplit = 16;
+        // split-K: a multiple of 8 chunks (one XCD each).  24 chunks, or -- with few node tiles (node-sharded ranks, late
+        // solver iterations) -- as many as it takes to give each of the 512 / TM resident workgroup slots one workgroup.
+        // Measured at the headline problem (backward ms at 16 / 24 / 32 / 64 chunks): 128 nodes 0.52 / 0.47 / 0.39 / 0.42,
+        // 256 nodes 0.75 / 0.73 / 0.77 / 0.75, 512 nodes 1.57 / 1.48 / 1.49 / 1.50, 1024 nodes 2.98 whatever the count.
+        int nsplit = (int)(((512 / TM + T - 1) / T + 7) / 8 * 8);
+        if (nsplit < 24) nsplit = 24;
+        if (nsplit > 256) nsplit = 256;
+        if (const char *e = getenv("GML_BWD_NSPLIT")) nsplit = atoi(e); // (experiments)
         int64_t kchunk = (d.Kp + nsplit - 1) / nsplit;
         kchunk = (kchunk + 63) / 64 * 64;
         if (kchunk < 2048) kchunk = 2048;
