@@ -75,6 +75,7 @@ struct I8Pass {
     const double *tauovr; // device [slots] or NULL: per-slot scale of V imposed by the caller (0 = from the bound)
     int hv;               // 1: Hessian-vector product -- theta rows are directions p, G receives sum_k h_k (x_k.p) x_k with the
                           //    curvature weights h_k of the objective pass that last ran in slot vmap[slot]
+                          //    2: the same with the products h_k (x_k.p) carried in 2 backward limbs (15 bits) instead of 4
     const int *vmap;      // hv: device [slots]
     int lf;               // forward limb planes (3, 4, 5; 0 = the default, 5): 8 lf - 2 significant bits of theta
 };

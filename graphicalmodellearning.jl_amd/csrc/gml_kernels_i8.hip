@@ -135,7 +135,10 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
             // Hessian-vector pass: the row is a direction p, the forward epilogue forms u_k = h_k (x_k . p) with
             // h_k = tau_V |q_V| the weights of the row's last objective pass (slot vmap[r]); |x_k . p| <= emax, so
             // u_k / (tau_V emax) = |q_V| * (x_k . p) / emax is an integer of at most 31 bits.
-            const double pn = emax > 0.0 ? emax : 1.0;
+            // (hv == 2: the products go to the backward GEMM in 2 limbs instead of 4 -- 15 bits of the largest one, which is
+            // ample for the matrix-free Newton-CG that stops at a 5 % residual; the factor 1.01 keeps |u| inside the
+            // +-32639 of two balanced digits)
+            const double pn = (emax > 0.0 ? emax : 1.0) * (hv == 2 ? 65536.0 * 1.01 : 1.0);
             t = tauV[vmap[r]] * pn;
             it = 1.0 / pn;
         } else {
@@ -718,13 +721,15 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 // 2 KB of bits), 2 waves/SIMD.  All (tile, column-tile) blocks of one k-chunk run on one XCD so that
 // the chunk's slabs of Vq and of the bit image are fetched from HBM once and shared through that XCD's L2.
 // ------------------------------------------------------------------------------------------
-template <int TM /* node tiles per workgroup: 1 (4 waves, two workgroups per CU) or 2 (8 waves) */>
+template <int TM /* node tiles per workgroup: 1 (4 waves, two workgroups per CU) or 2 (8 waves) */,
+          int NL /* limb planes of Vq that are non-zero: 4, or 2 for the products of a 2-limb Hessian-vector pass (TM = 1) */>
 __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
     const int8_t *__restrict__ Vq, const unsigned *__restrict__ Xtb, const int *__restrict__ groups, int ngroups_t,
     int nNt, int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit, int32_t *__restrict__ Gacc) {
     constexpr int NW = 4 * TM;
     constexpr int AR = 128 * TM, NPIECE = 8 * TM + 2, STAGE = NPIECE * 1024, NS = 4;
-    constexpr int WMT = 4, WNT = 2; // wave tile 128 x 64
+    constexpr int WMT = NL, WNT = 2; // wave tile 128 (64) x 64: MFMA tile i <-> limb plane i of the node tile
+    static_assert(NL == 4 || (NL == 2 && TM == 1), "the 2-limb form exists for 4-wave workgroups");
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lr = lane & 31, h = lane >> 5;
@@ -741,13 +746,16 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
     const int64_t ke = (kb + kchunk < Kp) ? kb + kchunk : Kp;
     const int64_t n0 = (int64_t)nt * 256, nkk = Kp >> 6, kt0 = kb >> 6;
 
-    // 8*TM + 2 pieces over 4*TM waves: waves 0 and 1 load three (the third is a piece of bits), the others two
-    const bool three = wave < 2;
+    // 8*TM + 2 pieces over 4*TM waves: waves 0 and 1 load three (the third is a piece of bits), the others two.
+    // NL = 2: only the four pieces of limb planes 0 and 1 (rows 0..63 of the image) + the bits: two per wave.
+    const bool three = NL == 4 && wave < 2;
     const int8_t *src[3];
-    int adv[3];
+    int adv[3], dst[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int pc = wave + NW * j;
+        int pc = wave + NW * j; // piece of the full stage image: 0 .. 8 TM - 1 rows of Vq, then the bits
+        if (NL == 2) pc = j == 0 ? wave : 8 * TM + (wave & 1);
+        dst[j] = pc * 1024;
         if (pc < 8 * TM) {
             int tl = tiles[pc >> 3];
             if (tl < 0) tl = tiles[0];
@@ -765,9 +773,8 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
         int8_t *stage_base = lds + (kt & (NS - 1)) * STAGE;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (int64_t)kt * adv[j]), (lptr_t)(stage_base + (wave + NW * j) * 1024), 16, 0, 0);
-        if (three)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[2] + (int64_t)kt * adv[2]), (lptr_t)(stage_base + (wave + 2 * NW) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (int64_t)kt * adv[j]), (lptr_t)(stage_base + dst[j]), 16, 0, 0);
+        if (three) __builtin_amdgcn_global_load_lds((gptr_t)(src[2] + (int64_t)kt * adv[2]), (lptr_t)(stage_base + dst[2]), 16, 0, 0);
     };
     v16i acc[WMT][WNT];
 #pragma unroll
@@ -797,7 +804,7 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
             v4i fa[WMT], fb[WNT];
 #pragma unroll
             for (int i = 0; i < WMT; ++i)
-                fa[i] = *reinterpret_cast<const v4i *>(cur + lds_off(wm * 32 * WMT + i * 32 + lr, 2 * t + h));
+                fa[i] = *reinterpret_cast<const v4i *>(cur + lds_off(wm * 128 + i * 32 + lr, 2 * t + h));
 #pragma unroll
             for (int jn = 0; jn < WNT; ++jn)
 #pragma unroll
@@ -814,7 +821,7 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
 #pragma unroll
         for (int jn = 0; jn < WNT; ++jn) {
             const int64_t c = n0 + wn * 64 + jn * 32 + lr;
-            const int grow = wm * 32 * WMT + i * 32; // first row of this MFMA tile within the workgroup tile
+            const int grow = wm * 128 + i * 32; // first row of this MFMA tile within the workgroup tile
             const int tl = tiles[grow >> 7];
             if (c < Qfp && tl >= 0) {
 #pragma unroll
@@ -1317,12 +1324,12 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
         if (err) *err = "bad slot range";
         return GML_EINVAL;
     }
-    const int hv = a.hv ? 1 : 0;
+    const int hv = a.hv ? (a.hv == 2 ? 2 : 1) : 0; // 2: Hessian-vector products in 2 backward limbs
     if (hv && !w->Uq) {
         I8CHK(hipMalloc(&w->Uq, (size_t)w->slots * LB * d.Kp));
         I8CHK(hipMemsetAsync(w->Uq, 0, (size_t)w->slots * LB * d.Kp, st));
     }
-    const SlotScalars &sc = w->sc[hv];
+    const SlotScalars &sc = w->sc[hv ? 1 : 0];
     const int ns = a.slot1 - a.slot0;
     const bool grad = a.want_grad || hv;
     int32_t *gacc0 = w->Gacc + (int64_t)a.slot0 * LB * d.Qfp;
@@ -1348,7 +1355,8 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     if (ev) I8CHK(hipEventRecord(ev[1], st));
     if (grad) {
         const int nNt = (int)((d.Qfp + 255) / 256);
-        static const int TM = [] { const char *e = getenv("GML_BWD_TM"); return e && atoi(e) == 2 ? 2 : 1; }();
+        static const int TMenv = [] { const char *e = getenv("GML_BWD_TM"); return e && atoi(e) == 2 ? 2 : 1; }();
+        const int TM = hv == 2 ? 1 : TMenv;
         const int ngt = (a.ngroups + TM - 1) / TM;
         const int T = ngt * nNt;
         // split-K: a multiple of 8 chunks (one XCD each).  24 chunks, or -- with few node tiles (node-sharded ranks, late
@@ -1368,13 +1376,19 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
         const int8_t *Vin = hv ? w->Uq : w->Vq;
         // the tile list is padded with -1 to an even count
         if (TM == 2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-            hipLaunchKernelGGL(k_bwd_i8<2>, dim3(grid), dim3(512), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+            hipLaunchKernelGGL((k_bwd_i8<2, 4>), dim3(grid), dim3(512), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
                                nsplit, w->Gacc);
         } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-            hipLaunchKernelGGL(k_bwd_i8<1>, dim3(grid), dim3(256), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
-                               nsplit, w->Gacc);
+            if (hv == 2) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+                hipLaunchKernelGGL((k_bwd_i8<1, 2>), dim3(grid), dim3(256), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
+                                   nsplit, w->Gacc);
+            } else {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+                hipLaunchKernelGGL((k_bwd_i8<1, 4>), dim3(grid), dim3(256), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
+                                   nsplit, w->Gacc);
+            }
         }
     }
     if (ev) I8CHK(hipEventRecord(ev[2], st));
