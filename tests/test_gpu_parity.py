@@ -402,6 +402,24 @@ def test_dense_solutions_large_working_sets(prec):
     assert _kkt_from_oracle(spins, capped, [0, 50, 191], lam) <= 5e-9
 
 
+def test_newton_cg_reduced_limbs_reach_the_same_optimum(monkeypatch):
+    # The matrix-free Newton-CG carries the direction in 3 forward limbs and the Hessian-vector products in 2 backward
+    # limbs by default; with the full 5 / 4 it must arrive at the same (unique) optimum -- only the inexact Newton steps
+    # on the way differ.
+    n, K = 192, 30000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=7)
+    lam = O.lam(0.05, n, K)
+    with gml.Problem(spins=spins) as p:
+        dflt, _, st_d = p.learn("RISE", 0.05, tol=1e-9, precision="i8x", max_working=128, max_iter=200)
+        monkeypatch.setenv("GML_HV_LF", "5")
+        monkeypatch.setenv("GML_HV_LB", "4")
+        wide, _, st_w = p.learn("RISE", 0.05, tol=1e-9, precision="i8x", max_working=128, max_iter=200)
+    assert st_d["not_converged"] == 0 and st_w["not_converged"] == 0
+    assert st_d["hessian_passes"] > 0  # the matrix-free path really ran
+    assert np.abs(dflt - wide).max() <= 1e-7
+    assert _kkt_from_oracle(spins, dflt, [0, 50, 191], lam) <= 5e-9
+
+
 def test_multibody_dense_optimum_matrix_free_newton_cg():
     # multiRISE at the reference's default regulariser on a multi-body problem: lambda comes from n^2, not from the number of
     # parameters (:86), so the optimum is dense (a sizeable share of the P noise coefficients exceed lambda).  Reduced n;
