@@ -178,6 +178,9 @@ def main():
     if "c4" in which:
         jobs.append(lambda: pairwise("C4_rank0of8", "n=4096 sparse (8-spin block) Ising, 1e6 samples, RISE(0.4): the shard of rank 0 of 8",
                                      syn.block_ising_model(4096, 8, 1), 1000000, "RISE", 0.4, 4, node_range=(0, 512), cpu_learn="extrapolate"))
+    if "c4full" in which:  # the whole of config 4 on ONE GPU (what an 8-GPU run shards): all 4096 nodes, 1e6 samples
+        jobs.append(lambda: pairwise("C4_full_1gpu", "n=4096 sparse (8-spin block) Ising, 1e6 samples, RISE(0.4): all nodes on one GPU",
+                                     syn.block_ising_model(4096, 8, 1), 1000000, "RISE", 0.4, 4, cpu_learn="extrapolate"))
     if "c5" in which:
         jobs.append(lambda: c5("C5"))
     if "c5d" in which:  # the reference's default regulariser (multiRISE(0.4, true, 3) / ISODUS()): dense optimum, matrix-free Newton-CG
