@@ -518,6 +518,65 @@ __global__ __launch_bounds__(256) void k_newton_solve(double *__restrict__ H, co
         __syncthreads();
         ridge = ridge == 0.0 ? 1e-12 * fmax(dmax, 1e-300) : ridge * 100.0;
     }
+    if (m <= 256) {
+        // Both triangular solves by ONE wave, the right-hand side in registers (index i in lane i & 63, register i >> 6),
+        // the rows of U = L^T streamed one step ahead (they do not depend on the solution, so their L2 latency hides):
+        // no workgroup barrier per column -- with working sets of a few dozen entries the 2 m barriers and dependent
+        // global reads of the general path below were most of this kernel's 0.45 ms.
+        if (tid < 64) {
+            const int l = tid;
+            auto urow = [&](int j, double (&u)[4]) { // U[j][i] = L[i][j], i > j
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = l + 64 * q;
+                    u[q] = (j < m && i > j && i < m) ? A[(int64_t)j * hp + i] : 0.0;
+                }
+            };
+            double yv[4], cur[4], nxt[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) yv[q] = l + 64 * q < m ? -pg[l + 64 * q] : 0.0;
+            // forward substitution L y = -pg, column by column
+            urow(0, cur);
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) {
+                for (int jl = 0; jl < 64; ++jl) {
+                    const int j = jq * 64 + jl;
+                    if (j >= m) break;
+                    urow(j + 1, nxt);
+                    const double yj = __shfl(yv[jq], jl) / dg[j];
+                    if (l == jl) yv[jq] = yj;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        yv[q] = fma(-cur[q], yj, yv[q]); // cur is zero for i <= j
+                        cur[q] = nxt[q];
+                    }
+                }
+            }
+            // back substitution L^T d = y, row by row: d[j] = (y[j] - sum_{i > j} U[j][i] d[i]) / dg[j]
+            urow(m - 1, cur);
+#pragma unroll
+            for (int jq = 3; jq >= 0; --jq) {
+                for (int jl = 63; jl >= 0; --jl) {
+                    const int j = jq * 64 + jl;
+                    if (j >= m) continue;
+                    urow(j - 1 >= 0 ? j - 1 : m, nxt); // (row m: zeros)
+                    double part = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        part = fma(cur[q], yv[q], part); // entries i > j already hold d[i]
+                        cur[q] = nxt[q];
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+                    if (l == jl) yv[jq] = (yv[jq] - part) / dg[j];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (l + 64 * q < m) dout[(int64_t)r * cap + l + 64 * q] = bad ? 0.0 : yv[q];
+        }
+        return;
+    }
     // forward substitution L y = -pg
     for (int i = tid; i < m; i += 256) y[i] = -pg[i];
     __syncthreads();
