@@ -812,7 +812,7 @@ extern "C" void gml_problem_destroy(gml_problem *p) {
     void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.Sb, p->d.keys, p->d.Xb, p->d.Xtb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dSrow};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    void *hptrs[] = {p->hTh, p->hG, p->hF, p->hCtl};
+    void *hptrs[] = {p->hTh, p->hG, p->hF, p->hCtl, p->stage};
     for (void *q : hptrs)
         if (q) (void)hipHostFree(q);
     if (p->i8ws) gml::i8_free(p->i8ws);

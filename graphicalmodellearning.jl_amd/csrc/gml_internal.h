@@ -46,6 +46,9 @@ struct gml_problem {
     double *hTh = nullptr, *hG = nullptr, *hF = nullptr; // pinned staging (ws_rows x Qp, ws_rows)
     // int8-limb path workspace (gml_kernels_i8.hip, allocated lazily)
     void *i8ws = nullptr;
+    // pinned staging arena of the solver's small control / scalar transfers (gml_solver.cpp), allocated on first use
+    char *stage = nullptr;
+    size_t stage_bytes = 0;
 };
 
 // reference parameter vector of node u <-> internal column layout (pairwise :162, multi-body :94-104)

@@ -48,6 +48,50 @@ struct Arena {
     }
 };
 
+// Small host <-> device transfers of the solver (control blocks up, per-row scalars down) go through one pinned arena:
+// a copy from or to pageable memory is staged by the runtime and costs the host 20-30 us each, and an iteration makes
+// about twenty-five of them -- at 128 rows per GPU that was a third of learn().  h2d copies the bytes into the arena and
+// queues an asynchronous copy from there; d2h queues the copy into the arena and hands the bytes to the caller's buffer at
+// the next sync(), which is the only place the stream is waited for.  Transfers too large for the arena go the plain way.
+struct Stage {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+    hipStream_t st = nullptr;
+    struct Pend {
+        void *host;
+        const void *pin;
+        size_t n;
+    };
+    std::vector<Pend> pend;
+    void *take(size_t n) {
+        const size_t a = (off + 63) & ~(size_t)63;
+        if (a + n > cap) return nullptr;
+        off = a + n;
+        return base + a;
+    }
+    hipError_t h2d(void *dev, const void *host, size_t n) {
+        if (n == 0) return hipSuccess;
+        void *q = n <= cap / 4 ? take(n) : nullptr;
+        if (!q) return hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, st);
+        std::memcpy(q, host, n);
+        return hipMemcpyAsync(dev, q, n, hipMemcpyHostToDevice, st);
+    }
+    hipError_t d2h(void *host, const void *dev, size_t n) {
+        if (n == 0) return hipSuccess;
+        void *q = n <= cap / 4 ? take(n) : nullptr;
+        if (!q) return hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, st);
+        pend.push_back({host, q, n});
+        return hipMemcpyAsync(q, dev, n, hipMemcpyDeviceToHost, st);
+    }
+    hipError_t sync() {
+        const hipError_t e = hipStreamSynchronize(st);
+        for (const Pend &x : pend) std::memcpy(x.host, x.pin, x.n);
+        pend.clear();
+        off = 0;
+        return e;
+    }
+};
+
 } // namespace
 
 extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, const gml_opts *opts_in, double *out,
@@ -74,6 +118,14 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     gml_stats *stats = &stl;
     const double t_start = gml_now_s();
     hipStream_t st = p->st;
+    if (!p->stage) {
+        p->stage_bytes = (size_t)8 << 20;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p->stage), p->stage_bytes, hipHostMallocDefault));
+    }
+    Stage stg;
+    stg.base = p->stage;
+    stg.cap = p->stage_bytes;
+    stg.st = st;
     const DevProblem &d = p->d;
 
     const int64_t R = p->node1 - p->node0, Rp = gml_round_up(R, 32), Qp = d.Qp, P = p->P;
@@ -147,9 +199,9 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         std::vector<int> node((size_t)Rp, -1);
         for (int64_t r = 0; r < R; ++r) node[r] = (int)(p->node0 + r);
         std::vector<double> inf((size_t)Rp, INFINITY);
-        HIPCHK(hipMemcpyAsync(dNode, node.data(), sizeof(int) * Rp, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(dBest, inf.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(stg.h2d(dNode, node.data(), sizeof(int) * Rp));
+        HIPCHK(stg.h2d(dBest, inf.data(), sizeof(double) * Rp));
+        HIPCHK(stg.sync());
     }
     launch_kind(d, p->order, dNode, (int)Rp, kind, st);
 
@@ -190,13 +242,13 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
 
     auto stage = [&](const char *name) {
         if (o.verbose >= 3) {
-            (void)hipStreamSynchronize(st);
+            (void)stg.sync();
             fprintf(stderr, "[gml]     stage %s (last error: %s)\n", name, hipGetErrorString(hipGetLastError()));
             fflush(stderr);
         }
     };
     auto upload_rows = [&](const std::vector<int> &rows, int *dst) -> int {
-        if (!rows.empty()) HIPCHK(hipMemcpyAsync(dst, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice, st));
+        if (!rows.empty()) HIPCHK(stg.h2d(dst, rows.data(), sizeof(int) * rows.size()));
         return GML_OK;
     };
 
@@ -281,10 +333,10 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             const int ng = (int)groups.size();
             while (groups.size() % 4) groups.push_back(-1);
             // device control block: srow | rowcol are indexed by slot, so they are placed at the slot range
-            HIPCHK(hipMemcpyAsync(dCtl + lo, srow.data(), sizeof(int) * ns, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dCtl + Scap + lo, rowcol.data(), sizeof(int) * ns, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dCtl + 2 * Scap, groups.data(), sizeof(int) * groups.size(), hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dOvr + lo, ovr.data(), sizeof(double) * ns, hipMemcpyHostToDevice, st));
+            HIPCHK(stg.h2d(dCtl + lo, srow.data(), sizeof(int) * ns));
+            HIPCHK(stg.h2d(dCtl + Scap + lo, rowcol.data(), sizeof(int) * ns));
+            HIPCHK(stg.h2d(dCtl + 2 * Scap, groups.data(), sizeof(int) * groups.size()));
+            HIPCHK(stg.h2d(dOvr + lo, ovr.data(), sizeof(double) * ns));
             I8Pass a{};
             a.theta = src;
             a.srow = dCtl;
@@ -306,11 +358,11 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             const double *dtau = nullptr;
             const unsigned *dmm = nullptr;
             i8_slot_results(p->i8ws, 0, &dtau, &dmm);
-            HIPCHK(hipMemcpyAsync(fr.data(), dFs + lo, sizeof(double) * ns, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(taur.data(), dtau + lo, sizeof(double) * ns, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(mmr.data(), dmm + lo, sizeof(unsigned) * ns, hipMemcpyDeviceToHost, st));
+            HIPCHK(stg.d2h(fr.data(), dFs + lo, sizeof(double) * ns));
+            HIPCHK(stg.d2h(taur.data(), dtau + lo, sizeof(double) * ns));
+            HIPCHK(stg.d2h(mmr.data(), dmm + lo, sizeof(unsigned) * ns));
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(stg.sync());
             fh.resize((size_t)n);
             tauh.resize((size_t)n);
             mmh.resize((size_t)n);
@@ -335,7 +387,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             for (int64_t g = 0; g < Rp / 32; ++g)
                 if (tile[g]) ctl[Rp + ng++] = (int)g;
             const int ng4 = (int)gml_round_up(ng, 4);
-            HIPCHK(hipMemcpyAsync(dCtl, ctl.data(), sizeof(int) * (Rp + ng4), hipMemcpyHostToDevice, st));
+            HIPCHK(stg.h2d(dCtl, ctl.data(), sizeof(int) * (Rp + ng4)));
             HIPCHK(hipMemsetAsync(dFs, 0, sizeof(double) * Rp, st));
             launch_fwd_f64(d, src, dCtl, dCtl + Rp, ng4, formulation, p->dV, dFs, st);
             if (want_grad) {
@@ -345,14 +397,14 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 launch_copy_rows(dRowsP, (int)n, Qp, Gs, dst, nullptr, nullptr, st);
             }
             fh.resize((size_t)Rp);
-            HIPCHK(hipMemcpyAsync(fh.data(), dFs, sizeof(double) * Rp, hipMemcpyDeviceToHost, st));
+            HIPCHK(stg.d2h(fh.data(), dFs, sizeof(double) * Rp));
             for (int64_t a = 0; a < n; ++a) { // (V [row][Kp] of the FP64 path is indexed by row)
                 vstale[rows[a]] = 0;
                 if (vslot[rows[a]] < 0) vslot[rows[a]] = 0;
             }
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(stg.sync());
         std::vector<int> again;
         std::vector<double> ovr2;
         std::vector<double> scale;
@@ -414,10 +466,10 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 sc[r] = 1.0 / zo[r];
             }
             if (!keep.empty()) {
-                HIPCHK(hipMemcpyAsync(dScale, sc.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
+                HIPCHK(stg.h2d(dScale, sc.data(), sizeof(double) * Rp));
                 RCCHK(upload_rows(keep, dRowsP));
                 launch_scale_rows(dRowsP, (int)keep.size(), dScale, Qp, dst, st);
-                HIPCHK(hipStreamSynchronize(st)); // sc, keep are locals
+                HIPCHK(stg.sync()); // sc, keep are locals
             }
         }
         if (again.empty()) stats->t_pass += gml_now_s() - t0;
@@ -467,9 +519,9 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         RCCHK(upload_rows(act, dRows));
         stage("select");
         launch_select(dRows, (int)act.size(), X, G, kind, Qp, lambda, o.max_add, capW, capP, viol_frac, PG, dFidx, dgF, dpgF, dSel, dBest, Xb, st);
-        HIPCHK(hipMemcpyAsync(sel.data(), dSel, sizeof(SelectOut) * Rp, hipMemcpyDeviceToHost, st));
+        HIPCHK(stg.d2h(sel.data(), dSel, sizeof(SelectOut) * Rp));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(stg.sync());
         int64_t nactive = 0, ncg = 0;
         double worst_all = 0;
         int maxm = 0;
@@ -530,8 +582,8 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             RCCHK(upload_rows(fl, dRows));
             launch_copy_rows(dRows, (int)fl.size(), Qp, Xb, X, nullptr, nullptr, st); // back to the best iterate
             std::vector<double> inf((size_t)Rp, INFINITY);
-            HIPCHK(hipMemcpyAsync(dBest, inf.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(stg.h2d(dBest, inf.data(), sizeof(double) * Rp));
+            HIPCHK(stg.sync());
             for (int r : fl) {
                 done[r] = 0;
                 atfloor[r] = 0;
@@ -602,13 +654,13 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 dH_elems = htotal + htotal / 4;
                 HIPCHK(A.get(&dH, (size_t)dH_elems));
             }
-            HIPCHK(hipMemcpyAsync(dMt, mt2.data(), sizeof(int) * 3 * R, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dMsCg, mscg.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dHoff, hoff.data(), sizeof(long long) * (R + 1), hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dS1, s1.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dDinv, dinv.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dS1cg, s1cg.data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dVslot, vslot.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
+            HIPCHK(stg.h2d(dMt, mt2.data(), sizeof(int) * 3 * R));
+            HIPCHK(stg.h2d(dMsCg, mscg.data(), sizeof(int) * R));
+            HIPCHK(stg.h2d(dHoff, hoff.data(), sizeof(long long) * (R + 1)));
+            HIPCHK(stg.h2d(dS1, s1.data(), sizeof(double) * Rp));
+            HIPCHK(stg.h2d(dDinv, dinv.data(), sizeof(double) * Rp));
+            HIPCHK(stg.h2d(dS1cg, s1cg.data(), sizeof(double) * Rp));
+            HIPCHK(stg.h2d(dVslot, vslot.data(), sizeof(int) * R));
             HIPCHK(hipMemsetAsync(dH, 0, sizeof(double) * htotal, st));
             stage("hessian");
             if (prec == GML_PREC_I8X)
@@ -625,7 +677,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 launch_hess_f64(d, p->dV, dMt + R, dFidx, dMt, dHoff, (int)R, capP, formulation, Kh, kstride, dH, st);
             }
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(st)); // the vectors above are locals
+            HIPCHK(stg.sync()); // the vectors above are locals
             ++stats->hessian_passes;
         }
         const double s2 = formulation == GML_LOGRISE ? 1.0 : 0.0;
@@ -679,7 +731,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                     ctl[2 * np + a] = a < n ? vslot[live[a]] : 0;
                 }
                 for (int64_t g = 0; g < np / 32; ++g) ctl[3 * np + g] = (int)g;
-                HIPCHK(hipMemcpyAsync(dHv, ctl.data(), sizeof(int) * ctl.size(), hipMemcpyHostToDevice, st));
+                HIPCHK(stg.h2d(dHv, ctl.data(), sizeof(int) * ctl.size()));
                 I8Pass a{};
                 a.theta = Pv;
                 a.srow = dHv;
@@ -700,9 +752,9 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 if (rc) return fail(rc, "%s", err.c_str());
                 RCCHK(upload_rows(live, dRows));
                 launch_pcg_step(dRows, (int)live.size(), X, PG, G, kind, Qp, dS1cg, s2, dFidx, dMsCg, capP, Hp, D, Rv, Pv, dpgF, dCg, st);
-                HIPCHK(hipMemcpyAsync(cgs.data(), dCg, sizeof(CgState) * Rp, hipMemcpyDeviceToHost, st));
+                HIPCHK(stg.d2h(cgs.data(), dCg, sizeof(CgState) * Rp));
                 HIPCHK(hipGetLastError());
-                HIPCHK(hipStreamSynchronize(st));
+                HIPCHK(stg.sync());
                 ++stats->hessian_passes;
                 stats->node_evals += n;
                 std::vector<int> nxt;
@@ -718,7 +770,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 launch_pcg_dir(dRows, (int)live.size(), Qp, dFidx, dMsCg, capP, dsol, dDinv, Rv, Zv, Pv, 0, dCg, st);
             }
         }
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(stg.sync());
         stats->t_hess += gml_now_s() - th1;
 
         // ---- projected backtracking line search ----------------------------------------------------------------------------------------
@@ -741,12 +793,12 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 if (need[r]) rows.push_back((int)r);
             if (rows.empty()) break;
             RCCHK(upload_rows(rows, dRows));
-            HIPCHK(hipMemcpyAsync(dAlpha, alpha.data(), sizeof(double) * R, hipMemcpyHostToDevice, st));
+            HIPCHK(stg.h2d(dAlpha, alpha.data(), sizeof(double) * R));
             stage("trial");
             launch_trial(dRows, (int)rows.size(), X, D, PG, kind, Qp, lambda, dAlpha, Xt, dTrial, st);
-            HIPCHK(hipMemcpyAsync(trial.data(), dTrial, sizeof(TrialOut) * Rp, hipMemcpyDeviceToHost, st));
+            HIPCHK(stg.d2h(trial.data(), dTrial, sizeof(TrialOut) * Rp));
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(stg.sync());
             bool anynoise = false;
             for (int r : rows) {
                 dd[r] = trial[r].dd;
@@ -762,8 +814,8 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             const double th3 = gml_now_s();
             if (full) {
                 launch_back(dRows, (int)rows.size(), X, Xt, Gt, kind, Qp, lambda, dTrial, st);
-                HIPCHK(hipMemcpyAsync(trial.data(), dTrial, sizeof(TrialOut) * Rp, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
+                HIPCHK(stg.d2h(trial.data(), dTrial, sizeof(TrialOut) * Rp));
+                HIPCHK(stg.sync());
             }
             std::vector<int> acc;
             for (int r : rows) {
@@ -804,7 +856,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             RCCHK(upload_rows(acc, dRows2));
             launch_copy_rows(dRows2, (int)acc.size(), Qp, Xt, X, full ? Gt : nullptr, G, st);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(stg.sync());
             stats->t_host += gml_now_s() - th3;
         }
         // rows accepted on an objective-only trial still need their gradient (and V)
@@ -837,8 +889,8 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     RCCHK(upload_rows(fromx, dRows2));
     launch_copy_rows(dRows2, (int)fromx.size(), Qp, X, Xt, nullptr, nullptr, st);
     std::vector<double> xh((size_t)R * Qp);
-    HIPCHK(hipMemcpyAsync(xh.data(), Xt, sizeof(double) * R * Qp, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(stg.d2h(xh.data(), Xt, sizeof(double) * R * Qp));
+    HIPCHK(stg.sync());
     std::vector<double> res((size_t)R * P);
     gml_parallel_for(R, [&](int64_t r) {
         NodeLayout L;
