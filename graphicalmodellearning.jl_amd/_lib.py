@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GML_LIB_OVERRIDE") or os.path.join(_HERE, "libgml_hip
 GML_OK, GML_EINVAL, GML_ENOTCONV, GML_EHIP, GML_ENOMEM, GML_EUNSUPPORTED = range(6)
 FORMULATION_IDS = {"RISE": 0, "RISEA": 0, "multiRISE": 0, "logRISE": 1, "RPLE": 2}
 DTYPES = {np.dtype(np.int8): 0, np.dtype(np.int32): 1, np.dtype(np.int64): 2, np.dtype(np.float64): 3}
-PRECISIONS = {"f64": 0, "i8x": 1}
+PRECISIONS = {"f64": 0, "i8x": 1, "auto": 2}  # auto (learn only): i8x, FP64 for launch-bound sizes
 
 
 class GMLError(RuntimeError):
@@ -209,7 +209,7 @@ class Problem:
                                       theta.shape[1], _ptr(out)))
         return out
 
-    def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="i8x", max_working=512, max_add=64,
+    def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="auto", max_working=512, max_add=64,
               verbose=0, hess_samples=0, polish=True, max_cg=0, out_ptr=None, raise_on_fail=True):
         L = lib()
         o = Opts()
@@ -305,7 +305,7 @@ class MultiProblem:
     def __exit__(self, *a):
         self.close()
 
-    def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="i8x", max_working=512, max_add=64, verbose=0,
+    def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="auto", max_working=512, max_add=64, verbose=0,
               hess_samples=0, polish=True, dev_out=None, raise_on_fail=True):
         """dev_out: optional list of device pointers (ints), one per part, each an n x P float64 buffer on that part's GPU;
         the gathered matrix is left in all of them (RCCL all-gather)."""

@@ -147,7 +147,7 @@ extern "C" void gml_default_opts(gml_opts *o) {
     std::memset(o, 0, sizeof *o);
     o->tol = 1e-9;
     o->max_iter = 100;
-    o->precision = GML_PREC_I8X; // the fast path; rows it leaves above tol are finished in FP64 (polish = 0)
+    o->precision = GML_PREC_AUTO; // the int8-limb fast path (rows it leaves above tol are finished in FP64: polish = 0), FP64 for tiny problems
     o->max_working = 512;
     o->max_add = 64;
     o->verbose = 0;

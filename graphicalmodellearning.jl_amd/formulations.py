@@ -52,15 +52,16 @@ class HIP(GMLMethod):
     """Solve every node-wise problem on MI355X through libgml_hip (include/gml.h).
 
     tol        KKT tolerance (max |pseudo-gradient| per node)
-    precision  "i8x" (int8-limb fixed point on the i8 MFMA: the fast path, the default; rows it cannot bring
-               below tol are finished on the FP64 path unless polish=False) or "f64" (FP64 MFMA throughout)
+    precision  "i8x" (int8-limb fixed point on the i8 MFMA: the fast path; rows it cannot bring below tol are finished
+               on the FP64 path unless polish=False), "f64" (FP64 MFMA throughout) or "auto" (the default: "i8x", except
+               for problems so small that every kernel is launch-bound, which run in FP64)
     device     HIP device ordinal; with distributed=True the local rank's device
     devices    several GPUs of this node from this one process: the library shards the nodes over them (one host thread
                per GPU, gml_multi_*); what the Julia wrapper's HIP(devices = 0:7) binds
     distributed  shard the nodes over torch.distributed ranks (one process per GPU) and gather the rows (RCCL)
     """
     tol: float = 1e-9
-    precision: str = "i8x"
+    precision: str = "auto"
     device: Optional[int] = None
     devices: Optional[Sequence[int]] = None
     max_iter: int = 100

@@ -26,7 +26,7 @@ const libgml = get(ENV, "LIBGML_HIP", "libgml_hip.so")
 const GML_OK, GML_ENOTCONV = Cint(0), Cint(2)
 const GML_RISE, GML_LOGRISE, GML_RPLE = Cint(0), Cint(1), Cint(2)
 const GML_I64, GML_F64 = Cint(2), Cint(3)
-const GML_PREC_F64, GML_PREC_I8X = Cint(0), Cint(1)
+const GML_PREC_F64, GML_PREC_I8X, GML_PREC_AUTO = Cint(0), Cint(1), Cint(2)
 
 struct GmlOpts                      # struct gml_opts
     tol::Cdouble; max_iter::Int32; precision::Int32; max_working::Int32; max_add::Int32
@@ -41,12 +41,12 @@ struct GmlStats                     # struct gml_stats
 end
 
 """
-    HIP(; tol=1e-9, precision=:i8x, device=0, devices=nothing, max_iter=100, max_working=512, max_add=64,
+    HIP(; tol=1e-9, precision=:auto, device=0, devices=nothing, max_iter=100, max_working=512, max_add=64,
         hess_samples=0, polish=true, verbose=0, node_range=nothing)
 
 GMLMethod that solves every node-wise problem on MI355X through libgml_hip (same fields and defaults as the Python
 twin, graphicalmodellearning.jl_amd/formulations.py).
-`precision = :i8x` (default) is the int8-limb fixed-point pass; rows it cannot bring below `tol` are finished on the
+`precision = :auto` (default) is `:i8x` except for launch-bound sizes, which run in FP64; `:i8x` is the int8-limb fixed-point pass; rows it cannot bring below `tol` are finished on the
 FP64 path unless `polish = false`; `:f64` runs FP64 MFMA throughout.  `devices = 0:7` shards the nodes over several
 GPUs of this node from this one process (gml_multi_*: one handle and one host thread per GPU inside the library, the
 row blocks are written straight into the result matrix).
@@ -64,12 +64,12 @@ mutable struct HIP <: GMLMethod
     verbose::Int
     node_range::Union{Nothing,Tuple{Int,Int}}   # 1-based inclusive, for one-process-per-GPU sharding
 end
-HIP(; tol=1e-9, precision=:i8x, device=0, devices=nothing, max_iter=100, max_working=512, max_add=64, hess_samples=0,
+HIP(; tol=1e-9, precision=:auto, device=0, devices=nothing, max_iter=100, max_working=512, max_add=64, hess_samples=0,
     polish=true, verbose=0, node_range=nothing) =
     HIP(tol, precision, device, devices === nothing ? nothing : collect(Int, devices), max_iter, max_working, max_add,
         hess_samples, polish, verbose, node_range)
 
-gmlopts(m::HIP) = Ref(GmlOpts(m.tol, m.max_iter, m.precision == :i8x ? GML_PREC_I8X : GML_PREC_F64, m.max_working, m.max_add,
+gmlopts(m::HIP) = Ref(GmlOpts(m.tol, m.max_iter, m.precision == :i8x ? GML_PREC_I8X : (m.precision == :f64 ? GML_PREC_F64 : GML_PREC_AUTO), m.max_working, m.max_add,
                               m.verbose, m.hess_samples, m.polish ? 0 : -1, 0))
 
 lasterr() = unsafe_string(ccall((:gml_last_error, libgml), Cstring, ()))

@@ -50,7 +50,9 @@ def kkt_from_oracle(form, spins, rows, nodes, lam, counts=None):
 def pairwise(name, desc, J, K, form, c, seed, node_range=None, sample_nodes=4, cpu_learn="measure", tol=1e-9, hist=None):
     n = J.shape[0] if J is not None else hist.shape[1] - 1
     n0, n1 = node_range or (0, n)
-    rec = {"config": desc, "n": n, "K": K, "formulation": f"{form}({c})", "seed": seed, "precision": "i8x", "tol": tol,
+    rec = {"config": desc, "n": n, "K": K, "formulation": f"{form}({c})", "seed": seed,
+           # learn() at the library default: "auto" = the int8-limb path, FP64 for launch-bound sizes (config 1)
+           "precision": "auto -> " + ("f64" if K * ((n + 1 + 63) // 64 * 64) * (n1 - n0) <= 2 ** 28 else "i8x"), "tol": tol,
            "node_range": [n0, n1], "n_gpus": 1, **cpu_info()}
     t0 = time.time()
     prob = gml.Problem(hist, node_range=node_range) if hist is not None else \
@@ -59,7 +61,7 @@ def pairwise(name, desc, J, K, form, c, seed, node_range=None, sample_nodes=4, c
     with prob as p:
         K = p.K
         t0 = time.time()
-        out, kkt, st = p.learn(form, c, tol=tol, precision="i8x", raise_on_fail=False)
+        out, kkt, st = p.learn(form, c, tol=tol, raise_on_fail=False)
         rec["learn_s"] = time.time() - t0
         rec.update({"lambda": st["lambda_"], "iterations": st["iterations"], "passes": st["passes"],
                     "forward_passes": st["forward_passes"], "hessian_passes": st["hessian_passes"], "node_evals": st["node_evals"],
