@@ -93,6 +93,24 @@ def test_learn_abc_goldens(name, form, prec):
     assert m.stats["max_kkt"] <= tol
 
 
+def test_default_precision_takes_the_fp64_path_at_launch_bound_sizes():
+    # HIP() = precision "auto": the int8-limb path, except where every kernel is launch-bound anyway (samples x parameters x
+    # nodes <= 2^28): there the FP64 path needs fewer iterations.  The reference's own fixtures are all of that size.
+    s = load_csv("a_samples.csv")
+    auto, f64, i8x = gml.HIP(tol=1e-11), gml.HIP(tol=1e-11, precision="f64"), gml.HIP(tol=1e-9, precision="i8x")
+    assert auto.precision == "auto"
+    Ra, Rf, Ri = gml.learn(s, gml.RISE(), auto), gml.learn(s, gml.RISE(), f64), gml.learn(s, gml.RISE(), i8x)
+    assert np.array_equal(Ra, Rf)  # the same path, bit for bit
+    assert auto.stats["passes"] == f64.stats["passes"] and auto.stats["max_kkt"] <= 1e-11
+    assert np.abs(Ra - Ri).max() <= 1e-7
+    # a problem of the benchmark's kind is far above the threshold: "auto" is the int8-limb path there
+    spins, J = synthetic.block_ising(64, 200000, block=8, seed=2)
+    with gml.Problem(spins=spins) as p:
+        a, _, sa = p.learn("RISE", 0.4, tol=1e-9)
+        b, _, sb = p.learn("RISE", 0.4, tol=1e-9, precision="i8x")
+    assert np.array_equal(a, b) and sa["passes"] == sb["passes"]
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("form", FORMS)
 def test_learn_mvt_goldens(form, prec):

@@ -40,6 +40,8 @@ def test_type_defaults_match_reference():
     for T in (gml.RISE, gml.RISEA, gml.logRISE, gml.RPLE, gml.multiRISE):
         assert issubclass(T, gml.GMLFormulation)
     assert issubclass(gml.NLP, gml.GMLMethod) and issubclass(gml.HIP, gml.GMLMethod)
+    # the device method's own defaults (include/gml.h: gml_default_opts)
+    assert (gml.HIP().tol, gml.HIP().precision, gml.HIP().max_iter) == (1e-9, "auto", 100)
 
 
 def test_learn_rejects_wrong_types():
