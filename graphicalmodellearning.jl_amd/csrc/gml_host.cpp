@@ -1089,6 +1089,11 @@ extern "C" int gml_objgrad_batch(gml_problem *p, int formulation, int precision,
     if (formulation < 0 || formulation > 2) return fail(GML_EINVAL, "unknown formulation %d", formulation);
     if (nrows <= 0) return fail(GML_EINVAL, "nrows must be positive");
     if (ld < p->P) return fail(GML_EINVAL, "ld %lld smaller than the %lld parameters per node", (long long)ld, (long long)p->P);
+    {
+        const int asked = precision;
+        precision = gml_resolve_precision(p, asked, nrows);
+        if (precision < 0) return fail(GML_EINVAL, "unknown precision %d", asked);
+    }
     for (int64_t r = 0; r < nrows; ++r)
         if (nodes[r] < 0 || nodes[r] >= p->n) return fail(GML_EINVAL, "node id %lld out of range", (long long)nodes[r]);
     HIPCHK(hipSetDevice(p->device));

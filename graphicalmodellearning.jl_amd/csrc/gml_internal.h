@@ -57,5 +57,11 @@ struct NodeLayout {
 };
 void gml_build_layout(const gml_problem *p, int64_t u, NodeLayout &L);
 
+// GML_PREC_AUTO -> the int8-limb path, or FP64 where samples x parameters x rows is launch-bound either way; -1: unknown value
+inline int gml_resolve_precision(const gml_problem *p, int precision, int64_t rows) {
+    if (precision == GML_PREC_AUTO) return (double)p->K * (double)p->d.Qp * (double)rows <= 268435456.0 ? GML_PREC_F64 : GML_PREC_I8X;
+    return precision == GML_PREC_F64 || precision == GML_PREC_I8X ? precision : -1;
+}
+
 int gml_ensure_ws(gml_problem *p, int64_t rows);
 int gml_ensure_f64(gml_problem *p, int64_t vrows); // byte images + V [vrows][Kp] of the FP64 path

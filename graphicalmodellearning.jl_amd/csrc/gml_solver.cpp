@@ -110,9 +110,12 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     if (o.max_working > 512) o.max_working = 512;
     o.max_working = (int)gml_round_up(o.max_working, 32);
     if (o.max_add <= 0) o.max_add = 64;
-    if (o.precision == GML_PREC_AUTO) // launch-bound sizes gain nothing from the int8 path and converge in fewer FP64 iterations
-        o.precision = (double)p->K * (double)p->d.Qp * (double)(p->node1 - p->node0) <= 268435456.0 ? GML_PREC_F64 : GML_PREC_I8X;
-    if (o.precision != GML_PREC_F64 && o.precision != GML_PREC_I8X) return fail(GML_EINVAL, "unknown precision %d", o.precision);
+    {
+        // (auto: launch-bound sizes gain nothing from the int8 path and converge in fewer FP64 iterations)
+        const int asked = o.precision;
+        o.precision = gml_resolve_precision(p, asked, p->node1 - p->node0);
+        if (o.precision < 0) return fail(GML_EINVAL, "unknown precision %d", asked);
+    }
     HIPCHK(hipSetDevice(p->device));
     const int64_t dbg_row = getenv("GML_DEBUG_ROW") ? atoll(getenv("GML_DEBUG_ROW")) : 0; // row traced at verbose >= 2
     gml_stats stl;

@@ -44,9 +44,9 @@ extern "C" {
 #define GML_PREC_F64 0   /* FP64 MFMA (v_mfma_f64_16x16x4_f64)                             */
 #define GML_PREC_I8X 1   /* fixed point on v_mfma_i32_*_i8: Theta in 38-bit and V in 31-bit int8 limbs (V rounded
                             with a dither), integer GEMMs without further rounding: f, grad to ~1e-9 relative      */
-#define GML_PREC_AUTO 2  /* gml_learn only: GML_PREC_I8X, except for problems so small (samples x parameters x local
-                            nodes <= 2^28) that every kernel is launch-bound either way: those run in FP64, which
-                            needs fewer iterations near tight tolerances (README example: 1.2 ms against 5.5)   */
+#define GML_PREC_AUTO 2  /* GML_PREC_I8X, except for calls so small (samples x parameters x rows <= 2^28) that
+                            every kernel is launch-bound either way: those run in FP64, which needs fewer
+                            iterations near tight tolerances (README example: 1.2 ms against 5.5)              */
 
 typedef struct gml_problem gml_problem; /* opaque: packed spins + weights resident in HBM  */
 
