@@ -306,6 +306,32 @@ def test_ragged_and_tiny_inputs():
     assert np.abs(out - R0).max() <= 1e-8
 
 
+@pytest.mark.parametrize("prec", PRECS)
+def test_histogram_collisions_zero_counts_and_row_order(prec):
+    # The histogram is a weighted multiset (:76-81, :170): a configuration listed twice counts with the sum of its rows, a row
+    # with count 0 does not count at all, and the order of the rows is immaterial.
+    spins, _ = synthetic.block_ising(12, 4000, block=12, seed=5)
+    u, cnt = np.unique(spins, axis=0, return_counts=True)
+    h = np.column_stack([cnt.astype(np.float64), u.astype(np.float64)])  # unique rows with counts
+    assert cnt.max() > 1
+    rng = np.random.default_rng(0)
+    split = h.copy()
+    split[:, 0] = np.floor(h[:, 0] / 2)
+    rest = h.copy()
+    rest[:, 0] = h[:, 0] - split[:, 0]
+    ghosts = h[:50].copy()
+    ghosts[:, 0] = 0  # present, weightless
+    ghosts[:, 1:] *= -1
+    messy = np.vstack([split, ghosts, rest])
+    messy = messy[rng.permutation(len(messy))]
+    tol = 1e-11 if prec == "f64" else 1e-9
+    A = gml.learn(h, gml.RISE(0.4, False), gml.HIP(tol=tol, precision=prec))
+    B = gml.learn(messy, gml.RISE(0.4, False), gml.HIP(tol=tol, precision=prec))
+    assert np.abs(A - B).max() <= (1e-9 if prec == "f64" else 1e-7)
+    R0, _, _ = O.learn_pair(h, "RISE", c=0.4, symmetrize=False)
+    assert np.abs(B - R0).max() <= SOLTOL[prec]
+
+
 def _quantise_like_device(theta, LF=5):
     # gml_kernels_i8.hip k_quant_theta: sigma = 2^(ex-(8LF-2)), max|theta_r| < 2^ex
     mx = np.abs(theta).max(1)
