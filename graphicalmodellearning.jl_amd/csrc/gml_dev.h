@@ -77,7 +77,7 @@ struct I8Pass {
                           //    curvature weights h_k of the objective pass that last ran in slot vmap[slot]
                           //    2: the same with the products h_k (x_k.p) carried in 2 backward limbs (15 bits) instead of 4
     const int *vmap;      // hv: device [slots]
-    int lf;               // forward limb planes (3, 4, 5; 0 = the default, 5): 8 lf - 2 significant bits of theta
+    int lf;               // forward limb planes (3, 4, 5; 0 = the default, 5; 2 for Hessian-vector directions): 8 lf - 2 significant bits of theta
 };
 int i8_pass(void **ws, const DevProblem &d, int64_t slot_capacity, const I8Pass &a, hipStream_t st, hipEvent_t *ev /* [3] or NULL */,
             std::string *err);

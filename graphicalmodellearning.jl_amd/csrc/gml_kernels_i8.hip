@@ -622,9 +622,11 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     const int lo = acc[i][0][e] + (acc[i][1][e] << 8);
                     const int mid = acc[i][2][e] + (acc[i][3][e] << 8);
                     a = fma((double)mid, 65536.0, (double)lo);
-                } else {
+                } else if (LF == 3) {
                     const int lo = acc[i][0][e] + (acc[i][1][e] << 8);
                     a = fma((double)acc[i][2][e], 65536.0, (double)lo);
+                } else { // 2 limbs: directions of the Hessian-vector passes
+                    a = (double)(acc[i][0][e] + (acc[i][1][e] << 8));
                 }
                 const double Ea = fma(a, sg2, sgq0);                // |E| pre-sign: sigma * (q0 + S - 2 A)
                 const double dith = (double)(int)(dh0 + (unsigned)(i * 32 + 8 * g + j) * 0x9E3779B9u) * 2.3283064365386963e-10; // [-1/2, 1/2)
@@ -1338,7 +1340,9 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
 #define QUANT(LFV)                                                                                                                    \
     hipLaunchKernelGGL((k_quant_theta<LFV>), dim3(ns), dim3(256), 0, st, a.theta, a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.cconst,   \
                        d.wmax, a.form, hv, a.vmap, w->sc[0].tau, w->Tq, sc.sigma, sc.tau, sc.invtau, sc.qconst, a.tauovr)
+    if (LF < 3 && !hv) LF = 3; // 2 limbs exist for the directions of Hessian-vector passes only
     switch (LF) {
+    case 2: QUANT(2); break;
     case 3: QUANT(3); break;
     case 4: QUANT(4); break;
     default: QUANT(5);
@@ -1348,6 +1352,10 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     FwdLaunch fl{w, &d, &sc, a.rowcol, a.groups, a.vmap, a.ngroups, a.F, hv ? w->Uq : w->Vq, st};
     switch (LF) {
     // with the gradient requested, f comes out of the backward GEMM for free (column u of row u)
+    case 2: // (Hessian-vector forms only)
+        if (a.form == 2) launch_fwd2<2, 4, false>(fl);
+        else launch_fwd2<2, 3, false>(fl);
+        break;
     case 3: launch_fwd<3>(fl, a.form, !a.want_grad, hv); break;
     case 4: launch_fwd<4>(fl, a.form, !a.want_grad, hv); break;
     default: launch_fwd<5>(fl, a.form, !a.want_grad, hv);

@@ -717,11 +717,11 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
             // the accuracy of the directions (order-3 probe: 32 iterations with a cap of 40, 16 or 15 -- 545 / 349 / 333
             // Hessian-vector passes; 40 iterations, 279 passes with a cap of 8)
             const int maxcg = o.max_cg > 0 ? o.max_cg : (getenv("GML_CG_MAX") ? atoi(getenv("GML_CG_MAX")) : 16);
-            // limbs of the CG direction p in the Hessian-vector passes: 3 (22 bits of max|p|) are plenty for an inexact Newton
-            // step that stops at a residual of 5 % -- same iteration counts as with 4, 18 % less time per H.v (64-node
-            // probe of config 5)
-            int hv_lf = getenv("GML_HV_LF") ? atoi(getenv("GML_HV_LF")) : 3;
-            hv_lf = hv_lf < 3 ? 3 : (hv_lf > 5 ? 5 : hv_lf);
+            // limbs of the CG direction p in the Hessian-vector passes: 2 (14 bits of max|p|) are enough for an inexact Newton
+            // step that stops at a residual of 5 % -- the iteration counts of the 64-node probe of config 5 are 59 / 59 / 56
+            // with 4 / 3 / 2 limbs, and the forward GEMM of an H.v pass costs in proportion
+            int hv_lf = getenv("GML_HV_LF") ? atoi(getenv("GML_HV_LF")) : 2;
+            hv_lf = hv_lf < 2 ? 2 : (hv_lf > 5 ? 5 : hv_lf);
             // ... and the products u_k = h_k (x_k . p) go to the backward GEMM in 2 limbs (15 bits of the largest) instead of 4:
             // half the MFMAs and half the V reads of that GEMM; config 5 at the default regulariser 116 -> 93 s with
             // 10 % more iterations (GML_HV_LB=4 restores the 31 bits)
