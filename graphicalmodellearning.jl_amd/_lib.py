@@ -39,7 +39,7 @@ class Stats(C.Structure):
                 ("hessian_passes", C.c_int32), ("node_evals", C.c_int64), ("max_kkt", C.c_double),
                 ("lambda_", C.c_double), ("t_pack", C.c_double), ("t_pass", C.c_double),
                 ("t_hess", C.c_double), ("t_host", C.c_double), ("t_total", C.c_double),
-                ("not_converged", C.c_int32), ("polished", C.c_int32)]
+                ("not_converged", C.c_int32), ("polished", C.c_int32), ("hv_evals", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -69,6 +69,13 @@ def lib():
     L.gml_lambda.restype = dbl
     L.gml_lambda.argtypes = [dbl, i64, dbl]
     L.gml_problem_create.argtypes = [p, i32, i64, i64, i64, i32, i32, i64, i64, i32, C.POINTER(p)]
+    L.gml_problem_create_device_convert.argtypes = L.gml_problem_create.argtypes
+    L.gml_problem_ingest_times.argtypes = [p, p]
+    L.gml_packed_words.restype = i64
+    L.gml_packed_words.argtypes = [i64]
+    L.gml_pack_histogram.argtypes = [p, i32, i64, i64, i64, i32, p, i64, p, C.POINTER(dbl)]
+    L.gml_problem_create_packed.argtypes = [p, i64, p, i64, i64, i32, i64, i64, i32, C.POINTER(p)]
+    L.gml_problem_get_sign_bits.argtypes = [p, p]
     L.gml_problem_create_spins.argtypes = [p, p, i64, i64, i32, i64, i64, i32, C.POINTER(p)]
     L.gml_problem_create_sampled.argtypes = [p, i64, i64, C.c_uint64, i32, i64, i64, i32, C.POINTER(p)]
     L.gml_problem_create_sampled_terms.argtypes = [p, i32, p, i64, i64, i64, C.c_uint64, i32, i64, i64, i32, C.POINTER(p)]
@@ -102,14 +109,50 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def _hist_args(samples):
+    """(array kept alive, dtype id, K, n, ld, col_major) of a K x (1+n) histogram in the layout it already has"""
+    s = np.asarray(samples)
+    if s.ndim != 2 or s.shape[1] < 2:
+        raise GMLError(GML_EINVAL, "samples must be a K x (1+n) histogram matrix")
+    if s.dtype not in DTYPES:
+        s = s.astype(np.float64)
+    col_major = bool(s.flags.f_contiguous and not s.flags.c_contiguous)
+    if not (s.flags.c_contiguous or s.flags.f_contiguous):
+        s = np.ascontiguousarray(s)
+    K, n = s.shape[0], s.shape[1] - 1
+    return s, DTYPES[s.dtype], K, n, (K if col_major else n + 1), int(col_major)
+
+
+def pack_histogram(samples):
+    """Host-only (gml_pack_histogram): histogram matrix -> (sign_bits [n][words] uint32, counts [K] float64, M)."""
+    L = lib()
+    s, dt, K, n, ld, cm = _hist_args(samples)
+    wpr = L.gml_packed_words(K)
+    bits = np.empty((n, wpr), dtype=np.uint32)
+    counts = np.empty(K, dtype=np.float64)
+    M = C.c_double()
+    check(L.gml_pack_histogram(_ptr(s), dt, K, n, ld, cm, _ptr(bits), wpr, _ptr(counts), C.byref(M)))
+    return bits, counts, M.value
+
+
 class Problem:
     """RAII wrapper of a gml_problem handle (packed spins + weights resident in HBM)."""
 
-    def __init__(self, samples=None, *, counts=None, spins=None, model=None, terms=None, n=None, num_samples=None, seed=0,
-                 mcmc_sweeps=None, order=2, node_range=None, device=0):
+    def __init__(self, samples=None, *, counts=None, spins=None, packed=None, model=None, terms=None, n=None, num_samples=None,
+                 seed=0, mcmc_sweeps=None, order=2, node_range=None, device=0, ingest="host"):
         L = lib()
         h = C.c_void_p()
-        if terms is not None:
+        if packed is not None:
+            # (sign_bits [n][words] uint32, counts [K] or None, K): the packed form (pack_histogram / sign_bits())
+            bits, cnt, K = packed
+            bits = np.ascontiguousarray(bits, dtype=np.uint32)
+            if cnt is not None:
+                cnt = np.ascontiguousarray(cnt, dtype=np.float64)
+            n = bits.shape[0]
+            n0, n1 = node_range if node_range is not None else (0, n)
+            check(L.gml_problem_create_packed(_ptr(bits), bits.shape[1], _ptr(cnt), int(K), n, int(order), n0, n1, int(device),
+                                              C.byref(h)))
+        elif terms is not None:
             # sample on the device from a model of any order given as {1-based key tuple: weight}: sampling.jl:60-88
             if n is None:
                 n = max(max(k) for k in terms if len(k))
@@ -134,19 +177,11 @@ class Problem:
             check(L.gml_problem_create_sampled(_ptr(m), n, int(num_samples), int(seed), int(order), n0, n1, int(device),
                                                C.byref(h)))
         elif samples is not None:
-            s = np.asarray(samples)
-            if s.ndim != 2 or s.shape[1] < 2:
-                raise GMLError(GML_EINVAL, "samples must be a K x (1+n) histogram matrix")
-            if s.dtype not in DTYPES:
-                s = s.astype(np.float64)
-            col_major = bool(s.flags.f_contiguous and not s.flags.c_contiguous)
-            if not (s.flags.c_contiguous or s.flags.f_contiguous):
-                s = np.ascontiguousarray(s)
-            K, n = s.shape[0], s.shape[1] - 1
-            ld = K if col_major else n + 1
+            s, dt, K, n, ld, cm = _hist_args(samples)
             n0, n1 = node_range if node_range is not None else (0, n)
-            check(L.gml_problem_create(_ptr(s), DTYPES[s.dtype], K, n, ld, int(col_major), int(order), n0, n1,
-                                       int(device), C.byref(h)))
+            # ingest: "host" = packed on the host, bits uploaded (default); "device" = raw upload, converted on the device
+            create = {"host": L.gml_problem_create, "device": L.gml_problem_create_device_convert}[ingest]
+            check(create(_ptr(s), dt, K, n, ld, cm, int(order), n0, n1, int(device), C.byref(h)))
         else:
             spins = np.ascontiguousarray(spins, dtype=np.int8)
             K, n = spins.shape
@@ -184,6 +219,17 @@ class Problem:
         out = np.zeros((self.K, self.n), dtype=np.int8)
         check(lib().gml_problem_get_spins(self._h, _ptr(out)))
         return out
+
+    def sign_bits(self):
+        """the packed form of the handle's samples: [n][gml_packed_words(K)] uint32, bit set <=> spin -1"""
+        out = np.zeros((self.n, lib().gml_packed_words(self.K)), dtype=np.uint32)
+        check(lib().gml_problem_get_sign_bits(self._h, _ptr(out)))
+        return out
+
+    def ingest_times(self):
+        t = np.zeros(4)
+        check(lib().gml_problem_ingest_times(self._h, _ptr(t)))
+        return {"pack_s": t[0], "upload_s": t[1], "images_s": t[2], "total_s": t[3]}
 
     def multi_keys(self, u):
         keys = np.zeros((self.P, self.order), dtype=np.int32)
@@ -263,19 +309,10 @@ class MultiProblem:
 
     def __init__(self, samples, devices, order=2):
         L = lib()
-        s = np.asarray(samples)
-        if s.ndim != 2 or s.shape[1] < 2:
-            raise GMLError(GML_EINVAL, "samples must be a K x (1+n) histogram matrix")
-        if s.dtype not in DTYPES:
-            s = s.astype(np.float64)
-        col_major = bool(s.flags.f_contiguous and not s.flags.c_contiguous)
-        if not (s.flags.c_contiguous or s.flags.f_contiguous):
-            s = np.ascontiguousarray(s)
-        K, n = s.shape[0], s.shape[1] - 1
+        s, dt, K, n, ld, cm = _hist_args(samples)
         dev = np.ascontiguousarray(devices, dtype=np.int32)
         h = C.c_void_p()
-        check(L.gml_multi_create(_ptr(s), DTYPES[s.dtype], K, n, K if col_major else n + 1, int(col_major), int(order), _ptr(dev),
-                                 len(dev), C.byref(h)))
+        check(L.gml_multi_create(_ptr(s), dt, K, n, ld, cm, int(order), _ptr(dev), len(dev), C.byref(h)))
         self._h = h
         nn, KK, PP, nd = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
         M = C.c_double()

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <functional>
 #include <string>
+#include <utility>
 #include <vector>
 
 int gml_fail(int code, const char *fmt, ...);
@@ -49,6 +50,8 @@ struct gml_problem {
     // pinned staging arena of the solver's small control / scalar transfers (gml_solver.cpp), allocated on first use
     char *stage = nullptr;
     size_t stage_bytes = 0;
+    // how long building the handle took (gml_problem_ingest_times): host packing, uploads not hidden by it, bit images, total
+    double t_ingest[4] = {0, 0, 0, 0};
 };
 
 // reference parameter vector of node u <-> internal column layout (pairwise :162, multi-body :94-104)
@@ -57,11 +60,17 @@ struct NodeLayout {
 };
 void gml_build_layout(const gml_problem *p, int64_t u, NodeLayout &L);
 
-// GML_PREC_AUTO -> the int8-limb path, or FP64 where samples x parameters x rows is launch-bound either way; -1: unknown value
-inline int gml_resolve_precision(const gml_problem *p, int precision, int64_t rows) {
-    if (precision == GML_PREC_AUTO) return (double)p->K * (double)p->d.Qp * (double)rows <= 268435456.0 ? GML_PREC_F64 : GML_PREC_I8X;
+// GML_PREC_AUTO -> the int8-limb path, or FP64 where samples x parameters x nodes is launch-bound either way (decided on
+// the whole problem, not on the rows of one call or one shard: the arithmetic does not depend on the GPU count); -1: unknown value
+inline int gml_resolve_precision(const gml_problem *p, int precision) {
+    if (precision == GML_PREC_AUTO) return (double)p->K * (double)p->P * (double)p->n <= 268435456.0 ? GML_PREC_F64 : GML_PREC_I8X;
     return precision == GML_PREC_F64 || precision == GML_PREC_I8X ? precision : -1;
 }
+
+// handles for several node ranges / devices from one host histogram: packed once, the bits copied to every device
+int gml_create_parts(const void *samples, int dtype, int64_t K, int64_t n, int64_t ld, int col_major, int order,
+                     const std::vector<std::pair<int64_t, int64_t>> &ranges, const std::vector<int> &devices,
+                     std::vector<gml_problem *> &parts);
 
 int gml_ensure_ws(gml_problem *p, int64_t rows);
 int gml_ensure_f64(gml_problem *p, int64_t vrows); // byte images + V [vrows][Kp] of the FP64 path

@@ -52,7 +52,8 @@ struct I8Ws {
     int64_t slots = 0; // capacity (multiple of 32)
     int LF = 5;        // limb planes the Tq buffer is sized for
     int8_t *Tq = nullptr, *Vq = nullptr, *Uq = nullptr; // Uq: the V-like limb planes of Hessian-vector passes (on first use)
-    int32_t *Gacc = nullptr;
+    int32_t *Gacc = nullptr; // [gplanes][slots * LB][Qfp]: one set of i32 gradient accumulators per 2^24 configurations
+    int gplanes = 1;
     SlotScalars sc[2]; // [0] objective/gradient passes, [1] Hessian-vector passes
     double *tauovr = nullptr; // per-slot tau imposed by the caller (tracked scale, rescaled re-run), 0 = derive from the bound
     // working-set Hessian on the int8 cores (indexed by ROW of the caller's arrays)
@@ -727,7 +728,9 @@ template <int TM /* node tiles per workgroup: 1 (4 waves, two workgroups per CU)
           int NL /* limb planes of Vq that are non-zero: 4, or 2 for the products of a 2-limb Hessian-vector pass (TM = 1) */>
 __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
     const int8_t *__restrict__ Vq, const unsigned *__restrict__ Xtb, const int *__restrict__ groups, int ngroups_t,
-    int nNt, int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit, int32_t *__restrict__ Gacc) {
+    int nNt, int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit, int32_t *__restrict__ Gacc,
+    int chunks_per_plane /* split-K chunks that share one set of i32 accumulators (<= 2^24 configurations: |sum| < 2^31) */,
+    int64_t plane_stride /* elements between the accumulator sets */) {
     constexpr int NW = 4 * TM;
     constexpr int AR = 128 * TM, NPIECE = 8 * TM + 2, STAGE = NPIECE * 1024, NS = 4;
     constexpr int WMT = NL, WNT = 2; // wave tile 128 (64) x 64: MFMA tile i <-> limb plane i of the node tile
@@ -740,6 +743,7 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
     const int b = blockIdx.x, xcd = b & 7, bi = b >> 3;
     const int chunk = (bi / T) * 8 + xcd, ti = bi % T; // all tiles of one k-chunk on one XCD
     if (chunk >= nsplit) return;
+    Gacc += (int64_t)(chunk / chunks_per_plane) * plane_stride;
     const int gi = ti / nNt, nt = ti % nNt;
     int tiles[TM];
 #pragma unroll
@@ -842,7 +846,8 @@ __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__
                                                      const long long *__restrict__ asum, const int *__restrict__ srow,
                                                      const int *__restrict__ rowcol, int slot0, int64_t Qp, int64_t Qfp, int64_t Qf,
                                                      int64_t cconst, int form, int want_grad, int hv,
-                                                     double *__restrict__ G, double *__restrict__ f) {
+                                                     double *__restrict__ G, double *__restrict__ f, int nplanes,
+                                                     int64_t plane_stride) {
     const int r = slot0 + blockIdx.y;
     if (rowcol[r] < 0) return;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -852,7 +857,11 @@ __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__
             const int tile = r >> 5, rl = r & 31, u = rowcol[r];
             long long s = 0;
 #pragma unroll
-            for (int l = LB - 1; l >= 0; --l) s = s * 256 + (long long)Gacc[((int64_t)(tile * LB + l) * 32 + rl) * Qfp + u];
+            for (int l = LB - 1; l >= 0; --l) {
+                long long a = 0;
+                for (int pl = 0; pl < nplanes; ++pl) a += (long long)Gacc[pl * plane_stride + ((int64_t)(tile * LB + l) * 32 + rl) * Qfp + u];
+                s = s * 256 + a;
+            }
             f[r] = -t * (double)(csum[r] - 2 * s);
         } else {
             f[r] = t * (double)asum[r];
@@ -864,7 +873,11 @@ __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__
         const int tile = r >> 5, rl = r & 31;
         long long s = 0;
 #pragma unroll
-        for (int l = LB - 1; l >= 0; --l) s = s * 256 + (long long)Gacc[((int64_t)(tile * LB + l) * 32 + rl) * Qfp + c];
+        for (int l = LB - 1; l >= 0; --l) {
+            long long a = 0;
+            for (int pl = 0; pl < nplanes; ++pl) a += (long long)Gacc[pl * plane_stride + ((int64_t)(tile * LB + l) * 32 + rl) * Qfp + c];
+            s = s * 256 + a;
+        }
         v = t * (double)(csum[r] - 2 * s);
     } else if (c == cconst) {
         v = t * (double)csum[r];
@@ -1145,7 +1158,10 @@ static int i8_ensure(void **wsp, const DevProblem &d, int64_t slots, std::string
     *wsp = w; // owned by the handle from here on: a failed allocation below is released by i8_free
     I8CHK(hipMalloc(&w->Tq, (size_t)slots * w->LF * d.Qfp));
     I8CHK(hipMalloc(&w->Vq, (size_t)slots * LB * d.Kp));
-    I8CHK(hipMalloc(&w->Gacc, sizeof(int32_t) * (size_t)slots * LB * d.Qfp));
+    // i32 accumulators of the backward GEMM hold |sum_k v_k b_k| <= 128 K: exact up to 2^24 configurations per set
+    // (beyond 2^24: sets of <= 2^23 configurations + the slack of whole split-K chunks, see i8_pass)
+    w->gplanes = d.Kp <= ((int64_t)1 << 24) ? 1 : (int)((d.Kp + ((int64_t)1 << 23) - 1) >> 23);
+    I8CHK(hipMalloc(&w->Gacc, sizeof(int32_t) * (size_t)w->gplanes * slots * LB * d.Qfp));
     for (auto &sc : w->sc) {
         I8CHK(hipMalloc(&sc.sigma, sizeof(double) * slots));
         I8CHK(hipMalloc(&sc.tau, sizeof(double) * slots));
@@ -1178,6 +1194,7 @@ static void launch_hess_blk(const I8Ws *w, const DevProblem &d, const int *dF, c
     if (ns < 1) ns = 1;
     int64_t kc = (Kh + ns - 1) / ns;
     kc = (kc + 511) / 512 * 512;
+    if (kc > ((int64_t)1 << 24)) kc = (int64_t)1 << 24; // i32 sums per workgroup: |sum| <= 128 kc
     ns = (int)((Kh + kc - 1) / kc);
     constexpr int shmem = 3 * ((64 + 32 * BT) * 64 + 4 * 512) + 2 * (4 + 2 * BT) * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hess_bits_blk<BT>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
@@ -1243,7 +1260,7 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
 // gradient planes of those slots' tiles
 __global__ __launch_bounds__(256) void k_zero_pass(long long *__restrict__ csum, long long *__restrict__ asum,
                                                    unsigned *__restrict__ mmax, double *__restrict__ f, int slot0, int ns,
-                                                   v4i *__restrict__ gacc, int64_t ngacc) {
+                                                   v4i *__restrict__ gacc, int64_t ngacc, int nplanes, int64_t plane_stride4) {
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
     if (i0 < ns) {
         csum[slot0 + i0] = 0;
@@ -1252,7 +1269,8 @@ __global__ __launch_bounds__(256) void k_zero_pass(long long *__restrict__ csum,
         if (f) f[slot0 + i0] = 0.0;
     }
     const v4i z = {0, 0, 0, 0};
-    for (int64_t i = i0; i < ngacc; i += stride) gacc[i] = z;
+    for (int pl = 0; pl < nplanes; ++pl)
+        for (int64_t i = i0; i < ngacc; i += stride) gacc[pl * plane_stride4 + i] = z;
 }
 
 int i8_limbs_forward() {
@@ -1313,10 +1331,6 @@ static void launch_fwd(const FwdLaunch &a, int form, bool wantf, int hv) {
 
 // One pass of the int8-limb operator over the slots the caller lists (I8Pass, gml_dev.h).
 int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass &a, hipStream_t st, hipEvent_t *ev, std::string *err) {
-    if (d.Kp > (int64_t)1 << 24) {
-        if (err) *err = "GML_PREC_I8X supports up to 2^24 configurations per handle (i32 accumulators)";
-        return GML_EUNSUPPORTED;
-    }
     int rc = i8_ensure(wsp, d, slot_capacity, err);
     if (rc) return rc;
     I8Ws *w = static_cast<I8Ws *>(*wsp);
@@ -1335,8 +1349,9 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     const int ns = a.slot1 - a.slot0;
     const bool grad = a.want_grad || hv;
     int32_t *gacc0 = w->Gacc + (int64_t)a.slot0 * LB * d.Qfp;
+    const int64_t gplane_stride = (int64_t)w->slots * LB * d.Qfp;
     hipLaunchKernelGGL(k_zero_pass, dim3(1024), dim3(256), 0, st, sc.csum, sc.asum, sc.mmax, a.F, a.slot0, ns, reinterpret_cast<v4i *>(gacc0),
-                       grad ? (int64_t)ns * LB * d.Qfp / 4 : 0);
+                       grad ? (int64_t)ns * LB * d.Qfp / 4 : 0, w->gplanes, gplane_stride / 4);
 #define QUANT(LFV)                                                                                                                    \
     hipLaunchKernelGGL((k_quant_theta<LFV>), dim3(ns), dim3(256), 0, st, a.theta, a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.cconst,   \
                        d.wmax, a.form, hv, a.vmap, w->sc[0].tau, w->Tq, sc.sigma, sc.tau, sc.invtau, sc.qconst, a.tauovr)
@@ -1378,7 +1393,11 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
         int64_t kchunk = (d.Kp + nsplit - 1) / nsplit;
         kchunk = (kchunk + 63) / 64 * 64;
         if (kchunk < 2048) kchunk = 2048;
+        if (w->gplanes > 1 && kchunk > ((int64_t)1 << 22)) kchunk = (int64_t)1 << 22;
         nsplit = (int)((d.Kp + kchunk - 1) / kchunk);
+        // chunks per set of i32 accumulators: one set up to 2^24 configurations; beyond, gplanes = ceil(Kp / 2^23) sets of
+        // cpp chunks each: cpp * kchunk < (Kp + kchunk) / gplanes + kchunk <= 2^23 + 1.5 * 2^22 < 2^24, so |sum| < 2^31
+        const int cpp = (nsplit + w->gplanes - 1) / w->gplanes;
         const int grid = ((nsplit + 7) / 8) * 8 * T;
         const int shmem = 4 * (8 * TM + 2) * 1024;
         const int8_t *Vin = hv ? w->Uq : w->Vq;
@@ -1386,22 +1405,22 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
         if (TM == 2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
             hipLaunchKernelGGL((k_bwd_i8<2, 4>), dim3(grid), dim3(512), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
-                               nsplit, w->Gacc);
+                               nsplit, w->Gacc, cpp, gplane_stride);
         } else {
             if (hv == 2) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
                 hipLaunchKernelGGL((k_bwd_i8<1, 2>), dim3(grid), dim3(256), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
-                                   nsplit, w->Gacc);
+                                   nsplit, w->Gacc, cpp, gplane_stride);
             } else {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
                 hipLaunchKernelGGL((k_bwd_i8<1, 4>), dim3(grid), dim3(256), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
-                                   nsplit, w->Gacc);
+                                   nsplit, w->Gacc, cpp, gplane_stride);
             }
         }
     }
     if (ev) I8CHK(hipEventRecord(ev[2], st));
     hipLaunchKernelGGL(k_finalize_i8, dim3((unsigned)((d.Qp + 255) / 256), (unsigned)ns), dim3(256), 0, st, w->Gacc, sc.tau, sc.csum, sc.asum,
-                       a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.Qf, d.cconst, a.form, grad ? 1 : 0, hv, a.G, a.F);
+                       a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.Qf, d.cconst, a.form, grad ? 1 : 0, hv, a.G, a.F, w->gplanes, gplane_stride);
     I8CHK(hipGetLastError());
     return GML_OK;
 }

@@ -78,25 +78,17 @@ extern "C" int gml_multi_create(const void *samples, int dtype, int64_t K, int64
     if (!devices || ndev < 1) return fail(GML_EINVAL, "empty device list");
     if (n < ndev) return fail(GML_EINVAL, "more devices (%d) than nodes (%lld)", ndev, (long long)n);
     gml_multi *m = new gml_multi();
-    m->part.assign((size_t)ndev, nullptr);
     m->device.assign(devices, devices + ndev);
-    std::vector<int> rc((size_t)ndev, GML_OK);
-    std::vector<std::string> msg((size_t)ndev);
-    std::vector<std::thread> th;
-    for (int g = 0; g < ndev; ++g)
-        th.emplace_back([&, g] {
-            const int64_t n0 = (int64_t)g * n / ndev, n1 = (int64_t)(g + 1) * n / ndev; // contiguous node ranges
-            rc[g] = gml_problem_create(samples, dtype, K, n, ld, col_major, order, n0, n1, devices[g], &m->part[g]);
-            if (rc[g]) msg[g] = gml_last_error();
-        });
-    for (auto &t : th) t.join();
-    for (int g = 0; g < ndev; ++g)
-        if (rc[g]) {
-            const int code = rc[g];
-            const std::string keep = msg[g];
-            gml_multi_destroy(m);
-            return fail(code, "device %d: %s", devices[g], keep.c_str());
-        }
+    // contiguous node ranges; the histogram is packed once and its bits are copied to every device
+    std::vector<std::pair<int64_t, int64_t>> ranges;
+    for (int g = 0; g < ndev; ++g) ranges.emplace_back((int64_t)g * n / ndev, (int64_t)(g + 1) * n / ndev);
+    const int rc = gml_create_parts(samples, dtype, K, n, ld, col_major, order, ranges, m->device, m->part);
+    if (rc) {
+        const std::string keep = gml_last_error();
+        m->part.clear();
+        gml_multi_destroy(m);
+        return fail(rc, "%s", keep.c_str());
+    }
     (void)gml_problem_info(m->part[0], &m->n, &m->K, &m->M, &m->P, nullptr, nullptr);
     // RCCL communicators, when every part sits on its own GPU
     std::vector<int> uniq(m->device);

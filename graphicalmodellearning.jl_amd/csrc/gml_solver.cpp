@@ -113,7 +113,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     {
         // (auto: launch-bound sizes gain nothing from the int8 path and converge in fewer FP64 iterations)
         const int asked = o.precision;
-        o.precision = gml_resolve_precision(p, asked, p->node1 - p->node0);
+        o.precision = gml_resolve_precision(p, asked);
         if (o.precision < 0) return fail(GML_EINVAL, "unknown precision %d", asked);
     }
     HIPCHK(hipSetDevice(p->device));
@@ -761,7 +761,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
                 HIPCHK(hipGetLastError());
                 HIPCHK(stg.sync());
                 ++stats->hessian_passes;
-                stats->node_evals += n;
+                stats->hv_evals += n;
                 std::vector<int> nxt;
                 for (int r : live) {
                     const double eta = std::min(cg_eta, std::sqrt(std::max(kkt[r], 1e-300)));
@@ -916,6 +916,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     stats->max_kkt = maxk;
     stats->not_converged = notconv;
     stats->t_total = gml_now_s() - t_start;
+    stats->t_pack = p->t_ingest[3];
     if (stats_out) *stats_out = *stats;
     if (notconv)
         return fail(GML_ENOTCONV, "%d of %lld nodes did not reach the KKT tolerance %.1e (worst %.3e)", notconv, (long long)R, o.tol, maxk);

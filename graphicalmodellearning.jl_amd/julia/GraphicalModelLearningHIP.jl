@@ -38,6 +38,7 @@ struct GmlStats                     # struct gml_stats
     node_evals::Int64; max_kkt::Cdouble; lambda::Cdouble
     t_pack::Cdouble; t_pass::Cdouble; t_hess::Cdouble; t_host::Cdouble; t_total::Cdouble
     not_converged::Int32; polished::Int32
+    hv_evals::Int64
 end
 
 """
@@ -69,7 +70,14 @@ HIP(; tol=1e-9, precision=:auto, device=0, devices=nothing, max_iter=100, max_wo
     HIP(tol, precision, device, devices === nothing ? nothing : collect(Int, devices), max_iter, max_working, max_add,
         hess_samples, polish, verbose, node_range)
 
-gmlopts(m::HIP) = Ref(GmlOpts(m.tol, m.max_iter, m.precision == :i8x ? GML_PREC_I8X : (m.precision == :f64 ? GML_PREC_F64 : GML_PREC_AUTO), m.max_working, m.max_add,
+function precision_id(s::Symbol)
+    s == :auto && return GML_PREC_AUTO
+    s == :i8x && return GML_PREC_I8X
+    s == :f64 && return GML_PREC_F64
+    throw(ArgumentError("HIP: unknown precision :$s (use :auto, :i8x or :f64)"))   # as the C ABI and the Python twin do
+end
+
+gmlopts(m::HIP) = Ref(GmlOpts(m.tol, m.max_iter, precision_id(m.precision), m.max_working, m.max_add,
                               m.verbose, m.hess_samples, m.polish ? 0 : -1, 0))
 
 lasterr() = unsafe_string(ccall((:gml_last_error, libgml), Cstring, ()))
@@ -83,6 +91,8 @@ function solve_rows(samples::Array{T,2}, formulation, method::HIP, order::Int) w
     s = T <: AbstractFloat ? convert(Array{Float64,2}, samples) : convert(Array{Int64,2}, samples)
     dtype = eltype(s) == Float64 ? GML_F64 : GML_I64
     K, n = size(s, 1), size(s, 2) - 1
+    method.devices === nothing || method.node_range === nothing ||
+        throw(ArgumentError("HIP: devices (all nodes over several GPUs) and node_range (one shard) exclude each other"))
     method.devices === nothing || return solve_rows_multi(s, dtype, formulation, method, order)
     n0, n1 = method.node_range === nothing ? (0, n) : (method.node_range[1] - 1, method.node_range[2])
     handle = Ref{Ptr{Cvoid}}(C_NULL)

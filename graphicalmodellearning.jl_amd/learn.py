@@ -21,6 +21,7 @@ def _node_partition(n, world, rank):
 
 
 def _local_solve_hip(samples, formulation, method, order, node_range, device):
+    """rows of the local node range through libgml_hip: (out, kkt, stats, keys)"""
     with _lib.Problem(samples, order=order, node_range=node_range, device=device) as prob:
         out, kkt, st = prob.learn(_form_name(formulation), formulation.regularizer, tol=method.tol,
                                   max_iter=method.max_iter, precision=method.precision,
@@ -34,6 +35,9 @@ def _local_solve_hip(samples, formulation, method, order, node_range, device):
             else:
                 keys = [prob.multi_keys(u) for u in range(node_range[0], node_range[1])]
     return out, kkt, st, keys
+
+
+_local_solve_hip.pairwise_slots = True  # the C ABI keeps the pairwise slot layout for order 2 (slot u = field)
 
 
 def _local_solve_multi(samples, formulation, method, order):
@@ -63,7 +67,7 @@ def _gather_rows(local, n, P, method):
     return np.concatenate([allb[r, : sizes[r]] for r in range(world)], axis=0)
 
 
-def learn(samples, formulation=None, method=None, *, _local_solve=None):
+def learn(samples, formulation=None, method=None):
     """learn(samples) / learn(samples, formulation) / learn(samples, formulation, method)
     (:69-70: defaults RISE(), NLP()).
 
@@ -87,6 +91,12 @@ def learn(samples, formulation=None, method=None, *, _local_solve=None):
     n = samples.shape[1] - 1
     order = int(formulation.interaction_order) if isinstance(formulation, multiRISE) else 2
 
+    if method.devices is not None and (method.distributed or method.node_range is not None or method.device is not None):
+        raise ValueError("HIP: devices (all nodes over several GPUs from this process) excludes distributed, node_range and device")
+    if method.distributed and method.node_range is not None:
+        raise ValueError("HIP: distributed=True derives the node range from the rank; node_range must not be given")
+    if method.precision not in _lib.PRECISIONS:
+        raise ValueError(f"HIP: unknown precision {method.precision!r} (use 'auto', 'i8x' or 'f64')")
     world, rank = 1, 0
     if method.distributed:
         import torch.distributed as dist
@@ -98,9 +108,9 @@ def learn(samples, formulation=None, method=None, *, _local_solve=None):
         if method.distributed:
             import torch
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
-    solve = _local_solve or _local_solve_hip
+    solve = _local_solve_hip  # (module attribute, looked up per call: the CPU-only tests of this layer substitute the oracle)
     try:
-        if method.devices is not None and _local_solve is None and not method.distributed:
+        if method.devices is not None:
             out, kkt, st, keys = _local_solve_multi(samples, formulation, method, order)
             node_range = (0, n)
         else:
@@ -121,7 +131,7 @@ def learn(samples, formulation=None, method=None, *, _local_solve=None):
 
     if isinstance(formulation, multiRISE):
         if keys is None or method.distributed and world > 1:
-            keys = _all_multi_keys(n, order, node_range, pairwise_slots=(order == 2 and _local_solve is None))
+            keys = _all_multi_keys(n, order, node_range, pairwise_slots=(order == 2 and getattr(solve, "pairwise_slots", False)))
         rec = {}
         for r, u in enumerate(range(node_range[0], node_range[1])):
             for key, v in zip(keys[r], out[r]):

@@ -44,9 +44,12 @@ extern "C" {
 #define GML_PREC_F64 0   /* FP64 MFMA (v_mfma_f64_16x16x4_f64)                             */
 #define GML_PREC_I8X 1   /* fixed point on v_mfma_i32_*_i8: Theta in 38-bit and V in 31-bit int8 limbs (V rounded
                             with a dither), integer GEMMs without further rounding: f, grad to ~1e-9 relative      */
-#define GML_PREC_AUTO 2  /* GML_PREC_I8X, except for calls so small (samples x parameters x rows <= 2^28) that
-                            every kernel is launch-bound either way: those run in FP64, which needs fewer
-                            iterations near tight tolerances (README example: 1.2 ms against 5.5)              */
+#define GML_PREC_AUTO 2  /* GML_PREC_I8X, except for problems so small (samples x parameters x spins <= 2^28: a
+                            property of the problem, not of the call or of the node shard) that every kernel is
+                            launch-bound either way: those run in FP64, which needs fewer iterations near tight
+                            tolerances (README example: 1.2 ms against 5.5).  Never GML_EUNSUPPORTED for a
+                            valid histogram: beyond 2^24 configurations the int8 path keeps one set of i32
+                            gradient accumulators per 2^23 configurations and adds them in int64             */
 
 typedef struct gml_problem gml_problem; /* opaque: packed spins + weights resident in HBM  */
 
@@ -72,12 +75,14 @@ typedef struct gml_stats {
     int32_t passes;          /* full objective+gradient passes (all local nodes)            */
     int32_t forward_passes;  /* objective-only passes (line-search trials)                  */
     int32_t hessian_passes;
-    int64_t node_evals;      /* sum over passes of the number of nodes evaluated            */
+    int64_t node_evals;      /* sum over the objective(/gradient) passes of the number of nodes evaluated (their time: t_pass) */
     double max_kkt;          /* worst final KKT residual over local nodes                   */
     double lambda;           /* the regulariser actually used (:157)                        */
-    double t_pack, t_pass, t_hess, t_host, t_total; /* seconds                              */
+    double t_pack, t_pass, t_hess, t_host, t_total; /* seconds; t_pack = building the handle (gml_problem_ingest_times
+                                t[3]: host packing + uploads + operand images), not part of t_total */
     int32_t not_converged;   /* number of local nodes above tol                             */
     int32_t polished;        /* 1 if rows were finished on the FP64 path (precision i8x, see gml_opts.polish) */
+    int64_t hv_evals;        /* node evaluations of the Hessian-vector passes of the matrix-free rows (their time: t_hess) */
 } gml_stats;
 
 const char *gml_last_error(void);
@@ -102,6 +107,40 @@ void gml_default_opts(gml_opts *o);
 int gml_problem_create(const void *samples, int dtype, int64_t K, int64_t n, int64_t ld,
                        int col_major, int order, int64_t node0, int64_t node1, int device,
                        gml_problem **out);
+
+/*
+ * Ingest.  gml_problem_create reads the caller's matrix exactly ONCE, on the host: a streaming packer (worker threads,
+ * AVX2) turns 32 consecutive 8-byte elements of a spin column into one sign word, validates the +-1 alphabet and the
+ * counts in the same sweep, and K n / 8 bytes of sign bits + 8 K bytes of weights cross PCIe instead of the
+ * 8 K (n+1) of the Matrix{Int64} (`copy` of the Adjoint at :73; C3: 0.13 GB instead of 8.2 GB).  Packing overlaps the
+ * copies (two pinned stages).  gml_problem_ingest_times reports the split:
+ *   t[0] host packing (counts + sign words), t[1] allocations / uploads not hidden behind it, t[2] MFMA operand images
+ *   (device), t[3] whole create call; seconds.
+ */
+int gml_problem_ingest_times(const gml_problem *p, double t[4]);
+
+/* The other route: the raw matrix is uploaded as it is and converted / validated on the device (64x the PCIe bytes;
+ * for hosts with few cores).  Same arguments and the same resulting handle, bit for bit. */
+int gml_problem_create_device_convert(const void *samples, int dtype, int64_t K, int64_t n, int64_t ld,
+                                      int col_major, int order, int64_t node0, int64_t node1, int device,
+                                      gml_problem **out);
+
+/*
+ * Packed form of a histogram, for callers that build several handles from one matrix (other processes, other GPUs) or
+ * keep the samples packed: sign_bits [n][words_per_spin] dwords, spin-major, bit j of word w <-> configuration 32 w + j,
+ * set <=> the spin is -1 (bits beyond K ignored); counts [K] doubles (NULL = all ones).
+ *   gml_packed_words(K)         words_per_spin of the device image (K rounded up to 1024, / 32)
+ *   gml_pack_histogram          host only (no device needed): matrix -> sign_bits, counts, *M = sum of counts (:76-81)
+ *   gml_problem_create_packed   handle from the packed form
+ *   gml_problem_get_sign_bits   the packed form of a handle's samples ([n][gml_packed_words(K)] dwords, host pointer),
+ *                               e.g. of a handle sampled on the device
+ */
+int64_t gml_packed_words(int64_t K);
+int gml_pack_histogram(const void *samples, int dtype, int64_t K, int64_t n, int64_t ld, int col_major,
+                       uint32_t *sign_bits, int64_t words_per_spin, double *counts, double *M);
+int gml_problem_create_packed(const uint32_t *sign_bits, int64_t words_per_spin, const double *counts, int64_t K, int64_t n,
+                              int order, int64_t node0, int64_t node1, int device, gml_problem **out);
+int gml_problem_get_sign_bits(gml_problem *p, uint32_t *sign_bits);
 
 /* Same, from split inputs: counts (K doubles, NULL = all ones) and spins (K x n int8,
  * row-major).  Used by the synthetic benchmark so that no 8-byte histogram is built. */
@@ -204,7 +243,9 @@ int gml_learn(gml_problem *p, int formulation, double regularizer_c, const gml_o
  * `learn(samples, RISE(), HIP(devices = 0:7))` binds these).  GPU g owns the nodes [g n / G, (g+1) n / G): one handle and
  * one host thread per device, the sample bits replicated, no communication while solving.
  *
- *   gml_multi_create   as gml_problem_create, for the devices listed (a device may be listed more than once)
+ *   gml_multi_create   as gml_problem_create, for the devices listed (a device may be listed more than once): the matrix
+ *                      is packed ONCE on the host and each chunk of sign bits is copied to every device while the next
+ *                      one is being packed (C4: 0.5 GB per GPU instead of 32.8 GB per GPU)
  *   gml_multi_learn    out: n x P row-major host matrix (may be NULL), rows written by the part that owns them; kkt: n.
  *                      dev_out: NULL, or one device pointer per part (n x P doubles on that part's GPU): the full
  *                      matrix is left on EVERY GPU by one RCCL all-gather over xGMI (librccl is loaded at run time;

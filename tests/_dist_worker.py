@@ -18,10 +18,9 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     out_dir, mode = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "oracle")
-    kw = {}
-    if mode == "oracle":
-        from test_host_api import oracle_local_solve
-        kw["_local_solve"] = oracle_local_solve
+    if mode == "oracle":  # the CPU oracle stands in for the device solver of every rank
+        from test_host_api import learn_module, oracle_local_solve
+        learn_module._local_solve_hip = oracle_local_solve
         method = lambda: gml.HIP(distributed=True)  # noqa: E731
     else:
         import torch
@@ -29,10 +28,10 @@ def main():
         method = lambda: gml.HIP(distributed=True, device=dev, tol=1e-11)  # noqa: E731
     s = np.loadtxt(os.path.join(ROOT, "tests", "golden", "mvt_samples.csv"), delimiter=",")
     res = {}
-    res["rise_sym"] = gml.learn(s, gml.RISE(0.2, True), method(), **kw)
-    res["rise"] = gml.learn(s, gml.RISE(0.2, False), method(), **kw)
+    res["rise_sym"] = gml.learn(s, gml.RISE(0.2, True), method())
+    res["rise"] = gml.learn(s, gml.RISE(0.2, False), method())
     c = np.loadtxt(os.path.join(ROOT, "tests", "golden", "c_samples.csv"), delimiter=",")
-    fg = gml.learn(c, gml.multiRISE(0.2, True, 3), method(), **kw)
+    fg = gml.learn(c, gml.multiRISE(0.2, True, 3), method())
     keys = sorted(fg.keys(), key=lambda k: (len(k), k))
     res["multi_vals"] = np.array([fg[k] for k in keys])
     if mode == "hip":

@@ -11,7 +11,7 @@ import pytest
 
 import gml_amd as gml
 from conftest import ROOT, load_csv
-from test_host_api import oracle_local_solve
+from test_host_api import oracle_learn
 
 
 def _free_port():
@@ -33,12 +33,12 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     r1 = np.load(tmp_path / "rank1.npz")
     assert int(r0["world"]) == 2
     s = load_csv("mvt_samples.csv")
-    single = gml.learn(s, gml.RISE(0.2, False), _local_solve=oracle_local_solve)
-    single_sym = gml.learn(s, gml.RISE(0.2, True), _local_solve=oracle_local_solve)
+    single = oracle_learn(s, gml.RISE(0.2, False))
+    single_sym = oracle_learn(s, gml.RISE(0.2, True))
     for rr in (r0, r1):  # every rank holds the full gathered result
         assert np.array_equal(rr["rise"], single)
         assert np.array_equal(rr["rise_sym"], single_sym)
-    fg = gml.learn(load_csv("c_samples.csv"), gml.multiRISE(0.2, True, 3), _local_solve=oracle_local_solve)
+    fg = oracle_learn(load_csv("c_samples.csv"), gml.multiRISE(0.2, True, 3))
     keys = sorted(fg.keys(), key=lambda k: (len(k), k))
     assert np.allclose(r0["multi_vals"], [fg[k] for k in keys], atol=1e-15)
     assert np.array_equal(r0["multi_vals"], r1["multi_vals"])

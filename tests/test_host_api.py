@@ -9,6 +9,7 @@ from conftest import DEFAULT_C, MODELS, load_csv
 from oracle import oracle as O
 
 synthetic = __import__("importlib").import_module("gml_amd.synthetic")
+learn_module = __import__("importlib").import_module("gml_amd.learn")
 
 
 def oracle_local_solve(samples, formulation, method, order, node_range, device):
@@ -26,6 +27,16 @@ def oracle_local_solve(samples, formulation, method, order, node_range, device):
     form = {"RISEA": "RISE"}.get(name, name)
     R, kkt, _ = O.learn_pair(samples, form, c=formulation.regularizer, symmetrize=False)
     return R[node_range[0]:node_range[1]], kkt[node_range[0]:node_range[1]], {}, None
+
+
+def oracle_learn(*args):
+    """gml.learn with the CPU oracle standing in for the per-rank device solver (host-layer tests without a GPU)"""
+    old = learn_module._local_solve_hip
+    learn_module._local_solve_hip = oracle_local_solve
+    try:
+        return gml.learn(*args)
+    finally:
+        learn_module._local_solve_hip = old
 
 
 def test_type_defaults_match_reference():
@@ -59,7 +70,7 @@ def test_learn_rejects_wrong_types():
 def test_learn_assembly_against_goldens(name, form):
     # runtests.jl:68-80 through the host layer (oracle injected as the node solver)
     F = getattr(gml, form)
-    R = gml.learn(load_csv(f"{name}_samples.csv"), F(), _local_solve=oracle_local_solve)
+    R = oracle_learn(load_csv(f"{name}_samples.csv"), F())
     G = load_csv(f"{name}_{form}_learned.csv")
     assert np.abs(R - G).max() <= 5e-8
     assert np.allclose(R, R.T)
@@ -67,8 +78,8 @@ def test_learn_assembly_against_goldens(name, form):
 
 def test_learn_default_arguments_are_rise():
     s = load_csv("a_samples.csv")
-    R1 = gml.learn(s, _local_solve=oracle_local_solve)
-    R2 = gml.learn(s, gml.RISE(), gml.NLP(), _local_solve=oracle_local_solve)
+    R1 = oracle_learn(s)
+    R2 = oracle_learn(s, gml.RISE(), gml.NLP())
     assert np.array_equal(R1, R2)
 
 
@@ -76,7 +87,7 @@ def test_unsymmetrised_and_fortran_and_transposed_inputs():
     s = load_csv("mvt_samples.csv")
     G = load_csv("mvt_RISE_learned.csv")
     for arr in (s, np.asfortranarray(s), np.ascontiguousarray(s.T).T, s.astype(np.int64)):
-        R = gml.learn(arr, gml.RISE(0.2, False), _local_solve=oracle_local_solve)
+        R = oracle_learn(arr, gml.RISE(0.2, False))
         assert np.abs(R - G).max() <= 3e-4
         assert not np.allclose(R, R.T)
 
@@ -85,8 +96,8 @@ def test_multirise_returns_factor_graph_and_matches_rise():
     # runtests.jl:132-146
     for name in "abc":
         s = load_csv(f"{name}_samples.csv")
-        ising = gml.learn(s, gml.RISE(0.2, False), _local_solve=oracle_local_solve)
-        two = gml.learn(s, gml.multiRISE(0.2, False, 2), _local_solve=oracle_local_solve)
+        ising = oracle_learn(s, gml.RISE(0.2, False))
+        two = oracle_learn(s, gml.multiRISE(0.2, False, 2))
         assert isinstance(two, gml.FactorGraph) and two.order == 2
         d = gml.matrix_to_terms(ising)
         assert len(d) == len(two)
@@ -96,8 +107,8 @@ def test_multirise_returns_factor_graph_and_matches_rise():
 
 def test_multirise_symmetrisation_groups_sorted_keys():
     s = load_csv("c_samples.csv")
-    fg = gml.learn(s, gml.multiRISE(0.2, True, 3), _local_solve=oracle_local_solve)
-    raw = gml.learn(s, gml.multiRISE(0.2, False, 3), _local_solve=oracle_local_solve)
+    fg = oracle_learn(s, gml.multiRISE(0.2, True, 3))
+    raw = oracle_learn(s, gml.multiRISE(0.2, False, 3))
     assert all(tuple(sorted(k)) == k for k in fg.keys())
     assert fg[(1, 2, 3)] == pytest.approx(np.mean([raw[(1, 2, 3)], raw[(2, 1, 3)], raw[(3, 1, 2)]]))
     assert fg[(2,)] == pytest.approx(raw[(2,)])
@@ -123,7 +134,7 @@ def test_learned_model_accuracy_thresholds():
             hist = synthetic.enumerate_sample(m, N, seed=0)
             assert hist[:, 0].sum() == N
             for F in (gml.RISE, gml.logRISE, gml.RPLE):
-                R = gml.learn(hist, F(), _local_solve=oracle_local_solve)
+                R = oracle_learn(hist, F())
                 assert np.abs(R - m).max() <= thr
 
 
@@ -131,7 +142,7 @@ def test_docs_example():
     # runtests.jl:188-196 / README quick start
     model = np.array([[0.0, 0.1, 0.2], [0.1, 0.0, 0.3], [0.2, 0.3, 0.0]])
     hist = synthetic.enumerate_sample(model, 100000, seed=0)
-    learned = gml.learn(hist, _local_solve=oracle_local_solve)
+    learned = oracle_learn(hist)
     assert np.abs(learned - model).max() <= 0.01
 
 
