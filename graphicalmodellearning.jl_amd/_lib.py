@@ -90,11 +90,12 @@ def lib():
     L.gml_multi_create.argtypes = [p, i32, i64, i64, i64, i32, i32, p, i32, C.POINTER(p)]
     L.gml_multi_info.argtypes = [p] + [p] * 6
     L.gml_multi_learn.argtypes = [p, i32, dbl, C.POINTER(Opts), p, p, C.POINTER(Stats), p]
+    L.gml_multi_part_stats.argtypes = [p, p]
     L.gml_multi_destroy.argtypes = [p]
     L.gml_multi_destroy.restype = None
     L.gml_learn.argtypes = [p, i32, dbl, C.POINTER(Opts), p, p, C.POINTER(Stats)]
     L.gml_bench_pass.argtypes = [p, i32, i32, p, i32, i32, p]
-    L.gml_bench_pass_resident.argtypes = [p, i32, i32, p, i32, i32, p, p, p]
+    L.gml_bench_pass_resident.argtypes = [p, i32, i32, p, i32, i32, p, p, p, p]
     _lib = L
     return L
 
@@ -297,9 +298,10 @@ class Problem:
         nloc = self.node1 - self.node0
         f = np.zeros(nloc) if want_output else None
         g = np.zeros((nloc, self.P)) if want_output else None
+        step = np.zeros(int(steps))
         check(lib().gml_bench_pass_resident(self._h, FORMULATION_IDS[formulation], PRECISIONS[precision], _ptr(th), int(steps),
-                                            int(warmup), _ptr(ms), _ptr(f), _ptr(g)))
-        out = {"fwd_ms": ms[0], "bwd_ms": ms[1], "pass_ms": ms[2], "device_ms_per_pass": ms[3]}
+                                            int(warmup), _ptr(ms), _ptr(f), _ptr(g), _ptr(step)))
+        out = {"fwd_ms": ms[0], "bwd_ms": ms[1], "pass_ms": ms[2], "device_ms_per_pass": ms[3], "step_ms": step}
         return (out, f, g) if want_output else out
 
 
@@ -319,6 +321,12 @@ class MultiProblem:
         check(L.gml_multi_info(h, C.byref(nn), C.byref(KK), C.byref(M), C.byref(PP), C.byref(nd), None))
         self.n, self.K, self.M, self.P, self.ndev = nn.value, KK.value, M.value, PP.value, nd.value
         self.devices = [int(v) for v in dev]
+
+    def part_stats(self):
+        """statistics of every part (node shard) of the last learn(): list of dicts"""
+        arr = (Stats * self.ndev)()
+        check(lib().gml_multi_part_stats(self._h, arr))
+        return [a.asdict() for a in arr]
 
     def gather_kind(self):
         buf = C.create_string_buffer(32)

@@ -1447,7 +1447,7 @@ extern "C" int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows,
 // to back on the handle's stream with no host round trip (a device-side optimiser would call the operator this
 // way); f and the gradient of the last pass are downloaded once at the end.  kernel_ms[3] = device time per pass.
 extern "C" int gml_bench_pass_resident(gml_problem *p, int formulation, int precision, const double *theta, int steps,
-                                       int warmup, double kernel_ms[4], double *f_out, double *g_out) {
+                                       int warmup, double kernel_ms[4], double *f_out, double *g_out, double *step_ms) {
     if (!p || !kernel_ms || !theta || steps < 1 || warmup < 0) return fail(GML_EINVAL, "bad argument");
     if (formulation < 0 || formulation > 2) return fail(GML_EINVAL, "unknown formulation %d", formulation);
     HIPCHK(hipSetDevice(p->device));
@@ -1531,6 +1531,11 @@ extern "C" int gml_bench_pass_resident(gml_problem *p, int formulation, int prec
         HIPCHK(hipEventElapsedTime(&ms, ev[(size_t)3 * s + 1], ev[(size_t)3 * s + 2]));
         sum[1] += ms;
     }
+    if (step_ms) // device time of every pass: from its forward launch to the next pass's (the last one: to the end)
+        for (int s = 0; s < steps; ++s) {
+            HIPCHK(hipEventElapsedTime(&ms, ev[(size_t)3 * s], s + 1 < steps ? ev[(size_t)3 * (s + 1)] : e_end));
+            step_ms[s] = ms;
+        }
     HIPCHK(hipEventElapsedTime(&ms, ev[0], e_end));
     kernel_ms[0] = sum[0] / steps;
     kernel_ms[1] = sum[1] / steps;

@@ -30,6 +30,7 @@
 #include "gml_bits.h"
 #include <algorithm>
 #include <string>
+#include <type_traits>
 
 namespace gml {
 
@@ -499,13 +500,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
         }
     };
 
-    v16i acc[WM][LF];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int l = 0; l < LF; ++l)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][l][e] = 0;
+    v16i acc[WM][LF]; // first written by the peeled step 0 below (C operand = the constant 0: no clearing moves)
 
     // the epilogue's per-lane inputs are fetched now, so that their latency hides under the GEMM
     const int r = mytile * 32 + lr;
@@ -530,7 +525,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s);
-    for (int kt = 0; kt < nk; ++kt) {
+    auto gemm_step = [&](int kt, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
         ring_wait_ahead<NP>(nk - 1 - kt);
         if (kt + NS - 1 < nk) issue(kt + NS - 1);
         const int8_t *cur = lds + (kt & (NS - 1)) * STAGE;
@@ -553,9 +549,14 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int l = 0; l < LF; ++l) acc[i][l] = MFMA_I8(fa[i], fb[l], acc[i][l]);
+                for (int l = 0; l < LF; ++l) {
+                    if (FIRST && t == 0) acc[i][l] = MFMA_I8(fa[i], fb[l], ((v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}));
+                    else acc[i][l] = MFMA_I8(fa[i], fb[l], acc[i][l]);
+                }
         }
-    }
+    };
+    gemm_step(0, std::true_type{}); // nk >= 1: Qfp >= 64
+    for (int kt = 1; kt < nk; ++kt) gemm_step(kt, std::false_type{});
     __builtin_amdgcn_s_setprio(0);
     // ---- epilogue ----------------------------------------------------------------------------
     // lane <-> node row (lr), register e <-> sample (e&3) + 8*(e>>2) + 4*h within the 32-sample tile.  The
@@ -579,6 +580,186 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     // dither of the V rounding: golden-ratio (Weyl) sequence in the global sample index, offset per node --
     // independent of tiling, node sharding and compaction, so results stay bit-identical across GPU counts
     const unsigned dh0 = (unsigned)rc * 0x85EBCA6Bu + (unsigned)(kw + 4 * h) * 0x9E3779B9u;
+    if constexpr (FORM == 0) {
+        // Exp forms (RISE, logRISE): the arithmetic of vq_exp(), laid out in STAGES over 8 elements at a time (two 4-sample
+        // groups).  Every stage is 8 independent copies of a short chain, fenced by sched_barriers: a wave in its epilogue
+        // then issues back to back instead of waiting out the 16-20 cycle latency of each dependent FP64 instruction (the
+        // element-at-a-time form left the scheduler, at 200+ live registers, emitting each element's chain serially).
+        // Fewer instructions per element as well: the sign is applied to the rounded magnitude in integers (one bit-field
+        // extract serves both sign flips), sum_k V comes from dot4 over the packed digit planes, max|V| from the unsigned
+        // magnitudes, and padding samples are masked in a branch only the last sample tile takes.
+        constexpr double MAGIC = 6755399441055744.0, MAGIC32 = 6755399441055744.0 * 4294967296.0;
+        constexpr unsigned GOLD = 0x9E3779B9u, CB = 0x80808080u;
+        const int wleft = (int)((Kreal - kw) < 64 ? (Kreal - kw) : 64); // wave-uniform: real samples among this wave's 64
+        int csl[LB] = {0, 0, 0, 0};
+        unsigned mxu = 0;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const unsigned nsg = ~sgn[i]; // bit 8g + j set <=> s = +1
+            v4i pl[LB];
+#pragma unroll
+            for (int hg = 0; hg < 2; ++hg) {
+                // Layers of 8 independent instructions each, fenced (SB): whatever order the scheduler picks inside a layer, a
+                // result is not needed before 8 issue slots later.
+#define SB __builtin_amdgcn_sched_barrier(0)
+                double a[8], Ea[8], wk[8], tm[8], x[8], tj0[8], yy[8];
+                int mneg[8], nn[8];
+                float rf[8], dd[8];
+                unsigned mag[8];
+                // A: exact recombination of the limb planes (pairs in int32, then FP64; all planes through FP64 when WIDE)
+                if (WIDE || LF != 5) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = 8 * hg + q;
+                        if (WIDE) {
+                            a[q] = (double)acc[i][LF - 1][e];
+#pragma unroll
+                            for (int l = LF - 2; l >= 0; --l) a[q] = fma(a[q], 256.0, (double)acc[i][l][e]);
+                        } else if (LF == 4) {
+                            const int lo = acc[i][0][e] + (acc[i][1][e] << 8);
+                            const int mid = acc[i][2][e] + (acc[i][3][e] << 8);
+                            a[q] = fma((double)mid, 65536.0, (double)lo);
+                        } else {
+                            const int lo = acc[i][0][e] + (acc[i][1][e] << 8);
+                            a[q] = fma((double)acc[i][2][e], 65536.0, (double)lo);
+                        }
+                    }
+                    SB;
+                } else { // LF == 5, the production form, layer by layer
+                    int lo[8], mid[8];
+                    double c4[8], cm[8], cl[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = 8 * hg + q;
+                        lo[q] = acc[i][0][e] + (acc[i][1][e] << 8);
+                        mid[q] = acc[i][2][e] + (acc[i][3][e] << 8);
+                        c4[q] = (double)acc[i][4][e];
+                    }
+                    SB;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        cm[q] = (double)mid[q];
+                        cl[q] = (double)lo[q];
+                    }
+                    SB;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = fma(c4[q], 65536.0, cm[q]);
+                    SB;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = fma(a[q], 65536.0, cl[q]);
+                    SB;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int pos = 8 * (2 * hg + (q >> 2)) + (q & 3);
+                    Ea[q] = fma(a[q], sg2, sgq0);
+                    // -1 iff s = +1 (v_bfe_i32 spelled out: the generic lowering is a shift pair, and the compiler then
+                    // re-derives the two sign flips below from the shifted word with an and + an arithmetic shift each)
+                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mneg[q]) : "v"(nsg), "n"(pos));
+                    if (!UNIW) wk[q] = w[kw + i * 32 + 8 * (2 * hg + (q >> 2)) + 4 * h + (q & 3)];
+                }
+                SB;
+                // B: x = -s E, range reduction n = rint(64 x / ln2), r = x - n ln2 / 64
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    x[q] = __hiloint2double(__double2hiint(Ea[q]) + (mneg[q] << 31), __double2loint(Ea[q]));
+                    tm[q] = fma(x[q], 92.33248261689366, MAGIC);
+                }
+                SB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    nn[q] = __double2loint(tm[q]);
+                    tm[q] = tm[q] - MAGIC;
+                    tj0[q] = etab[nn[q] & 63]; // 2^(j/64) (exponent bits of j << 14 taken off: see the table's construction)
+                }
+                SB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = fma(tm[q], -0.010830424696249145, x[q]); // r
+                SB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rf[q] = (float)x[q];
+                SB;
+                // C: expm1(r) in FP32
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dd[q] = fmaf(rf[q], 4.1666668e-02f, 1.6666667e-01f);
+                SB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dd[q] = fmaf(dd[q], rf[q], 0.5f);
+                SB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dd[q] = fmaf(dd[q], rf[q], 1.0f);
+                SB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dd[q] = dd[q] * rf[q];
+                SB;
+                // D: 2^32 (w / tau exp(-E) + dither), rounded to an integer magnitude
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int idx = i * 32 + 8 * (2 * hg + (q >> 2)) + (q & 3);
+                    tj0[q] = __hiloint2double((int)((unsigned)__double2hiint(tj0[q]) + ((unsigned)nn[q] << 14)), __double2loint(tj0[q]));
+                    x[q] = (double)dd[q];
+                    yy[q] = (double)(int)(dh0 + (unsigned)idx * GOLD); // the dither
+                }
+                SB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = fma(tj0[q], x[q], tj0[q]); // exp(-E)
+                SB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) yy[q] = fma(UNIW ? wk32 : 4294967296.0 * (wk[q] * it), x[q], yy[q]);
+                SB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mag[q] = (unsigned)__double2loint(yy[q] + MAGIC32); // >= 0: y > -2^31
+                if (UNIW && wleft < 64) { // the last sample tile: padding samples carry no weight
+                    asm volatile("; padding samples" ::: "memory"); // (keeps this a branch: as selects it costs every tile 2 instructions per element)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (i * 32 + 8 * (2 * hg + (q >> 2)) + (q & 3) >= nreal) mag[q] = 0u;
+                }
+                SB;
+#undef SB
+                // E: sign, 4 balanced base-256 digits per sample, 4 samples x 4 limbs byte transpose
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    unsigned dj[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = 4 * gg + j;
+                        mxu = mag[q] > mxu ? mag[q] : mxu;
+                        if (WANTF) as += (long long)mag[q];
+                        // V / tau = -s |V| / tau = (mag ^ m) - m, then the 4 balanced digits (v + CB) ^ CB: one v_xad
+                        unsigned tq;
+                        asm("v_xad_u32 %0, %1, %2, %3" : "=v"(tq) : "v"(mag[q]), "v"(mneg[q]), "v"(CB - (unsigned)mneg[q]));
+                        dj[j] = tq ^ CB;
+                    }
+#pragma unroll
+                    for (int lb = 0; lb < LB; ++lb) {
+                        const unsigned sel = ((4u + lb) << 8) | (unsigned)lb;
+                        const unsigned t01 = __builtin_amdgcn_perm(dj[1], dj[0], sel);
+                        const unsigned t23 = __builtin_amdgcn_perm(dj[3], dj[2], sel);
+                        const unsigned pk = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+                        pl[lb][2 * hg + gg] = (int)pk;
+                        csl[lb] = __builtin_amdgcn_sdot4((int)pk, 0x01010101, csl[lb], false); // sum of the 4 digits
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (active) {
+#pragma unroll
+                for (int lb = 0; lb < LB; ++lb) *reinterpret_cast<v4i *>(vimg + lb * 32 * 64 + i * 16) = pl[lb];
+            }
+        }
+        cs = (long long)csl[0] + 256ll * csl[1] + 65536ll * csl[2] + 16777216ll * csl[3];
+        cs += __shfl_xor(cs, 32);
+        as += __shfl_xor(as, 32);
+        const unsigned mo = (unsigned)__shfl_xor((int)mxu, 32);
+        mxu = mo > mxu ? mo : mxu;
+        if (active && h == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&csum[r]), (unsigned long long)cs);
+            if (WANTF) atomicAdd(reinterpret_cast<unsigned long long *>(&asum[r]), (unsigned long long)as);
+            atomicMax(&mmax[r], mxu);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         v4i pl[LB], pv[LB];

@@ -58,6 +58,7 @@ struct gml_multi {
     double M = 0;
     std::vector<Rccl::comm_t> comm; // one per part when RCCL is usable for this device list
     char gather_kind[32] = "host";
+    std::vector<gml_stats> last;    // per-part statistics of the last gml_multi_learn
 };
 
 extern "C" void gml_multi_destroy(gml_multi *m) {
@@ -113,29 +114,63 @@ extern "C" int gml_multi_info(const gml_multi *m, int64_t *n, int64_t *K, double
     return GML_OK;
 }
 
+extern "C" int gml_multi_part_stats(const gml_multi *m, gml_stats *parts) {
+    if (!m || !parts) return fail(GML_EINVAL, "NULL argument");
+    for (size_t g = 0; g < m->part.size(); ++g) parts[g] = g < m->last.size() ? m->last[g] : gml_stats{};
+    return GML_OK;
+}
+
+namespace {
+// streams of the gather, destroyed on every path; the caller's current device is restored
+struct GatherStreams {
+    std::vector<hipStream_t> st;
+    const std::vector<int> &dev;
+    int caller_dev = 0;
+    explicit GatherStreams(const std::vector<int> &d) : st(d.size(), nullptr), dev(d) { (void)hipGetDevice(&caller_dev); }
+    ~GatherStreams() {
+        for (size_t g = 0; g < st.size(); ++g)
+            if (st[g]) {
+                (void)hipSetDevice(dev[g]);
+                (void)hipStreamSynchronize(st[g]);
+                (void)hipStreamDestroy(st[g]);
+            }
+        (void)hipSetDevice(caller_dev);
+    }
+};
+} // namespace
+
 extern "C" int gml_multi_learn(gml_multi *m, int formulation, double regularizer_c, const gml_opts *opts, double *out, double *kkt,
                                gml_stats *stats, double **dev_out) {
     if (!m || (!out && !dev_out)) return fail(GML_EINVAL, "NULL argument");
     const int G = (int)m->part.size();
     const int64_t n = m->n, P = m->P;
+    if (dev_out)
+        for (int g = 0; g < G; ++g)
+            if (!dev_out[g]) return fail(GML_EINVAL, "dev_out[%d] is NULL", g);
     std::vector<int> rc((size_t)G, GML_OK);
     std::vector<std::string> msg((size_t)G);
-    std::vector<gml_stats> st((size_t)G);
-    std::vector<std::vector<double>> rows((size_t)G);
+    m->last.assign((size_t)G, gml_stats{});
+    std::vector<gml_stats> &st = m->last;
     std::vector<std::thread> th;
     for (int g = 0; g < G; ++g)
         th.emplace_back([&, g] {
             const int64_t n0 = (int64_t)g * n / G, n1 = (int64_t)(g + 1) * n / G;
-            double *dst = out ? out + n0 * P : nullptr; // disjoint row blocks of the caller's matrix: the host-side gather
-            if (!dst) {
-                rows[g].resize((size_t)((n1 - n0) * P));
-                dst = rows[g].data();
-            }
+            // Each part writes its rows where they belong: with dev_out, straight into its block of the device-resident matrix
+            // on its own GPU (device to device inside gml_learn: the block sits where the all-gather expects it), and from
+            // there once to the caller's host matrix; without, into the disjoint row block of the host matrix.
+            double *dst = dev_out ? dev_out[g] + n0 * P : out + n0 * P;
             rc[g] = gml_learn(m->part[g], formulation, regularizer_c, opts, dst, kkt ? kkt + n0 : nullptr, &st[g]);
             if (rc[g]) msg[g] = gml_last_error();
+            if ((rc[g] == GML_OK || rc[g] == GML_ENOTCONV) && dev_out && out) {
+                if (hipSetDevice(m->device[g]) != hipSuccess ||
+                    hipMemcpy(out + n0 * P, dst, sizeof(double) * (n1 - n0) * P, hipMemcpyDeviceToHost) != hipSuccess) {
+                    rc[g] = GML_EHIP;
+                    msg[g] = std::string("download of the learned rows failed: ") + hipGetErrorString(hipGetLastError());
+                }
+            }
         });
     for (auto &t : th) t.join();
-    if (stats) { // totals over the parts, the wall-clock entries of the slowest part
+    if (stats) { // totals over the parts, the wall-clock entries of the slowest part (per part: gml_multi_part_stats)
         std::memset(stats, 0, sizeof *stats);
         for (int g = 0; g < G; ++g) {
             stats->iterations = std::max(stats->iterations, st[g].iterations);
@@ -143,8 +178,10 @@ extern "C" int gml_multi_learn(gml_multi *m, int formulation, double regularizer
             stats->forward_passes += st[g].forward_passes;
             stats->hessian_passes += st[g].hessian_passes;
             stats->node_evals += st[g].node_evals;
+            stats->hv_evals += st[g].hv_evals;
             stats->max_kkt = std::max(stats->max_kkt, st[g].max_kkt);
             stats->lambda = st[g].lambda;
+            stats->t_pack = std::max(stats->t_pack, st[g].t_pack);
             stats->t_pass = std::max(stats->t_pass, st[g].t_pass);
             stats->t_hess = std::max(stats->t_hess, st[g].t_hess);
             stats->t_host = std::max(stats->t_host, st[g].t_host);
@@ -162,38 +199,36 @@ extern "C" int gml_multi_learn(gml_multi *m, int formulation, double regularizer
         }
     if (worst != GML_OK && worst != GML_ENOTCONV) return fail(worst, "%s", wmsg.c_str());
     if (dev_out) {
-        // the full matrix on every GPU: one all-gather of the row blocks over xGMI (RCCL), or peer copies
+        // the full matrix on every GPU: one in-place all-gather of the row blocks over xGMI (RCCL), or peer copies
         const bool even = n % G == 0;
-        std::vector<double *> send((size_t)G, nullptr);
-        std::vector<hipStream_t> sts((size_t)G, nullptr);
+        GatherStreams gs(m->device);
         for (int g = 0; g < G; ++g) {
-            const int64_t n0 = (int64_t)g * n / G, n1 = (int64_t)(g + 1) * n / G;
             HIPCHK(hipSetDevice(m->device[g]));
-            HIPCHK(hipStreamCreate(&sts[g]));
-            const double *src = out ? out + n0 * P : rows[g].data();
-            send[g] = dev_out[g] + n0 * P; // in place: the block sits where the all-gather expects it
-            HIPCHK(hipMemcpyAsync(send[g], src, sizeof(double) * (n1 - n0) * P, hipMemcpyHostToDevice, sts[g]));
+            HIPCHK(hipStreamCreate(&gs.st[g]));
         }
         if (!m->comm.empty() && even) {
             std::strcpy(m->gather_kind, "rccl-allgather");
             int e = rccl().GroupStart();
-            for (int g = 0; g < G && e == 0; ++g) e = rccl().AllGather(send[g], dev_out[g], (size_t)(n / G * P), kNcclFloat64, m->comm[g], sts[g]);
-            if (e == 0) e = rccl().GroupEnd();
+            if (e == 0) {
+                for (int g = 0; g < G && e == 0; ++g)
+                    e = rccl().AllGather(dev_out[g] + (int64_t)g * (n / G) * P, dev_out[g], (size_t)(n / G * P), kNcclFloat64, m->comm[g], gs.st[g]);
+                const int e2 = rccl().GroupEnd(); // always closed: an open group would hang the process's later RCCL calls
+                if (e == 0) e = e2;
+            }
             if (e != 0) return fail(GML_EHIP, "RCCL all-gather failed: %s", rccl().GetErrorString ? rccl().GetErrorString(e) : "?");
         } else {
             std::strcpy(m->gather_kind, "peer-copy");
-            for (int g = 0; g < G; ++g) HIPCHK(hipStreamSynchronize(sts[g]));
             for (int g = 0; g < G; ++g)
                 for (int h = 0; h < G; ++h) {
                     if (h == g || dev_out[h] == dev_out[g]) continue;
                     const int64_t n0 = (int64_t)h * n / G, n1 = (int64_t)(h + 1) * n / G;
-                    HIPCHK(hipMemcpyPeerAsync(dev_out[g] + n0 * P, m->device[g], dev_out[h] + n0 * P, m->device[h], sizeof(double) * (n1 - n0) * P, sts[g]));
+                    HIPCHK(hipSetDevice(m->device[g]));
+                    HIPCHK(hipMemcpyPeerAsync(dev_out[g] + n0 * P, m->device[g], dev_out[h] + n0 * P, m->device[h], sizeof(double) * (n1 - n0) * P, gs.st[g]));
                 }
         }
         for (int g = 0; g < G; ++g) {
             HIPCHK(hipSetDevice(m->device[g]));
-            HIPCHK(hipStreamSynchronize(sts[g]));
-            (void)hipStreamDestroy(sts[g]);
+            HIPCHK(hipStreamSynchronize(gs.st[g]));
         }
     }
     if (worst == GML_ENOTCONV) return fail(GML_ENOTCONV, "%s", wmsg.c_str());

@@ -893,25 +893,29 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     launch_copy_rows(dRows, (int)frombest.size(), Qp, Xb, Xt, nullptr, nullptr, st);
     RCCHK(upload_rows(fromx, dRows2));
     launch_copy_rows(dRows2, (int)fromx.size(), Qp, X, Xt, nullptr, nullptr, st);
-    std::vector<double> xh((size_t)R * Qp);
-    HIPCHK(stg.d2h(xh.data(), Xt, sizeof(double) * R * Qp));
-    HIPCHK(stg.sync());
-    std::vector<double> res((size_t)R * P);
-    gml_parallel_for(R, [&](int64_t r) {
-        NodeLayout L;
-        gml_build_layout(p, p->node0 + r, L);
-        const double *x = xh.data() + r * Qp;
-        for (int64_t j = 0; j < P; ++j) res[(size_t)r * P + j] = x[L.cols[j]];
-    });
+    // reference layout on the device (the direction array D is free now), then ONE copy: to the caller's host matrix, or --
+    // `out` a device pointer (gml_multi_learn's dev_out blocks, device-side callers) -- device to device
+    double *dres = D; // [R][P], P <= Qp
+    int32_t *dcols = nullptr;
+    if (p->order != 2) { // multi-body key order (:94-104): column of every parameter slot, from the host
+        std::vector<int32_t> cols((size_t)R * P);
+        gml_parallel_for(R, [&](int64_t r) {
+            NodeLayout L;
+            gml_build_layout(p, p->node0 + r, L);
+            std::memcpy(cols.data() + (size_t)r * P, L.cols.data(), sizeof(int32_t) * P);
+        });
+        HIPCHK(A.get(&dcols, (size_t)R * P));
+        HIPCHK(hipMemcpyAsync(dcols, cols.data(), sizeof(int32_t) * R * P, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st)); // cols is a local
+    }
+    launch_rows_to_reference(Xt, R, Qp, P, p->node0, d.cconst, dcols, dres, st);
+    HIPCHK(hipGetLastError());
     hipPointerAttribute_t attr;
     bool dev_out = false;
     if (hipPointerGetAttributes(&attr, out) == hipSuccess) dev_out = (attr.type == hipMemoryTypeDevice);
     else (void)hipGetLastError();
-    if (dev_out) {
-        HIPCHK(hipMemcpy(out, res.data(), sizeof(double) * R * P, hipMemcpyHostToDevice));
-    } else {
-        std::memcpy(out, res.data(), sizeof(double) * R * P);
-    }
+    HIPCHK(hipMemcpyAsync(out, dres, sizeof(double) * R * P, dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    HIPCHK(stg.sync());
     stats->iterations = it;
     stats->max_kkt = maxk;
     stats->not_converged = notconv;

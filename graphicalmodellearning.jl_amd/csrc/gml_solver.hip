@@ -96,6 +96,23 @@ __global__ __launch_bounds__(256) void k_copy_rows(const int *__restrict__ rows,
     d0[(int64_t)r * Qp + c] = s0[(int64_t)r * Qp + c];
     if (s1) d1[(int64_t)r * Qp + c] = s1[(int64_t)r * Qp + c];
 }
+// Rows of the internal column layout -> the reference's parameter order: out[r][j] = X[r][col(r, j)].  Pairwise (cols ==
+// NULL): slot j <-> spin j, slot u = the field (the u-th column of nodal_stat is s_u, GraphicalModelLearning.jl:162);
+// multi-body: cols [R][P] from the host (node_cols: the key order of :94-104).
+__global__ __launch_bounds__(256) void k_rows_to_reference(const double *__restrict__ X, int64_t Qp, int64_t P, int64_t node0,
+                                                           int64_t cconst, const int32_t *__restrict__ cols, double *__restrict__ out) {
+    const int64_t r = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= P) return;
+    const int64_t c = cols ? cols[r * P + j] : (j == node0 + r ? cconst : j);
+    out[r * P + j] = X[r * Qp + c];
+}
+
+void launch_rows_to_reference(const double *X, int64_t R, int64_t Qp, int64_t P, int64_t node0, int64_t cconst, const int32_t *cols, double *out,
+                              hipStream_t st) {
+    if (R > 0)
+        hipLaunchKernelGGL(k_rows_to_reference, dim3((unsigned)((P + 255) / 256), (unsigned)R), dim3(256), 0, st, X, Qp, P, node0, cconst, cols, out);
+}
+
 void launch_copy_rows(const int *drows, int nrows, int64_t Qp, const double *s0, double *d0, const double *s1, double *d1, hipStream_t st) {
     if (nrows > 0)
         hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((Qp + 255) / 256), (unsigned)nrows), dim3(256), 0, st, drows, Qp, s0, d0, s1, d1);

@@ -251,8 +251,12 @@ int gml_learn(gml_problem *p, int formulation, double regularizer_c, const gml_o
  *                      matrix is left on EVERY GPU by one RCCL all-gather over xGMI (librccl is loaded at run time;
  *                      peer copies when it is absent, the device list repeats a GPU, or n is not a multiple of G).
  *                      stats: totals over the parts, times of the slowest part.
+ *                      With dev_out every part writes its rows device to device into its own block of dev_out[g]
+ *                      (nothing returns to the host on the way) and the all-gather runs in place.
  *   gml_multi_info     gather_kind (>= 32 bytes or NULL): how the last dev_out gather was done
  *                      ("rccl-allgather", "peer-copy", "host" when none was asked for)
+ *   gml_multi_part_stats  parts: ndev gml_stats, the statistics of every part of the last gml_multi_learn (iterations,
+ *                      node evaluations, t_total ...): exposes stragglers among the node shards
  */
 typedef struct gml_multi gml_multi;
 int gml_multi_create(const void *samples, int dtype, int64_t K, int64_t n, int64_t ld, int col_major, int order,
@@ -260,6 +264,7 @@ int gml_multi_create(const void *samples, int dtype, int64_t K, int64_t n, int64
 int gml_multi_info(const gml_multi *m, int64_t *n, int64_t *K, double *M, int64_t *P, int *ndev, char *gather_kind);
 int gml_multi_learn(gml_multi *m, int formulation, double regularizer_c, const gml_opts *opts, double *out, double *kkt,
                     gml_stats *stats, double **dev_out);
+int gml_multi_part_stats(const gml_multi *m, gml_stats *parts);
 void gml_multi_destroy(gml_multi *m);
 
 /* Timing hook for the benchmark: runs `steps` full objective+gradient passes over the local
@@ -272,9 +277,10 @@ int gml_bench_pass(gml_problem *p, int formulation, int precision, const double 
 
 /* The same with Theta resident in HBM: uploaded once, then warmup + steps passes back to back without host round
  * trips (how a device-side optimiser would drive the operator); f ((node1-node0)) and g ((node1-node0) x P) of the
- * last pass are returned if not NULL.  kernel_ms[3] = device time per pass. */
+ * last pass are returned if not NULL.  kernel_ms[3] = device time per pass; step_ms (steps doubles, or NULL) = the
+ * device time of every timed pass. */
 int gml_bench_pass_resident(gml_problem *p, int formulation, int precision, const double *theta, int steps,
-                            int warmup, double kernel_ms[4], double *f_out, double *g_out);
+                            int warmup, double kernel_ms[4], double *f_out, double *g_out, double *step_ms);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,9 @@ def test_multi_matches_single_handle():
     with gml.MultiProblem(hist, [0, 0, 0]) as m:
         assert (m.n, m.K, m.P, m.ndev) == (96, 20000, 96, 3)
         out, kkt, st = m.learn("RISE", 0.4, tol=1e-10)
+        parts = m.part_stats()  # per node shard: what a scaling run reads to see stragglers
+    assert len(parts) == 3 and sum(q["node_evals"] for q in parts) == st["node_evals"]
+    assert max(q["t_total"] for q in parts) == st["t_total"] and all(q["iterations"] > 0 and q["t_pack"] > 0 for q in parts)
     assert st["not_converged"] == 0 and kkt.max() <= 1e-10
     assert np.abs(out - ref).max() <= 2e-9  # same optimum (the parts' Newton trajectories differ: adaptive Hessian budget)
     assert st["node_evals"] > 0 and st["passes"] >= sref["passes"]

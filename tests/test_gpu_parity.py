@@ -671,3 +671,54 @@ def test_hessvec_multibody_wide():
         _, gm = p.objgrad("RISE", nodes, theta - eps * vec, precision="f64")
     fd = (gp - gm) / (2 * eps)
     assert np.abs(hv - fd).max() <= 2e-6 * max(1.0, np.abs(fd).max())
+
+
+def test_hessvec_batch_mixing_dense_and_sparse_rows():
+    # One dense row (sum|theta| ~ 25: its objective pass is re-run with the scale it observed) next to sparse rows that
+    # are not re-run: the H.v pass must still see every row (control block rebuilt after the partial re-run).
+    n, K = 64, 20000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=21)
+    rng = np.random.default_rng(8)
+    nodes = np.array([5, 40, 12, 63])
+    theta = J[nodes].copy()
+    theta[1] = rng.normal(scale=0.5, size=n)  # dense
+    assert np.abs(theta[1]).sum() > 20 and np.abs(theta[0]).sum() < 5
+    vec = rng.normal(size=(4, n)) * (rng.random((4, n)) < 0.5)
+    eps = 1e-5
+    with gml.Problem(spins=spins) as p:
+        hv = p.hessvec("RISE", nodes, theta, vec)
+        _, gp = p.objgrad("RISE", nodes, theta + eps * vec, precision="f64")
+        _, gm = p.objgrad("RISE", nodes, theta - eps * vec, precision="f64")
+        solo = [p.hessvec("RISE", nodes[r:r + 1], theta[r:r + 1], vec[r:r + 1])[0] for r in range(4)]
+    fd = (gp - gm) / (2 * eps)
+    for r in range(4):
+        scale = max(1.0, np.abs(fd[r]).max())
+        assert np.abs(hv[r] - fd[r]).max() <= 5e-6 * scale, r
+        assert np.abs(hv[r] - solo[r]).max() <= 1e-6 * scale, r  # the batch gives what one-row calls give
+
+
+def test_more_than_2_pow_24_configurations_default_precision():
+    # precision "auto" must never refuse a valid histogram: beyond 2^24 configurations the int8 path keeps one set of
+    # i32 gradient accumulators per 2^23 configurations.  Checked against the oracle on two nodes.
+    n, K = 64, 2**24 + 4096
+    J = synthetic.block_ising_model(n, block=8, seed=2)
+    with gml.Problem(model=J, num_samples=K, seed=5, node_range=(0, 32)) as p:
+        spins = p.spins()
+        nodes = np.array([3, 40])
+        f8, g8 = p.objgrad("RISE", nodes, J[nodes], precision="i8x")
+        fa, ga = p.objgrad("RISE", nodes, J[nodes], precision="auto")
+        assert np.array_equal(f8, fa) and np.array_equal(g8, ga)  # auto = the int8 path at this size
+        fo, go = O.objgrad_nodes("RISE", None, spins, nodes, J[nodes])
+        assert np.abs(f8 / fo - 1).max() <= 1e-8
+        assert np.abs(g8 - go).max() <= 1e-8
+        out, kkt, st = p.learn("RISE", 0.4, tol=1e-8)  # default (auto) precision
+        assert st["not_converged"] == 0
+        lam = 0.4 * np.sqrt(np.log(n * n / 0.05) / K)
+        chk = np.array([3, 17])
+        _, g = O.objgrad_nodes("RISE", None, spins, chk, out[chk])
+        for a, u in enumerate(chk):  # KKT certificate by the oracle's own gradient
+            x = out[u]
+            pen = np.arange(n) != u
+            r = np.where(x != 0, g[a] + lam * np.sign(x) * pen, np.sign(g[a]) * np.maximum(np.abs(g[a]) - lam * pen, 0))
+            assert np.abs(r).max() <= 5e-8
+        assert np.abs(0.5 * (out[:32, :32] + out[:32, :32].T) - J[:32, :32]).max() < 0.02
