@@ -100,7 +100,7 @@ def pass_roofline(km, K, P, nloc, precision):
           "frac_pass": 2 * flops_kernel / (km["device_ms_per_pass"] * 1e-3) / peak}
     if precision == "i8x":
         # the int8-limb pass issues LF forward + 4 backward digit-plane products per algorithmic one
-        LF = int(os.environ.get("GML_I8_LF", "5"))
+        LF = 5  # forward limb planes of the objective passes (gml_opts.limbs_fwd default)
         limbs = {"fwd": LF, "bwd": 4}[dom]
         rf["limb_products"] = limbs
         rf["mfma_issue_frac"] = limbs * achieved / peak

@@ -31,7 +31,9 @@ class GMLConvergenceError(AssertionError):
 class Opts(C.Structure):
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("precision", C.c_int32),
                 ("max_working", C.c_int32), ("max_add", C.c_int32), ("verbose", C.c_int32),
-                ("hess_samples", C.c_int32), ("polish", C.c_int32), ("max_cg", C.c_int32)]
+                ("hess_samples", C.c_int32), ("polish", C.c_int32), ("max_cg", C.c_int32),
+                ("limbs_fwd", C.c_int32), ("hv_limbs_fwd", C.c_int32), ("hv_limbs_bwd", C.c_int32), ("debug_row", C.c_int32),
+                ("hv_subsample", C.c_int32), ("reserved0", C.c_int32), ("cg_viol_frac", C.c_double), ("cg_eta", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -80,6 +82,8 @@ def lib():
     L.gml_problem_create_sampled.argtypes = [p, i64, i64, C.c_uint64, i32, i64, i64, i32, C.POINTER(p)]
     L.gml_problem_create_sampled_terms.argtypes = [p, i32, p, i64, i64, i64, C.c_uint64, i32, i64, i64, i32, C.POINTER(p)]
     L.gml_problem_create_mcmc_terms.argtypes = [p, i32, p, i64, i64, i64, C.c_uint64, i32, i32, i64, i64, i32, C.POINTER(p)]
+    L.gml_problem_create_sampled_hist.argtypes = [p, i32, p, i64, i64, i64, C.c_uint64, i32, i32, i64, i64, i32, C.POINTER(p)]
+    L.gml_problem_get_counts.argtypes = [p, p]
     L.gml_problem_get_spins.argtypes = [p, p]
     L.gml_problem_destroy.argtypes = [p]
     L.gml_problem_destroy.restype = None
@@ -140,9 +144,18 @@ class Problem:
     """RAII wrapper of a gml_problem handle (packed spins + weights resident in HBM)."""
 
     def __init__(self, samples=None, *, counts=None, spins=None, packed=None, model=None, terms=None, n=None, num_samples=None,
-                 seed=0, mcmc_sweeps=None, order=2, node_range=None, device=0, ingest="host"):
+                 seed=0, mcmc_sweeps=None, order=2, node_range=None, device=0, ingest="host", histogram=False):
+        """histogram=True (sampled handles, n <= 64): the handle holds the distinct configurations with their counts
+        (gml_problem_create_sampled_hist: sorted and run-length encoded on the device), not one row per draw."""
         L = lib()
         h = C.c_void_p()
+        if histogram and model is not None and terms is None:
+            m = np.asarray(model, dtype=np.float64)  # matrix -> terms: fields on the diagonal, couplings above it (models.jl:105-134)
+            terms = {(i + 1,): m[i, i] for i in range(m.shape[0]) if m[i, i] != 0.0}
+            terms.update({(i + 1, j + 1): m[i, j] for i in range(m.shape[0]) for j in range(i + 1, m.shape[0]) if m[i, j] != 0.0})
+            n, model = m.shape[0], None
+            if not terms:
+                terms = {(1,): 0.0}
         if packed is not None:
             # (sign_bits [n][words] uint32, counts [K] or None, K): the packed form (pack_histogram / sign_bits())
             bits, cnt, K = packed
@@ -164,7 +177,10 @@ class Problem:
                 keys[t, :len(k)] = np.asarray(k, dtype=np.int64) - 1
                 wts[t] = v
             n0, n1 = node_range if node_range is not None else (0, int(n))
-            if mcmc_sweeps:  # Glauber chains instead of exact enumeration (components above 22 spins)
+            if histogram:
+                check(L.gml_problem_create_sampled_hist(_ptr(keys), stride, _ptr(wts), len(terms), int(n), int(num_samples), int(seed),
+                                                        int(mcmc_sweeps or 0), int(order), n0, n1, int(device), C.byref(h)))
+            elif mcmc_sweeps:  # Glauber chains instead of exact enumeration (components above 22 spins)
                 check(L.gml_problem_create_mcmc_terms(_ptr(keys), stride, _ptr(wts), len(terms), int(n), int(num_samples),
                                                       int(seed), int(mcmc_sweeps), int(order), n0, n1, int(device), C.byref(h)))
             else:
@@ -221,6 +237,12 @@ class Problem:
         check(lib().gml_problem_get_spins(self._h, _ptr(out)))
         return out
 
+    def counts(self):
+        """the counts of the handle's K rows (column 1 of the histogram, sampling.jl:54)"""
+        out = np.zeros(self.K)
+        check(lib().gml_problem_get_counts(self._h, _ptr(out)))
+        return out
+
     def sign_bits(self):
         """the packed form of the handle's samples: [n][gml_packed_words(K)] uint32, bit set <=> spin -1"""
         out = np.zeros((self.n, lib().gml_packed_words(self.K)), dtype=np.uint32)
@@ -257,7 +279,8 @@ class Problem:
         return out
 
     def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="auto", max_working=512, max_add=64,
-              verbose=0, hess_samples=0, polish=True, max_cg=0, out_ptr=None, raise_on_fail=True):
+              verbose=0, hess_samples=0, polish=True, max_cg=0, limbs_fwd=0, hv_limbs_fwd=0, hv_limbs_bwd=0, debug_row=0,
+              hv_subsample=0, cg_viol_frac=0.0, cg_eta=0.0, out_ptr=None, raise_on_fail=True):
         L = lib()
         o = Opts()
         L.gml_default_opts(C.byref(o))
@@ -266,6 +289,8 @@ class Problem:
         o.hess_samples = int(hess_samples)
         o.polish = 0 if polish else -1
         o.max_cg = int(max_cg)
+        o.limbs_fwd, o.hv_limbs_fwd, o.hv_limbs_bwd, o.debug_row = int(limbs_fwd), int(hv_limbs_fwd), int(hv_limbs_bwd), int(debug_row)
+        o.cg_viol_frac, o.cg_eta, o.hv_subsample = float(cg_viol_frac), float(cg_eta), int(hv_subsample)
         R = self.node1 - self.node0
         out = None
         if out_ptr is None:

@@ -61,6 +61,10 @@ __host__ __device__ inline int64_t vq_off(int64_t r, int l, int64_t k, int64_t K
 // (32 slots = one MFMA node tile; slot0, slot1 multiples of 32), so the tiles that run are full whatever subset of the
 // caller's rows is active; all per-slot arrays (and the limb planes of V the Hessians are built from) live in the
 // workspace, indexed by slot.
+struct SlotResult { // per-slot scalars of a pass, packed for one download
+    double f, tau;      // f per slot (RISE f, logRISE Z, RPLE f); scale of the V planes
+    unsigned mmax, pad; // largest |V| / tau seen (dynamic-range check)
+};
 struct I8Pass {
     const double *theta;  // device, [rows][Qp]: the parameter rows (internal column layout, masked slots zero)
     const int *srow;      // device [slots]: slot -> row of theta / G (unused slots: anything)
@@ -77,8 +81,12 @@ struct I8Pass {
                           //    curvature weights h_k of the objective pass that last ran in slot vmap[slot]
                           //    2: the same with the products h_k (x_k.p) carried in 2 backward limbs (15 bits) instead of 4
     const int *vmap;      // hv: device [slots]
+    int ksub;             // hv: the products run over ~1/ksub of the configurations (i8_split_plan); 0, 1 = all of them
+    int64_t kchunk, kpart; // hv: a split plan fixed by the caller (one operator for all the steps of a CG solve); 0 = plan here
+    SlotResult *res;      // device [slots] or NULL: {f, tau, mmax} of every slot of the pass, written by its last kernel
     int lf;               // forward limb planes (3, 4, 5; 0 = the default, 5; 2 for Hessian-vector directions): 8 lf - 2 significant bits of theta
 };
+void i8_split_plan(const DevProblem &d, int ngroups, int ksub, int64_t *kchunk, int64_t *kpart, int *nsplit);
 int i8_pass(void **ws, const DevProblem &d, int64_t slot_capacity, const I8Pass &a, hipStream_t st, hipEvent_t *ev /* [3] or NULL */,
             std::string *err);
 void i8_free(void *ws);
@@ -114,6 +122,12 @@ void launch_hess_f64(const DevProblem &P, const double *V,
 void launch_block_sampler(const unsigned *dmasks, const double *dwts, int nt, int sb, const int *dmembers, int64_t N, int64_t n,
                           unsigned long long seed, int block, double *den, double *dcdf, int8_t *dS, hipStream_t st);
 
+// Histogramming on the device (gml_dedupe.hip): distinct configurations of N samples held as +-1 bytes (n <= 64, N < 2^31) as
+// ascending 64-bit keys (bit i set <=> spin i is -1) with their multiplicities; both arrays are device memory owned by the caller.
+int dedupe_samples(const int8_t *dS, bool spin_major, int64_t ld, int64_t N, int64_t n, hipStream_t st, unsigned long long **dkeys_out,
+                   int **dcounts_out, int64_t *K_out, std::string *err);
+void launch_bits_from_keys(const unsigned long long *dkeys, int64_t K, int64_t n, int64_t Kp, unsigned *Sb, hipStream_t st);
+
 // Glauber dynamics (N independent chains, `sweeps` sweeps) on incidence lists; St [n][Np] spin-major.
 void launch_glauber(const int *dioff, const double *diw, const int *dooff, const int *doth, int64_t n, int64_t N, int64_t Np,
                     int sweeps, unsigned long long seed, int8_t *dSt, hipStream_t st);
@@ -121,6 +135,6 @@ void launch_glauber(const int *dioff, const double *diw, const int *dooff, const
 // Batched Newton solve on the ragged Hessian blocks: A = s1[r]*H_r - s2*gF gF^T, A d = -pgF, in place
 // (Cholesky, ridge restart).  gF/pgF/dout are R x cap; Sdiag[r] = A[m-1][m-1].
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
-                         const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st);
+                         const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st, int maxm = 0);
 
 } // namespace gml

@@ -367,16 +367,47 @@ static gml_problem *new_problem(int64_t K, int64_t n, double M, int order, int64
 }
 
 // Handle from +-1 bytes that are already on the device (the samplers): sample-major [K][n] or, with spin_major,
-// [n][ld].  `dbytes` is owned from here on and freed on every path.
-static int create_from_device_bytes(gml_problem *p, int8_t *dbytes, bool spin_major, int64_t ld, const double *counts, gml_problem **out) {
+// [n][ld].  `dbytes` is owned from here on and freed on every path.  dedupe: the handle holds the DISTINCT configurations
+// with their multiplicities (the reference's countmap, sampling.jl:52) instead of one row per draw.
+static int create_from_device_bytes(gml_problem *p, int8_t *dbytes, bool spin_major, int64_t ld, const double *counts, gml_problem **out,
+                                    bool dedupe = false) {
     struct Guard {
-        int8_t *b;
+        void *b[3];
         ~Guard() {
-            if (b) (void)hipFree(b);
+            for (void *q : b)
+                if (q) (void)hipFree(q);
         }
-    } guard{dbytes};
+    } guard{{dbytes, nullptr, nullptr}};
     const double t0 = now_s();
-    int rc = prob_layout(p);
+    int rc = GML_OK;
+    unsigned long long *dkeys = nullptr;
+    std::vector<double> hcounts;
+    if (dedupe) {
+        if (p->n > 64 || p->K >= ((int64_t)1 << 31)) rc = fail(GML_EUNSUPPORTED, "histogramming on the device needs n <= 64 spins and fewer than 2^31 samples");
+        hipStream_t st0 = nullptr;
+        if (rc == GML_OK && (hipSetDevice(p->device) != hipSuccess || hipStreamCreate(&st0) != hipSuccess)) rc = fail(GML_EHIP, "hipStreamCreate failed");
+        if (rc == GML_OK) {
+            std::string err;
+            int *dcnt = nullptr;
+            int64_t Kd = 0;
+            rc = dedupe_samples(dbytes, spin_major, ld, p->K, p->n, st0, &dkeys, &dcnt, &Kd, &err);
+            guard.b[1] = dkeys;
+            guard.b[2] = dcnt;
+            if (rc) rc = fail(rc, "%s", err.c_str());
+            else {
+                std::vector<int> hc((size_t)Kd);
+                if (hipMemcpy(hc.data(), dcnt, sizeof(int) * Kd, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(GML_EHIP, "download of the counts failed");
+                hcounts.assign(hc.begin(), hc.end());
+                p->M = (double)p->K; // every draw counted once
+                p->K = Kd;
+                counts = hcounts.data();
+            }
+        }
+        if (st0) (void)hipStreamDestroy(st0);
+        (void)hipFree(dbytes); // the draws are no longer needed
+        guard.b[0] = nullptr;
+    }
+    if (rc == GML_OK) rc = prob_layout(p);
     if (rc == GML_OK) {
         WeightInfo wi;
         weight_info(counts, p->K, p->d.Kp, p->M, wi);
@@ -386,7 +417,8 @@ static int create_from_device_bytes(gml_problem *p, int8_t *dbytes, bool spin_ma
         if (hipMemsetAsync(p->d.Sb, 0, (size_t)p->n * (p->d.Kp / 8), p->st) != hipSuccess) rc = fail(GML_EHIP, "hipMemsetAsync failed");
     }
     if (rc == GML_OK) {
-        launch_spin_bits(dbytes, spin_major, p->K, p->n, ld, p->d.Kp, p->d.Sb, p->st);
+        if (dedupe) launch_bits_from_keys(dkeys, p->K, p->n, p->d.Kp, p->d.Sb, p->st);
+        else launch_spin_bits(dbytes, spin_major, p->K, p->n, ld, p->d.Kp, p->d.Sb, p->st);
         const double t1 = now_s();
         rc = prob_images(p);
         if (rc == GML_OK && hipStreamSynchronize(p->st) != hipSuccess) rc = fail(GML_EHIP, "building the bit images failed: %s", hipGetErrorString(hipGetLastError()));
@@ -755,7 +787,7 @@ extern "C" int gml_problem_create_device_convert(const void *samples, int dtype,
 // Terms of one model: spins of term t = keys[t*stride .. +stride) (0-based, -1 = unused slot).
 static int create_sampled_terms(const int32_t *keys, int stride, const double *weights, int64_t nterms, int64_t n,
                                 int64_t N, uint64_t seed, int order, int64_t node0, int64_t node1, int device,
-                                gml_problem **out) {
+                                gml_problem **out, bool dedupe = false) {
     if (!out) return fail(GML_EINVAL, "out is NULL");
     *out = nullptr;
     if ((nterms > 0 && (!keys || !weights)) || stride < 1) return fail(GML_EINVAL, "NULL or malformed term list");
@@ -883,12 +915,11 @@ static int create_sampled_terms(const int32_t *keys, int stride, const double *w
     }
 #undef SCHK
     cleanup(0);
-    return create_from_device_bytes(p, dS, false, 0, nullptr, out);
+    return create_from_device_bytes(p, dS, false, 0, nullptr, out, dedupe);
 }
 
-extern "C" int gml_problem_create_mcmc_terms(const int32_t *keys, int key_stride, const double *weights, int64_t nterms,
-                                             int64_t n, int64_t N, uint64_t seed, int sweeps, int order, int64_t node0,
-                                             int64_t node1, int device, gml_problem **out) {
+static int create_mcmc_terms(const int32_t *keys, int key_stride, const double *weights, int64_t nterms, int64_t n, int64_t N, uint64_t seed,
+                             int sweeps, int order, int64_t node0, int64_t node1, int device, gml_problem **out, bool dedupe) {
     if (!out) return fail(GML_EINVAL, "out is NULL");
     *out = nullptr;
     if ((nterms > 0 && (!keys || !weights)) || key_stride < 1) return fail(GML_EINVAL, "NULL or malformed term list");
@@ -980,7 +1011,30 @@ extern "C" int gml_problem_create_mcmc_terms(const int32_t *keys, int key_stride
     SCHK(hipStreamSynchronize(st));
 #undef SCHK
     cleanup(0);
-    return create_from_device_bytes(p, dSt, true, Np, nullptr, out); // the chains' final states, spin-major
+    return create_from_device_bytes(p, dSt, true, Np, nullptr, out, dedupe); // the chains' final states, spin-major
+}
+
+extern "C" int gml_problem_create_mcmc_terms(const int32_t *keys, int key_stride, const double *weights, int64_t nterms,
+                                             int64_t n, int64_t N, uint64_t seed, int sweeps, int order, int64_t node0,
+                                             int64_t node1, int device, gml_problem **out) {
+    return create_mcmc_terms(keys, key_stride, weights, nterms, n, N, seed, sweeps, order, node0, node1, device, out, false);
+}
+
+extern "C" int gml_problem_create_sampled_hist(const int32_t *keys, int key_stride, const double *weights, int64_t nterms, int64_t n,
+                                               int64_t N, uint64_t seed, int mcmc_sweeps, int order, int64_t node0, int64_t node1,
+                                               int device, gml_problem **out) {
+    if (n > 64) return fail(GML_EUNSUPPORTED, "histogramming on the device needs n <= 64 spins (n = %lld)", (long long)n);
+    if (mcmc_sweeps > 0) return create_mcmc_terms(keys, key_stride, weights, nterms, n, N, seed, mcmc_sweeps, order, node0, node1, device, out, true);
+    return create_sampled_terms(keys, key_stride, weights, nterms, n, N, seed, order, node0, node1, device, out, true);
+}
+
+extern "C" int gml_problem_get_counts(gml_problem *p, double *counts) {
+    if (!p || !counts) return fail(GML_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpyAsync(counts, p->d.w, sizeof(double) * p->K, hipMemcpyDeviceToHost, p->st));
+    HIPCHK(hipStreamSynchronize(p->st));
+    for (int64_t k = 0; k < p->K; ++k) counts[k] = std::nearbyint(counts[k] * p->M * 1e6) / 1e6; // w_k = counts_k / M (:170)
+    return GML_OK;
 }
 
 extern "C" int gml_problem_create_sampled_terms(const int32_t *keys, int key_stride, const double *weights, int64_t nterms,
@@ -1586,5 +1640,68 @@ extern "C" int gml_bench_pass(gml_problem *p, int formulation, int precision, co
     kernel_ms[0] = sum[0] / steps;
     kernel_ms[1] = sum[1] / steps;
     kernel_ms[2] = kernel_ms[0] + kernel_ms[1];
+    return GML_OK;
+}
+
+// Test hook (not part of include/gml.h): the batched Newton solve on caller-given blocks -- A_r d_r = -pg_r for R symmetric positive
+// definite m_r x m_r blocks (row-major, m_r <= cap <= 512), exactly as gml_learn's direction phase calls it.  tests/test_gpu_newton_solve.py.
+extern "C" int gml_test_newton_solve(int R, const int *m, int cap, const double *blocks /* R x cap x cap, block r uses its leading m_r x m_r */,
+                                     const double *pg /* R x cap */, double s2, const double *g /* R x cap or NULL */, double *d_out /* R x cap */,
+                                     int device) {
+    HIPCHK(hipSetDevice(device));
+    std::vector<long long> hoff((size_t)R + 1, 0);
+    std::vector<int> mt((size_t)R);
+    int maxm = 0;
+    for (int r = 0; r < R; ++r) {
+        if (m[r] < 0 || m[r] > cap || cap > 512) return fail(GML_EINVAL, "bad block size");
+        mt[r] = (m[r] + 31) / 32;
+        hoff[r + 1] = hoff[r] + (long long)mt[r] * 32 * mt[r] * 32;
+        maxm = std::max(maxm, m[r]);
+    }
+    std::vector<double> H((size_t)std::max<long long>(hoff[R], 1), 0.0), s1((size_t)R, 1.0), gz((size_t)R * cap, 0.0);
+    for (int r = 0; r < R; ++r) {
+        const int hp = 32 * mt[r];
+        for (int i = 0; i < m[r]; ++i)
+            for (int j = 0; j < m[r]; ++j) H[(size_t)hoff[r] + (size_t)i * hp + j] = blocks[((size_t)r * cap + i) * cap + j];
+        for (int i = m[r]; i < hp; ++i) H[(size_t)hoff[r] + (size_t)i * hp + i] = 1.0; // padding: identity
+    }
+    double *dH = nullptr, *dS1 = nullptr, *dG = nullptr, *dPg = nullptr, *dOut = nullptr, *dSd = nullptr;
+    long long *dHoff = nullptr;
+    int *dMt = nullptr, *dM = nullptr;
+    auto freeall = [&]() {
+        void *ptrs[] = {dH, dS1, dG, dPg, dOut, dSd, dHoff, dMt, dM};
+        for (void *q : ptrs)
+            if (q) (void)hipFree(q);
+    };
+#define TCHK(expr)                                                           \
+    do {                                                                     \
+        if ((expr) != hipSuccess) {                                          \
+            freeall();                                                       \
+            return fail(GML_EHIP, "%s failed: %s", #expr, hipGetErrorString(hipGetLastError())); \
+        }                                                                    \
+    } while (0)
+    TCHK(hipMalloc(&dH, sizeof(double) * H.size()));
+    TCHK(hipMalloc(&dS1, sizeof(double) * R));
+    TCHK(hipMalloc(&dG, sizeof(double) * R * cap));
+    TCHK(hipMalloc(&dPg, sizeof(double) * R * cap));
+    TCHK(hipMalloc(&dOut, sizeof(double) * R * cap));
+    TCHK(hipMalloc(&dSd, sizeof(double) * R));
+    TCHK(hipMalloc(&dHoff, sizeof(long long) * (R + 1)));
+    TCHK(hipMalloc(&dMt, sizeof(int) * R));
+    TCHK(hipMalloc(&dM, sizeof(int) * R));
+    TCHK(hipMemcpy(dH, H.data(), sizeof(double) * H.size(), hipMemcpyHostToDevice));
+    TCHK(hipMemcpy(dS1, s1.data(), sizeof(double) * R, hipMemcpyHostToDevice));
+    TCHK(hipMemcpy(dG, g ? g : gz.data(), sizeof(double) * R * cap, hipMemcpyHostToDevice));
+    TCHK(hipMemcpy(dPg, pg, sizeof(double) * R * cap, hipMemcpyHostToDevice));
+    TCHK(hipMemcpy(dHoff, hoff.data(), sizeof(long long) * (R + 1), hipMemcpyHostToDevice));
+    TCHK(hipMemcpy(dMt, mt.data(), sizeof(int) * R, hipMemcpyHostToDevice));
+    TCHK(hipMemcpy(dM, m, sizeof(int) * R, hipMemcpyHostToDevice));
+    TCHK(hipMemset(dOut, 0, sizeof(double) * R * cap));
+    launch_newton_solve(dH, dHoff, dMt, dM, dS1, s2, dG, dPg, R, cap, dOut, dSd, nullptr, maxm);
+    TCHK(hipGetLastError());
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(d_out, dOut, sizeof(double) * R * cap, hipMemcpyDeviceToHost));
+#undef TCHK
+    freeall();
     return GML_OK;
 }

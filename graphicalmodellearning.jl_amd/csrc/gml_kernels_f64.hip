@@ -13,6 +13,7 @@
 // leaves ample time for the few loads per step), no LDS.
 #include "../../include/gml.h"
 #include "gml_dev.h"
+#include <algorithm>
 
 namespace gml {
 
@@ -400,11 +401,103 @@ void launch_hess_f64(const DevProblem &P, const double *V,
 // triangle (U[k][i] = L[i][k]: coalesced row reads), the diagonal of L lives in LDS, the lower triangle
 // keeps A for a ridge restart.  Sdiag[r] = A[m-1][m-1] (the constant column, the Hessian's diagonal scale).
 // ------------------------------------------------------------------------------------------
+// Working sets of up to 64 NR entries -- all of them on sparse optima -- by ONE wave with the whole block in LDS: lane t owns
+// the rows t + 64 q of L, the right-hand side lives in registers, no workgroup barrier and no dependent global read anywhere
+// (the general path of k_newton_solve spends ~250 us per call on such blocks in its per-column barriers and L2 round trips;
+// on small node shards that was a quarter of an iteration).  A is left untouched.
+template <int NR>
+__device__ __forceinline__ void newton_small(const double *__restrict__ A, int hp, int m, double sc, double s2, const double *__restrict__ g,
+                                             const double *__restrict__ pg, double *__restrict__ L, double *__restrict__ dout,
+                                             double *__restrict__ Sdiag) {
+    constexpr int LP = 64 * NR + 1;
+    const int t = threadIdx.x;
+    double gt[NR], b[NR], invd[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) gt[q] = (s2 != 0.0 && t + 64 * q < m) ? g[t + 64 * q] : 0.0;
+    double ridge = 0.0, dmax = 0.0;
+    bool failed = true;
+    for (int attempt = 0; attempt < 10 && failed; ++attempt) {
+        for (int i = 0; i < m; ++i) { // row i, lanes = columns: coalesced reads of the lower triangle
+            const double gi = __shfl(gt[i >> 6], i & 63);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int j = t + 64 * q;
+                L[i * LP + j] = (j <= i) ? sc * A[(int64_t)i * hp + j] - s2 * gi * gt[q] + (j == i ? ridge : 0.0) : 0.0;
+            }
+        }
+        if (attempt == 0) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) dmax = fmax(dmax, t + 64 * q < m ? fabs(L[(t + 64 * q) * LP + t + 64 * q]) : 0.0);
+            for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
+            if (t == 0) *Sdiag = L[(m - 1) * LP + (m - 1)];
+        }
+        failed = false;
+        for (int c = 0; c < m; ++c) {
+            double x[NR];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int row = t + 64 * q;
+                double x0 = L[row * LP + c], x1 = 0.0, x2 = 0.0, x3 = 0.0; // four partial sums: the FP64 FMA chain is the latency
+                int k = 0;
+                for (; k + 3 < c; k += 4) {
+                    x0 = fma(-L[row * LP + k], L[c * LP + k], x0);
+                    x1 = fma(-L[row * LP + k + 1], L[c * LP + k + 1], x1);
+                    x2 = fma(-L[row * LP + k + 2], L[c * LP + k + 2], x2);
+                    x3 = fma(-L[row * LP + k + 3], L[c * LP + k + 3], x3);
+                }
+                for (; k < c; ++k) x0 = fma(-L[row * LP + k], L[c * LP + k], x0);
+                x[q] = (x0 + x1) + (x2 + x3);
+            }
+            const double piv = __shfl(x[c >> 6], c & 63); // L[c][c]^2
+            if (!(piv > 1e-300 * dmax) || !isfinite(piv)) {
+                failed = true;
+                break;
+            }
+            const double dgc = sqrt(piv);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int row = t + 64 * q;
+                if (row == c) L[row * LP + c] = dgc;
+                else if (row > c && row < m) L[row * LP + c] = x[q] / dgc;
+            }
+        }
+        if (failed) ridge = ridge == 0.0 ? 1e-12 * fmax(dmax, 1e-300) : ridge * 100.0;
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int row = t + 64 * q;
+        b[q] = row < m ? -pg[row] : 0.0;
+        invd[q] = row < m ? 1.0 / L[row * LP + row] : 0.0;
+    }
+    for (int c = 0; c < m; ++c) { // L y = -pg, column by column
+        const double yc = __shfl(b[c >> 6], c & 63) * __shfl(invd[c >> 6], c & 63);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int row = t + 64 * q;
+            if (row == c) b[q] = yc;
+            else if (row > c && row < m) b[q] = fma(-L[row * LP + c], yc, b[q]);
+        }
+    }
+    for (int c = m - 1; c >= 0; --c) { // L^T d = y, row c of L against the entries before c
+        const double dc = __shfl(b[c >> 6], c & 63) * __shfl(invd[c >> 6], c & 63);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int row = t + 64 * q;
+            if (row == c) b[q] = dc;
+            else if (row < c) b[q] = fma(-L[c * LP + row], dc, b[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+        if (t + 64 * q < m) dout[t + 64 * q] = failed ? 0.0 : b[q];
+}
+
 __global__ __launch_bounds__(256) void k_newton_solve(double *__restrict__ H, const long long *__restrict__ hoff,
                                                       const int *__restrict__ mt, const int *__restrict__ msz,
                                                       const double *__restrict__ s1, double s2,
                                                       const double *__restrict__ gF, const double *__restrict__ pgF,
-                                                      int cap, double *__restrict__ dout, double *__restrict__ Sdiag) {
+                                                      int cap, double *__restrict__ dout, double *__restrict__ Sdiag,
+                                                      int small_cap /* blocks up to this size (0, 64 or 128) take the one-wave LDS path */) {
     constexpr int PW = 32;
     const int r = blockIdx.x;
     const int m = msz[r];
@@ -413,10 +506,16 @@ __global__ __launch_bounds__(256) void k_newton_solve(double *__restrict__ H, co
     double *A = H + hoff[r];
     const double sc = s1[r];
     const double *g = gF + (int64_t)r * cap, *pg = pgF + (int64_t)r * cap;
-    extern __shared__ double sm[]; // dg[cap] | y[cap] | gg[cap] | Ul[32][33] | D[32][33]
+    extern __shared__ double sm[]; // dg[cap] | y[cap] | gg[cap] | Ul[32][33] | D[32][33]   (small blocks: L[64][65])
     double *dg = sm, *y = sm + cap, *gg = sm + 2 * cap, *Ul = sm + 3 * cap, *D = Ul + PW * (PW + 1);
     __shared__ int bad;
     const int tid = threadIdx.x;
+    if (m <= small_cap) {
+        if (tid >= 64) return; // one wave, no workgroup barrier below
+        if (m <= 64) newton_small<1>(A, hp, m, sc, s2, g, pg, sm, dout + (int64_t)r * cap, Sdiag + r);
+        else newton_small<2>(A, hp, m, sc, s2, g, pg, sm, dout + (int64_t)r * cap, Sdiag + r);
+        return;
+    }
     for (int i = tid; i < m; i += 256) gg[i] = s2 != 0.0 ? g[i] : 0.0;
     __syncthreads();
     auto a_at = [&](int i, int j) { return sc * A[(int64_t)i * hp + j] - s2 * gg[i] * gg[j]; }; // i >= j
@@ -599,9 +698,12 @@ __global__ __launch_bounds__(256) void k_newton_solve(double *__restrict__ H, co
 }
 
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
-                         const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st) {
-    hipLaunchKernelGGL(k_newton_solve, dim3((unsigned)R), dim3(256), sizeof(double) * (3 * cap + 2 * 32 * 33), st, H, hoff, mt, msz, s1, s2, gF,
-                       pgF, cap, dout, Sdiag);
+                         const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st, int maxm) {
+    // maxm: largest block of this call, as far as the host knows it (0 = unknown): picks the LDS the one-wave path needs
+    const int small_cap = maxm <= 0 ? 64 : (maxm <= 64 ? 64 : (maxm <= 128 ? 128 : 64));
+    const size_t lds = sizeof(double) * std::max<size_t>((size_t)3 * cap + 2 * 32 * 33, small_cap == 128 ? 128 * 129 : 64 * 65);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_newton_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_newton_solve, dim3((unsigned)R), dim3(256), lds, st, H, hoff, mt, msz, s1, s2, gF, pgF, cap, dout, Sdiag, small_cap);
 }
 
 } // namespace gml

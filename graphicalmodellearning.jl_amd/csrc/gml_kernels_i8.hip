@@ -425,7 +425,11 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     double *__restrict__ fsum, unsigned *__restrict__ mmax,
     // Hessian-vector forms only: the limb planes of V written by the rows' last objective pass, the slot that holds
     // them for each slot of this pass, and their scales
-    const int8_t *__restrict__ Vsrc, const int *__restrict__ vmap, const double *__restrict__ tauV) {
+    const int8_t *__restrict__ Vsrc, const int *__restrict__ vmap, const double *__restrict__ tauV,
+    // sub-sampled passes (Hessian-vector products over a part of the configurations): compact sample tile t stands for the
+    // tile (t / part_tiles) * chunk_tiles + t % part_tiles -- the first part_tiles tiles of every split-K chunk of the
+    // backward kernel.  chunk_tiles == part_tiles: every configuration.
+    int chunk_tiles, int part_tiles) {
     constexpr int WM = 2;                 // 32-sample MFMA tiles per wave
     constexpr bool HV = FORM >= 3;
     constexpr int BR = 32 * LF;           // rows of the Tq image
@@ -470,7 +474,9 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
         gi = nfull * TG + rem % lastn;
     }
     if (st >= ntiles_k) return;
+    if (chunk_tiles != part_tiles) st = (st / part_tiles) * chunk_tiles + st % part_tiles;
     const int64_t k0 = (int64_t)st * 256;
+    if (k0 >= Kp) return;
     const int mytile = groups[gi];
 
     // per-lane source of each 1-KB piece this wave loads, and its advance per 64-column step
@@ -911,7 +917,8 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
     const int8_t *__restrict__ Vq, const unsigned *__restrict__ Xtb, const int *__restrict__ groups, int ngroups_t,
     int nNt, int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit, int32_t *__restrict__ Gacc,
     int chunks_per_plane /* split-K chunks that share one set of i32 accumulators (<= 2^24 configurations: |sum| < 2^31) */,
-    int64_t plane_stride /* elements between the accumulator sets */) {
+    int64_t plane_stride /* elements between the accumulator sets */,
+    int64_t kpart /* configurations of every chunk that take part (== kchunk: all; less: sub-sampled Hessian-vector products) */) {
     constexpr int NW = 4 * TM;
     constexpr int AR = 128 * TM, NPIECE = 8 * TM + 2, STAGE = NPIECE * 1024, NS = 4;
     constexpr int WMT = NL, WNT = 2; // wave tile 128 (64) x 64: MFMA tile i <-> limb plane i of the node tile
@@ -930,7 +937,7 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
 #pragma unroll
     for (int t = 0; t < TM; ++t) tiles[t] = groups[gi * TM + t]; // -1: padding (computed on tile 0, not stored)
     const int64_t kb = (int64_t)chunk * kchunk;
-    const int64_t ke = (kb + kchunk < Kp) ? kb + kchunk : Kp;
+    const int64_t ke = (kb + kpart < Kp) ? kb + kpart : Kp;
     const int64_t n0 = (int64_t)nt * 256, nkk = Kp >> 6, kt0 = kb >> 6;
 
     // 8*TM + 2 pieces over 4*TM waves: waves 0 and 1 load three (the third is a piece of bits), the others two.
@@ -1028,25 +1035,31 @@ __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__
                                                      const int *__restrict__ rowcol, int slot0, int64_t Qp, int64_t Qfp, int64_t Qf,
                                                      int64_t cconst, int form, int want_grad, int hv,
                                                      double *__restrict__ G, double *__restrict__ f, int nplanes,
-                                                     int64_t plane_stride) {
+                                                     int64_t plane_stride, const unsigned *__restrict__ mmax,
+                                                     SlotResult *__restrict__ res) {
     const int r = slot0 + blockIdx.y;
     if (rowcol[r] < 0) return;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const double t = tau[r];
-    if (c == 0 && form != 2 && !hv) {
-        if (want_grad) { // f = sum_k w exp(-E) = -sum_k V_k s_k = -G[r][u] (u = the node's own, masked, column)
-            const int tile = r >> 5, rl = r & 31, u = rowcol[r];
-            long long s = 0;
+    if (c == 0) {
+        double fv = f ? f[r] : 0.0; // RPLE: the forward kernel's FP64 sum
+        if (form != 2 && !hv) {
+            if (want_grad) { // f = sum_k w exp(-E) = -sum_k V_k s_k = -G[r][u] (u = the node's own, masked, column)
+                const int tile = r >> 5, rl = r & 31, u = rowcol[r];
+                long long s = 0;
 #pragma unroll
-            for (int l = LB - 1; l >= 0; --l) {
-                long long a = 0;
-                for (int pl = 0; pl < nplanes; ++pl) a += (long long)Gacc[pl * plane_stride + ((int64_t)(tile * LB + l) * 32 + rl) * Qfp + u];
-                s = s * 256 + a;
+                for (int l = LB - 1; l >= 0; --l) {
+                    long long a = 0;
+                    for (int pl = 0; pl < nplanes; ++pl) a += (long long)Gacc[pl * plane_stride + ((int64_t)(tile * LB + l) * 32 + rl) * Qfp + u];
+                    s = s * 256 + a;
+                }
+                fv = -t * (double)(csum[r] - 2 * s);
+            } else {
+                fv = t * (double)asum[r];
             }
-            f[r] = -t * (double)(csum[r] - 2 * s);
-        } else {
-            f[r] = t * (double)asum[r];
+            f[r] = fv;
         }
+        if (res) res[r] = SlotResult{fv, t, mmax[r], 0u};
     }
     if (!want_grad || c >= Qp) return;
     double v = 0.0;
@@ -1364,13 +1377,16 @@ int64_t i8_hess_kmax(const DevProblem &d) { return d.Kp; }
 
 template <int BT>
 static void launch_hess_blk(const I8Ws *w, const DevProblem &d, const int *dF, const int *dMt, const long long *dHoff, int R, int cap,
-                            int maxm, int64_t Kh, int64_t kstride, hipStream_t st) {
+                            int maxm, int64_t Kh, int64_t kstride, int nrows_active /* rows of this size class */, hipStream_t st) {
     // blocks (a, b) with BT b <= 2a + 1 for a < ceil(maxm / 2)
     int nblk = 0;
     for (int a = 0; 2 * a < maxm; ++a) nblk += (2 * a + 1) / BT + 1;
     // k-split so that the grid fills the chip (~4096 workgroups), in chunks of whole 512-sample groups
     const int maxsplit = (int)(Kh / 1024) > 0 ? (int)(Kh / 1024) : 1;
-    int ns = (int)((4096 + (int64_t)R * nblk - 1) / ((int64_t)R * nblk));
+    // (counted on the rows that have a working set: late in a solve a handful of rows remain, each with all K configurations,
+    // and sized on R they would get a few long workgroups each)
+    const int64_t wg = (int64_t)(nrows_active > 0 ? nrows_active : 1) * nblk;
+    int ns = (int)((4096 + wg - 1) / wg);
     if (ns > maxsplit) ns = maxsplit;
     if (ns < 1) ns = 1;
     int64_t kc = (Kh + ns - 1) / ns;
@@ -1395,10 +1411,12 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
         if (err) *err = "no int8 pass has run on this handle";
         return GML_EINVAL;
     }
-    int maxm = 0, maxsmall = 0;
+    int maxm = 0, maxsmall = 0, nsmall = 0, nlarge = 0;
     for (int r = 0; r < R; ++r) {
         maxm = hMt[r] > maxm ? hMt[r] : maxm;
         if (hMt[r] <= 4) maxsmall = hMt[r] > maxsmall ? hMt[r] : maxsmall;
+        if (hMt[r] > 4) ++nlarge;
+        else if (hMt[r] > 0) ++nsmall;
     }
     if (maxm > 16) return GML_EUNSUPPORTED;
     const int64_t pitch = d.Kp, Rp = (R + 31) / 32 * 32;
@@ -1429,8 +1447,8 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
     I8CHK(hipMemsetAsync(w->hS, 0, sizeof(long long) * Rp, st));
     hipLaunchKernelGGL(k_make_hw, dim3((unsigned)(Kh / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Sb, d.w, w->sc[0].tau, dRowcol, dVslot,
                        dMt, d.Kp, pitch, kstride, form, w->Hq, w->hS);
-    if (maxsmall > 0) launch_hess_blk<2>(w, d, dF, dMt, dHoff, R, cap, maxsmall, Kh, kstride, st);
-    if (maxm > 4) launch_hess_blk<4>(w, d, dF, dMt, dHoff, R, cap, maxm, Kh, kstride, st);
+    if (maxsmall > 0) launch_hess_blk<2>(w, d, dF, dMt, dHoff, R, cap, maxsmall, Kh, kstride, nsmall, st);
+    if (maxm > 4) launch_hess_blk<4>(w, d, dF, dMt, dHoff, R, cap, maxm, Kh, kstride, nlarge, st);
     hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64,
                        w->hS, w->sc[0].tau, dVslot, dMt, dHoff, dH);
     I8CHK(hipGetLastError());
@@ -1454,16 +1472,8 @@ __global__ __launch_bounds__(256) void k_zero_pass(long long *__restrict__ csum,
         for (int64_t i = i0; i < ngacc; i += stride) gacc[pl * plane_stride4 + i] = z;
 }
 
-int i8_limbs_forward() {
-    static int lf = [] {
-        const char *e = getenv("GML_I8_LF");
-        int v = e ? atoi(e) : 5;
-        return (v == 3 || v == 4 || v == 5) ? v : 5;
-    }();
-    return lf;
-}
-
 struct FwdLaunch {
+    int chunk_tiles, part_tiles, ntk; // sample tiles: per backward chunk, of them taking part, compact count
     const I8Ws *w;
     const DevProblem *d;
     const SlotScalars *sc;
@@ -1481,11 +1491,11 @@ static void launch_fwd4(const FwdLaunch &a) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF, WIDE, UNIW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
     const DevProblem &d = *a.d;
-    const int ntk = (int)(d.Kp / 256);
+    const int ntk = a.ntk;
     const int grid = ((ntk + 7) / 8) * 8 * a.ngroups; // one workgroup per (sample tile, node tile); see the kernel's block mapping
     hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE, UNIW>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.w->Tq, a.rowcol, a.groups,
                        a.ngroups, d.w, a.sc->sigma, a.sc->qconst, a.sc->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, a.Vout,
-                       a.sc->csum, a.sc->asum, a.F, a.sc->mmax, a.w->Vq, a.vmap, a.w->sc[0].tau);
+                       a.sc->csum, a.sc->asum, a.F, a.sc->mmax, a.w->Vq, a.vmap, a.w->sc[0].tau, a.chunk_tiles, a.part_tiles);
 }
 
 template <int LF, int FORM, bool WANTF, bool WIDE>
@@ -1510,12 +1520,37 @@ static void launch_fwd(const FwdLaunch &a, int form, bool wantf, int hv) {
     else launch_fwd2<LF, 0, false>(a);
 }
 
+// Split-K plan of the backward GEMM for `ngroups` node tiles: nsplit chunks of kchunk configurations each, of which the first
+// kpart take part (ksub > 1: a sub-sampled Hessian-vector pass over ~1/ksub of the configurations, spread over the whole
+// histogram chunk by chunk; kpart is then a multiple of 512, the granularity of gml_problem's block weights).
+void i8_split_plan(const DevProblem &d, int ngroups, int ksub, int64_t *kchunk_out, int64_t *kpart_out, int *nsplit_out) {
+    const int nNt = (int)((d.Qfp + 255) / 256);
+    const int T = ngroups * nNt;
+    const int gplanes = d.Kp <= ((int64_t)1 << 24) ? 1 : (int)((d.Kp + ((int64_t)1 << 23) - 1) >> 23);
+    // a multiple of 8 chunks (one XCD each).  24 chunks, or -- with few node tiles (node-sharded ranks, late solver
+    // iterations) -- as many as it takes to give each of the 512 resident workgroup slots one workgroup.
+    // Measured at the headline problem (backward ms at 16 / 24 / 32 / 64 chunks): 128 nodes 0.52 / 0.47 / 0.39 / 0.42,
+    // 256 nodes 0.75 / 0.73 / 0.77 / 0.75, 512 nodes 1.57 / 1.48 / 1.49 / 1.50, 1024 nodes 2.98 whatever the count.
+    int nsplit = (int)(((512 + T - 1) / T + 7) / 8 * 8);
+    if (nsplit < 24) nsplit = 24;
+    if (nsplit > 256) nsplit = 256;
+    int64_t kchunk = (d.Kp + nsplit - 1) / nsplit;
+    if (ksub < 1) ksub = 1;
+    const int64_t gran = ksub > 1 ? 512 * (int64_t)ksub : 256; // (whole 256-sample forward tiles either way)
+    kchunk = (kchunk + gran - 1) / gran * gran;
+    if (kchunk < 2048) kchunk = (2048 + gran - 1) / gran * gran;
+    if (gplanes > 1 && kchunk > ((int64_t)1 << 22)) kchunk = ((int64_t)1 << 22) / gran * gran;
+    *nsplit_out = (int)((d.Kp + kchunk - 1) / kchunk);
+    *kchunk_out = kchunk;
+    *kpart_out = kchunk / ksub;
+}
+
 // One pass of the int8-limb operator over the slots the caller lists (I8Pass, gml_dev.h).
 int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass &a, hipStream_t st, hipEvent_t *ev, std::string *err) {
     int rc = i8_ensure(wsp, d, slot_capacity, err);
     if (rc) return rc;
     I8Ws *w = static_cast<I8Ws *>(*wsp);
-    int LF = a.lf ? a.lf : i8_limbs_forward();
+    int LF = a.lf ? a.lf : 5;
     if (LF > w->LF) LF = w->LF;
     if (a.ngroups + 1 > 65536 || a.slot1 > w->slots || a.slot0 % 32 || a.slot1 % 32) {
         if (err) *err = "bad slot range";
@@ -1544,8 +1579,25 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     default: QUANT(5);
     }
 #undef QUANT
+    // split-K plan of the backward GEMM (made here: a sub-sampled pass runs its forward kernel over the same parts)
+    const int nNt = (int)((d.Qfp + 255) / 256);
+    constexpr int TM = 1; // node tiles per backward workgroup (the 8-wave form with two, TM = 2, measured slower)
+    const int ngt = (a.ngroups + TM - 1) / TM;
+    const int T = ngt * nNt;
+    int64_t kchunk = 0, kpart = 0;
+    int nsplit = 0;
+    if (hv && a.kchunk > 0) {
+        kchunk = a.kchunk;
+        kpart = a.kpart > 0 ? a.kpart : a.kchunk;
+        nsplit = (int)((d.Kp + kchunk - 1) / kchunk);
+    } else {
+        i8_split_plan(d, a.ngroups, hv ? a.ksub : 1, &kchunk, &kpart, &nsplit);
+    }
+    const int ksub = kpart < kchunk ? (int)(kchunk / kpart) : 1;
     if (ev) I8CHK(hipEventRecord(ev[0], st));
-    FwdLaunch fl{w, &d, &sc, a.rowcol, a.groups, a.vmap, a.ngroups, a.F, hv ? w->Uq : w->Vq, st};
+    FwdLaunch fl{(int)(kchunk / 256), (int)(kpart / 256), 0, w, &d, &sc, a.rowcol, a.groups, a.vmap, a.ngroups, a.F, hv ? w->Uq : w->Vq, st};
+    fl.ntk = ksub > 1 ? nsplit * fl.part_tiles : (int)(d.Kp / 256);
+    if (ksub == 1) fl.chunk_tiles = fl.part_tiles = 1; // (every tile: no remapping)
     switch (LF) {
     // with the gradient requested, f comes out of the backward GEMM for free (column u of row u)
     case 2: // (Hessian-vector forms only)
@@ -1558,50 +1610,25 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     }
     if (ev) I8CHK(hipEventRecord(ev[1], st));
     if (grad) {
-        const int nNt = (int)((d.Qfp + 255) / 256);
-        static const int TMenv = [] { const char *e = getenv("GML_BWD_TM"); return e && atoi(e) == 2 ? 2 : 1; }();
-        const int TM = hv == 2 ? 1 : TMenv;
-        const int ngt = (a.ngroups + TM - 1) / TM;
-        const int T = ngt * nNt;
-        // split-K: a multiple of 8 chunks (one XCD each).  24 chunks, or -- with few node tiles (node-sharded ranks, late
-        // solver iterations) -- as many as it takes to give each of the 512 / TM resident workgroup slots one workgroup.
-        // Measured at the headline problem (backward ms at 16 / 24 / 32 / 64 chunks): 128 nodes 0.52 / 0.47 / 0.39 / 0.42,
-        // 256 nodes 0.75 / 0.73 / 0.77 / 0.75, 512 nodes 1.57 / 1.48 / 1.49 / 1.50, 1024 nodes 2.98 whatever the count.
-        int nsplit = (int)(((512 / TM + T - 1) / T + 7) / 8 * 8);
-        if (nsplit < 24) nsplit = 24;
-        if (nsplit > 256) nsplit = 256;
-        if (const char *e = getenv("GML_BWD_NSPLIT")) nsplit = atoi(e); // (experiments)
-        int64_t kchunk = (d.Kp + nsplit - 1) / nsplit;
-        kchunk = (kchunk + 63) / 64 * 64;
-        if (kchunk < 2048) kchunk = 2048;
-        if (w->gplanes > 1 && kchunk > ((int64_t)1 << 22)) kchunk = (int64_t)1 << 22;
-        nsplit = (int)((d.Kp + kchunk - 1) / kchunk);
         // chunks per set of i32 accumulators: one set up to 2^24 configurations; beyond, gplanes = ceil(Kp / 2^23) sets of
         // cpp chunks each: cpp * kchunk < (Kp + kchunk) / gplanes + kchunk <= 2^23 + 1.5 * 2^22 < 2^24, so |sum| < 2^31
         const int cpp = (nsplit + w->gplanes - 1) / w->gplanes;
         const int grid = ((nsplit + 7) / 8) * 8 * T;
         const int shmem = 4 * (8 * TM + 2) * 1024;
         const int8_t *Vin = hv ? w->Uq : w->Vq;
-        // the tile list is padded with -1 to an even count
-        if (TM == 2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-            hipLaunchKernelGGL((k_bwd_i8<2, 4>), dim3(grid), dim3(512), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
-                               nsplit, w->Gacc, cpp, gplane_stride);
+        if (hv == 2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+            hipLaunchKernelGGL((k_bwd_i8<1, 2>), dim3(grid), dim3(256), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
+                               nsplit, w->Gacc, cpp, gplane_stride, kpart);
         } else {
-            if (hv == 2) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-                hipLaunchKernelGGL((k_bwd_i8<1, 2>), dim3(grid), dim3(256), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
-                                   nsplit, w->Gacc, cpp, gplane_stride);
-            } else {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-                hipLaunchKernelGGL((k_bwd_i8<1, 4>), dim3(grid), dim3(256), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
-                                   nsplit, w->Gacc, cpp, gplane_stride);
-            }
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+            hipLaunchKernelGGL((k_bwd_i8<1, 4>), dim3(grid), dim3(256), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
+                               nsplit, w->Gacc, cpp, gplane_stride, kpart);
         }
     }
     if (ev) I8CHK(hipEventRecord(ev[2], st));
     hipLaunchKernelGGL(k_finalize_i8, dim3((unsigned)((d.Qp + 255) / 256), (unsigned)ns), dim3(256), 0, st, w->Gacc, sc.tau, sc.csum, sc.asum,
-                       a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.Qf, d.cconst, a.form, grad ? 1 : 0, hv, a.G, a.F, w->gplanes, gplane_stride);
+                       a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.Qf, d.cconst, a.form, grad ? 1 : 0, hv, a.G, a.F, w->gplanes, gplane_stride, sc.mmax, a.res);
     I8CHK(hipGetLastError());
     return GML_OK;
 }

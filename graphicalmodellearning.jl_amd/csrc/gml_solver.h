@@ -25,6 +25,8 @@ struct TrialOut {
 void launch_kind(const DevProblem &d, int order, const int *dnode, int R, uint8_t *kind, hipStream_t st);
 void launch_scale_rows(const int *drows, int nrows, const double *dscale, int64_t Qp, double *G, hipStream_t st);
 void launch_copy_rows(const int *drows, int nrows, int64_t Qp, const double *s0, double *d0, const double *s1, double *d1, hipStream_t st);
+void launch_scale_slots_inv(const int *srow, const int *rowcol, int slot0, int ns, const SlotResult *res, int64_t Qp, double *G, hipStream_t st);
+void launch_scale_rows_inv(const int *drows, int nrows, const double *fs, int64_t Qp, double *G, hipStream_t st);
 void launch_rows_to_reference(const double *X, int64_t R, int64_t Qp, int64_t P, int64_t node0, int64_t cconst, const int32_t *cols, double *out,
                               hipStream_t st);
 void launch_select(const int *drows, int nrows, const double *X, const double *G, const uint8_t *kind, int64_t Qp, double lambda,

@@ -113,6 +113,30 @@ void launch_rows_to_reference(const double *X, int64_t R, int64_t Qp, int64_t P,
         hipLaunchKernelGGL(k_rows_to_reference, dim3((unsigned)((P + 255) / 256), (unsigned)R), dim3(256), 0, st, X, Qp, P, node0, cconst, cols, out);
 }
 
+// logRISE: grad log Z = grad Z / Z (:279), with Z taken from the pass results on the device (no host round trip between the
+// pass and whatever consumes its gradient).  By slot (int8 path: row srow[slot], Z = res[slot].f) or by row (FP64 path).
+__global__ __launch_bounds__(256) void k_scale_slots_inv(const int *__restrict__ srow, const int *__restrict__ rowcol, int slot0,
+                                                         const SlotResult *__restrict__ res, int64_t Qp, double *__restrict__ G) {
+    const int s = slot0 + blockIdx.y;
+    if (rowcol[s] < 0) return;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < Qp) G[(int64_t)srow[s] * Qp + c] *= 1.0 / res[s].f;
+}
+__global__ __launch_bounds__(256) void k_scale_rows_inv(const int *__restrict__ rows, const double *__restrict__ fs, int64_t Qp,
+                                                        double *__restrict__ G) {
+    const int r = rows[blockIdx.y];
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < Qp) G[(int64_t)r * Qp + c] *= 1.0 / fs[r];
+}
+void launch_scale_slots_inv(const int *srow, const int *rowcol, int slot0, int ns, const SlotResult *res, int64_t Qp, double *G, hipStream_t st) {
+    if (ns > 0)
+        hipLaunchKernelGGL(k_scale_slots_inv, dim3((unsigned)((Qp + 255) / 256), (unsigned)ns), dim3(256), 0, st, srow, rowcol, slot0, res, Qp, G);
+}
+void launch_scale_rows_inv(const int *drows, int nrows, const double *fs, int64_t Qp, double *G, hipStream_t st) {
+    if (nrows > 0)
+        hipLaunchKernelGGL(k_scale_rows_inv, dim3((unsigned)((Qp + 255) / 256), (unsigned)nrows), dim3(256), 0, st, drows, fs, Qp, G);
+}
+
 void launch_copy_rows(const int *drows, int nrows, int64_t Qp, const double *s0, double *d0, const double *s1, double *d1, hipStream_t st) {
     if (nrows > 0)
         hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((Qp + 255) / 256), (unsigned)nrows), dim3(256), 0, st, drows, Qp, s0, d0, s1, d1);
@@ -170,6 +194,13 @@ __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, co
     nviol = block_sum_i(nviol, redi);
     if (!(worst == worst)) worst = INFINITY; // NaN
     const bool addv = !(worstW > worst * 0.999999 && worstW > 0 && nsupp > 1);
+    // The Hessian blocks and the Cholesky work on whole 32-entry tiles: admit as many violators as fill the working set up
+    // to a multiple of 32 rather than one entry into the next tile (support 1 + 64 violators = 65 entries would be three
+    // tiles, 2.2x the Hessian work of the 64 that two tiles hold), as long as at least half of max_add still get in.
+    {
+        const int full = (nsupp + max_add) / 32 * 32;
+        if (full - nsupp >= max_add / 2) max_add = full - nsupp;
+    }
     // threshold of the max_add largest violators: bisection on the float pattern of |pg| (monotone as unsigned)
     unsigned thr = 0;
     if (addv && nviol > max_add) {

@@ -31,6 +31,9 @@ const GML_PREC_F64, GML_PREC_I8X, GML_PREC_AUTO = Cint(0), Cint(1), Cint(2)
 struct GmlOpts                      # struct gml_opts
     tol::Cdouble; max_iter::Int32; precision::Int32; max_working::Int32; max_add::Int32
     verbose::Int32; hess_samples::Int32; polish::Int32; max_cg::Int32
+    limbs_fwd::Int32; hv_limbs_fwd::Int32; hv_limbs_bwd::Int32; debug_row::Int32   # 0 = the library's defaults
+    hv_subsample::Int32; reserved0::Int32
+    cg_viol_frac::Cdouble; cg_eta::Cdouble
 end
 
 struct GmlStats                     # struct gml_stats
@@ -78,7 +81,7 @@ function precision_id(s::Symbol)
 end
 
 gmlopts(m::HIP) = Ref(GmlOpts(m.tol, m.max_iter, precision_id(m.precision), m.max_working, m.max_add,
-                              m.verbose, m.hess_samples, m.polish ? 0 : -1, 0))
+                              m.verbose, m.hess_samples, m.polish ? 0 : -1, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0))
 
 lasterr() = unsafe_string(ccall((:gml_last_error, libgml), Cstring, ()))
 

@@ -47,10 +47,20 @@ def sample(model, number_sample, replicates=None, sampler=None, *, seed=0, devic
             args = {"terms": fg.terms, "n": fg.varible_count, "order": 2}
         args["mcmc_sweeps"] = sampler.sweeps
     reps = 1 if replicates is None else int(replicates)
+    nspins = args["model"].shape[0] if "model" in args else args["n"] if "n" in args else max(max(k) for k in args["terms"] if len(k))
     out = []
     for b in range(reps):
-        with _lib.Problem(num_samples=int(number_sample), seed=int(seed) + 7919 * b, device=device, **args) as p:
-            spins = p.spins()
-        states, counts = np.unique(spins, axis=0, return_counts=True)  # countmap (sampling.jl:52)
-        out.append(np.concatenate([counts[:, None].astype(np.int64), states.astype(np.int64)], axis=1))
+        kw = dict(num_samples=int(number_sample), seed=int(seed) + 7919 * b, device=device, **args)
+        if nspins <= 64 and int(number_sample) < 2 ** 31:
+            # countmap (sampling.jl:52) on the device: the draws are sorted and run-length encoded there; only the distinct
+            # configurations and their counts come back
+            with _lib.Problem(histogram=True, **kw) as p:
+                states, counts = p.spins(), p.counts()
+            order = np.lexsort(states.T[::-1])  # rows in the order np.unique would give them
+            states, counts = states[order], counts[order]
+        else:
+            with _lib.Problem(**kw) as p:
+                spins = p.spins()
+            states, counts = np.unique(spins, axis=0, return_counts=True)
+        out.append(np.concatenate([np.rint(counts)[:, None].astype(np.int64), states.astype(np.int64)], axis=1))
     return out[0] if replicates is None else out

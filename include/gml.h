@@ -68,6 +68,20 @@ typedef struct gml_opts {
                             arithmetic continue on the FP64 path when its workspaces fit (default); -1 = never */
     int32_t max_cg;      /* conjugate-gradient iterations per Newton step of the matrix-free rows (working sets above
                             max_working); each costs one Hessian-vector pass (default 16) */
+    /* tuning of the fixed-point arithmetic and of the matrix-free Newton-CG; 0 = the default named */
+    int32_t limbs_fwd;   /* int8 limb planes of Theta in the objective passes: 3, 4 or 5 (default 5: 38 significant bits)  */
+    int32_t hv_limbs_fwd; /* ... of the CG direction in the Hessian-vector passes: 2..5 (default 2: 14 bits, ample for an
+                            inexact Newton step that stops at a 5 % residual)                                              */
+    int32_t hv_limbs_bwd; /* limb planes of the products h_k (x_k . p) in those passes: 2 or 4 (default 2)                  */
+    int32_t debug_row;   /* local row traced on stderr when verbose >= 2 (default 0)                                       */
+    int32_t hv_subsample; /* the Hessian-vector products of the matrix-free rows run over 1/hv_subsample of the configurations,
+                            spread over the whole histogram (the gradient always uses all of them, so only the convergence
+                            rate is affected).  0 = automatic: as many as keep >= 32 configurations per working-set entry,
+                            at most 8; 1 = every configuration                                                             */
+    int32_t reserved0;
+    double cg_viol_frac; /* matrix-free rows admit, per iteration, the violators within this fraction of the largest
+                            violation (default 0.5: full Newton steps throughout on dense optima)           */
+    double cg_eta;       /* CG stops at a residual reduced by min(cg_eta, sqrt(kkt)) (default 0.05)                         */
 } gml_opts;
 
 typedef struct gml_stats {
@@ -173,6 +187,21 @@ int gml_problem_create_sampled_terms(const int32_t *keys, int key_stride, const 
 int gml_problem_create_mcmc_terms(const int32_t *keys, int key_stride, const double *weights, int64_t nterms,
                                   int64_t n, int64_t N, uint64_t seed, int sweeps, int order, int64_t node0,
                                   int64_t node1, int device, gml_problem **out);
+
+/*
+ * gml_problem_create_sampled_hist -- sample AND histogram on the device: what `sample(gm, N)` returns is the countmap of the
+ * draws (sampling.jl:52-54: one row per distinct configuration, column 1 = its count).  Same term-list arguments as above
+ * (mcmc_sweeps = 0: exact sampling, > 0: Glauber chains); n <= 64, N < 2^31.  The N draws become 64-bit keys, are radix-sorted
+ * and run-length encoded on the device, and the handle holds the K' <= min(N, 2^n) DISTINCT configurations (ascending key
+ * order: bit i of the key <=> spin i is -1) with their multiplicities as counts, M = N.  A 9-spin model sampled 1e8 times
+ * gives a 512-row handle, and learn() on it costs 512 rows, not 1e8.
+ */
+int gml_problem_create_sampled_hist(const int32_t *keys, int key_stride, const double *weights, int64_t nterms, int64_t n,
+                                    int64_t N, uint64_t seed, int mcmc_sweeps, int order, int64_t node0, int64_t node1,
+                                    int device, gml_problem **out);
+
+/* The counts of a handle's K rows (host pointer, K doubles): column 1 of the histogram (sampling.jl:54). */
+int gml_problem_get_counts(gml_problem *p, double *counts);
 
 /* The +-1 configurations held by a handle, K x n row-major (host pointer). */
 int gml_problem_get_spins(gml_problem *p, int8_t *spins);

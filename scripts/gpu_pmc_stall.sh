@@ -5,7 +5,7 @@ o=gpurun_out/prof_stall
 rm -rf $o; mkdir -p $o
 for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" "SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_IFETCH SQ_ACTIVE_INST_MISC"; do
   d=$o/$(echo $c | tr ' ' '_')
-  rocprofv3 --pmc $c --output-format csv -d $d -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-learn --no-f64 > $d.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $d -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-learn --no-host-learn --no-f64 > $d.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, json, collections

@@ -48,6 +48,9 @@ static int layout(void) {
     printf("sizeof gml_opts %zu\n", sizeof(gml_opts));
     OFF(gml_opts, tol); OFF(gml_opts, max_iter); OFF(gml_opts, precision); OFF(gml_opts, max_working); OFF(gml_opts, max_add);
     OFF(gml_opts, verbose); OFF(gml_opts, hess_samples); OFF(gml_opts, polish); OFF(gml_opts, max_cg);
+    OFF(gml_opts, limbs_fwd); OFF(gml_opts, hv_limbs_fwd); OFF(gml_opts, hv_limbs_bwd); OFF(gml_opts, debug_row);
+    OFF(gml_opts, hv_subsample); OFF(gml_opts, reserved0);
+    OFF(gml_opts, cg_viol_frac); OFF(gml_opts, cg_eta);
     printf("sizeof gml_stats %zu\n", sizeof(gml_stats));
     OFF(gml_stats, iterations); OFF(gml_stats, passes); OFF(gml_stats, forward_passes); OFF(gml_stats, hessian_passes);
     OFF(gml_stats, node_evals); OFF(gml_stats, max_kkt); OFF(gml_stats, lambda); OFF(gml_stats, t_pack); OFF(gml_stats, t_pass);
@@ -112,6 +115,8 @@ static int run(const char *samples_csv, const char *learned_csv, double c, int s
     o.hess_samples = 0;
     o.polish = 0;
     o.max_cg = 0;
+    o.limbs_fwd = o.hv_limbs_fwd = o.hv_limbs_bwd = o.debug_row = o.hv_subsample = o.reserved0 = 0;
+    o.cg_viol_frac = o.cg_eta = 0.0;
     gml_stats st;
     memset(&st, 0xEE, sizeof st); /* Ref{GmlStats}() is uninitialised memory */
     rc = gml_learn(h, GML_RISE, c, &o, out, NULL /* C_NULL */, &st);

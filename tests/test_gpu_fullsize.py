@@ -99,3 +99,53 @@ def test_c5_multibody_order3_full_size():
         assert np.abs(pg).max() <= 5e-8
     err = max(abs(v - terms.get(tuple(sorted(i + 1 for i in key)), 0.0)) for key, v in zip(keys0, out[0]))
     assert err <= 0.06  # node 0's terms are the generating ones up to sampling noise and the l1 shrinkage
+
+
+def test_c5_default_regulariser_full_size():
+    # config 5 AS BASELINE.json STATES IT: `ISODUS()` = multiRISE(0.4, true, 3), the reference's default regulariser (:28).
+    # lambda comes from n^2, not from the 130 817 parameters per node (:86), so the optimum is DENSE: thousands of the
+    # noise coefficients exceed lambda and a node's support outgrows the 512-entry Cholesky block -- those rows run the
+    # matrix-free Newton-CG (Hessian-vector products on the int8 cores over a sub-sample of the configurations), the rest
+    # the Cholesky blocks.  All 512 nodes must converge; the KKT certificate comes from the ORACLE's order-3 gradient.
+    n, K = 512, 1000000
+    terms = synthetic.block_multibody_terms(n, block=16, seed=0)
+    some = np.array([0, 257])
+    with gml.Problem(terms=terms, n=n, num_samples=K, seed=5, order=3) as p:
+        t0 = time.time()
+        out, kkt, st = p.learn("RISE", gml.ISODUS().regularizer, tol=1e-8, precision="i8x", max_iter=120)
+        t_learn = time.time() - t0
+        lam = st["lambda_"]
+        keys0 = p.multi_keys(0)
+        spins = p.spins()
+    print(f"C5 at the default regulariser: learn() {t_learn:.1f} s, {st['iterations']} iterations, {st['passes']} + {st['forward_passes']} passes, "
+          f"{st['hessian_passes']} Hessian steps, {st['hv_evals']} H.v node evaluations, max support {int((out != 0).sum(1).max())}")
+    assert gml.ISODUS().regularizer == 0.4 and lam == pytest.approx(0.4 * np.sqrt(np.log(n * n / 0.05) / K), rel=1e-12)
+    assert st["not_converged"] == 0 and kkt.max() <= 1e-8
+    supp = (out != 0).sum(1)
+    assert supp.min() > 512  # every support outgrows the Cholesky block (early iterations run on blocks, the rest matrix-free)
+    assert st["hv_evals"] > 0 and st["hessian_passes"] > st["iterations"]
+    fo, go = O.objgrad_multi3_nodes(None, spins, some, out[some])
+    for a in range(2):  # slot 0 (the field, key (u,)) is not penalised (:118)
+        x, g = out[some[a]], go[a]
+        pg = np.where(x > 0, g + lam, np.where(x < 0, g - lam, np.sign(g) * np.maximum(np.abs(g) - lam, 0)))
+        pg[0] = g[0]
+        assert np.abs(pg).max() <= 5e-8
+    err = max(abs(v - terms.get(tuple(sorted(i + 1 for i in key)), 0.0)) for key, v in zip(keys0, out[0]))
+    assert err <= 0.06
+    assert t_learn < 300.0
+
+
+@pytest.mark.parametrize("form,c", [("RPLE", 0.2), ("RISE", 0.4)])
+def test_headline_size_other_formulations_converge(form, c):
+    # RPLE at its default regulariser has the denser optimum of the three (lambda = 0.2 sqrt(log(n^2/0.05)/M) lies below the
+    # sampling noise 1/sqrt(M)): working sets of several hundred entries, the large-block paths of the Newton solve.
+    n, K = 1024, 1000000
+    J = synthetic.block_ising_model(n, block=16, seed=0)
+    some = np.array([0, 500, 1023])
+    with gml.Problem(model=J, num_samples=K, seed=3) as p:
+        out, kkt, st = p.learn(form, c, tol=1e-9, precision="i8x")
+        lam = st["lambda_"]
+        spins = p.spins()
+    assert st["not_converged"] == 0 and kkt.max() <= 1e-9
+    assert _oracle_kkt(form, spins, out[some], some, lam) <= 5e-9
+    assert np.abs(0.5 * (out + out.T) - J).max() <= 0.06

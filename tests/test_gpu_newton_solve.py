@@ -1,0 +1,49 @@
+"""The batched Newton solve of the direction phase (k_newton_solve: A d = -pg on ragged symmetric positive definite blocks, one
+workgroup per row) against numpy, for every path it has: one-wave LDS blocks (<= 64, <= 128 entries), the panel Cholesky with
+single-wave triangular solves (<= 256) and with workgroup solves (<= 512); with and without the logRISE rank-one term."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gml_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def solve(blocks, pg, s2=0.0, g=None):
+    L = _lib.lib()
+    L.gml_test_newton_solve.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+    R, cap = blocks.shape[0], blocks.shape[1]
+    ms = np.array([b for b in pg[1]], dtype=np.int32)
+    out = np.zeros((R, cap))
+    _lib.check(L.gml_test_newton_solve(R, _lib._ptr(ms), cap, _lib._ptr(np.ascontiguousarray(blocks)), _lib._ptr(np.ascontiguousarray(pg[0])),
+                                       float(s2), _lib._ptr(g), _lib._ptr(out), 0))
+    return out
+
+
+@pytest.mark.parametrize("sizes", [[1, 5, 31, 32, 33, 63, 64], [65, 90, 96, 127, 128], [129, 160, 191, 192, 193, 200, 224, 255, 256],
+                                   [257, 300, 384, 511, 512], [7, 64, 100, 128, 150, 200, 256, 300, 512]])
+@pytest.mark.parametrize("logrise", [False, True])
+def test_batched_newton_solve_matches_numpy(sizes, logrise):
+    rng = np.random.default_rng(sum(sizes))
+    cap = 512
+    R = len(sizes)
+    blocks = np.zeros((R, cap, cap))
+    pg = np.zeros((R, cap))
+    g = np.zeros((R, cap)) if logrise else None
+    want = []
+    for r, m in enumerate(sizes):
+        X = rng.choice([-1.0, 1.0], size=(4 * m + 50, m))  # a Hessian-like block: weighted +-1 outer products
+        h = rng.random(4 * m + 50)
+        A = (X * h[:, None]).T @ X / len(h)
+        gg = rng.normal(size=m) * 0.1 if logrise else np.zeros(m)
+        blocks[r, :m, :m] = A + (np.outer(gg, gg) if logrise else 0.0)  # so that A_eff = H - g g^T stays positive definite
+        pg[r, :m] = rng.normal(size=m)
+        if logrise:
+            g[r, :m] = gg
+        want.append(np.linalg.solve(A, -pg[r, :m]))
+    got = solve(blocks, (pg, sizes), s2=1.0 if logrise else 0.0, g=g)
+    for r, m in enumerate(sizes):
+        scale = np.abs(want[r]).max()
+        assert np.abs(got[r, :m] - want[r]).max() <= 1e-9 * scale, (m, np.abs(got[r, :m] - want[r]).max() / scale)

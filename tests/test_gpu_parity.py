@@ -446,7 +446,7 @@ def test_dense_solutions_large_working_sets(prec):
     assert _kkt_from_oracle(spins, capped, [0, 50, 191], lam) <= 5e-9
 
 
-def test_newton_cg_reduced_limbs_reach_the_same_optimum(monkeypatch):
+def test_newton_cg_reduced_limbs_reach_the_same_optimum():
     # The matrix-free Newton-CG carries the direction in 3 forward limbs and the Hessian-vector products in 2 backward
     # limbs by default; with the full 5 / 4 it must arrive at the same (unique) optimum -- only the inexact Newton steps
     # on the way differ.
@@ -455,9 +455,7 @@ def test_newton_cg_reduced_limbs_reach_the_same_optimum(monkeypatch):
     lam = O.lam(0.05, n, K)
     with gml.Problem(spins=spins) as p:
         dflt, _, st_d = p.learn("RISE", 0.05, tol=1e-9, precision="i8x", max_working=128, max_iter=200)
-        monkeypatch.setenv("GML_HV_LF", "5")
-        monkeypatch.setenv("GML_HV_LB", "4")
-        wide, _, st_w = p.learn("RISE", 0.05, tol=1e-9, precision="i8x", max_working=128, max_iter=200)
+        wide, _, st_w = p.learn("RISE", 0.05, tol=1e-9, precision="i8x", max_working=128, max_iter=200, hv_limbs_fwd=5, hv_limbs_bwd=4)
     assert st_d["not_converged"] == 0 and st_w["not_converged"] == 0
     assert st_d["hessian_passes"] > 0  # the matrix-free path really ran
     assert np.abs(dflt - wide).max() <= 1e-7

@@ -167,3 +167,52 @@ def test_multibody_learn_sample_relearn_round_trip():
         learned_gm2 = gml.learn(hist2, gml.multiRISE(0.0, False, order), gml.HIP(tol=1e-10))
         for key, value in gm_tmp:
             assert learned_gm2[key] / 2.0 == pytest.approx(value, abs=0.16)
+
+
+def _mvt_model(golden):
+    m = golden("mvt_RISE_learned.csv")
+    return 0.5 * (m + m.T)
+
+
+def test_histogramming_on_the_device_1e8_draws_of_a_9_spin_model(golden):
+    # sample(gm, N) = countmap of the draws (sampling.jl:52-54): sorted and run-length encoded on the device, so 1e8 draws of a
+    # 9-spin model come back as the 512 distinct configurations with their counts -- no K x n download, no host pass
+    m = _mvt_model(golden)
+    N = 100_000_000
+    with gml.Problem(model=m, num_samples=N, seed=4, histogram=True) as p:
+        assert (p.K, p.n, p.M) == (512, 9, float(N))
+        states, counts = p.spins(), p.counts()
+        out, kkt, st = p.learn("RISE", 0.2, tol=1e-10)
+    assert counts.sum() == N and len({tuple(s) for s in states}) == 512
+    allstates, pr = exact_probabilities(m)
+    lookup = {tuple(s): pi for s, pi in zip(allstates, pr)}
+    for s, c in zip(states, counts):
+        expect = lookup[tuple(s)] * N
+        assert abs(c - expect) <= 6 * np.sqrt(expect) + 1
+    assert np.abs(0.5 * (out + out.T) - m).max() <= 2e-3  # 1e8 samples pin the model down
+    hist = gml.sample(gml.FactorGraph(m), 1_000_000, seed=4)  # the front door goes the same way
+    assert hist.shape[1] == 10 and 256 <= len(hist) <= 512 and hist[:, 0].sum() == 1_000_000  # (the rarest states need more than 1e6 draws)
+
+
+@pytest.mark.parametrize("form", ["RISE", "logRISE", "RPLE"])
+def test_histogram_handle_learns_what_the_count_one_handle_learns(golden, form):
+    m = _mvt_model(golden)
+    N = 2_000_000
+    with gml.Problem(model=m, num_samples=N, seed=9) as p, gml.Problem(model=m, num_samples=N, seed=9, histogram=True) as q:
+        assert p.K == N and q.K <= 512 and p.M == q.M == N
+        a, _, _ = p.learn(form, 0.2, tol=1e-11, precision="f64")
+        b, _, sb = q.learn(form, 0.2, tol=1e-11, precision="f64")
+        # the same draws: the histogram of the count-one handle's samples is the deduplicated handle
+        st, ct = np.unique(p.spins(), axis=0, return_counts=True)
+        qs, qc = q.spins(), q.counts()
+        order = np.lexsort(qs.T[::-1])
+        assert np.array_equal(qs[order], st) and np.array_equal(qc[order], ct)
+    assert np.abs(a - b).max() <= 1e-9
+
+
+def test_histogram_of_glauber_chains_and_limits():
+    terms = {(i + 1, (i + 1) % 12 + 1): 0.3 for i in range(12)}  # a 12-spin ring
+    with gml.Problem(terms=terms, n=12, num_samples=300000, seed=2, mcmc_sweeps=50, histogram=True) as p:
+        assert p.K <= 4096 and p.M == 300000 and p.counts().sum() == 300000
+    with pytest.raises(gml.GMLError, match="n <= 64"):
+        gml.Problem(terms={(1, 70): 0.1}, n=70, num_samples=1000, histogram=True)
