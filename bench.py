@@ -313,7 +313,8 @@ def main():
                     Rh = 0.5 * (oh + oh.T)  # :184-186
                     t2 = time.perf_counter()
                     it = ph.ingest_times()
-                runs.append({"pack_s": it["pack_s"], "upload_s": it["upload_s"], "images_s": it["images_s"], "create_s": t1 - t0,
+                runs.append({"pack_s": it["pack_s"], "upload_s": it["upload_s"], "images_s": it["images_s"], "alloc_s": it["alloc_s"],
+                             "weights_s": it["weights_s"], "create_s": t1 - t0,
                              "solve_s": t2 - t1, "total_s": t2 - t0})
             med = sorted(runs, key=lambda r: r["total_s"])[1]
             extra["learn_from_host"] = dict(med, input="column-major Int64 K x (1+n) histogram (Matrix{Int64} of sample())",

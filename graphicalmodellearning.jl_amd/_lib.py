@@ -250,9 +250,9 @@ class Problem:
         return out
 
     def ingest_times(self):
-        t = np.zeros(4)
+        t = np.zeros(6)
         check(lib().gml_problem_ingest_times(self._h, _ptr(t)))
-        return {"pack_s": t[0], "upload_s": t[1], "images_s": t[2], "total_s": t[3]}
+        return {"pack_s": t[0], "upload_s": t[1], "images_s": t[2], "total_s": t[3], "alloc_s": t[4], "weights_s": t[5]}
 
     def multi_keys(self, u):
         keys = np.zeros((self.P, self.order), dtype=np.int32)

@@ -539,11 +539,16 @@ static int create_parts(const std::function<int64_t(int64_t, int64_t, uint32_t *
         return code;
     };
     WeightInfo wi;
+    double t_alloc = 0, t_weights = 0;
     for (size_t g = 0; g < G; ++g) {
         parts[g] = new_problem(K, n, M, order, ranges[g].first, ranges[g].second, devices[g]);
+        const double ta = now_s();
         int rc = prob_layout(parts[g]);
+        const double tb = now_s();
+        t_alloc += tb - ta;
         if (rc == GML_OK && g == 0) weight_info(counts, K, parts[0]->d.Kp, M, wi);
         if (rc == GML_OK) rc = prob_weights(parts[g], wi);
+        t_weights += now_s() - tb;
         if (rc) return destroy_all(rc);
     }
     double t_fill = t_counts, t_wait = 0;
@@ -561,6 +566,8 @@ static int create_parts(const std::function<int64_t(int64_t, int64_t, uint32_t *
         q->t_ingest[1] = (t1 - t_begin) - (t_fill - t_counts);        // allocations, weights, copies not hidden by the packing
         q->t_ingest[2] = t2 - t1;                                      // Xb, Xtb
         q->t_ingest[3] = t2 - t_begin + t_counts;
+        q->t_ingest[4] = t_alloc;   // of t[1]: stream + device allocations (all parts)
+        q->t_ingest[5] = t_weights; // of t[1]: weights w = counts / M, their summaries and upload
     }
     return GML_OK;
 }
@@ -700,9 +707,9 @@ extern "C" int gml_problem_get_sign_bits(gml_problem *p, uint32_t *sign_bits) {
     return GML_OK;
 }
 
-extern "C" int gml_problem_ingest_times(const gml_problem *p, double t[4]) {
+extern "C" int gml_problem_ingest_times(const gml_problem *p, double t[6]) {
     if (!p || !t) return fail(GML_EINVAL, "NULL argument");
-    for (int i = 0; i < 4; ++i) t[i] = p->t_ingest[i];
+    for (int i = 0; i < 6; ++i) t[i] = p->t_ingest[i];
     return GML_OK;
 }
 

@@ -51,7 +51,7 @@ struct gml_problem {
     char *stage = nullptr;
     size_t stage_bytes = 0;
     // how long building the handle took (gml_problem_ingest_times): host packing, uploads not hidden by it, bit images, total
-    double t_ingest[4] = {0, 0, 0, 0};
+    double t_ingest[6] = {0, 0, 0, 0, 0, 0};
 };
 
 // reference parameter vector of node u <-> internal column layout (pairwise :162, multi-body :94-104)

@@ -129,9 +129,9 @@ int gml_problem_create(const void *samples, int dtype, int64_t K, int64_t n, int
  * 8 K (n+1) of the Matrix{Int64} (`copy` of the Adjoint at :73; C3: 0.13 GB instead of 8.2 GB).  Packing overlaps the
  * copies (two pinned stages).  gml_problem_ingest_times reports the split:
  *   t[0] host packing (counts + sign words), t[1] allocations / uploads not hidden behind it, t[2] MFMA operand images
- *   (device), t[3] whole create call; seconds.
+ *   (device), t[3] whole create call, t[4] of t[1]: stream + device allocations, t[5] of t[1]: weights; seconds.
  */
-int gml_problem_ingest_times(const gml_problem *p, double t[4]);
+int gml_problem_ingest_times(const gml_problem *p, double t[6]);
 
 /* The other route: the raw matrix is uploaded as it is and converted / validated on the device (64x the PCIe bytes;
  * for hosts with few cores).  Same arguments and the same resulting handle, bit for bit. */
