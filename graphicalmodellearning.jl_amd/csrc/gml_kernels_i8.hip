@@ -434,7 +434,10 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     constexpr bool HV = FORM >= 3;
     constexpr int BR = 32 * LF;           // rows of the Tq image
     constexpr int NPIECE = 2 + BR / 16, NP = (NPIECE + 3) / 4;
-    constexpr int STAGE = NPIECE * 1024, NS = 4;
+    // Ring stages hold DS consecutive 64-column steps: one barrier per DS steps (the waves of a workgroup then re-align
+    // half as often, and the LDS reads of a stage's second step issue under the MFMAs of its first).
+    constexpr int DS = 2;
+    constexpr int STEP = NPIECE * 1024, STAGE = DS * STEP, NS = 3;
     constexpr int RING = NS * STAGE;
     extern __shared__ __attribute__((aligned(16))) int8_t lds[]; // ring, then the exp (and log) tables
     double *etab = reinterpret_cast<double *>(lds + RING);
@@ -496,13 +499,20 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
             adv[j] = BR * 64;
         }
     }
-    auto issue = [&](int kt) {
-        int8_t *stage_base = lds + (kt & (NS - 1)) * STAGE;
+    const int nst = (nk + DS - 1) / DS; // ring stages of this tile
+    auto issue = [&](int ks) { // stage ks = steps DS ks .. DS ks + DS - 1 (a step beyond the last one: the last one again, so
+                               // that every stage counts the same number of loads for the vmcnt waits)
+        int8_t *stage_base = lds + (ks % NS) * STAGE;
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            int pc = wave + 4 * j;
-            if (pc >= NPIECE) pc = NPIECE - 1;
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (int64_t)kt * adv[j]), (lptr_t)(stage_base + pc * 1024), 16, 0, 0);
+        for (int sub = 0; sub < DS; ++sub) {
+            int kt = DS * ks + sub;
+            kt = kt < nk ? kt : nk - 1;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                int pc = wave + 4 * j;
+                if (pc >= NPIECE) pc = NPIECE - 1;
+                __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (int64_t)kt * adv[j]), (lptr_t)(stage_base + sub * STEP + pc * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -530,39 +540,43 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) issue(s);
-    auto gemm_step = [&](int kt, auto first) {
+        if (s < nst) issue(s);
+    auto gemm_stage = [&](int ks, auto first) {
         constexpr bool FIRST = decltype(first)::value;
-        ring_wait_ahead<NP>(nk - 1 - kt);
-        if (kt + NS - 1 < nk) issue(kt + NS - 1);
-        const int8_t *cur = lds + (kt & (NS - 1)) * STAGE;
-        unsigned vb[WM];
+        ring_wait_ahead<DS * NP>(nst - 1 - ks > NS - 2 ? NS - 2 : nst - 1 - ks); // NS - 2 later stages may still be in flight
+        if (ks + NS - 1 < nst) issue(ks + NS - 1);
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            const int row = wave * 64 + i * 32 + lr;
-            vb[i] = *reinterpret_cast<const unsigned *>(cur + (row >> 7) * 1024 + (((row & 127) * 2 + h) << 2));
-        }
+        for (int sub = 0; sub < DS; ++sub) {
+            if (sub > 0 && DS * ks + sub >= nk) break; // (an odd number of steps: the last stage is half full)
+            const int8_t *cur = lds + (ks % NS) * STAGE + sub * STEP;
+            unsigned vb[WM];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            v4i fa[WM], fb[LF];
+            for (int i = 0; i < WM; ++i) {
+                const int row = wave * 64 + i * 32 + lr;
+                vb[i] = *reinterpret_cast<const unsigned *>(cur + (row >> 7) * 1024 + (((row & 127) * 2 + h) << 2));
+            }
 #pragma unroll
-            for (int l = 0; l < LF; ++l)
-                fb[l] = *reinterpret_cast<const v4i *>(cur + 2048 + lds_off(l * 32 + lr, 2 * t + h));
+            for (int t = 0; t < 2; ++t) {
+                v4i fa[WM], fb[LF];
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int l = 0; l < LF; ++l)
+                    fb[l] = *reinterpret_cast<const v4i *>(cur + 2048 + lds_off(l * 32 + lr, 2 * t + h));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) fa[i][e] = (int)((vb[i] >> (4 * t + e)) & 0x01010101u);
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                    for (int e = 0; e < 4; ++e) fa[i][e] = (int)((vb[i] >> (4 * t + e)) & 0x01010101u);
 #pragma unroll
-                for (int l = 0; l < LF; ++l) {
-                    if (FIRST && t == 0) acc[i][l] = MFMA_I8(fa[i], fb[l], ((v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}));
-                    else acc[i][l] = MFMA_I8(fa[i], fb[l], acc[i][l]);
-                }
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int l = 0; l < LF; ++l) {
+                        if (FIRST && sub == 0 && t == 0) acc[i][l] = MFMA_I8(fa[i], fb[l], ((v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}));
+                        else acc[i][l] = MFMA_I8(fa[i], fb[l], acc[i][l]);
+                    }
+            }
         }
     };
-    gemm_step(0, std::true_type{}); // nk >= 1: Qfp >= 64
-    for (int kt = 1; kt < nk; ++kt) gemm_step(kt, std::false_type{});
+    gemm_stage(0, std::true_type{}); // nk >= 1: Qfp >= 64
+    for (int ks = 1; ks < nst; ++ks) gemm_stage(ks, std::false_type{});
     __builtin_amdgcn_s_setprio(0);
     // ---- epilogue ----------------------------------------------------------------------------
     // lane <-> node row (lr), register e <-> sample (e&3) + 8*(e>>2) + 4*h within the 32-sample tile.  The
@@ -1486,8 +1500,8 @@ struct FwdLaunch {
 
 template <int LF, int FORM, bool WANTF, bool WIDE, bool UNIW>
 static void launch_fwd4(const FwdLaunch &a) {
-    constexpr int STAGE = (2 + 2 * LF) * 1024;
-    constexpr int shmem = 4 * STAGE + 512 + 1024; // ring + exp, log tables
+    constexpr int STAGE = 2 * (2 + 2 * LF) * 1024; // two 64-column steps per ring stage, three stages
+    constexpr int shmem = 3 * STAGE + 512 + 1024;   // ring + exp, log tables
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF, WIDE, UNIW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
     const DevProblem &d = *a.d;
