@@ -92,9 +92,17 @@ int i8_pass(void **ws, const DevProblem &d, int64_t slot_capacity, const I8Pass 
 void i8_free(void *ws);
 // per-slot results of the last pass of the given kind (device pointers)
 void i8_slot_results(void *ws, int hv, const double **tau, const unsigned **mmax);
+// Extra blocks of a Hessian call: the preconditioner tiles of the matrix-free rows.  Block R + t (t < n) is the T x T Hessian of
+// the T columns F[t T ..] under the weights of row wrow[t]; the caller's mt / hoff arrays cover R + n blocks (mt = T / 32 for a
+// tile).  hflag [R]: rows whose weights are needed (those with a working set, and those with tiles).
+struct HessTiles {
+    int64_t n = 0;
+    int T = 0;
+    const int *F = nullptr, *wrow = nullptr, *hflag = nullptr;
+};
 int i8_hessian(void *ws, const DevProblem &d, const int *dRowcol, const int *dVslot, const int *dF, const int *dMt, const int *hMt,
                const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh, int64_t kstride, double *dH,
-               hipStream_t st, std::string *err);
+               hipStream_t st, std::string *err, const HessTiles *tiles = nullptr);
 
 // ---- FP64 path -----------------------------------------------------------------------------
 // Theta [Rp][Qp] (internal column layout, masked slots zero), rowcol[r] = u (row of Xt
@@ -136,5 +144,10 @@ void launch_glauber(const int *dioff, const double *diw, const int *dooff, const
 // (Cholesky, ridge restart).  gF/pgF/dout are R x cap; Sdiag[r] = A[m-1][m-1].
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
                          const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st, int maxm = 0);
+// Preconditioner tiles (T = 64 or 128): tile t holds the lower triangle of its T x T Hessian block at H + hoff[t] (pitch T);
+// A = s1[wrow[t]] * H_t - s2 * g g^T on its first vm[t] entries is replaced, in place, by its inverse (full symmetric matrix);
+// a block that is not positive definite even with a ridge becomes its inverse diagonal.
+void launch_tile_inverse(int T, double *H, const long long *hoff, const int *vm, const int *wrow, const double *s1, double s2, const double *gV,
+                         int64_t ntiles, hipStream_t st);
 
 } // namespace gml

@@ -697,6 +697,133 @@ __global__ __launch_bounds__(256) void k_newton_solve(double *__restrict__ H, co
     for (int i = tid; i < m; i += 256) dout[(int64_t)r * cap + i] = bad ? 0.0 : y[i];
 }
 
+// ------------------------------------------------------------------------------------------
+// Inverse of a preconditioner tile (see gml_solver.hip, Newton-CG): A = sc * H_t - s2 g g^T on the tile's first m entries,
+// Cholesky A = L L^T in LDS (left-looking, one thread per row), L^-1 into the upper triangle (thread j owns column j of
+// L^-1, kept as row j above the diagonal), A^-1 = L^-T L^-1 written over the tile as a full symmetric matrix.
+// ------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(256) void k_tile_inverse(double *__restrict__ H, const long long *__restrict__ hoff, const int *__restrict__ vm,
+                                                      const int *__restrict__ wrow, const double *__restrict__ s1, double s2,
+                                                      const double *__restrict__ gV) {
+    constexpr int LP = T + 1;
+    const int64_t v = blockIdx.x;
+    const int m = vm[v], tid = threadIdx.x;
+    if (m == 0) return;
+    double *A = H + hoff[v];
+    const double sc = s1[wrow[v]];
+    extern __shared__ double sm[]; // L [T][T + 1] | gg [T] | dinv [T] | adiag [T]
+    double *L = sm, *gg = sm + T * LP, *dinv = gg + T, *adiag = dinv + T;
+    __shared__ double red[4], pivot;
+    __shared__ int bad;
+    if (tid < T) gg[tid] = (s2 != 0.0 && tid < m) ? gV[v * T + tid] : 0.0;
+    __syncthreads();
+    double dmax = 0.0;
+    if (tid < m) {
+        adiag[tid] = sc * A[(int64_t)tid * T + tid] - s2 * gg[tid] * gg[tid];
+        dmax = fabs(adiag[tid]);
+    }
+    for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
+    if ((tid & 63) == 0) red[tid >> 6] = dmax;
+    __syncthreads();
+    dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    double ridge = 0.0;
+    bool ok = false;
+    for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
+        for (int idx = tid; idx < m * T; idx += 256) {
+            const int i = idx / T, j = idx % T;
+            if (j <= i) L[i * LP + j] = sc * A[(int64_t)i * T + j] - s2 * gg[i] * gg[j] + (i == j ? ridge : 0.0);
+        }
+        if (tid == 0) bad = 0;
+        __syncthreads();
+        for (int c = 0; c < m; ++c) {
+            double x = 0.0;
+            if (tid >= c && tid < m) {
+                double x0 = L[tid * LP + c], x1 = 0.0, x2 = 0.0, x3 = 0.0;
+                int k = 0;
+                for (; k + 3 < c; k += 4) {
+                    x0 = fma(-L[tid * LP + k], L[c * LP + k], x0);
+                    x1 = fma(-L[tid * LP + k + 1], L[c * LP + k + 1], x1);
+                    x2 = fma(-L[tid * LP + k + 2], L[c * LP + k + 2], x2);
+                    x3 = fma(-L[tid * LP + k + 3], L[c * LP + k + 3], x3);
+                }
+                for (; k < c; ++k) x0 = fma(-L[tid * LP + k], L[c * LP + k], x0);
+                x = (x0 + x1) + (x2 + x3);
+                if (tid == c) pivot = x;
+            }
+            __syncthreads();
+            const double piv = pivot;
+            if (!(piv > 1e-12 * dmax) || !isfinite(piv)) { // (uniform: every thread reads the same pivot)
+                if (tid == 0) bad = 1;
+                break;
+            }
+            const double dgc = sqrt(piv);
+            if (tid == c) {
+                L[c * LP + c] = dgc;
+                dinv[c] = 1.0 / dgc;
+            } else if (tid > c && tid < m) {
+                L[tid * LP + c] = x / dgc;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        ok = !bad;
+        __syncthreads();
+        if (!ok) ridge = ridge == 0.0 ? 1e-10 * fmax(dmax, 1e-300) : ridge * 100.0;
+    }
+    if (!ok) { // not positive definite (duplicate statistics): the diagonal
+        for (int idx = tid; idx < m * T; idx += 256) {
+            const int i = idx / T, j = idx % T;
+            if (j < m) A[(int64_t)i * T + j] = i == j ? 1.0 / fmax(adiag[i], 1e-300) : 0.0;
+        }
+        return;
+    }
+    // column j of L^-1 by forward substitution, stored as row j right of the diagonal: U[j][i] = (L^-1)[i][j], i > j
+    if (tid < m) {
+        const int j = tid;
+        const double dj = dinv[j];
+        for (int i = j + 1; i < m; ++i) {
+            double s0 = L[i * LP + j] * dj, s1 = 0.0;
+            int k = j + 1;
+            for (; k + 1 < i; k += 2) {
+                s0 = fma(L[i * LP + k], L[j * LP + k], s0);
+                s1 = fma(L[i * LP + k + 1], L[j * LP + k + 1], s1);
+            }
+            if (k < i) s0 = fma(L[i * LP + k], L[j * LP + k], s0);
+            L[j * LP + i] = -(s0 + s1) * dinv[i];
+        }
+    }
+    __syncthreads();
+    // A^-1[i][j] = sum_{k >= i} (L^-1)[k][i] (L^-1)[k][j],  j <= i
+    for (int idx = tid; idx < m * m; idx += 256) {
+        const int i = idx / m, j = idx % m;
+        if (j > i) continue;
+        double a0 = dinv[i] * (i == j ? dinv[i] : L[j * LP + i]), a1 = 0.0;
+        int k = i + 1;
+        for (; k + 1 < m; k += 2) {
+            a0 = fma(L[i * LP + k], L[j * LP + k], a0);
+            a1 = fma(L[i * LP + k + 1], L[j * LP + k + 1], a1);
+        }
+        if (k < m) a0 = fma(L[i * LP + k], L[j * LP + k], a0);
+        const double a = a0 + a1;
+        A[(int64_t)i * T + j] = a;
+        A[(int64_t)j * T + i] = a;
+    }
+}
+
+void launch_tile_inverse(int T, double *H, const long long *hoff, const int *vm, const int *wrow, const double *s1, double s2, const double *gV,
+                         int64_t ntiles, hipStream_t st) {
+    if (ntiles <= 0) return;
+    const size_t lds = sizeof(double) * ((size_t)T * (T + 1) + 3 * T);
+    if (T == 64) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_inverse<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_tile_inverse<64>, dim3((unsigned)ntiles), dim3(256), lds, st, H, hoff, vm, wrow, s1, s2, gV);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_inverse<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_tile_inverse<128>, dim3((unsigned)ntiles), dim3(256), lds, st, H, hoff, vm, wrow, s1, s2, gV);
+    }
+}
+
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
                          const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st, int maxm) {
     // maxm: largest block of this call, as far as the host knows it (0 = unknown): picks the LDS the one-wave path needs

@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(256) void k_make_hw(const int8_t *__restrict__ Vq, 
                                                  const double *__restrict__ w, const double *__restrict__ tau,
                                                  const int *__restrict__ rowcol /* row -> node */,
                                                  const int *__restrict__ vslot /* row -> slot of its V planes */,
-                                                 const int *__restrict__ mt, int64_t Kp,
+                                                 const int *__restrict__ mt /* rows with mt[r] = 0 are skipped */, int64_t Kp,
                                                  int64_t Hpitch, int64_t kstride, int form, int8_t *__restrict__ Hq,
                                                  long long *__restrict__ hS) {
     const int r = blockIdx.y;
@@ -1168,14 +1168,15 @@ __global__ __launch_bounds__(256, 2) void k_hess_bits_blk(const unsigned *__rest
                                                           const int *__restrict__ F, const int *__restrict__ mt,
                                                           const long long *__restrict__ hoff, int cap, int64_t Kh,
                                                           int64_t Kp, int64_t Hpitch, int64_t kchunk /* multiple of 512 */,
-                                                          int64_t kstride, long long *__restrict__ H64) {
+                                                          int64_t kstride, long long *__restrict__ H64, int z0, int R0,
+                                                          const int *__restrict__ tF, const int *__restrict__ trow, int tT) {
     constexpr int AR = 64, BR = 32 * BT, RP = (AR + BR) / 16; // row pieces
     constexpr int STAGE = (AR + BR) * 64 + 4 * 512, NPIECE = STAGE / 1024, NSG = 3;
     constexpr int NPJ = (NPIECE + 3) / 4;                     // pieces of the waves that carry one more
     constexpr int EBUF = (4 + 2 * BT) * 1024;                 // expanded operands of one step
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     int8_t *eb = lds + NSG * STAGE;
-    const int r = blockIdx.z;
+    const int r = blockIdx.z + z0; // block: a row's working set (r < R0), or tile r - R0 of the matrix-free rows' preconditioner
     const int m = mt[r];
     if (m == 0 || (m <= 4) != (BT == 2)) return; // one launch per size class
     // decode the block index: a = tile-row pair, b = group of BT tile columns, needed iff BT b <= 2a+1
@@ -1193,8 +1194,9 @@ __global__ __launch_bounds__(256, 2) void k_hess_bits_blk(const unsigned *__rest
     if (kb >= Kh) return;
     const int64_t ke = (kb + kchunk < Kh) ? kb + kchunk : Kh;
     const int ngrp = (int)((ke - kb + 511) / 512);
-    const int tile = r >> 5, rl = r & 31;
-    const int *Fr = F + (int64_t)r * cap;
+    const int wr = r < R0 ? r : trow[r - R0]; // the row whose weights this block uses
+    const int tile = wr >> 5, rl = wr & 31;
+    const int *Fr = r < R0 ? F + (int64_t)r * cap : tF + (int64_t)(r - R0) * tT;
     const int mrows = m * 32;
     const int64_t nkk = Kp >> 6;
 
@@ -1312,8 +1314,10 @@ __global__ __launch_bounds__(256, 2) void k_hess_bits_blk(const unsigned *__rest
 __global__ __launch_bounds__(256) void k_hess_i8_fin(const long long *__restrict__ H64, const long long *__restrict__ hS,
                                                      const double *__restrict__ tau, const int *__restrict__ vslot,
                                                      const int *__restrict__ mt,
-                                                     const long long *__restrict__ hoff, double *__restrict__ H) {
-    const int r = blockIdx.y;
+                                                     const long long *__restrict__ hoff, double *__restrict__ H, int y0, int R0,
+                                                     const int *__restrict__ trow) {
+    const int r = blockIdx.y + y0;
+    const int wr = r < R0 ? r : trow[r - R0];
     const int m = mt[r] * 32;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= m * m) return;
@@ -1321,7 +1325,7 @@ __global__ __launch_bounds__(256) void k_hess_i8_fin(const long long *__restrict
     if ((j >> 5) > (i >> 5)) return;
     const long long *Hr = H64 + hoff[r];
     const long long T = Hr[(int64_t)i * m + j], Ti = Hr[(int64_t)i * m + i], Tj = Hr[(int64_t)j * m + j];
-    H[hoff[r] + (int64_t)i * m + j] = tau[vslot[r]] * (double)(hS[r] - 2 * Ti - 2 * Tj + 4 * T);
+    H[hoff[r] + (int64_t)i * m + j] = tau[vslot[wr]] * (double)(hS[wr] - 2 * Ti - 2 * Tj + 4 * T);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1391,7 +1395,8 @@ int64_t i8_hess_kmax(const DevProblem &d) { return d.Kp; }
 
 template <int BT>
 static void launch_hess_blk(const I8Ws *w, const DevProblem &d, const int *dF, const int *dMt, const long long *dHoff, int R, int cap,
-                            int maxm, int64_t Kh, int64_t kstride, int nrows_active /* rows of this size class */, hipStream_t st) {
+                            int maxm, int64_t Kh, int64_t kstride, int64_t nrows_active /* blocks of this size class */, hipStream_t st,
+                            const HessTiles &tl) {
     // blocks (a, b) with BT b <= 2a + 1 for a < ceil(maxm / 2)
     int nblk = 0;
     for (int a = 0; 2 * a < maxm; ++a) nblk += (2 * a + 1) / BT + 1;
@@ -1409,8 +1414,10 @@ static void launch_hess_blk(const I8Ws *w, const DevProblem &d, const int *dF, c
     ns = (int)((Kh + kc - 1) / kc);
     constexpr int shmem = 3 * ((64 + 32 * BT) * 64 + 4 * 512) + 2 * (4 + 2 * BT) * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hess_bits_blk<BT>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-    hipLaunchKernelGGL(k_hess_bits_blk<BT>, dim3((unsigned)ns, (unsigned)nblk, (unsigned)R), dim3(256), shmem, st, w->Mb, w->Hq, dF, dMt,
-                       dHoff, cap, Kh, d.Kp, w->hKh, kc, kstride, w->H64);
+    const int64_t nv = R + tl.n;
+    for (int64_t z0 = 0; z0 < nv; z0 += 32768)
+        hipLaunchKernelGGL(k_hess_bits_blk<BT>, dim3((unsigned)ns, (unsigned)nblk, (unsigned)std::min<int64_t>(32768, nv - z0)), dim3(256), shmem,
+                           st, w->Mb, w->Hq, dF, dMt, dHoff, cap, Kh, d.Kp, w->hKh, kc, kstride, w->H64, (int)z0, R, tl.F, tl.wrow, tl.T);
 }
 
 // Working-set Hessians of the rows 0..R-1 of the caller's arrays (mt[r] = 0: skip) from the int8 limb planes their
@@ -1419,13 +1426,16 @@ static void launch_hess_blk(const I8Ws *w, const DevProblem &d, const int *dF, c
 // (the solver handles larger ones matrix-free).
 int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node */, const int *dVslot /* row -> slot */, const int *dF,
                const int *dMt, const int *hMt, const long long *dHoff, int64_t htotal, int R, int cap, int form, int64_t Kh,
-               int64_t kstride, double *dH, hipStream_t st, std::string *err) {
+               int64_t kstride, double *dH, hipStream_t st, std::string *err, const HessTiles *tiles) {
+    const HessTiles tl = tiles ? *tiles : HessTiles{};
+    const int *dFlag = tl.n > 0 ? tl.hflag : dMt; // rows whose weights are needed
     I8Ws *w = static_cast<I8Ws *>(wsp);
     if (!w) {
         if (err) *err = "no int8 pass has run on this handle";
         return GML_EINVAL;
     }
-    int maxm = 0, maxsmall = 0, nsmall = 0, nlarge = 0;
+    int maxm = 0, maxsmall = 0;
+    int64_t nsmall = 0, nlarge = 0;
     for (int r = 0; r < R; ++r) {
         maxm = hMt[r] > maxm ? hMt[r] : maxm;
         if (hMt[r] <= 4) maxsmall = hMt[r] > maxsmall ? hMt[r] : maxsmall;
@@ -1433,6 +1443,11 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
         else if (hMt[r] > 0) ++nsmall;
     }
     if (maxm > 16) return GML_EUNSUPPORTED;
+    if (tl.n > 0) { // the tiles: tl.n blocks of T / 32 <= 4 tiles each
+        maxm = std::max(maxm, tl.T / 32);
+        maxsmall = std::max(maxsmall, tl.T / 32);
+        nsmall += tl.n;
+    }
     const int64_t pitch = d.Kp, Rp = (R + 31) / 32 * 32;
     if (Kh > pitch) Kh = pitch;
     if (w->hKh != pitch || w->hrows < Rp) {
@@ -1460,11 +1475,15 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
     I8CHK(hipMemsetAsync(w->H64, 0, sizeof(long long) * need, st));
     I8CHK(hipMemsetAsync(w->hS, 0, sizeof(long long) * Rp, st));
     hipLaunchKernelGGL(k_make_hw, dim3((unsigned)(Kh / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Sb, d.w, w->sc[0].tau, dRowcol, dVslot,
-                       dMt, d.Kp, pitch, kstride, form, w->Hq, w->hS);
-    if (maxsmall > 0) launch_hess_blk<2>(w, d, dF, dMt, dHoff, R, cap, maxsmall, Kh, kstride, nsmall, st);
-    if (maxm > 4) launch_hess_blk<4>(w, d, dF, dMt, dHoff, R, cap, maxm, Kh, kstride, nlarge, st);
-    hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64,
-                       w->hS, w->sc[0].tau, dVslot, dMt, dHoff, dH);
+                       dFlag, d.Kp, pitch, kstride, form, w->Hq, w->hS);
+    if (maxsmall > 0) launch_hess_blk<2>(w, d, dF, dMt, dHoff, R, cap, maxsmall, Kh, kstride, nsmall, st, tl);
+    if (maxm > 4) launch_hess_blk<4>(w, d, dF, dMt, dHoff, R, cap, maxm, Kh, kstride, nlarge, st, tl);
+    hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64, w->hS,
+                       w->sc[0].tau, dVslot, dMt, dHoff, dH, 0, R, tl.wrow);
+    const int tm = tl.T / 32;
+    for (int64_t y0 = 0; y0 < tl.n; y0 += 32768)
+        hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((tm * 32 * tm * 32 + 255) / 256), (unsigned)std::min<int64_t>(32768, tl.n - y0)), dim3(256),
+                           0, st, w->H64, w->hS, w->sc[0].tau, dVslot, dMt, dHoff, dH, (int)(R + y0), R, tl.wrow);
     I8CHK(hipGetLastError());
     return GML_OK;
 }

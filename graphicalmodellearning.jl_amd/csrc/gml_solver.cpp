@@ -148,9 +148,10 @@ struct Solver {
     int capW = 0, capP = 0;
     double lambda = 0;
     int64_t Smain = 0, Scap = 0; // slots of the int8-limb workspace: main range (V planes feed the Hessians) + scratch range
-    double viol_frac = 0.5, cg_eta = 0.05;
+    double viol_frac = 0.5, cg_eta = 0.05, eta_admit = 0.25;
     int maxcg = 16, hv_lf = 2, hv_lb = 2;
-    int64_t dbg_row = 0;
+    int64_t dbg_row = 0, worst_row = 0;
+    const double t_begin = gml_now_s();
     int prec = GML_PREC_I8X; // arithmetic of the passes: switches to FP64 for the rows the int8 path leaves above tol ("polish")
     bool can_polish = false;
     int stall_cap = 10;
@@ -158,6 +159,10 @@ struct Solver {
     // ---- device state ----------------------------------------------------------------------------------------------------
     double *X = nullptr, *G = nullptr, *Xt = nullptr, *Gt = nullptr, *Xb = nullptr, *D = nullptr, *PG = nullptr, *Gs = nullptr;
     double *Rv = nullptr, *Pv = nullptr, *Hp = nullptr, *Zv = nullptr; // CG vectors, on first use
+    uint8_t *Wm = nullptr;                                             // ... and the mask of the system's coordinates
+    FaceOut *dFaces = nullptr;
+    int face_rounds = 2;      // re-solves of a CG system without the coordinates its step would push through zero
+    double face_share = 0.05; // ... for the rows where those carry more than this share of the predicted decrease
     uint8_t *kind = nullptr;
     int *dNode = nullptr, *dRows = nullptr, *dRows2 = nullptr, *dRowsP = nullptr, *dFidx = nullptr, *dHv = nullptr;
     char *dPass = nullptr;  // control block of a pass: srow | rowcol | groups | tau overrides (one upload)
@@ -170,14 +175,21 @@ struct Solver {
     TrialOut *dTrial = nullptr;
     int64_t dH_elems = 0;
     // pointers into dHctl (set by direction_blocks)
-    int *dMt = nullptr, *dMsCg = nullptr, *dVslot = nullptr;
+    int *dMt = nullptr, *dVslot = nullptr;
     long long *dHoff = nullptr;
-    double *dS1 = nullptr, *dS1cg = nullptr, *dDinv = nullptr;
+    double *dS1 = nullptr, *dS1cg = nullptr;
+    // preconditioner tiles of the matrix-free rows (direction_blocks): control block, column lists, gradient entries
+    static constexpr int kTile = 128;
+    char *dTctl = nullptr;
+    size_t dTctl_bytes = 0;
+    int *dFV = nullptr, *dVm = nullptr, *dWrow = nullptr, *dLive = nullptr;
+    double *dgV = nullptr;
+    int64_t tile_cap = 0, ntiles = 0, tile_base = 0; // capacity of dFV / dgV in tiles; tiles of this iteration; offset of the first in dH
 
     // ---- host state (scalars per row) ------------------------------------------------------------------------------------
     std::vector<double> f, ft, Fobj, kkt, best, Z, Zt, alpha, dd, fn, fnt, l1t, Fbest;
     std::vector<uint8_t> done, vstale, atfloor, nreg, accepted_fwd, need, iscg;
-    std::vector<int> stall, msz, vslot, vprev, owner, pslot;
+    std::vector<int> stall, msz, nW, vslot, vprev, owner, pslot;
     std::vector<SelectOut> sel;
     std::vector<TrialOut> trial;
     int64_t slot_next = 0;
@@ -201,6 +213,9 @@ struct Solver {
             fflush(stderr);
         }
     }
+    // still building its support: violators at the scale of the support itself (k_select admits them by halves of the largest
+    // violation; once they are few next to the support, all at once)
+    bool admitting(int64_t r) const { return (int64_t)sel[r].nviol * 16 > sel[r].nsupp; }
     int upload_rows(const std::vector<int> &rows, int *dst) {
         if (!rows.empty()) HIPCHK(stg.h2d(dst, rows.data(), sizeof(int) * rows.size()));
         return GML_OK;
@@ -241,6 +256,8 @@ int Solver::init() {
     // 0.7 converges too, in 1.6x the iterations)
     viol_frac = o.cg_viol_frac > 0 ? o.cg_viol_frac : 0.5;
     cg_eta = o.cg_eta > 0 ? o.cg_eta : 0.05;
+    if (o.reserved0 != 0) face_rounds = o.reserved0 < 0 ? 0 : o.reserved0; // (experiment)
+    eta_admit = o.cg_eta < 0 ? -o.cg_eta : 0.25; // (experiment: a negative cg_eta sets the residual target of the admitting rows)
     // at most 16 CG steps per Newton step: the number of Newton iterations is set by the admission of the violators, not by
     // the accuracy of the directions (order-3 probe: 32 iterations with a cap of 40, 16 or 15 -- 545 / 349 / 333
     // Hessian-vector passes; 40 iterations, 279 passes with a cap of 8)
@@ -294,6 +311,7 @@ int Solver::init() {
     HIPCHK(A.get(&dRowsP, (size_t)Rp));
     HIPCHK(A.get(&dPass, (size_t)(sizeof(int) * (2 * Scap + Scap / 32 + 16) + sizeof(double) * Scap + 64)));
     HIPCHK(A.get(&dHctl, (size_t)(sizeof(int) * 5 * Rp + sizeof(long long) * (Rp + 1) + sizeof(double) * 3 * Rp + 256)));
+    HIPCHK(A.get(&dLive, (size_t)Rp));
     HIPCHK(A.get(&dRes, (size_t)Scap));
     HIPCHK(A.get(&dFidx, (size_t)Rp * capP));
     HIPCHK(A.get(&dCg, (size_t)Rp));
@@ -335,6 +353,7 @@ int Solver::init() {
     for (auto *v : {&done, &vstale, &atfloor, &nreg, &accepted_fwd, &need, &iscg}) v->assign((size_t)R, 0);
     stall.assign((size_t)R, 0);
     msz.assign((size_t)R, 0);
+    nW.assign((size_t)R, 0);
     vslot.assign((size_t)R, -1);
     vprev.assign((size_t)R, -1);
     pslot.assign((size_t)R, -1);
@@ -634,20 +653,27 @@ int Solver::select(int it, int64_t *nactive_out) {
         }
         ++nactive;
         iscg[r] = s.m < 0;
-        msz[r] = s.m < 0 ? s.pad : s.m; // working set of the Cholesky step, or the preconditioner block of a matrix-free row
+        msz[r] = s.m < 0 ? 0 : s.m; // working set of the Cholesky step
+        nW[r] = s.m < 0 ? -s.m : 0; // ... of a matrix-free row (listed in tiles for its preconditioner)
         if (iscg[r]) ++ncg;
         maxm = std::max(maxm, msz[r]);
     }
+    worst_row = 0;
     for (int64_t r = 0; r < R; ++r) {
         if (done[r]) msz[r] = 0;
-        worst_all = std::max(worst_all, std::min(kkt[r], best[r]));
+        const double k = std::min(kkt[r], best[r]);
+        if (k > worst_all) worst_row = r;
+        worst_all = std::max(worst_all, k);
     }
     if (o.verbose)
-        fprintf(stderr, "[gml] it %3d active %6lld (cg %lld)  max-kkt %.3e  max|W| %d  passes %d fwd %d%s\n", it, (long long)nactive,
-                (long long)ncg, worst_all, maxm, stats.passes, stats.forward_passes, prec == GML_PREC_F64 && o.precision != prec ? "  [fp64 polish]" : "");
-    if (o.verbose >= 2 && dbg_row < R)
-        fprintf(stderr, "[gml]   row %lld: kkt %.3e best %.3e F %.15e m %d nsupp %d nviol %d stall %d\n", (long long)dbg_row, kkt[dbg_row],
-                best[dbg_row], Fobj[dbg_row], sel[dbg_row].m, sel[dbg_row].nsupp, sel[dbg_row].nviol, stall[dbg_row]);
+        fprintf(stderr, "[gml] it %3d active %6lld (cg %lld)  max-kkt %.3e  max|W| %d  passes %d fwd %d  hv %lld  t %.2f s%s\n", it, (long long)nactive,
+                (long long)ncg, worst_all, maxm, stats.passes, stats.forward_passes, (long long)stats.hv_evals, gml_now_s() - t_begin,
+                prec == GML_PREC_F64 && o.precision != prec ? "  [fp64 polish]" : "");
+    if (o.verbose >= 2)
+        for (int64_t r : {dbg_row, worst_row})
+            if (r < R && (r == dbg_row || worst_row != dbg_row))
+                fprintf(stderr, "[gml]   row %lld: kkt %.3e best %.3e F %.15e m %d nsupp %d nviol %d stall %d\n", (long long)r, kkt[r], best[r], Fobj[r],
+                        sel[r].m, sel[r].nsupp, sel[r].nviol, stall[r]);
     *nactive_out = nactive;
     return GML_OK;
 }
@@ -704,63 +730,136 @@ int Solver::refresh_stale() {
 }
 
 // Hessian blocks (int8 kernel over the limb planes of the rows' last passes, or the FP64 MFMA kernel over V): the working
-// set of a Cholesky row, the preconditioner block of a matrix-free row.  One upload carries the whole control block.
+// set of a Cholesky row; for a matrix-free row the tiles of its block-diagonal preconditioner (gml_solver.hip), inverted here.
+// One upload carries the control block of the rows, one that of the tiles.
 int Solver::direction_blocks(const std::vector<int> &cg_rows) {
     if (!cg_rows.empty() && prec != GML_PREC_I8X) {
-        // FP64 phase: the curvature weights of the matrix-free rows' Hessian-vector products come from an int8-limb objective
-        // pass at the same iterate (those products run on the int8 cores either way; only the curvature is approximate)
+        // FP64 phase: the curvature weights of the matrix-free rows' Hessian-vector products and preconditioner tiles come from
+        // an int8-limb objective pass at the same iterate (those run on the int8 cores either way; only the curvature is
+        // approximate)
         std::vector<double> tf((size_t)R), tz((size_t)R, 1.0), tn((size_t)R);
         RCCHK(run_pass(cg_rows, X, nullptr, false, false, tf, tz, tn, nullptr, 0, GML_PREC_I8X));
     }
-    // layout of the block: mt [R] | node [R] | msz of the Cholesky rows [R] | msz of the CG rows [R] | vslot [R] | hoff [R+1] |
-    // s1 [Rp] | dinv [Rp] | s1cg [Rp]
+    // layout of the block: mt [R] | node [R] | msz of the Cholesky rows [R] | (unused) [R] | vslot [R] | hoff [R+1] |
+    // s1 [Rp] | (unused) [Rp] | s1cg [Rp]
     const size_t ibytes = (sizeof(int) * 5 * R + 7) & ~(size_t)7, lbytes = sizeof(long long) * (R + 1);
     std::vector<char> blk(ibytes + lbytes + sizeof(double) * 3 * Rp, 0);
-    int *mt2 = reinterpret_cast<int *>(blk.data()), *mscg = mt2 + 3 * R, *vs = mt2 + 4 * R;
+    int *mt2 = reinterpret_cast<int *>(blk.data()), *vs = mt2 + 4 * R;
     long long *hoff = reinterpret_cast<long long *>(blk.data() + ibytes);
-    double *s1 = reinterpret_cast<double *>(blk.data() + ibytes + lbytes), *dinv = s1 + Rp, *s1cg = s1 + 2 * Rp;
+    double *s1 = reinterpret_cast<double *>(blk.data() + ibytes + lbytes), *s1cg = s1 + 2 * Rp;
     hoff[0] = 0;
-    for (int64_t r = 0; r < Rp; ++r) s1[r] = dinv[r] = s1cg[r] = 1.0;
+    for (int64_t r = 0; r < Rp; ++r) s1[r] = s1cg[r] = 1.0;
     for (int64_t r = 0; r < R; ++r) {
-        const int m = done[r] ? 0 : msz[r];
+        const int m = done[r] || iscg[r] ? 0 : msz[r];
         mt2[r] = (m + 31) / 32;
         mt2[R + r] = (int)(p->node0 + r);
-        mt2[2 * R + r] = iscg[r] ? 0 : m; // the Cholesky step solves these
-        mscg[r] = iscg[r] ? m : 0;        // the preconditioner solves of the matrix-free rows
+        mt2[2 * R + r] = m; // the Cholesky step solves these
         vs[r] = vslot[r];
         hoff[r + 1] = hoff[r] + (long long)mt2[r] * 32 * mt2[r] * 32;
         const double zi = formulation == GML_LOGRISE ? 1.0 / Z[r] : 1.0; // Hess log Z = Hess Z / Z - g g^T
         s1[r] = hscale * zi; // sub-sampled blocks
         s1cg[r] = zi;        // the Hessian-vector products use every configuration
-        // the common diagonal of the operator: sum_k h_k (RISE: f; logRISE: Z / Z = 1; RPLE: at most 1)
-        dinv[r] = formulation == GML_RISE ? 1.0 / std::max(f[r], 1e-300) : 1.0;
     }
-    const int64_t htotal = std::max<long long>(hoff[R], 1);
+    // the tiles: kTile consecutive entries of W each, behind the rows' blocks
+    constexpr int T = kTile;
+    std::vector<long long> t0((size_t)R, 0);
+    ntiles = 0;
+    for (int r : cg_rows) {
+        t0[r] = ntiles;
+        ntiles += (nW[r] + T - 1) / T;
+    }
+    tile_base = hoff[R];
+    const int64_t NV = R + ntiles, htotal = std::max<long long>(tile_base + ntiles * (long long)T * T, 1);
+    std::vector<int> mtV, vmV, wrowV, hflag;
+    std::vector<long long> hoffV;
+    if (ntiles > 0) {
+        mtV.assign((size_t)NV, T / 32);
+        hoffV.resize((size_t)NV);
+        vmV.resize((size_t)ntiles);
+        wrowV.resize((size_t)ntiles);
+        hflag.assign((size_t)R, 0);
+        const bool rows_i8 = prec == GML_PREC_I8X; // (FP64 phase: the rows' blocks come from launch_hess_f64, not from this call)
+        for (int64_t r = 0; r < R; ++r) {
+            mtV[r] = rows_i8 ? mt2[r] : 0;
+            hoffV[r] = hoff[r];
+            hflag[r] = mtV[r] > 0;
+        }
+        for (int r : cg_rows) {
+            const int64_t nt = (nW[r] + T - 1) / T;
+            hflag[r] = 1;
+            for (int64_t t = 0; t < nt; ++t) {
+                vmV[t0[r] + t] = (int)std::min<int64_t>(T, nW[r] - t * T);
+                wrowV[t0[r] + t] = r;
+                hoffV[R + t0[r] + t] = tile_base + (t0[r] + t) * (long long)T * T;
+            }
+        }
+    }
     if (htotal > dH_elems) {
         dH_elems = htotal + htotal / 4;
         HIPCHK(A.get(&dH, (size_t)dH_elems));
     }
-    if (prec == GML_PREC_I8X)
-        for (int64_t r = 0; r < R; ++r)
-            if (mt2[r] > 0 && (vslot[r] < 0 || vslot[r] >= Scap || owner[vslot[r]] != r || vstale[r]))
-                return fail(GML_EHIP, "internal: row %lld enters the Hessian without valid V planes (slot %d, owner %d, stale %d)",
-                            (long long)r, vslot[r], vslot[r] >= 0 && vslot[r] < Scap ? owner[vslot[r]] : -2, (int)vstale[r]);
+    for (int64_t r = 0; r < R; ++r) {
+        const bool needs_planes = (prec == GML_PREC_I8X && mt2[r] > 0) || (ntiles > 0 && iscg[r] && !done[r]);
+        if (needs_planes && (vslot[r] < 0 || vslot[r] >= Scap || owner[vslot[r]] != r || vstale[r]))
+            return fail(GML_EHIP, "internal: row %lld enters the Hessian without valid V planes (slot %d, owner %d, stale %d)", (long long)r,
+                        vslot[r], vslot[r] >= 0 && vslot[r] < Scap ? owner[vslot[r]] : -2, (int)vstale[r]);
+    }
     HIPCHK(stg.h2d(dHctl, blk.data(), blk.size()));
     dMt = reinterpret_cast<int *>(dHctl);
-    dMsCg = dMt + 3 * R;
     dVslot = dMt + 4 * R;
     dHoff = reinterpret_cast<long long *>(dHctl + ibytes);
     dS1 = reinterpret_cast<double *>(dHctl + ibytes + lbytes);
-    dDinv = dS1 + Rp;
     dS1cg = dS1 + 2 * Rp;
+    HessTiles tl;
+    int *dMtV = dMt;
+    long long *dHoffV = dHoff;
+    if (ntiles > 0) {
+        // control block of the tiles: hoffV [NV] | t0 [R] | mtV [NV] | vm [ntiles] | wrow [ntiles] | hflag [R]
+        const size_t tb = sizeof(long long) * (NV + R) + sizeof(int) * (NV + 2 * ntiles + R);
+        if (tb > dTctl_bytes) {
+            dTctl_bytes = tb + tb / 4;
+            HIPCHK(A.get(&dTctl, dTctl_bytes));
+        }
+        if (ntiles > tile_cap) {
+            tile_cap = ntiles + ntiles / 4;
+            HIPCHK(A.get(&dFV, (size_t)tile_cap * T));
+            HIPCHK(A.get(&dgV, (size_t)tile_cap * T));
+        }
+        std::vector<char> tblk(tb);
+        long long *h_hoff = reinterpret_cast<long long *>(tblk.data()), *h_t0 = h_hoff + NV;
+        int *h_mt = reinterpret_cast<int *>(h_t0 + R), *h_vm = h_mt + NV, *h_wrow = h_vm + ntiles, *h_flag = h_wrow + ntiles;
+        std::memcpy(h_hoff, hoffV.data(), sizeof(long long) * NV);
+        std::memcpy(h_t0, t0.data(), sizeof(long long) * R);
+        std::memcpy(h_mt, mtV.data(), sizeof(int) * NV);
+        std::memcpy(h_vm, vmV.data(), sizeof(int) * ntiles);
+        std::memcpy(h_wrow, wrowV.data(), sizeof(int) * ntiles);
+        std::memcpy(h_flag, hflag.data(), sizeof(int) * R);
+        HIPCHK(stg.h2d(dTctl, tblk.data(), tb));
+        dHoffV = reinterpret_cast<long long *>(dTctl);
+        const long long *dT0 = dHoffV + NV;
+        dMtV = reinterpret_cast<int *>(dTctl + sizeof(long long) * (NV + R));
+        dVm = dMtV + NV;
+        dWrow = dVm + ntiles;
+        RCCHK(upload_rows(cg_rows, dRows2));
+        launch_cg_tiles(dRows2, (int)cg_rows.size(), X, PG, G, kind, Qp, T, dT0, dFV, dgV, st);
+        tl.n = ntiles;
+        tl.T = T;
+        tl.F = dFV;
+        tl.wrow = dWrow;
+        tl.hflag = dWrow + ntiles;
+    }
     HIPCHK(hipMemsetAsync(dH, 0, sizeof(double) * htotal, st));
     trace("hessian");
-    if (prec == GML_PREC_I8X) {
+    if (prec == GML_PREC_I8X || ntiles > 0) {
         std::string err;
-        const int hrc = i8_hessian(p->i8ws, d, dMt + R, dVslot, dFidx, dMt, mt2, dHoff, htotal, (int)R, capP, formulation, Kh, kstride, dH, st, &err);
+        const int hrc = i8_hessian(p->i8ws, d, dMt + R, dVslot, dFidx, dMtV, ntiles > 0 ? mtV.data() : mt2, dHoffV, htotal, (int)R, capP, formulation, Kh,
+                                   kstride, dH, st, &err, ntiles > 0 ? &tl : nullptr);
         if (hrc) return fail(hrc, "%s", err.empty() ? "int8 Hessian: working set above 512 entries" : err.c_str());
-    } else {
-        launch_hess_f64(d, p->dV, dMt + R, dFidx, dMt, dHoff, (int)R, capP, formulation, Kh, kstride, dH, st);
+    }
+    if (prec != GML_PREC_I8X) launch_hess_f64(d, p->dV, dMt + R, dFidx, dMt, dHoff, (int)R, capP, formulation, Kh, kstride, dH, st);
+    if (ntiles > 0) {
+        trace("tile inverses");
+        launch_tile_inverse(T, dH, dHoffV + R, dVm, dWrow, dS1, formulation == GML_LOGRISE ? 1.0 : 0.0, dgV, ntiles, st);
     }
     HIPCHK(hipGetLastError());
     ++stats.hessian_passes;
@@ -783,7 +882,7 @@ int Solver::newton_blocks(const std::vector<int> &chol_rows) {
 
 // Matrix-free Newton-CG: H_WW d = -pg_W by preconditioned conjugate gradients, Hessian-vector products from the device
 // operator (forward GEMM of the direction, weights of the rows' last objective pass, backward GEMM), preconditioner =
-// the Cholesky-factored Hessian block of the row's strongest entries + the common diagonal elsewhere.  Inexact Newton:
+// the inverted Hessian blocks of tiles of kTile neighbouring entries of W (direction_blocks).  Inexact Newton:
 // the residual is reduced by eta = min(cg_eta, sqrt(kkt)), in at most max_cg steps.
 int Solver::newton_cg(const std::vector<int> &cg_rows) {
     if (cg_rows.empty()) return GML_OK;
@@ -797,7 +896,8 @@ int Solver::newton_cg(const std::vector<int> &cg_rows) {
     // iterations).
     std::vector<int> coarse, fine;
     const double thr = std::max(1e3 * o.tol, 1e-5);
-    for (int r : cg_rows) (sel[r].nviol > 0 && kkt[r] > thr ? coarse : fine).push_back(r);
+    for (int r : cg_rows) (o.hv_subsample != 1 && admitting(r) && kkt[r] > thr ? coarse : fine).push_back(r);
+    if (o.verbose >= 2) fprintf(stderr, "[gml]   cg groups: %zu rows admitting (sub-sampled curvature), %zu rows with every configuration\n", coarse.size(), fine.size());
     RCCHK(newton_cg_group(coarse, true));
     return newton_cg_group(fine, false);
 }
@@ -811,12 +911,17 @@ int Solver::newton_cg_group(const std::vector<int> &cg_rows, bool subsample) {
         HIPCHK(A.get(&Pv, nd));
         HIPCHK(A.get(&Hp, nd));
         HIPCHK(A.get(&Zv, nd));
+        HIPCHK(A.get(&Wm, nd));
+        HIPCHK(A.get(&dFaces, (size_t)Rp));
         HIPCHK(A.get(&dHv, (size_t)(3 * Rp + Rp / 32 + 8)));
     }
     RCCHK(upload_rows(cg_rows, dRows2));
-    launch_pcg_init(dRows2, (int)cg_rows.size(), X, PG, kind, Qp, dFidx, dMsCg, capP, D, Rv, dpgF, dCg, st);
-    launch_newton_solve(dH, dHoff, dMt, dMsCg, dS1, s2, dgF, dpgF, (int)R, capP, dsol, dSdiag, st);
-    launch_pcg_dir(dRows2, (int)cg_rows.size(), Qp, dFidx, dMsCg, capP, dsol, dDinv, Rv, Zv, Pv, 1, dCg, st);
+    std::vector<int> liveflag((size_t)Rp, 0);
+    for (int r : cg_rows) liveflag[r] = 1;
+    HIPCHK(stg.h2d(dLive, liveflag.data(), sizeof(int) * Rp));
+    launch_pcg_init(dRows2, (int)cg_rows.size(), X, PG, kind, Qp, D, Rv, Zv, Wm, dCg, st);
+    launch_tile_apply(kTile, dH + tile_base, dFV, dVm, dWrow, dLive, ntiles, Qp, Rv, Zv, st);
+    launch_pcg_dir(dRows2, (int)cg_rows.size(), Qp, Wm, Rv, Zv, Pv, 1, dCg, st);
     // Sub-sampled curvature: the Hessian-vector products run over ~1/ksub of the configurations -- as many as keep 32 of
     // them per working-set entry (the sample covariance of |W| statistics from 32 |W| configurations has its eigenvalues
     // within (1 +- 0.18)^2 of the true ones: a Newton step that is only solved to a 5 % residual loses nothing to that) --
@@ -847,21 +952,19 @@ int Solver::newton_cg_group(const std::vector<int> &cg_rows, bool subsample) {
             }
         }
     }
-    std::vector<CgState> cgs((size_t)Rp);
-    std::vector<int> live = cg_rows;
-    for (int ci = 0; ci < maxcg && !live.empty(); ++ci) {
-        // Hp = H p for the live rows: an hv pass over slots [0, n) of the u-plane workspace
-        const int64_t n = (int64_t)live.size(), np = gml_round_up(n, 32);
+    // Hout = (sum_k h_k x_k x_k^T) theta for the listed rows: an hv pass over slots [0, n) of the u-plane workspace
+    auto hv_pass = [&](const std::vector<int> &rows, const double *theta, double *Hout) -> int {
+        const int64_t n = (int64_t)rows.size(), np = gml_round_up(n, 32);
         std::vector<int> ctl((size_t)(3 * np + np / 32 + 4), -1);
         for (int64_t a = 0; a < np; ++a) {
-            ctl[a] = a < n ? live[a] : 0;
-            ctl[np + a] = a < n ? (int)(p->node0 + live[a]) : -1;
-            ctl[2 * np + a] = a < n ? vslot[live[a]] : 0;
+            ctl[a] = a < n ? rows[a] : 0;
+            ctl[np + a] = a < n ? (int)(p->node0 + rows[a]) : -1;
+            ctl[2 * np + a] = a < n ? vslot[rows[a]] : 0;
         }
         for (int64_t g = 0; g < np / 32; ++g) ctl[3 * np + g] = (int)g;
         HIPCHK(stg.h2d(dHv, ctl.data(), sizeof(int) * ctl.size()));
         I8Pass a{};
-        a.theta = Pv;
+        a.theta = theta;
         a.srow = dHv;
         a.rowcol = dHv + np;
         a.vmap = dHv + 2 * np;
@@ -872,7 +975,7 @@ int Solver::newton_cg_group(const std::vector<int> &cg_rows, bool subsample) {
         a.form = formulation;
         a.want_grad = true;
         a.F = nullptr;
-        a.G = Hp;
+        a.G = Hout;
         a.hv = hv_lb == 2 ? 2 : 1;
         a.lf = hv_lf;
         a.kchunk = kchunk;
@@ -880,24 +983,72 @@ int Solver::newton_cg_group(const std::vector<int> &cg_rows, bool subsample) {
         std::string err;
         const int rc = i8_pass(&p->i8ws, d, Scap, a, st, nullptr, &err);
         if (rc) return fail(rc, "%s", err.c_str());
-        RCCHK(upload_rows(live, dRows2));
-        launch_pcg_step(dRows2, (int)live.size(), X, PG, G, kind, Qp, dS1cg, s2, dFidx, dMsCg, capP, Hp, D, Rv, Pv, dpgF, dCg, st);
-        HIPCHK(stg.d2h(cgs.data(), dCg, sizeof(CgState) * Rp));
-        HIPCHK(hipGetLastError());
-        HIPCHK(stg.sync());
         ++stats.hessian_passes;
         stats.hv_evals += n;
-        std::vector<int> nxt;
-        for (int r : live) {
-            const double eta = std::min(cg_eta, std::sqrt(std::max(kkt[r], 1e-300)));
-            if (cgs[r].pHp > 0 && cgs[r].rs > eta * eta * cgs[r].rs0) nxt.push_back(r);
+        return GML_OK;
+    };
+    auto set_live = [&](const std::vector<int> &rows) -> int {
+        RCCHK(upload_rows(rows, dRows2));
+        std::fill(liveflag.begin(), liveflag.end(), 0);
+        for (int r : rows) liveflag[r] = 1;
+        HIPCHK(stg.h2d(dLive, liveflag.data(), sizeof(int) * Rp));
+        return GML_OK;
+    };
+    std::vector<CgState> cgs((size_t)Rp);
+    std::vector<FaceOut> faces((size_t)Rp);
+    std::vector<int> cur = cg_rows; // rows of this round
+    for (int round = 0;; ++round) {
+        std::vector<int> live = cur;
+        for (int ci = 0; ci < maxcg && !live.empty(); ++ci) {
+            RCCHK(hv_pass(live, Pv, Hp));
+            RCCHK(upload_rows(live, dRows2));
+            launch_pcg_step(dRows2, (int)live.size(), G, Wm, Qp, dS1cg, s2, Hp, D, Rv, Pv, dCg, st);
+            HIPCHK(stg.d2h(cgs.data(), dCg, sizeof(CgState) * Rp));
+            HIPCHK(hipGetLastError());
+            HIPCHK(stg.sync());
+            std::vector<int> nxt;
+            for (int r : live) {
+                // a row that is still admitting violators needs a step that is good at the scale of its largest violation, not more
+                const double eta = admitting(r) ? eta_admit : std::min(cg_eta, std::sqrt(std::max(kkt[r], 1e-300)));
+                if (cgs[r].pHp > 0 && cgs[r].rs > eta * eta * cgs[r].rs0) nxt.push_back(r);
+            }
+            if (o.verbose >= 2) {
+                fprintf(stderr, "[gml]   cg %2d: %zu rows live", ci, nxt.size());
+                for (int64_t r : {dbg_row, worst_row})
+                    if (r < R && std::find(cur.begin(), cur.end(), (int)r) != cur.end())
+                        fprintf(stderr, "  row %lld |r|/|r0| %.3e", (long long)r, std::sqrt(cgs[r].rs / std::max(cgs[r].rs0, 1e-300)));
+                fprintf(stderr, "\n");
+            }
+            live.swap(nxt);
+            if (live.empty()) break;
+            RCCHK(set_live(live));
+            launch_tile_apply(kTile, dH + tile_base, dFV, dVm, dWrow, dLive, ntiles, Qp, Rv, Zv, st);
+            launch_pcg_dir(dRows2, (int)live.size(), Qp, Wm, Rv, Zv, Pv, 0, dCg, st);
         }
-        if (o.verbose >= 2) fprintf(stderr, "[gml]   cg %2d: %zu rows live\n", ci, nxt.size());
-        live.swap(nxt);
-        if (live.empty()) break;
-        RCCHK(upload_rows(live, dRows2));
-        launch_newton_solve(dH, dHoff, dMt, dMsCg, dS1, s2, dgF, dpgF, (int)R, capP, dsol, dSdiag, st);
-        launch_pcg_dir(dRows2, (int)live.size(), Qp, dFidx, dMsCg, capP, dsol, dDinv, Rv, Zv, Pv, 0, dCg, st);
+        if (round >= face_rounds) break;
+        // orthant faces (gml_solver.hip, k_pcg_faces): the rows whose projected step would lose a noticeable part of its
+        // predicted decrease to the clipping solve again without the clipped coordinates
+        RCCHK(upload_rows(cur, dRows2));
+        launch_pcg_faces(dRows2, (int)cur.size(), X, PG, kind, Qp, D, Wm, dFaces, st);
+        HIPCHK(stg.d2h(faces.data(), dFaces, sizeof(FaceOut) * Rp));
+        HIPCHK(hipGetLastError());
+        HIPCHK(stg.sync());
+        std::vector<int> again;
+        int64_t nfixed = 0;
+        for (int r : cur) {
+            nfixed += faces[r].nfixed;
+            if (faces[r].nfixed > 0 && faces[r].mass > face_share * faces[r].total) again.push_back(r);
+        }
+        if (o.verbose >= 2)
+            fprintf(stderr, "[gml]   cg faces (round %d): %lld coordinates fixed at zero in %zu rows; %zu rows solve again\n", round, (long long)nfixed,
+                    cur.size(), again.size());
+        if (again.empty()) break;
+        cur.swap(again);
+        RCCHK(hv_pass(cur, D, Hp));
+        RCCHK(set_live(cur));
+        launch_pcg_resid(dRows2, (int)cur.size(), PG, G, Qp, dS1cg, s2, Hp, D, Wm, Rv, dCg, st);
+        launch_tile_apply(kTile, dH + tile_base, dFV, dVm, dWrow, dLive, ntiles, Qp, Rv, Zv, st);
+        launch_pcg_dir(dRows2, (int)cur.size(), Qp, Wm, Rv, Zv, Pv, 1, dCg, st);
     }
     return GML_OK;
 }
@@ -978,6 +1129,11 @@ int Solver::line_search() {
                     stall[r] += 3; // after at most three such line searches (each costs ~7 passes)
                 }
             }
+        }
+        if (o.verbose >= 2) {
+            int nn = 0;
+            for (int r : rows) nn += nreg[r] != 0;
+            fprintf(stderr, "[gml]   ls %2d: %zu rows (%d in the noise regime), %zu accepted, %s pass\n", ls, rows.size(), nn, acc.size(), full ? "full" : "forward");
         }
         RCCHK(upload_rows(acc, dRows2));
         launch_copy_rows(dRows2, (int)acc.size(), Qp, Xt, X, full ? Gt : nullptr, G, st);

@@ -10,10 +10,15 @@ struct SelectOut {
     double worstW; // the same over the current support
     int m;         // working-set size (Cholesky row), or -|W| for a matrix-free (Newton-CG) row
     int nsupp, nviol;
-    int pad;       // matrix-free rows: size of the preconditioner block S gathered in F (0 otherwise)
+    int pad;
 };
 struct CgState {
     double rs, rs0, pHp, rz;
+};
+struct FaceOut {
+    int nfixed, pad; // coordinates of W whose step left the orthant face (fixed at zero, removed from W)
+    double mass;     // their share sum |pg_c (d_c - fixed_c)| of ...
+    double total;    // ... sum |pg_c d_c| over W
 };
 struct TrialOut {
     double dd;    // pg . (xt - x)
@@ -38,12 +43,19 @@ void launch_trial(const int *drows, int nrows, const double *X, const double *D,
                   double lambda, const double *alpha, double *Xt, TrialOut *out, hipStream_t st);
 void launch_back(const int *drows, int nrows, const double *X, const double *Xt, const double *Gt, const uint8_t *kind, int64_t Qp,
                  double lambda, TrialOut *out, hipStream_t st);
-void launch_pcg_init(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, const int *F,
-                     const int *ms, int capP, double *D, double *Rv, double *nrS, CgState *cg, hipStream_t st);
-void launch_pcg_dir(const int *drows, int nrows, int64_t Qp, const int *F, const int *ms, int capP, const double *zS, const double *dinv,
-                    const double *Rv, double *Zv, double *Pv, int first, CgState *cg, hipStream_t st);
-void launch_pcg_step(const int *drows, int nrows, const double *X, const double *PG, const double *G, const uint8_t *kind, int64_t Qp,
-                     const double *s1, double s2, const int *F, const int *ms, int capP, double *Hp, double *D, double *Rv, const double *Pv,
-                     double *nrS, CgState *cg, hipStream_t st);
+void launch_cg_tiles(const int *drows, int nrows, const double *X, const double *PG, const double *G, const uint8_t *kind, int64_t Qp, int T,
+                     const long long *t0, int *FV, double *gV, hipStream_t st);
+void launch_tile_apply(int T, const double *Minv, const int *FV, const int *vm, const int *wrow, const int *live, int64_t ntiles, int64_t Qp,
+                       const double *Rv, double *Zv, hipStream_t st);
+void launch_pcg_init(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, double *D, double *Rv,
+                     double *Zv, uint8_t *Wm, CgState *cg, hipStream_t st);
+void launch_pcg_dir(const int *drows, int nrows, int64_t Qp, const uint8_t *Wm, const double *Rv, const double *Zv, double *Pv, int first,
+                    CgState *cg, hipStream_t st);
+void launch_pcg_step(const int *drows, int nrows, const double *G, const uint8_t *Wm, int64_t Qp, const double *s1, double s2, double *Hp,
+                     double *D, double *Rv, const double *Pv, CgState *cg, hipStream_t st);
+void launch_pcg_faces(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, double *D, uint8_t *Wm,
+                      FaceOut *out, hipStream_t st);
+void launch_pcg_resid(const int *drows, int nrows, const double *PG, const double *G, int64_t Qp, const double *s1, double s2, const double *Hd,
+                      const double *D, const uint8_t *Wm, double *Rv, CgState *cg, hipStream_t st);
 
 } // namespace gml

@@ -150,7 +150,7 @@ void launch_copy_rows(const int *drows, int nrows, int64_t Qp, const double *s0,
 //   none while the residual on the support still dominates (worstW ~ worst: the violations outside are then largely
 //   an artefact of the unconverged support) -- written in ascending column order to F[r][0..m), with g and pg
 //   gathered next to it; when W exceeds capW the row is flagged for the matrix-free Newton-CG instead (m = -|W|,
-//   W = every column with x != 0 or pg != 0; nothing is gathered).
+//   W = every column with x != 0 or pg != 0 after the admission cut; nothing is gathered).
 // Also keeps the best iterate: if worst < best[r], best[r] = worst and Xbest[r] = X[r].
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ G,
@@ -242,14 +242,12 @@ __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, co
     __syncthreads();
     const int m = scan[256];
     if (m > capW) {
-        // Matrix-free row: W = the support + every violator (dense vectors, nothing gathered).  For the block
-        // preconditioner of its CG the strongest capW entries of W are gathered instead: the free column plus the
-        // largest |x_c| + |pg_c| -- the strongly coupled statistics sit there, the remainder of W (coefficients at the
-        // noise level) has a Hessian close to a multiple of the identity.
+        // Matrix-free row: W = the support + the admitted violators (dense vectors, nothing gathered here: k_cg_tiles lists W
+        // for the preconditioner once the host knows its size, m = -|W|).
         // Only the violators within viol_frac of the largest one enter W in this iteration (the others keep pg = 0 in the
         // dense array, which defines W for the CG and the line search): thousands of coordinates leaving zero at once, most
         // of them to come back, make the projected Newton step a poor one.
-        if (viol_frac > 0.0) {
+        if (viol_frac > 0.0 && nviol * 16 > nsupp) { // (a few violators next to a large support: all of them)
             double mv = 0.0;
             for (int64_t c = tid; c < Qp; c += 256)
                 if (kr[c] == 2 && x[c] == 0.0) mv = fmax(mv, fabs(pgr[c]));
@@ -259,46 +257,11 @@ __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, co
                 if (kr[c] == 2 && x[c] == 0.0 && fabs(pgr[c]) < cut) pgr[c] = 0.0;
             __syncthreads();
         }
-        unsigned lo = 0, hi = 0x7f800000u; // invariant: count(score >= lo) > capW - 1 >= count(score >= hi)
-        while (hi - lo > 1) {
-            const unsigned mid = lo + (hi - lo) / 2;
-            int c2 = 0;
-            for (int64_t c = tid; c < Qp; c += 256)
-                if (kr[c] == 2 && (x[c] != 0.0 || pgr[c] != 0.0) && __float_as_uint((float)(fabs(x[c]) + fabs(pgr[c]))) >= mid) ++c2;
-            c2 = block_sum_i(c2, redi);
-            if (c2 > capW - 1) lo = mid;
-            else hi = mid;
-        }
-        int c3 = 0;
-        for (int64_t c = c0; c < c1; ++c) {
-            const uint8_t k = kr[c];
-            c3 += k == 1 || (k == 2 && (x[c] != 0.0 || pgr[c] != 0.0) && __float_as_uint((float)(fabs(x[c]) + fabs(pgr[c]))) >= hi);
-        }
-        __syncthreads();
-        scan[tid + 1] = c3;
-        if (tid == 0) scan[0] = 0;
-        __syncthreads();
-        if (tid == 0)
-            for (int t = 1; t <= 256; ++t) scan[t] += scan[t - 1];
-        __syncthreads();
-        const int ms = scan[256]; // <= capW
-        int pos = scan[tid];
-        for (int64_t c = c0; c < c1; ++c) {
-            const uint8_t k = kr[c];
-            if (k == 1 || (k == 2 && (x[c] != 0.0 || pgr[c] != 0.0) && __float_as_uint((float)(fabs(x[c]) + fabs(pgr[c]))) >= hi)) {
-                F[(int64_t)r * capP + pos] = (int)c;
-                gF[(int64_t)r * capP + pos] = g[c];
-                pgF[(int64_t)r * capP + pos] = pgr[c];
-                ++pos;
-            }
-        }
-        for (int a = ms + tid; a < capP; a += 256) {
-            F[(int64_t)r * capP + a] = (int)(Qp - 1);
-            gF[(int64_t)r * capP + a] = 0.0;
-            pgF[(int64_t)r * capP + a] = 0.0;
-        }
-        o.m = -(nsupp + (addv ? nviol : 0));
-        o.pad = ms;
+        int cw = 0;
+        for (int64_t c = tid; c < Qp; c += 256) cw += kr[c] && (x[c] != 0.0 || pgr[c] != 0.0);
+        cw = block_sum_i(cw, redi);
+        o.m = -cw;
+        o.pad = 0;
     } else {
         int pos = scan[tid];
         for (int64_t c = c0; c < c1; ++c) {
@@ -448,17 +411,100 @@ void launch_back(const int *drows, int nrows, const double *X, const double *Xt,
 // ------------------------------------------------------------------------------------------
 // Matrix-free Newton-CG on the rows whose working set is too large for a Cholesky block (dense optima: lambda at the
 // level of the sampling noise): solve H_WW d = -pg_W by preconditioned conjugate gradients, W = {c : x_c != 0 or
-// pg_c != 0}, with H p from the device operator (two GEMM passes, i8_pass with hv = 1).  Preconditioner
-// M = blockdiag(A_SS, a I): the (sub-sampled) Hessian block of the row's strongest capW entries S (k_select), solved by
-// the batched Cholesky kernel, and the common diagonal a of the rest (the statistics are +-1: every diagonal entry of
-// sum_k h_k x_k x_k^T is sum_k h_k).  Vectors live in [rows][Qp] arrays; the per-row scalars in CgState; the S parts
-// travel through the gathered arrays nrS / zS.
+// pg_c != 0}, with H p from the device operator (two GEMM passes, i8_pass with hv = 1).
+//
+// Preconditioner: block-diagonal.  W is listed in column order and cut into tiles of T consecutive entries; each tile's
+// (sub-sampled) Hessian block is inverted once per Newton iteration (k_tile_inverse) and applied as a dense T x T product
+// per CG step (k_tile_apply).  Why tiles of neighbours: the statistics are products of spins, so
+// H[(j,k),(l,m)] = E_h[s_j s_k s_l s_m] is largest between statistics that share a spin or pair up correlated ones -- and
+// the column order (sorted keys) puts those next to each other.  The common diagonal alone (every H_cc = sum_k h_k) or the
+// block of the |W|/14 strongest entries leaves CG at the condition number of the spin correlations squared (measured on a
+// 256-spin analogue of config 5: 11 steps to a 5 % residual, 29 to 1e-3; tiles of 64: 6 / 16; of 128: 5 / 13).
+// Vectors live in [rows][Qp] arrays; the per-row scalars in CgState.
 // ------------------------------------------------------------------------------------------
-// r = -pg on W, d = 0; nrS = -r gathered at S (the Cholesky kernel solves A z = -rhs)
+// W of the listed rows in column order, in tiles: FV[(t0[r] T + a)] = a-th column of W, gV = its gradient entry (logRISE:
+// the rank-one term of the block); the last tile of a row is padded with the all-plus column Qp - 1 (never used: the
+// inverse and the product stop at the tile's entry count).
+__global__ __launch_bounds__(256) void k_cg_tiles(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ PG,
+                                                  const double *__restrict__ G, const uint8_t *__restrict__ kind, int64_t Qp, int T,
+                                                  const long long *__restrict__ t0, int *__restrict__ FV, double *__restrict__ gV) {
+    const int r = rows[blockIdx.x], tid = threadIdx.x;
+    const int64_t base = (int64_t)r * Qp;
+    __shared__ int scan[257];
+    const int64_t chunk = (Qp + 255) / 256, c0 = tid * chunk, c1 = c0 + chunk < Qp ? c0 + chunk : Qp;
+    int cnt = 0;
+    for (int64_t c = c0; c < c1; ++c) cnt += kind[base + c] && (X[base + c] != 0.0 || PG[base + c] != 0.0);
+    scan[tid + 1] = cnt;
+    if (tid == 0) scan[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int t = 1; t <= 256; ++t) scan[t] += scan[t - 1];
+    __syncthreads();
+    int *fv = FV + t0[r] * T;
+    double *gv = gV + t0[r] * T;
+    int pos = scan[tid];
+    for (int64_t c = c0; c < c1; ++c)
+        if (kind[base + c] && (X[base + c] != 0.0 || PG[base + c] != 0.0)) {
+            fv[pos] = (int)c;
+            gv[pos] = G[base + c];
+            ++pos;
+        }
+    const int m = scan[256], mp = (m + T - 1) / T * T;
+    for (int a = m + tid; a < mp; a += 256) {
+        fv[a] = (int)(Qp - 1);
+        gv[a] = 0.0;
+    }
+}
+void launch_cg_tiles(const int *drows, int nrows, const double *X, const double *PG, const double *G, const uint8_t *kind, int64_t Qp, int T,
+                     const long long *t0, int *FV, double *gV, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_cg_tiles, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, PG, G, kind, Qp, T, t0, FV, gV);
+}
+
+// z_tile = Minv_tile r_tile for every tile of a live row (one workgroup per tile; Minv symmetric, pitch T, read by columns:
+// coalesced)
+template <int T>
+__global__ __launch_bounds__(256) void k_tile_apply(const double *__restrict__ Minv, const int *__restrict__ FV, const int *__restrict__ vm,
+                                                    const int *__restrict__ wrow, const int *__restrict__ live, int64_t Qp,
+                                                    const double *__restrict__ Rv, double *__restrict__ Zv) {
+    const int64_t v = blockIdx.x;
+    const int wr = wrow[v];
+    if (!live[wr]) return;
+    const int m = vm[v], tid = threadIdx.x;
+    constexpr int NH = 256 / T; // threads per output entry
+    __shared__ double rt[T], part[256];
+    const int *fv = FV + v * T;
+    if (tid < T) rt[tid] = tid < m ? Rv[(int64_t)wr * Qp + fv[tid]] : 0.0;
+    __syncthreads();
+    const int i = tid % T, hf = tid / T;
+    const double *Mi = Minv + v * T * T;
+    double s0 = 0.0, s1 = 0.0;
+    const int j0 = hf * (T / NH), j1 = min(m, j0 + T / NH);
+    int j = j0;
+    for (; j + 1 < j1; j += 2) {
+        s0 = fma(Mi[(int64_t)j * T + i], rt[j], s0);
+        s1 = fma(Mi[(int64_t)(j + 1) * T + i], rt[j + 1], s1);
+    }
+    if (j < j1) s0 = fma(Mi[(int64_t)j * T + i], rt[j], s0);
+    part[tid] = s0 + s1;
+    __syncthreads();
+    if (tid < T && tid < m) {
+        double z = part[tid];
+#pragma unroll
+        for (int q = 1; q < NH; ++q) z += part[tid + q * T];
+        Zv[(int64_t)wr * Qp + fv[tid]] = z;
+    }
+}
+void launch_tile_apply(int T, const double *Minv, const int *FV, const int *vm, const int *wrow, const int *live, int64_t ntiles, int64_t Qp,
+                       const double *Rv, double *Zv, hipStream_t st) {
+    if (ntiles <= 0) return;
+    if (T == 64) hipLaunchKernelGGL(k_tile_apply<64>, dim3((unsigned)ntiles), dim3(256), 0, st, Minv, FV, vm, wrow, live, Qp, Rv, Zv);
+    else hipLaunchKernelGGL(k_tile_apply<128>, dim3((unsigned)ntiles), dim3(256), 0, st, Minv, FV, vm, wrow, live, Qp, Rv, Zv);
+}
+
+// r = -pg on W, d = 0, z = 0;  Wm = the mask of W (k_pcg_faces shrinks it)
 __global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ PG,
-                                                  const uint8_t *__restrict__ kind, int64_t Qp, const int *__restrict__ F,
-                                                  const int *__restrict__ ms, int capP, double *__restrict__ D, double *__restrict__ Rv,
-                                                  double *__restrict__ nrS, CgState *__restrict__ cg) {
+                                                  const uint8_t *__restrict__ kind, int64_t Qp, double *__restrict__ D, double *__restrict__ Rv,
+                                                  double *__restrict__ Zv, uint8_t *__restrict__ Wm, CgState *__restrict__ cg) {
     const int r = rows[blockIdx.x];
     __shared__ double red[4];
     double rs = 0;
@@ -468,10 +514,11 @@ __global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ rows, 
         const double v = inW ? -PG[i] : 0.0;
         Rv[i] = v;
         D[i] = 0.0;
+        Zv[i] = 0.0;
+        Wm[i] = inW;
         rs += v * v;
     }
     rs = block_sum(rs, red);
-    for (int a = threadIdx.x; a < ms[r]; a += 256) nrS[(int64_t)r * capP + a] = -Rv[(int64_t)r * Qp + F[(int64_t)r * capP + a]];
     if (threadIdx.x == 0) {
         cg[r].rs = rs;
         cg[r].rs0 = rs;
@@ -479,45 +526,119 @@ __global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ rows, 
         cg[r].rz = 0.0;
     }
 }
-void launch_pcg_init(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, const int *F,
-                     const int *ms, int capP, double *D, double *Rv, double *nrS, CgState *cg, hipStream_t st) {
-    if (nrows > 0) hipLaunchKernelGGL(k_pcg_init, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, PG, kind, Qp, F, ms, capP, D, Rv, nrS, cg);
+void launch_pcg_init(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, double *D, double *Rv,
+                     double *Zv, uint8_t *Wm, CgState *cg, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_pcg_init, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, PG, kind, Qp, D, Rv, Zv, Wm, cg);
 }
 
-// z = M^-1 r: z_S = zS (from the Cholesky solve), z_c = dinv[r] * r_c elsewhere on W;  beta = r.z / (r.z)_old (0 on the first
-// call);  p = z + beta p.  Zv is scratch for z.
-__global__ __launch_bounds__(256) void k_pcg_dir(const int *__restrict__ rows, int64_t Qp, const int *__restrict__ F,
-                                                 const int *__restrict__ ms, int capP, const double *__restrict__ zS,
-                                                 const double *__restrict__ dinv, const double *__restrict__ Rv, double *__restrict__ Zv,
-                                                 double *__restrict__ Pv, int first, CgState *__restrict__ cg) {
+// With z = M^-1 r in Zv (k_tile_apply over the tiles of the original W; the preconditioner of the current, possibly smaller,
+// W is its restriction: z is masked):  beta = r.z / (r.z)_old (0 on the first call);  p = z + beta p.
+__global__ __launch_bounds__(256) void k_pcg_dir(const int *__restrict__ rows, int64_t Qp, const uint8_t *__restrict__ Wm,
+                                                 const double *__restrict__ Rv, const double *__restrict__ Zv, double *__restrict__ Pv, int first,
+                                                 CgState *__restrict__ cg) {
     const int r = rows[blockIdx.x];
     const int64_t base = (int64_t)r * Qp;
     __shared__ double red[4];
-    const double di = dinv[r], rzo = cg[r].rz;
-    for (int64_t c = threadIdx.x; c < Qp; c += 256) Zv[base + c] = di * Rv[base + c];
-    __syncthreads();
-    for (int a = threadIdx.x; a < ms[r]; a += 256) Zv[base + F[(int64_t)r * capP + a]] = zS[(int64_t)r * capP + a];
-    __syncthreads();
+    const double rzo = cg[r].rz;
     double rz = 0;
-    for (int64_t c = threadIdx.x; c < Qp; c += 256) rz += Rv[base + c] * Zv[base + c];
+    for (int64_t c = threadIdx.x; c < Qp; c += 256)
+        if (Wm[base + c]) rz += Rv[base + c] * Zv[base + c];
     rz = block_sum(rz, red);
     const double be = (!first && rzo > 0) ? rz / rzo : 0.0;
-    for (int64_t c = threadIdx.x; c < Qp; c += 256) Pv[base + c] = Zv[base + c] + (first ? 0.0 : be * Pv[base + c]);
+    for (int64_t c = threadIdx.x; c < Qp; c += 256) Pv[base + c] = Wm[base + c] ? Zv[base + c] + (first ? 0.0 : be * Pv[base + c]) : 0.0;
     if (threadIdx.x == 0) cg[r].rz = rz;
 }
-void launch_pcg_dir(const int *drows, int nrows, int64_t Qp, const int *F, const int *ms, int capP, const double *zS, const double *dinv,
-                    const double *Rv, double *Zv, double *Pv, int first, CgState *cg, hipStream_t st) {
-    if (nrows > 0) hipLaunchKernelGGL(k_pcg_dir, dim3((unsigned)nrows), dim3(256), 0, st, drows, Qp, F, ms, capP, zS, dinv, Rv, Zv, Pv, first, cg);
+void launch_pcg_dir(const int *drows, int nrows, int64_t Qp, const uint8_t *Wm, const double *Rv, const double *Zv, double *Pv, int first,
+                    CgState *cg, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_pcg_dir, dim3((unsigned)nrows), dim3(256), 0, st, drows, Qp, Wm, Rv, Zv, Pv, first, cg);
+}
+
+// Orthant faces.  The Newton system is solved on W without its sign constraints; the line search then projects the step onto
+// the orthant of the iterate (k_trial): a coordinate at zero may only move against its pseudo-gradient, a non-zero one not
+// past zero.  With correlated statistics the unconstrained solution is full of large moves that cancel each other; clipping
+// one of a pair leaves the other uncompensated and the projected step climbs (config 5 at the default regulariser: a
+// quarter of the rows accepted only alpha = 1/16 .. 1/64).  So after the CG solve the coordinates whose step leaves the face
+// are fixed where the projection would put them -- at zero -- and removed from W, and the system is solved again for the
+// others (bound-constrained QP by an active-set CG): out = {number fixed, their share of the predicted decrease}.
+__global__ __launch_bounds__(256) void k_pcg_faces(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ PG,
+                                                   const uint8_t *__restrict__ kind, int64_t Qp, double *__restrict__ D,
+                                                   uint8_t *__restrict__ Wm, FaceOut *__restrict__ out) {
+    const int r = rows[blockIdx.x];
+    const int64_t base = (int64_t)r * Qp;
+    __shared__ double red[4];
+    __shared__ int redi[4];
+    int nf = 0;
+    double mass = 0, total = 0;
+    for (int64_t c = threadIdx.x; c < Qp; c += 256) {
+        const int64_t i = base + c;
+        if (!Wm[i]) continue;
+        const double x = X[i], dc = D[i], pg = PG[i];
+        total += fabs(pg * dc);
+        if (kind[i] != 2) continue;
+        if (x == 0.0 ? dc * pg > 0.0 : (x + dc) * x < 0.0) {
+            const double fixed = x == 0.0 ? 0.0 : -x;
+            mass += fabs(pg * (dc - fixed));
+            D[i] = fixed;
+            Wm[i] = 0;
+            ++nf;
+        }
+    }
+    nf = block_sum_i(nf, redi);
+    mass = block_sum(mass, red);
+    total = block_sum(total, red);
+    if (threadIdx.x == 0) {
+        FaceOut o;
+        o.nfixed = nf;
+        o.pad = 0;
+        o.mass = mass;
+        o.total = total;
+        out[r] = o;
+    }
+}
+void launch_pcg_faces(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, double *D, uint8_t *Wm,
+                      FaceOut *out, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_pcg_faces, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, PG, kind, Qp, D, Wm, out);
+}
+
+// Residual of the shrunk system: given Hd = (sum_k h_k x_k x_k^T) d,  r = -pg - (s1 Hd - s2 g (g . d)) on W, 0 elsewhere
+__global__ __launch_bounds__(256) void k_pcg_resid(const int *__restrict__ rows, const double *__restrict__ PG, const double *__restrict__ G,
+                                                   int64_t Qp, const double *__restrict__ s1, double s2, const double *__restrict__ Hd,
+                                                   const double *__restrict__ D, const uint8_t *__restrict__ Wm, double *__restrict__ Rv,
+                                                   CgState *__restrict__ cg) {
+    const int r = rows[blockIdx.x];
+    const int64_t base = (int64_t)r * Qp;
+    __shared__ double red[4];
+    double gd = 0;
+    if (s2 != 0.0) {
+        for (int64_t c = threadIdx.x; c < Qp; c += 256) gd += G[base + c] * D[base + c];
+        gd = block_sum(gd, red);
+    }
+    const double sc = s1[r];
+    double rs = 0;
+    for (int64_t c = threadIdx.x; c < Qp; c += 256) {
+        const int64_t i = base + c;
+        const double v = Wm[i] ? -PG[i] - (sc * Hd[i] - s2 * G[i] * gd) : 0.0;
+        Rv[i] = v;
+        rs += v * v;
+    }
+    rs = block_sum(rs, red);
+    if (threadIdx.x == 0) {
+        cg[r].rs = rs;
+        cg[r].pHp = 0.0;
+        cg[r].rz = 0.0;
+    }
+}
+void launch_pcg_resid(const int *drows, int nrows, const double *PG, const double *G, int64_t Qp, const double *s1, double s2, const double *Hd,
+                      const double *D, const uint8_t *Wm, double *Rv, CgState *cg, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_pcg_resid, dim3((unsigned)nrows), dim3(256), 0, st, drows, PG, G, Qp, s1, s2, Hd, D, Wm, Rv, cg);
 }
 
 // Given Hp = (sum_k h_k x_k x_k^T) p from the device:
-//   Hp <- s1[r] * Hp - s2 * g (g . p), restricted to W   (logRISE: Hess log Z = Hess Z / Z - g g^T, s1 = 1/Z, s2 = 1)
-//   alpha = r.z / p.Hp;  d += alpha p;  r -= alpha Hp;  rs = r.r;  -r_S gathered for the next preconditioner solve
-__global__ __launch_bounds__(256) void k_pcg_step(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ PG,
-                                                  const double *__restrict__ G, const uint8_t *__restrict__ kind, int64_t Qp,
-                                                  const double *__restrict__ s1, double s2, const int *__restrict__ F,
-                                                  const int *__restrict__ ms, int capP, double *__restrict__ Hp, double *__restrict__ D,
-                                                  double *__restrict__ Rv, const double *__restrict__ Pv, double *__restrict__ nrS,
+//   Hp <- s1[r] * Hp - s2 * g (g . p), restricted to W (mask Wm)   (logRISE: Hess log Z = Hess Z / Z - g g^T, s1 = 1/Z, s2 = 1)
+//   alpha = r.z / p.Hp;  d += alpha p;  r -= alpha Hp;  rs = r.r
+__global__ __launch_bounds__(256) void k_pcg_step(const int *__restrict__ rows, const double *__restrict__ G, const uint8_t *__restrict__ Wm,
+                                                  int64_t Qp, const double *__restrict__ s1, double s2, double *__restrict__ Hp,
+                                                  double *__restrict__ D, double *__restrict__ Rv, const double *__restrict__ Pv,
                                                   CgState *__restrict__ cg) {
     const int r = rows[blockIdx.x];
     const int64_t base = (int64_t)r * Qp;
@@ -532,8 +653,7 @@ __global__ __launch_bounds__(256) void k_pcg_step(const int *__restrict__ rows, 
     double pHp = 0;
     for (int64_t c = threadIdx.x; c < Qp; c += 256) {
         const int64_t i = base + c;
-        const bool inW = kind[i] && (X[i] != 0.0 || PG[i] != 0.0);
-        const double h = inW ? sc * Hp[i] - s2 * G[i] * gp : 0.0;
+        const double h = Wm[i] ? sc * Hp[i] - s2 * G[i] * gp : 0.0;
         Hp[i] = h;
         pHp += Pv[i] * h;
     }
@@ -548,17 +668,14 @@ __global__ __launch_bounds__(256) void k_pcg_step(const int *__restrict__ rows, 
         rsn += rv * rv;
     }
     rsn = block_sum(rsn, red);
-    for (int a = threadIdx.x; a < ms[r]; a += 256) nrS[(int64_t)r * capP + a] = -Rv[base + F[(int64_t)r * capP + a]];
     if (threadIdx.x == 0) {
         cg[r].rs = rsn;
         cg[r].pHp = pHp;
     }
 }
-void launch_pcg_step(const int *drows, int nrows, const double *X, const double *PG, const double *G, const uint8_t *kind, int64_t Qp,
-                     const double *s1, double s2, const int *F, const int *ms, int capP, double *Hp, double *D, double *Rv, const double *Pv,
-                     double *nrS, CgState *cg, hipStream_t st) {
-    if (nrows > 0)
-        hipLaunchKernelGGL(k_pcg_step, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, PG, G, kind, Qp, s1, s2, F, ms, capP, Hp, D, Rv, Pv, nrS, cg);
+void launch_pcg_step(const int *drows, int nrows, const double *G, const uint8_t *Wm, int64_t Qp, const double *s1, double s2, double *Hp,
+                     double *D, double *Rv, const double *Pv, CgState *cg, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_pcg_step, dim3((unsigned)nrows), dim3(256), 0, st, drows, G, Wm, Qp, s1, s2, Hp, D, Rv, Pv, cg);
 }
 
 } // namespace gml

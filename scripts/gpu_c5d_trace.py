@@ -1,0 +1,19 @@
+"""Config 5 at the default regulariser, full size, with the solver's per-iteration trace on stderr (verbose 2); run under
+rocprofv3 --kernel-trace --stats for the kernel split of the direction phase.  usage: gpu_c5d_trace.py [key=value ...]"""
+import sys, time
+sys.path.insert(0, '.')
+import gml_amd as gml
+from importlib import import_module
+syn = import_module('gml_amd.synthetic')
+kw = {}
+for a in sys.argv[1:]:
+    k, v = a.split('=')
+    kw[k] = float(v) if '.' in v or 'e' in v else int(v)
+n, K = 512, 1000000
+terms = syn.block_multibody_terms(n, block=16, seed=0)
+with gml.Problem(terms=terms, n=n, num_samples=K, seed=5, order=3) as p:
+    t0 = time.time()
+    opts = dict(tol=1e-8, precision="i8x", max_iter=150, verbose=2, raise_on_fail=False)
+    opts.update(kw)
+    out, kkt, st = p.learn("RISE", 0.4, **opts)
+    print("learn_s", time.time() - t0, {k: st[k] for k in ("iterations", "passes", "forward_passes", "hessian_passes", "hv_evals", "t_pass", "t_hess", "t_host", "max_kkt", "not_converged")})
