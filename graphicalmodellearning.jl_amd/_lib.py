@@ -280,7 +280,7 @@ class Problem:
 
     def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="auto", max_working=512, max_add=64,
               verbose=0, hess_samples=0, polish=True, max_cg=0, limbs_fwd=0, hv_limbs_fwd=0, hv_limbs_bwd=0, debug_row=0,
-              hv_subsample=0, cg_viol_frac=0.0, cg_eta=0.0, reserved0=0, out_ptr=None, raise_on_fail=True):
+              hv_subsample=0, cg_viol_frac=0.0, cg_eta=0.0, out_ptr=None, raise_on_fail=True):
         L = lib()
         o = Opts()
         L.gml_default_opts(C.byref(o))
@@ -291,7 +291,6 @@ class Problem:
         o.max_cg = int(max_cg)
         o.limbs_fwd, o.hv_limbs_fwd, o.hv_limbs_bwd, o.debug_row = int(limbs_fwd), int(hv_limbs_fwd), int(hv_limbs_bwd), int(debug_row)
         o.cg_viol_frac, o.cg_eta, o.hv_subsample = float(cg_viol_frac), float(cg_eta), int(hv_subsample)
-        o.reserved0 = int(reserved0)
         R = self.node1 - self.node0
         out = None
         if out_ptr is None:

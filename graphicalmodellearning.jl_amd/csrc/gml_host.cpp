@@ -6,6 +6,7 @@
 // device passes.  All arithmetic over the K configurations happens in HIP kernels
 // (gml_kernels_f64.hip, gml_kernels_i8.hip); there is no CPU fallback for it.
 #include "gml_internal.h"
+#include "gml_solver.h"
 #include "gml_pack.h"
 
 #include <algorithm>
@@ -1647,6 +1648,65 @@ extern "C" int gml_bench_pass(gml_problem *p, int formulation, int precision, co
     kernel_ms[0] = sum[0] / steps;
     kernel_ms[1] = sum[1] / steps;
     kernel_ms[2] = kernel_ms[0] + kernel_ms[1];
+    return GML_OK;
+}
+
+// Test hook (not part of include/gml.h): the block-diagonal preconditioner of the matrix-free rows on caller-given tiles -- tile t is
+// a T x T row-major symmetric block of which the leading m_t x m_t part counts; z_t = (s1 H_t - s2 g_t g_t^T)^-1 r_t, by the same two
+// kernels the CG uses (launch_tile_inverse, then launch_tile_apply with the tiles' entries laid out consecutively in one row).
+// tests/test_gpu_newton_solve.py.
+extern "C" int gml_test_tile_precond(int T, int ntiles, const int *m, const double *tiles /* ntiles x T x T */, double s1, double s2,
+                                     const double *g /* ntiles x T */, const double *r /* ntiles x T */, double *z_out /* ntiles x T */,
+                                     int device) {
+    if ((T != 64 && T != 128) || ntiles <= 0) return fail(GML_EINVAL, "bad tile size");
+    HIPCHK(hipSetDevice(device));
+    const size_t nt = (size_t)ntiles, ne = nt * T;
+    std::vector<long long> hoff(nt);
+    std::vector<int> wrow(nt, 0), fv(ne), live(1, 1);
+    for (size_t t = 0; t < nt; ++t) hoff[t] = (long long)t * T * T;
+    for (size_t e = 0; e < ne; ++e) fv[e] = (int)e; // tile t owns the columns [t T, (t + 1) T) of the one row
+    double *dH = nullptr, *dS1 = nullptr, *dG = nullptr, *dR = nullptr, *dZ = nullptr;
+    long long *dHoff = nullptr;
+    int *dM = nullptr, *dWrow = nullptr, *dFv = nullptr, *dLive = nullptr;
+    auto freeall = [&]() {
+        void *ptrs[] = {dH, dS1, dG, dR, dZ, dHoff, dM, dWrow, dFv, dLive};
+        for (void *q : ptrs)
+            if (q) (void)hipFree(q);
+    };
+#define TCHK2(expr)                                                                              \
+    do {                                                                                        \
+        if ((expr) != hipSuccess) {                                                             \
+            freeall();                                                                          \
+            return fail(GML_EHIP, "%s failed: %s", #expr, hipGetErrorString(hipGetLastError())); \
+        }                                                                                       \
+    } while (0)
+    TCHK2(hipMalloc(&dH, sizeof(double) * ne * T));
+    TCHK2(hipMalloc(&dS1, sizeof(double)));
+    TCHK2(hipMalloc(&dG, sizeof(double) * ne));
+    TCHK2(hipMalloc(&dR, sizeof(double) * ne));
+    TCHK2(hipMalloc(&dZ, sizeof(double) * ne));
+    TCHK2(hipMalloc(&dHoff, sizeof(long long) * nt));
+    TCHK2(hipMalloc(&dM, sizeof(int) * nt));
+    TCHK2(hipMalloc(&dWrow, sizeof(int) * nt));
+    TCHK2(hipMalloc(&dFv, sizeof(int) * ne));
+    TCHK2(hipMalloc(&dLive, sizeof(int)));
+    TCHK2(hipMemcpy(dH, tiles, sizeof(double) * ne * T, hipMemcpyHostToDevice));
+    TCHK2(hipMemcpy(dS1, &s1, sizeof(double), hipMemcpyHostToDevice));
+    TCHK2(hipMemcpy(dG, g, sizeof(double) * ne, hipMemcpyHostToDevice));
+    TCHK2(hipMemcpy(dR, r, sizeof(double) * ne, hipMemcpyHostToDevice));
+    TCHK2(hipMemset(dZ, 0, sizeof(double) * ne));
+    TCHK2(hipMemcpy(dHoff, hoff.data(), sizeof(long long) * nt, hipMemcpyHostToDevice));
+    TCHK2(hipMemcpy(dM, m, sizeof(int) * nt, hipMemcpyHostToDevice));
+    TCHK2(hipMemcpy(dWrow, wrow.data(), sizeof(int) * nt, hipMemcpyHostToDevice));
+    TCHK2(hipMemcpy(dFv, fv.data(), sizeof(int) * ne, hipMemcpyHostToDevice));
+    TCHK2(hipMemcpy(dLive, live.data(), sizeof(int), hipMemcpyHostToDevice));
+    launch_tile_inverse(T, dH, dHoff, dM, dWrow, dS1, s2, dG, ntiles, nullptr);
+    launch_tile_apply(T, dH, dFv, dM, dWrow, dLive, ntiles, (int64_t)ne, dR, dZ, nullptr);
+    TCHK2(hipGetLastError());
+    TCHK2(hipDeviceSynchronize());
+    TCHK2(hipMemcpy(z_out, dZ, sizeof(double) * ne, hipMemcpyDeviceToHost));
+#undef TCHK2
+    freeall();
     return GML_OK;
 }
 

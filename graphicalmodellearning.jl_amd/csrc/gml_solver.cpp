@@ -256,8 +256,6 @@ int Solver::init() {
     // 0.7 converges too, in 1.6x the iterations)
     viol_frac = o.cg_viol_frac > 0 ? o.cg_viol_frac : 0.5;
     cg_eta = o.cg_eta > 0 ? o.cg_eta : 0.05;
-    if (o.reserved0 != 0) face_rounds = o.reserved0 < 0 ? 0 : o.reserved0; // (experiment)
-    eta_admit = o.cg_eta < 0 ? -o.cg_eta : 0.25; // (experiment: a negative cg_eta sets the residual target of the admitting rows)
     // at most 16 CG steps per Newton step: the number of Newton iterations is set by the admission of the violators, not by
     // the accuracy of the directions (order-3 probe: 32 iterations with a cap of 40, 16 or 15 -- 545 / 349 / 333
     // Hessian-vector passes; 40 iterations, 279 passes with a cap of 8)

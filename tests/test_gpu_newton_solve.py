@@ -47,3 +47,42 @@ def test_batched_newton_solve_matches_numpy(sizes, logrise):
     for r, m in enumerate(sizes):
         scale = np.abs(want[r]).max()
         assert np.abs(got[r, :m] - want[r]).max() <= 1e-9 * scale, (m, np.abs(got[r, :m] - want[r]).max() / scale)
+
+
+@pytest.mark.parametrize("T", [64, 128])
+@pytest.mark.parametrize("logrise", [False, True])
+def test_tile_preconditioner_matches_numpy(T, logrise):
+    """The block-diagonal preconditioner of the matrix-free rows (launch_tile_inverse + launch_tile_apply): full and partial tiles, a
+    tile of one entry, and a tile that is not positive definite (two identical statistics), which must fall back to its diagonal."""
+    L = _lib.lib()
+    L.gml_test_tile_precond.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(T + logrise)
+    sizes = [T, T, T - 1, T // 2 + 3, 1, 17, T]
+    nt = len(sizes)
+    tiles = np.zeros((nt, T, T))
+    g = np.zeros((nt, T))
+    r = rng.normal(size=(nt, T))
+    s1, s2 = 0.7, (1.0 if logrise else 0.0)
+    want = []
+    for t, m in enumerate(sizes):
+        X = rng.choice([-1.0, 1.0], size=(6 * m + 40, m))
+        if t == nt - 1:
+            X[:, 5] = X[:, 9]  # duplicate statistic: singular block
+        h = rng.random(len(X))
+        H = (X * h[:, None]).T @ X / len(h)
+        gg = rng.normal(size=m) * 0.05 if logrise else np.zeros(m)
+        tiles[t, :m, :m] = H / s1 + (np.outer(gg, gg) / s1 if logrise else 0.0)  # so that s1 H - s2 g g^T = the SPD matrix above
+        tiles[t, m:, m:] = np.eye(T - m) * 3.0  # padding entries (the kernels must not touch them)
+        g[t, :m] = gg
+        A = s1 * tiles[t, :m, :m] - s2 * np.outer(gg, gg)
+        want.append(r[t, :m] / np.diag(A) if t == nt - 1 else np.linalg.solve(A, r[t, :m]))
+    z = np.zeros((nt, T))
+    ms = np.array(sizes, dtype=np.int32)
+    _lib.check(L.gml_test_tile_precond(T, nt, _lib._ptr(ms), _lib._ptr(np.ascontiguousarray(tiles)), s1, s2, _lib._ptr(g), _lib._ptr(r), _lib._ptr(z), 0))
+    for t, m in enumerate(sizes):
+        if t == nt - 1:  # ridge-regularised inverse or the diagonal: either way a finite, symmetric positive definite action
+            assert np.isfinite(z[t]).all() and r[t, :m] @ z[t, :m] > 0
+            continue
+        scale = np.abs(want[t]).max()
+        assert np.abs(z[t, :m] - want[t]).max() <= 1e-9 * scale, (t, m, np.abs(z[t, :m] - want[t]).max() / scale)
+        assert (z[t, m:] == 0).all()
