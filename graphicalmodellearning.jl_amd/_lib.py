@@ -128,6 +128,13 @@ def _hist_args(samples):
     return s, DTYPES[s.dtype], K, n, (K if col_major else n + 1), int(col_major)
 
 
+def trim_cache():
+    """Return the device memory the library keeps for reuse to the driver (gml_trim_cache); bytes released."""
+    L = lib()
+    L.gml_trim_cache.restype = C.c_int64
+    return int(L.gml_trim_cache())
+
+
 def pack_histogram(samples):
     """Host-only (gml_pack_histogram): histogram matrix -> (sign_bits [n][words] uint32, counts [K] float64, M)."""
     L = lib()

@@ -59,25 +59,25 @@ int dedupe_samples(const int8_t *dS, bool spin_major, int64_t ld, int64_t N, int
     auto cleanup = [&]() {
         void *ptrs[] = {k0, k1, uniq, cnt, nruns, tmp};
         for (void *q : ptrs)
-            if (q) (void)hipFree(q);
+            if (q) (void)dev_free(q);
     };
-    DCHK(hipMalloc(&k0, sizeof(unsigned long long) * N));
-    DCHK(hipMalloc(&k1, sizeof(unsigned long long) * N));
+    DCHK(dev_malloc(&k0, sizeof(unsigned long long) * N));
+    DCHK(dev_malloc(&k1, sizeof(unsigned long long) * N));
     hipLaunchKernelGGL(k_make_keys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dS, spin_major ? 1 : 0, ld, N, (int)n, k0);
     size_t tb = 0;
     DCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, k0, k1, (int)N, 0, (int)n, st));
-    DCHK(hipMalloc(&tmp, tb ? tb : 1));
+    DCHK(dev_malloc(&tmp, tb ? tb : 1));
     DCHK(hipcub::DeviceRadixSort::SortKeys(tmp, tb, k0, k1, (int)N, 0, (int)n, st));
-    (void)hipFree(tmp);
+    (void)dev_free(tmp);
     tmp = nullptr;
     // k0 is free again: it receives the distinct keys (at most N of them)
     uniq = k0;
     k0 = nullptr;
-    DCHK(hipMalloc(&cnt, sizeof(int) * N));
-    DCHK(hipMalloc(&nruns, sizeof(int)));
+    DCHK(dev_malloc(&cnt, sizeof(int) * N));
+    DCHK(dev_malloc(&nruns, sizeof(int)));
     tb = 0;
     DCHK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb, k1, uniq, cnt, nruns, (int)N, st));
-    DCHK(hipMalloc(&tmp, tb ? tb : 1));
+    DCHK(dev_malloc(&tmp, tb ? tb : 1));
     DCHK(hipcub::DeviceRunLengthEncode::Encode(tmp, tb, k1, uniq, cnt, nruns, (int)N, st));
     int hruns = 0;
     DCHK(hipMemcpyAsync(&hruns, nruns, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -7,6 +7,14 @@
 
 namespace gml {
 
+// Device memory of the library (gml_alloc.cpp): freed blocks of >= 1 MB are kept per device and size for the next handle of
+// the same shape (a hipMalloc of a multi-GB block after a hipFree sporadically takes a second).
+hipError_t dev_malloc_bytes(void **out, size_t bytes);
+hipError_t dev_free(void *p);
+hipError_t dev_mem_info(size_t *free_bytes, size_t *total_bytes); // free = the driver's + the cache's
+size_t dev_trim_cache();
+template <typename T> inline hipError_t dev_malloc(T **out, size_t bytes) { return dev_malloc_bytes(reinterpret_cast<void **>(out), bytes); }
+
 // Device-resident problem data (all padded, padding is zero).  The samples are stored as ONE BIT per entry:
 //   Sb  [n][Kp/32]     sign bits of the spins, spin-major, natural order (bit j of word w <-> sample 32w + j; set <=> -1)
 //   Xb                 forward operand of the int8 path: the design matrix sample-major, in the piece layout of

@@ -276,7 +276,7 @@ static int prob_layout(gml_problem *p) {
     if (d.Qfp / 64 > 32000) return fail(GML_EUNSUPPORTED, "more than 2^21 statistics per node");
     {
         size_t freeb = 0, totalb = 0;
-        HIPCHK(hipMemGetInfo(&freeb, &totalb));
+        HIPCHK(dev_mem_info(&freeb, &totalb));
         const double need = 2.0 * (double)d.Kp * (double)round_up(d.Qfp, 256) / 8.0 + (double)d.Kp * (double)p->n / 8.0 + 8.0 * (double)d.Kp;
         if (need > 0.92 * (double)freeb)
             return fail(GML_ENOMEM, "the bit images of the %lld x %lld design matrix (%.1f GB) do not fit in %.1f GB of free HBM",
@@ -296,11 +296,11 @@ static int prob_layout(gml_problem *p) {
         }
     }
     d.Xs = d.Xt = nullptr; // FP64 path only, built on first use (ensure_f64)
-    HIPCHK(hipMalloc(&d.Sb, (size_t)p->n * (d.Kp / 8)));
-    HIPCHK(hipMalloc(&d.keys, sizeof(int32_t) * p->gkeys.size()));
-    HIPCHK(hipMalloc(&d.Xb, (size_t)d.Kp * (d.Qfp / 8)));
-    HIPCHK(hipMalloc(&d.Xtb, (size_t)xtb_bytes(d)));
-    HIPCHK(hipMalloc(&d.w, sizeof(double) * d.Kp));
+    HIPCHK(dev_malloc(&d.Sb, (size_t)p->n * (d.Kp / 8)));
+    HIPCHK(dev_malloc(&d.keys, sizeof(int32_t) * p->gkeys.size()));
+    HIPCHK(dev_malloc(&d.Xb, (size_t)d.Kp * (d.Qfp / 8)));
+    HIPCHK(dev_malloc(&d.Xtb, (size_t)xtb_bytes(d)));
+    HIPCHK(dev_malloc(&d.w, sizeof(double) * d.Kp));
     HIPCHK(hipMemcpyAsync(d.keys, p->gkeys.data(), sizeof(int32_t) * p->gkeys.size(), hipMemcpyHostToDevice, p->st));
     return GML_OK;
 }
@@ -376,7 +376,7 @@ static int create_from_device_bytes(gml_problem *p, int8_t *dbytes, bool spin_ma
         void *b[3];
         ~Guard() {
             for (void *q : b)
-                if (q) (void)hipFree(q);
+                if (q) (void)dev_free(q);
         }
     } guard{{dbytes, nullptr, nullptr}};
     const double t0 = now_s();
@@ -405,7 +405,7 @@ static int create_from_device_bytes(gml_problem *p, int8_t *dbytes, bool spin_ma
             }
         }
         if (st0) (void)hipStreamDestroy(st0);
-        (void)hipFree(dbytes); // the draws are no longer needed
+        (void)dev_free(dbytes); // the draws are no longer needed
         guard.b[0] = nullptr;
     }
     if (rc == GML_OK) rc = prob_layout(p);
@@ -740,9 +740,9 @@ extern "C" int gml_problem_create_device_convert(const void *samples, int dtype,
     auto cleanup = [&](int code) {
         void *ptrs[] = {dH, dC, dbad};
         for (void *q : ptrs)
-            if (q) (void)hipFree(q);
+            if (q) (void)dev_free(q);
         if (st) (void)hipStreamDestroy(st);
-        if (code != GML_OK && dS) (void)hipFree(dS);
+        if (code != GML_OK && dS) (void)dev_free(dS);
         return code;
     };
 #define CCHK(expr)                                                                                               \
@@ -753,10 +753,10 @@ extern "C" int gml_problem_create_device_convert(const void *samples, int dtype,
                                 hipGetErrorString(e_)));                                                         \
     } while (0)
     CCHK(hipStreamCreate(&st));
-    CCHK(hipMalloc(&dH, bytes));
-    CCHK(hipMalloc(&dS, (size_t)K * n));
-    CCHK(hipMalloc(&dC, sizeof(double) * K));
-    CCHK(hipMalloc(&dbad, sizeof(long long)));
+    CCHK(dev_malloc(&dH, bytes));
+    CCHK(dev_malloc(&dS, (size_t)K * n));
+    CCHK(dev_malloc(&dC, sizeof(double) * K));
+    CCHK(dev_malloc(&dbad, sizeof(long long)));
     CCHK(hipMemcpyAsync(dbad, &hbad, sizeof(long long), hipMemcpyHostToDevice, st));
     int urc = upload_pageable(dH, samples, bytes, st);
     if (urc) return cleanup(urc);
@@ -884,11 +884,11 @@ static int create_sampled_terms(const int32_t *keys, int stride, const double *w
     unsigned *dmask = nullptr;
     int *dmem = nullptr;
     auto cleanup = [&](int rc) {
-        if (dwt) (void)hipFree(dwt);
-        if (dmask) (void)hipFree(dmask);
-        if (den) (void)hipFree(den);
-        if (dcdf) (void)hipFree(dcdf);
-        if (dmem) (void)hipFree(dmem);
+        if (dwt) (void)dev_free(dwt);
+        if (dmask) (void)dev_free(dmask);
+        if (den) (void)dev_free(den);
+        if (dcdf) (void)dev_free(dcdf);
+        if (dmem) (void)dev_free(dmem);
         if (st) (void)hipStreamDestroy(st);
         return rc;
     };
@@ -896,19 +896,19 @@ static int create_sampled_terms(const int32_t *keys, int stride, const double *w
     do {                                                                                                        \
         hipError_t e_ = (expr);                                                                                 \
         if (e_ != hipSuccess) {                                                                                 \
-            if (dS) (void)hipFree(dS);                                                                          \
+            if (dS) (void)dev_free(dS);                                                                          \
             delete p;                                                                                           \
             return cleanup(fail(e_ == hipErrorOutOfMemory ? GML_ENOMEM : GML_EHIP, "%s failed: %s", #expr,      \
                                 hipGetErrorString(e_)));                                                        \
         }                                                                                                       \
     } while (0)
     SCHK(hipStreamCreate(&st));
-    SCHK(hipMalloc(&dS, (size_t)N * n));
-    SCHK(hipMalloc(&dwt, sizeof(double) * maxnt));
-    SCHK(hipMalloc(&dmask, sizeof(unsigned) * maxnt));
-    SCHK(hipMalloc(&den, sizeof(double) * ((size_t)1 << maxsb)));
-    SCHK(hipMalloc(&dcdf, sizeof(double) * ((size_t)1 << maxsb)));
-    SCHK(hipMalloc(&dmem, sizeof(int) * maxsb));
+    SCHK(dev_malloc(&dS, (size_t)N * n));
+    SCHK(dev_malloc(&dwt, sizeof(double) * maxnt));
+    SCHK(dev_malloc(&dmask, sizeof(unsigned) * maxnt));
+    SCHK(dev_malloc(&den, sizeof(double) * ((size_t)1 << maxsb)));
+    SCHK(dev_malloc(&dcdf, sizeof(double) * ((size_t)1 << maxsb)));
+    SCHK(dev_malloc(&dmem, sizeof(int) * maxsb));
     for (size_t b = 0; b < blocks.size(); ++b) {
         const auto &mem = blocks[b];
         const int sb = (int)mem.size(), nt = (int)bmask[b].size();
@@ -989,7 +989,7 @@ static int create_mcmc_terms(const int32_t *keys, int key_stride, const double *
     auto cleanup = [&](int rc) {
         void *ptrs[] = {dioff, dooff, doth, diw};
         for (void *q : ptrs)
-            if (q) (void)hipFree(q);
+            if (q) (void)dev_free(q);
         if (st) (void)hipStreamDestroy(st);
         return rc;
     };
@@ -997,18 +997,18 @@ static int create_mcmc_terms(const int32_t *keys, int key_stride, const double *
     do {                                                                                                        \
         hipError_t e_ = (expr);                                                                                 \
         if (e_ != hipSuccess) {                                                                                 \
-            if (dSt) (void)hipFree(dSt);                                                                        \
+            if (dSt) (void)dev_free(dSt);                                                                        \
             delete p;                                                                                           \
             return cleanup(fail(e_ == hipErrorOutOfMemory ? GML_ENOMEM : GML_EHIP, "%s failed: %s", #expr,      \
                                 hipGetErrorString(e_)));                                                        \
         }                                                                                                       \
     } while (0)
     SCHK(hipStreamCreate(&st));
-    SCHK(hipMalloc(&dSt, (size_t)n * Np));
-    SCHK(hipMalloc(&dioff, sizeof(int) * ioff.size()));
-    SCHK(hipMalloc(&dooff, sizeof(int) * ooff.size()));
-    SCHK(hipMalloc(&doth, sizeof(int) * oth.size()));
-    SCHK(hipMalloc(&diw, sizeof(double) * iw.size()));
+    SCHK(dev_malloc(&dSt, (size_t)n * Np));
+    SCHK(dev_malloc(&dioff, sizeof(int) * ioff.size()));
+    SCHK(dev_malloc(&dooff, sizeof(int) * ooff.size()));
+    SCHK(dev_malloc(&doth, sizeof(int) * oth.size()));
+    SCHK(dev_malloc(&diw, sizeof(double) * iw.size()));
     SCHK(hipMemcpyAsync(dioff, ioff.data(), sizeof(int) * ioff.size(), hipMemcpyHostToDevice, st));
     SCHK(hipMemcpyAsync(dooff, ooff.data(), sizeof(int) * ooff.size(), hipMemcpyHostToDevice, st));
     SCHK(hipMemcpyAsync(doth, oth.data(), sizeof(int) * oth.size(), hipMemcpyHostToDevice, st));
@@ -1080,7 +1080,7 @@ extern "C" int gml_problem_get_spins(gml_problem *p, int8_t *spins) {
     // sign bits -> +-1 bytes, sample-major, on the device (in slabs of <= 2^22 samples), one copy per slab
     const int64_t slab = std::min<int64_t>(p->K, (int64_t)1 << 22);
     int8_t *dT = nullptr;
-    HIPCHK(hipMalloc(&dT, (size_t)slab * p->n));
+    HIPCHK(dev_malloc(&dT, (size_t)slab * p->n));
     int rc = GML_OK;
     for (int64_t k0 = 0; k0 < p->K && rc == GML_OK; k0 += slab) {
         const int64_t kk = std::min(slab, p->K - k0);
@@ -1089,7 +1089,7 @@ extern "C" int gml_problem_get_spins(gml_problem *p, int8_t *spins) {
             hipStreamSynchronize(p->st) != hipSuccess)
             rc = fail(GML_EHIP, "download of the spins failed: %s", hipGetErrorString(hipGetLastError()));
     }
-    (void)hipFree(dT);
+    (void)dev_free(dT);
     return rc;
 }
 
@@ -1099,7 +1099,7 @@ extern "C" void gml_problem_destroy(gml_problem *p) {
     if (p->st) (void)hipStreamSynchronize(p->st);
     void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.Sb, p->d.keys, p->d.Xb, p->d.Xtb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dSrow};
     for (void *q : ptrs)
-        if (q) (void)hipFree(q);
+        if (q) (void)dev_free(q);
     void *hptrs[] = {p->hTh, p->hG, p->hF, p->hCtl, p->stage};
     for (void *q : hptrs)
         if (q) (void)hipHostFree(q);
@@ -1145,7 +1145,7 @@ int gml_ensure_ws(gml_problem *p, int64_t rows) {
     if (Rp <= p->ws_rows) return GML_OK;
     void *ptrs[] = {p->dTheta, p->dV, p->dG, p->dF, p->dSrow};
     for (void *q : ptrs)
-        if (q) (void)hipFree(q);
+        if (q) (void)dev_free(q);
     void *hptrs[] = {p->hTh, p->hG, p->hF, p->hCtl};
     for (void *q : hptrs)
         if (q) (void)hipHostFree(q);
@@ -1155,17 +1155,17 @@ int gml_ensure_ws(gml_problem *p, int64_t rows) {
     p->dSrow = p->dRowcol = p->dGroups = nullptr;
     p->ws_rows = 0;
     size_t freeb = 0, totalb = 0;
-    HIPCHK(hipMemGetInfo(&freeb, &totalb));
+    HIPCHK(dev_mem_info(&freeb, &totalb));
     const double need = 2.0 * Rp * p->d.Qp * 8.0;
     if (need > 0.9 * (double)freeb)
         return fail(GML_ENOMEM, "workspace of %.1f GB for %lld rows does not fit in %.1f GB free HBM", need / 1e9,
                     (long long)Rp, freeb / 1e9);
-    HIPCHK(hipMalloc(&p->dTheta, sizeof(double) * Rp * p->d.Qp));
-    HIPCHK(hipMalloc(&p->dG, sizeof(double) * Rp * p->d.Qp));
-    HIPCHK(hipMalloc(&p->dF, sizeof(double) * Rp));
+    HIPCHK(dev_malloc(&p->dTheta, sizeof(double) * Rp * p->d.Qp));
+    HIPCHK(dev_malloc(&p->dG, sizeof(double) * Rp * p->d.Qp));
+    HIPCHK(dev_malloc(&p->dF, sizeof(double) * Rp));
     // control block: srow [Rp] | rowcol [Rp] | active tiles, padded with -1 [Rp/32 + 4]; one pinned twin, one upload per pass
     const int64_t nctl = 2 * Rp + Rp / 32 + 4;
-    HIPCHK(hipMalloc(&p->dSrow, sizeof(int) * nctl));
+    HIPCHK(dev_malloc(&p->dSrow, sizeof(int) * nctl));
     p->dRowcol = p->dSrow + Rp;
     p->dGroups = p->dRowcol + Rp;
     HIPCHK(hipHostMalloc(&p->hCtl, sizeof(int) * nctl));
@@ -1183,12 +1183,12 @@ int gml_ensure_f64(gml_problem *p, int64_t vrows) {
     DevProblem &d = p->d;
     size_t freeb = 0, totalb = 0;
     if (!d.Xs) {
-        HIPCHK(hipMemGetInfo(&freeb, &totalb));
+        HIPCHK(dev_mem_info(&freeb, &totalb));
         if (2.0 * (double)d.Kp * d.Qp > 0.9 * (double)freeb)
             return fail(GML_EUNSUPPORTED, "the FP64 path needs two %.1f GB byte images of the design matrix: use precision i8x",
                         (double)d.Kp * d.Qp / 1e9);
-        HIPCHK(hipMalloc(&d.Xt, (size_t)d.Kp * d.Qp));
-        HIPCHK(hipMalloc(&d.Xs, (size_t)d.Kp * d.Qp));
+        HIPCHK(dev_malloc(&d.Xt, (size_t)d.Kp * d.Qp));
+        HIPCHK(dev_malloc(&d.Xs, (size_t)d.Kp * d.Qp));
         HIPCHK(hipMemsetAsync(d.Xt, 0, (size_t)d.Kp * d.Qp, p->st));
         HIPCHK(hipMemsetAsync(d.Xs, 0, (size_t)d.Kp * d.Qp, p->st));
         launch_expand_xt(d, d.Xt, p->st);
@@ -1197,13 +1197,13 @@ int gml_ensure_f64(gml_problem *p, int64_t vrows) {
     }
     vrows = round_up(vrows, 32);
     if (!p->dV || p->dVrows < vrows) {
-        if (p->dV) (void)hipFree(p->dV);
+        if (p->dV) (void)dev_free(p->dV);
         p->dV = nullptr;
         p->dVrows = 0;
-        HIPCHK(hipMemGetInfo(&freeb, &totalb));
+        HIPCHK(dev_mem_info(&freeb, &totalb));
         if ((double)vrows * d.Kp * 8.0 > 0.9 * (double)freeb)
             return fail(GML_ENOMEM, "FP64 workspace of %.1f GB does not fit: use precision i8x", (double)vrows * d.Kp * 8.0 / 1e9);
-        HIPCHK(hipMalloc(&p->dV, sizeof(double) * vrows * d.Kp));
+        HIPCHK(dev_malloc(&p->dV, sizeof(double) * vrows * d.Kp));
         HIPCHK(hipMemsetAsync(p->dV, 0, sizeof(double) * vrows * d.Kp, p->st));
         p->dVrows = vrows;
     }
@@ -1262,7 +1262,7 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
     double *dOvr = nullptr;
     if (precision == GML_PREC_I8X) {
         if (tau_ovr) {
-            HIPCHK(hipMalloc(&dOvr, sizeof(double) * Rp));
+            HIPCHK(dev_malloc(&dOvr, sizeof(double) * Rp));
             HIPCHK(hipMemcpyAsync(dOvr, tau_ovr->data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
         }
         std::string err;
@@ -1281,7 +1281,7 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
         a.tauovr = dOvr;
         rc = gml::i8_pass(&p->i8ws, p->d, W, a, st, ms ? ev : nullptr, &err);
         if (rc) {
-            if (dOvr) (void)hipFree(dOvr);
+            if (dOvr) (void)dev_free(dOvr);
             return fail(rc, "%s", err.c_str());
         }
     } else {
@@ -1313,7 +1313,7 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
         HIPCHK(hipMemcpyAsync(mmaxh.data(), mm, sizeof(unsigned) * Rp, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipStreamSynchronize(st));
-    if (dOvr) (void)hipFree(dOvr);
+    if (dOvr) (void)dev_free(dOvr);
     if (ms) {
         HIPCHK(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
         HIPCHK(hipEventElapsedTime(&ms[1], ev[1], ev[2]));
@@ -1671,7 +1671,7 @@ extern "C" int gml_test_tile_precond(int T, int ntiles, const int *m, const doub
     auto freeall = [&]() {
         void *ptrs[] = {dH, dS1, dG, dR, dZ, dHoff, dM, dWrow, dFv, dLive};
         for (void *q : ptrs)
-            if (q) (void)hipFree(q);
+            if (q) (void)dev_free(q);
     };
 #define TCHK2(expr)                                                                              \
     do {                                                                                        \
@@ -1680,16 +1680,16 @@ extern "C" int gml_test_tile_precond(int T, int ntiles, const int *m, const doub
             return fail(GML_EHIP, "%s failed: %s", #expr, hipGetErrorString(hipGetLastError())); \
         }                                                                                       \
     } while (0)
-    TCHK2(hipMalloc(&dH, sizeof(double) * ne * T));
-    TCHK2(hipMalloc(&dS1, sizeof(double)));
-    TCHK2(hipMalloc(&dG, sizeof(double) * ne));
-    TCHK2(hipMalloc(&dR, sizeof(double) * ne));
-    TCHK2(hipMalloc(&dZ, sizeof(double) * ne));
-    TCHK2(hipMalloc(&dHoff, sizeof(long long) * nt));
-    TCHK2(hipMalloc(&dM, sizeof(int) * nt));
-    TCHK2(hipMalloc(&dWrow, sizeof(int) * nt));
-    TCHK2(hipMalloc(&dFv, sizeof(int) * ne));
-    TCHK2(hipMalloc(&dLive, sizeof(int)));
+    TCHK2(dev_malloc(&dH, sizeof(double) * ne * T));
+    TCHK2(dev_malloc(&dS1, sizeof(double)));
+    TCHK2(dev_malloc(&dG, sizeof(double) * ne));
+    TCHK2(dev_malloc(&dR, sizeof(double) * ne));
+    TCHK2(dev_malloc(&dZ, sizeof(double) * ne));
+    TCHK2(dev_malloc(&dHoff, sizeof(long long) * nt));
+    TCHK2(dev_malloc(&dM, sizeof(int) * nt));
+    TCHK2(dev_malloc(&dWrow, sizeof(int) * nt));
+    TCHK2(dev_malloc(&dFv, sizeof(int) * ne));
+    TCHK2(dev_malloc(&dLive, sizeof(int)));
     TCHK2(hipMemcpy(dH, tiles, sizeof(double) * ne * T, hipMemcpyHostToDevice));
     TCHK2(hipMemcpy(dS1, &s1, sizeof(double), hipMemcpyHostToDevice));
     TCHK2(hipMemcpy(dG, g, sizeof(double) * ne, hipMemcpyHostToDevice));
@@ -1738,7 +1738,7 @@ extern "C" int gml_test_newton_solve(int R, const int *m, int cap, const double 
     auto freeall = [&]() {
         void *ptrs[] = {dH, dS1, dG, dPg, dOut, dSd, dHoff, dMt, dM};
         for (void *q : ptrs)
-            if (q) (void)hipFree(q);
+            if (q) (void)dev_free(q);
     };
 #define TCHK(expr)                                                           \
     do {                                                                     \
@@ -1747,15 +1747,15 @@ extern "C" int gml_test_newton_solve(int R, const int *m, int cap, const double 
             return fail(GML_EHIP, "%s failed: %s", #expr, hipGetErrorString(hipGetLastError())); \
         }                                                                    \
     } while (0)
-    TCHK(hipMalloc(&dH, sizeof(double) * H.size()));
-    TCHK(hipMalloc(&dS1, sizeof(double) * R));
-    TCHK(hipMalloc(&dG, sizeof(double) * R * cap));
-    TCHK(hipMalloc(&dPg, sizeof(double) * R * cap));
-    TCHK(hipMalloc(&dOut, sizeof(double) * R * cap));
-    TCHK(hipMalloc(&dSd, sizeof(double) * R));
-    TCHK(hipMalloc(&dHoff, sizeof(long long) * (R + 1)));
-    TCHK(hipMalloc(&dMt, sizeof(int) * R));
-    TCHK(hipMalloc(&dM, sizeof(int) * R));
+    TCHK(dev_malloc(&dH, sizeof(double) * H.size()));
+    TCHK(dev_malloc(&dS1, sizeof(double) * R));
+    TCHK(dev_malloc(&dG, sizeof(double) * R * cap));
+    TCHK(dev_malloc(&dPg, sizeof(double) * R * cap));
+    TCHK(dev_malloc(&dOut, sizeof(double) * R * cap));
+    TCHK(dev_malloc(&dSd, sizeof(double) * R));
+    TCHK(dev_malloc(&dHoff, sizeof(long long) * (R + 1)));
+    TCHK(dev_malloc(&dMt, sizeof(int) * R));
+    TCHK(dev_malloc(&dM, sizeof(int) * R));
     TCHK(hipMemcpy(dH, H.data(), sizeof(double) * H.size(), hipMemcpyHostToDevice));
     TCHK(hipMemcpy(dS1, s1.data(), sizeof(double) * R, hipMemcpyHostToDevice));
     TCHK(hipMemcpy(dG, g ? g : gz.data(), sizeof(double) * R * cap, hipMemcpyHostToDevice));

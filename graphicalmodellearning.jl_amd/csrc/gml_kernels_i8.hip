@@ -1352,11 +1352,11 @@ void i8_free(void *p) {
     if (!w) return;
     void *ptrs[] = {w->Tq, w->Vq, w->Uq, w->Gacc, w->tauovr, w->Hq, w->hS, w->H64, w->Mb};
     for (void *q : ptrs)
-        if (q) (void)hipFree(q);
+        if (q) (void)dev_free(q);
     for (auto &sc : w->sc) {
         void *qs[] = {sc.sigma, sc.tau, sc.invtau, sc.qconst, sc.csum, sc.asum, sc.mmax};
         for (void *q : qs)
-            if (q) (void)hipFree(q);
+            if (q) (void)dev_free(q);
     }
     delete w;
 }
@@ -1368,22 +1368,22 @@ static int i8_ensure(void **wsp, const DevProblem &d, int64_t slots, std::string
     *wsp = nullptr;
     w = new I8Ws();
     *wsp = w; // owned by the handle from here on: a failed allocation below is released by i8_free
-    I8CHK(hipMalloc(&w->Tq, (size_t)slots * w->LF * d.Qfp));
-    I8CHK(hipMalloc(&w->Vq, (size_t)slots * LB * d.Kp));
+    I8CHK(dev_malloc(&w->Tq, (size_t)slots * w->LF * d.Qfp));
+    I8CHK(dev_malloc(&w->Vq, (size_t)slots * LB * d.Kp));
     // i32 accumulators of the backward GEMM hold |sum_k v_k b_k| <= 128 K: exact up to 2^24 configurations per set
     // (beyond 2^24: sets of <= 2^23 configurations + the slack of whole split-K chunks, see i8_pass)
     w->gplanes = d.Kp <= ((int64_t)1 << 24) ? 1 : (int)((d.Kp + ((int64_t)1 << 23) - 1) >> 23);
-    I8CHK(hipMalloc(&w->Gacc, sizeof(int32_t) * (size_t)w->gplanes * slots * LB * d.Qfp));
+    I8CHK(dev_malloc(&w->Gacc, sizeof(int32_t) * (size_t)w->gplanes * slots * LB * d.Qfp));
     for (auto &sc : w->sc) {
-        I8CHK(hipMalloc(&sc.sigma, sizeof(double) * slots));
-        I8CHK(hipMalloc(&sc.tau, sizeof(double) * slots));
-        I8CHK(hipMalloc(&sc.invtau, sizeof(double) * slots));
-        I8CHK(hipMalloc(&sc.qconst, sizeof(long long) * slots));
-        I8CHK(hipMalloc(&sc.csum, sizeof(long long) * slots));
-        I8CHK(hipMalloc(&sc.asum, sizeof(long long) * slots));
-        I8CHK(hipMalloc(&sc.mmax, sizeof(unsigned) * slots));
+        I8CHK(dev_malloc(&sc.sigma, sizeof(double) * slots));
+        I8CHK(dev_malloc(&sc.tau, sizeof(double) * slots));
+        I8CHK(dev_malloc(&sc.invtau, sizeof(double) * slots));
+        I8CHK(dev_malloc(&sc.qconst, sizeof(long long) * slots));
+        I8CHK(dev_malloc(&sc.csum, sizeof(long long) * slots));
+        I8CHK(dev_malloc(&sc.asum, sizeof(long long) * slots));
+        I8CHK(dev_malloc(&sc.mmax, sizeof(unsigned) * slots));
     }
-    I8CHK(hipMalloc(&w->tauovr, sizeof(double) * slots));
+    I8CHK(dev_malloc(&w->tauovr, sizeof(double) * slots));
     I8CHK(hipMemset(w->Tq, 0, (size_t)slots * w->LF * d.Qfp));
     I8CHK(hipMemset(w->Vq, 0, (size_t)slots * LB * d.Kp));
     w->slots = slots;
@@ -1451,25 +1451,25 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
     const int64_t pitch = d.Kp, Rp = (R + 31) / 32 * 32;
     if (Kh > pitch) Kh = pitch;
     if (w->hKh != pitch || w->hrows < Rp) {
-        if (w->Hq) (void)hipFree(w->Hq);
-        if (w->hS) (void)hipFree(w->hS);
+        if (w->Hq) (void)dev_free(w->Hq);
+        if (w->hS) (void)dev_free(w->hS);
         w->Hq = nullptr;
         w->hS = nullptr;
-        I8CHK(hipMalloc(&w->Hq, (size_t)Rp * LB * pitch));
-        I8CHK(hipMalloc(&w->hS, sizeof(long long) * Rp));
+        I8CHK(dev_malloc(&w->Hq, (size_t)Rp * LB * pitch));
+        I8CHK(dev_malloc(&w->hS, sizeof(long long) * Rp));
         w->hKh = pitch;
         w->hrows = Rp;
     }
     if (!w->Mb) {
-        I8CHK(hipMalloc(&w->Mb, (size_t)d.Qp * (d.Kp / 8)));
+        I8CHK(dev_malloc(&w->Mb, (size_t)d.Qp * (d.Kp / 8)));
         I8CHK(hipMemsetAsync(w->Mb, 0, (size_t)d.Qp * (d.Kp / 8), st));
         hipLaunchKernelGGL(k_build_mb, dim3((unsigned)d.Qfp, (unsigned)((d.Kp / 64 + 255) / 256)), dim3(256), 0, st, d.Xtb, d.Kp / 64, w->Mb);
     }
     const int64_t need = htotal;
     if (need > w->hcap_elems) {
-        if (w->H64) (void)hipFree(w->H64);
+        if (w->H64) (void)dev_free(w->H64);
         w->H64 = nullptr;
-        I8CHK(hipMalloc(&w->H64, sizeof(long long) * need));
+        I8CHK(dev_malloc(&w->H64, sizeof(long long) * need));
         w->hcap_elems = need;
     }
     I8CHK(hipMemsetAsync(w->H64, 0, sizeof(long long) * need, st));
@@ -1591,7 +1591,7 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     }
     const int hv = a.hv ? (a.hv == 2 ? 2 : 1) : 0; // 2: Hessian-vector products in 2 backward limbs
     if (hv && !w->Uq) {
-        I8CHK(hipMalloc(&w->Uq, (size_t)w->slots * LB * d.Kp));
+        I8CHK(dev_malloc(&w->Uq, (size_t)w->slots * LB * d.Kp));
         I8CHK(hipMemsetAsync(w->Uq, 0, (size_t)w->slots * LB * d.Kp, st));
     }
     const SlotScalars &sc = w->sc[hv ? 1 : 0];

@@ -44,11 +44,11 @@ struct Arena {
     std::vector<void *> ptrs;
     ~Arena() {
         for (void *q : ptrs)
-            if (q) (void)hipFree(q);
+            if (q) (void)dev_free(q);
     }
     template <typename T> hipError_t get(T **out, size_t count) {
         *out = nullptr;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(out), sizeof(T) * std::max<size_t>(count, 1));
+        hipError_t e = dev_malloc(reinterpret_cast<void **>(out), sizeof(T) * std::max<size_t>(count, 1));
         if (e == hipSuccess) ptrs.push_back(*out);
         return e;
     }
@@ -289,7 +289,7 @@ int Solver::init() {
     Scap = Smain + Rp;
     {
         size_t freeb = 0, totalb = 0;
-        HIPCHK(hipMemGetInfo(&freeb, &totalb));
+        HIPCHK(dev_mem_info(&freeb, &totalb));
         const double need_b = 7.0 * 8.0 * (double)nd + (double)nd;
         if (need_b > 0.9 * (double)freeb)
             return fail(GML_ENOMEM, "solver state of %.1f GB for %lld rows does not fit in %.1f GB free HBM", need_b / 1e9, (long long)R,
@@ -364,7 +364,7 @@ int Solver::init() {
 
     if (o.precision == GML_PREC_I8X && o.polish >= 0) {
         size_t freeb = 0, totalb = 0;
-        if (hipMemGetInfo(&freeb, &totalb) == hipSuccess) {
+        if (dev_mem_info(&freeb, &totalb) == hipSuccess) {
             const double need_b = (d.Xs ? 0.0 : 2.0 * (double)d.Kp * (double)Qp) + (p->dV && p->dVrows >= Rp ? 0.0 : 8.0 * (double)Rp * (double)d.Kp) +
                                   8.0 * (double)nd + 4.0 * (double)Scap * d.Kp /* the i8 workspace still to come */;
             can_polish = need_b < 0.8 * (double)freeb;

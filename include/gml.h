@@ -208,6 +208,12 @@ int gml_problem_get_spins(gml_problem *p, int8_t *spins);
 
 void gml_problem_destroy(gml_problem *p);
 
+/* Device blocks of >= 1 MB that handles and solves release are kept by the library, per device and size, for the next handle of the
+ * same shape (up to a quarter of the device's memory; an allocation that fails empties the cache and tries again): on MI355X /
+ * ROCm 7 a hipMalloc of a multi-GB block after a hipFree sporadically takes 0.4-1.3 s, several times the headline solve.
+ * gml_trim_cache() returns all of it to the driver; the return value is the number of bytes released. */
+int64_t gml_trim_cache(void);
+
 /* sizes: n, K (rows given), M = sum(counts) (:79), P = parameters per node
  * (n for order 2; sum_{p<=order} C(n-1,p-1) in general), local node range */
 int gml_problem_info(const gml_problem *p, int64_t *n, int64_t *K, double *M, int64_t *P,
