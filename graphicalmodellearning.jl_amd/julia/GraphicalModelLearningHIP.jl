@@ -18,7 +18,7 @@ import GraphicalModelLearning: learn, GMLMethod, GMLFormulation, RISE, RISEA, lo
 import LinearAlgebra
 import Statistics: mean
 
-export HIP
+export HIP, trim_cache
 
 const libgml = get(ENV, "LIBGML_HIP", "libgml_hip.so")
 
@@ -132,6 +132,10 @@ function solve_rows(samples::Array{T,2}, formulation, method::HIP, order::Int) w
         ccall((:gml_problem_destroy, libgml), Cvoid, (Ptr{Cvoid},), handle[])
     end
 end
+
+# The library keeps the device blocks of destroyed handles for the next problem of the same shape (gml.h: gml_trim_cache);
+# this hands them back to the driver and returns the number of bytes released.
+trim_cache() = Int(ccall((:gml_trim_cache, libgml), Int64, ()))
 
 # all nodes over method.devices: gml_multi_* (one handle + one host thread per GPU inside the library)
 function solve_rows_multi(s, dtype, formulation, method::HIP, order::Int)

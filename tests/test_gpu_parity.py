@@ -446,6 +446,22 @@ def test_dense_solutions_large_working_sets(prec):
     assert _kkt_from_oracle(spins, capped, [0, 50, 191], lam) <= 5e-9
 
 
+@pytest.mark.parametrize("form", ["logRISE", "RPLE"])
+def test_matrix_free_newton_cg_other_formulations(form):
+    # The matrix-free path on the other two objectives: logRISE adds the rank-one term -g g^T to every Hessian block (tile
+    # preconditioner, CG residuals), RPLE has its own curvature weights.  With the Newton blocks capped below the support
+    # the solve must arrive at the optimum of the uncapped (Cholesky) solve.
+    n, K = 192, 30000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=7)
+    c = 0.05 if form == "logRISE" else 0.02
+    with gml.Problem(spins=spins) as p:
+        full, _, st_f = p.learn(form, c, tol=1e-9, precision="i8x", max_working=512, max_iter=200)
+        capped, _, st_c = p.learn(form, c, tol=1e-9, precision="i8x", max_working=128, max_iter=200)
+    assert st_f["not_converged"] == 0 and st_c["not_converged"] == 0
+    assert (full != 0).sum(1).max() > 128 and st_c["hessian_passes"] > st_f["hessian_passes"]  # the matrix-free path really ran
+    assert np.abs(full - capped).max() <= 1e-7
+
+
 def test_newton_cg_reduced_limbs_reach_the_same_optimum():
     # The matrix-free Newton-CG carries the direction in 3 forward limbs and the Hessian-vector products in 2 backward
     # limbs by default; with the full 5 / 4 it must arrive at the same (unique) optimum -- only the inexact Newton steps
