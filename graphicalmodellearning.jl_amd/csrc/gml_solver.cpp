@@ -161,6 +161,7 @@ struct Solver {
     double *Rv = nullptr, *Pv = nullptr, *Hp = nullptr, *Zv = nullptr; // CG vectors, on first use
     uint8_t *Wm = nullptr;                                             // ... and the mask of the system's coordinates
     FaceOut *dFaces = nullptr;
+    bool use_secant = true;
     int face_rounds = 2;      // re-solves of a CG system without the coordinates its step would push through zero
     double face_share = 0.05; // ... for the rows where those carry more than this share of the predicted decrease
     uint8_t *kind = nullptr;
@@ -178,6 +179,9 @@ struct Solver {
     int *dMt = nullptr, *dVslot = nullptr;
     long long *dHoff = nullptr;
     double *dS1 = nullptr, *dS1cg = nullptr;
+    // secant pairs of the Cholesky rows (k_secant): previous working set, x and g on it, the last two (s, y)
+    int *dFprev = nullptr, *dMprev = nullptr, *dNpairs = nullptr;
+    double *dXprev = nullptr, *dGprev = nullptr, *dSec = nullptr, *dYnoise = nullptr;
     // preconditioner tiles of the matrix-free rows (direction_blocks): control block, column lists, gradient entries
     static constexpr int kTile = 128;
     char *dTctl = nullptr;
@@ -310,6 +314,14 @@ int Solver::init() {
     HIPCHK(A.get(&dPass, (size_t)(sizeof(int) * (2 * Scap + Scap / 32 + 16) + sizeof(double) * Scap + 64)));
     HIPCHK(A.get(&dHctl, (size_t)(sizeof(int) * 5 * Rp + sizeof(long long) * (Rp + 1) + sizeof(double) * 3 * Rp + 256)));
     HIPCHK(A.get(&dLive, (size_t)Rp));
+    HIPCHK(A.get(&dFprev, (size_t)Rp * capP));
+    HIPCHK(A.get(&dMprev, (size_t)Rp));
+    HIPCHK(A.get(&dNpairs, (size_t)Rp));
+    HIPCHK(A.get(&dXprev, (size_t)Rp * capP));
+    HIPCHK(A.get(&dGprev, (size_t)Rp * capP));
+    HIPCHK(A.get(&dSec, (size_t)4 * Rp * capP)); // S[0], S[1], Y[0], Y[1]
+    HIPCHK(hipMemsetAsync(dMprev, 0, sizeof(int) * Rp, st));
+    HIPCHK(hipMemsetAsync(dNpairs, 0, sizeof(int) * Rp, st));
     HIPCHK(A.get(&dRes, (size_t)Scap));
     HIPCHK(A.get(&dFidx, (size_t)Rp * capP));
     HIPCHK(A.get(&dCg, (size_t)Rp));
@@ -739,14 +751,15 @@ int Solver::direction_blocks(const std::vector<int> &cg_rows) {
         RCCHK(run_pass(cg_rows, X, nullptr, false, false, tf, tz, tn, nullptr, 0, GML_PREC_I8X));
     }
     // layout of the block: mt [R] | node [R] | msz of the Cholesky rows [R] | (unused) [R] | vslot [R] | hoff [R+1] |
-    // s1 [Rp] | (unused) [Rp] | s1cg [Rp]
+    // s1 [Rp] | ynoise [Rp] | s1cg [Rp]
     const size_t ibytes = (sizeof(int) * 5 * R + 7) & ~(size_t)7, lbytes = sizeof(long long) * (R + 1);
     std::vector<char> blk(ibytes + lbytes + sizeof(double) * 3 * Rp, 0);
     int *mt2 = reinterpret_cast<int *>(blk.data()), *vs = mt2 + 4 * R;
     long long *hoff = reinterpret_cast<long long *>(blk.data() + ibytes);
-    double *s1 = reinterpret_cast<double *>(blk.data() + ibytes + lbytes), *s1cg = s1 + 2 * Rp;
+    double *s1 = reinterpret_cast<double *>(blk.data() + ibytes + lbytes), *yn = s1 + Rp, *s1cg = s1 + 2 * Rp;
     hoff[0] = 0;
     for (int64_t r = 0; r < Rp; ++r) s1[r] = s1cg[r] = 1.0;
+    for (int64_t r = 0; r < R; ++r) yn[r] = 100.0 * fn[r]; // a gradient difference below this is noise of the pass arithmetic, not curvature
     for (int64_t r = 0; r < R; ++r) {
         const int m = done[r] || iscg[r] ? 0 : msz[r];
         mt2[r] = (m + 31) / 32;
@@ -807,6 +820,7 @@ int Solver::direction_blocks(const std::vector<int> &cg_rows) {
     dVslot = dMt + 4 * R;
     dHoff = reinterpret_cast<long long *>(dHctl + ibytes);
     dS1 = reinterpret_cast<double *>(dHctl + ibytes + lbytes);
+    dYnoise = dS1 + Rp;
     dS1cg = dS1 + 2 * Rp;
     HessTiles tl;
     int *dMtV = dMt;
@@ -871,8 +885,21 @@ int Solver::newton_blocks(const std::vector<int> &chol_rows) {
     trace("cholesky");
     int maxm = 1;
     for (int r : chol_rows) maxm = std::max(maxm, msz[r]);
-    launch_newton_solve(dH, dHoff, dMt, dMt + 2 * R, dS1, s2, dgF, dpgF, (int)R, capP, dsol, dSdiag, st, maxm);
     RCCHK(upload_rows(chol_rows, dRows));
+    // (a block over every configuration is the Hessian itself: nothing to correct -- and a secant over a finite step would spoil it)
+    const bool secant = use_secant && Kh < d.Kp;
+    if (secant)
+        launch_secant(dRows, (int)chol_rows.size(), dFidx, dMt + 2 * R, capP, X, Qp, dgF, dH, dHoff, dMt, dS1, s2, dYnoise, dFprev, dMprev, dXprev, dGprev,
+                      dSec, dSec + 2 * Rp * capP, dNpairs, Rp * (int64_t)capP, st);
+    if (secant && o.verbose >= 2) {
+        std::vector<int> npv((size_t)Rp);
+        HIPCHK(hipMemcpyAsync(npv.data(), dNpairs, sizeof(int) * Rp, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        int c[3] = {0, 0, 0};
+        for (int r : chol_rows) ++c[std::min(2, npv[r])];
+        fprintf(stderr, "[gml]   secant pairs in use: none %d rows, one %d, two %d\n", c[0], c[1], c[2]);
+    }
+    launch_newton_solve(dH, dHoff, dMt, dMt + 2 * R, dS1, s2, dgF, dpgF, (int)R, capP, dsol, dSdiag, st, maxm);
     launch_scatter_dir(dRows, (int)chol_rows.size(), dFidx, dsol, dMt + 2 * R, capP, Qp, D, st);
     HIPCHK(hipGetLastError());
     return GML_OK;
