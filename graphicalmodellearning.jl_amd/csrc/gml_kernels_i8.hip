@@ -1415,8 +1415,10 @@ static void launch_hess_blk(const I8Ws *w, const DevProblem &d, const int *dF, c
     constexpr int shmem = 3 * ((64 + 32 * BT) * 64 + 4 * 512) + 2 * (4 + 2 * BT) * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hess_bits_blk<BT>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
     const int64_t nv = R + tl.n;
-    for (int64_t z0 = 0; z0 < nv; z0 += 32768)
-        hipLaunchKernelGGL(k_hess_bits_blk<BT>, dim3((unsigned)ns, (unsigned)nblk, (unsigned)std::min<int64_t>(32768, nv - z0)), dim3(256), shmem,
+    // (grid z is limited to 65 535; slices of 8 192 blocks so that the slicing is exercised by config 5's 28 k tiles, not only
+    // by problems ten times its size)
+    for (int64_t z0 = 0; z0 < nv; z0 += 8192)
+        hipLaunchKernelGGL(k_hess_bits_blk<BT>, dim3((unsigned)ns, (unsigned)nblk, (unsigned)std::min<int64_t>(8192, nv - z0)), dim3(256), shmem,
                            st, w->Mb, w->Hq, dF, dMt, dHoff, cap, Kh, d.Kp, w->hKh, kc, kstride, w->H64, (int)z0, R, tl.F, tl.wrow, tl.T);
 }
 
@@ -1477,12 +1479,16 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
     hipLaunchKernelGGL(k_make_hw, dim3((unsigned)(Kh / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Sb, d.w, w->sc[0].tau, dRowcol, dVslot,
                        dFlag, d.Kp, pitch, kstride, form, w->Hq, w->hS);
     if (maxsmall > 0) launch_hess_blk<2>(w, d, dF, dMt, dHoff, R, cap, maxsmall, Kh, kstride, nsmall, st, tl);
-    if (maxm > 4) launch_hess_blk<4>(w, d, dF, dMt, dHoff, R, cap, maxm, Kh, kstride, nlarge, st, tl);
+    if (maxm > 4) { // (tiles hold at most 4 x 32 entries: only the rows' own blocks are in this size class)
+        HessTiles rows_only = tl;
+        rows_only.n = 0;
+        launch_hess_blk<4>(w, d, dF, dMt, dHoff, R, cap, maxm, Kh, kstride, nlarge, st, rows_only);
+    }
     hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64, w->hS,
                        w->sc[0].tau, dVslot, dMt, dHoff, dH, 0, R, tl.wrow);
     const int tm = tl.T / 32;
-    for (int64_t y0 = 0; y0 < tl.n; y0 += 32768)
-        hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((tm * 32 * tm * 32 + 255) / 256), (unsigned)std::min<int64_t>(32768, tl.n - y0)), dim3(256),
+    for (int64_t y0 = 0; y0 < tl.n; y0 += 8192)
+        hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((tm * 32 * tm * 32 + 255) / 256), (unsigned)std::min<int64_t>(8192, tl.n - y0)), dim3(256),
                            0, st, w->H64, w->hS, w->sc[0].tau, dVslot, dMt, dHoff, dH, (int)(R + y0), R, tl.wrow);
     I8CHK(hipGetLastError());
     return GML_OK;
