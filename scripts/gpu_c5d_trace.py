@@ -11,6 +11,10 @@ for a in sys.argv[1:]:
     kw[k] = float(v) if '.' in v or 'e' in v else int(v)
 n, K = 512, 1000000
 terms = syn.block_multibody_terms(n, block=16, seed=0)
+if kw.pop('perm', 0):  # the same model with its spins renumbered at random
+    import numpy as np
+    pm = np.random.default_rng(11).permutation(n)
+    terms = {tuple(sorted(int(pm[k - 1]) + 1 for k in key)): v for key, v in terms.items()}
 with gml.Problem(terms=terms, n=n, num_samples=K, seed=5, order=3) as p:
     t0 = time.time()
     opts = dict(tol=1e-8, precision="i8x", max_iter=150, verbose=2, raise_on_fail=False)
