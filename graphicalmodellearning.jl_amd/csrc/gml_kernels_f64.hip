@@ -391,313 +391,6 @@ void launch_hess_f64(const DevProblem &P, const double *V,
 
 
 // ------------------------------------------------------------------------------------------
-// Batched Newton solve on the device: for every row r, A d = -pg with
-//   A = s1[r] * H_r  -  s2 * gF gF^T        (s2 = 1 for logRISE: Hess log Z = Hess Z / Z - g g^T)
-// H_r is row r's ragged block (lower 32x32 tiles valid, pitch hp).  Panel-blocked left-looking Cholesky
-// in place, one workgroup per row: for each panel of 32 columns every thread owns one matrix row and
-// keeps its 32 panel entries in registers -- 32 FMAs per loaded element of the factor (the previous
-// panels' rows of U = L^T, staged 32 x 32 at a time in LDS) -- wave 0 factors the 32 x 32 diagonal block
-// in LDS, then every row finishes its triangular solve against it.  L^T is written into the strict upper
-// triangle (U[k][i] = L[i][k]: coalesced row reads), the diagonal of L lives in LDS, the lower triangle
-// keeps A for a ridge restart.  Sdiag[r] = A[m-1][m-1] (the constant column, the Hessian's diagonal scale).
-// ------------------------------------------------------------------------------------------
-// Working sets of up to 64 NR entries -- all of them on sparse optima -- by ONE wave with the whole block in LDS: lane t owns
-// the rows t + 64 q of L, the right-hand side lives in registers, no workgroup barrier and no dependent global read anywhere
-// (the general path of k_newton_solve spends ~250 us per call on such blocks in its per-column barriers and L2 round trips;
-// on small node shards that was a quarter of an iteration).  A is left untouched.
-template <int NR>
-__device__ __forceinline__ void newton_small(const double *__restrict__ A, int hp, int m, double sc, double s2, const double *__restrict__ g,
-                                             const double *__restrict__ pg, double *__restrict__ L, double *__restrict__ dout,
-                                             double *__restrict__ Sdiag) {
-    constexpr int LP = 64 * NR + 1;
-    const int t = threadIdx.x;
-    double gt[NR], b[NR], invd[NR];
-#pragma unroll
-    for (int q = 0; q < NR; ++q) gt[q] = (s2 != 0.0 && t + 64 * q < m) ? g[t + 64 * q] : 0.0;
-    double ridge = 0.0, dmax = 0.0;
-    bool failed = true;
-    for (int attempt = 0; attempt < 10 && failed; ++attempt) {
-        for (int i = 0; i < m; ++i) { // row i, lanes = columns: coalesced reads of the lower triangle
-            const double gi = __shfl(gt[i >> 6], i & 63);
-#pragma unroll
-            for (int q = 0; q < NR; ++q) {
-                const int j = t + 64 * q;
-                L[i * LP + j] = (j <= i) ? sc * A[(int64_t)i * hp + j] - s2 * gi * gt[q] + (j == i ? ridge : 0.0) : 0.0;
-            }
-        }
-        if (attempt == 0) {
-#pragma unroll
-            for (int q = 0; q < NR; ++q) dmax = fmax(dmax, t + 64 * q < m ? fabs(L[(t + 64 * q) * LP + t + 64 * q]) : 0.0);
-            for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
-            if (t == 0) *Sdiag = L[(m - 1) * LP + (m - 1)];
-        }
-        failed = false;
-        for (int c = 0; c < m; ++c) {
-            double x[NR];
-#pragma unroll
-            for (int q = 0; q < NR; ++q) {
-                const int row = t + 64 * q;
-                double x0 = L[row * LP + c], x1 = 0.0, x2 = 0.0, x3 = 0.0; // four partial sums: the FP64 FMA chain is the latency
-                int k = 0;
-                for (; k + 3 < c; k += 4) {
-                    x0 = fma(-L[row * LP + k], L[c * LP + k], x0);
-                    x1 = fma(-L[row * LP + k + 1], L[c * LP + k + 1], x1);
-                    x2 = fma(-L[row * LP + k + 2], L[c * LP + k + 2], x2);
-                    x3 = fma(-L[row * LP + k + 3], L[c * LP + k + 3], x3);
-                }
-                for (; k < c; ++k) x0 = fma(-L[row * LP + k], L[c * LP + k], x0);
-                x[q] = (x0 + x1) + (x2 + x3);
-            }
-            const double piv = __shfl(x[c >> 6], c & 63); // L[c][c]^2
-            if (!(piv > 1e-300 * dmax) || !isfinite(piv)) {
-                failed = true;
-                break;
-            }
-            const double dgc = sqrt(piv);
-#pragma unroll
-            for (int q = 0; q < NR; ++q) {
-                const int row = t + 64 * q;
-                if (row == c) L[row * LP + c] = dgc;
-                else if (row > c && row < m) L[row * LP + c] = x[q] / dgc;
-            }
-        }
-        if (failed) ridge = ridge == 0.0 ? 1e-12 * fmax(dmax, 1e-300) : ridge * 100.0;
-    }
-#pragma unroll
-    for (int q = 0; q < NR; ++q) {
-        const int row = t + 64 * q;
-        b[q] = row < m ? -pg[row] : 0.0;
-        invd[q] = row < m ? 1.0 / L[row * LP + row] : 0.0;
-    }
-    for (int c = 0; c < m; ++c) { // L y = -pg, column by column
-        const double yc = __shfl(b[c >> 6], c & 63) * __shfl(invd[c >> 6], c & 63);
-#pragma unroll
-        for (int q = 0; q < NR; ++q) {
-            const int row = t + 64 * q;
-            if (row == c) b[q] = yc;
-            else if (row > c && row < m) b[q] = fma(-L[row * LP + c], yc, b[q]);
-        }
-    }
-    for (int c = m - 1; c >= 0; --c) { // L^T d = y, row c of L against the entries before c
-        const double dc = __shfl(b[c >> 6], c & 63) * __shfl(invd[c >> 6], c & 63);
-#pragma unroll
-        for (int q = 0; q < NR; ++q) {
-            const int row = t + 64 * q;
-            if (row == c) b[q] = dc;
-            else if (row < c) b[q] = fma(-L[c * LP + row], dc, b[q]);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NR; ++q)
-        if (t + 64 * q < m) dout[t + 64 * q] = failed ? 0.0 : b[q];
-}
-
-__global__ __launch_bounds__(256) void k_newton_solve(double *__restrict__ H, const long long *__restrict__ hoff,
-                                                      const int *__restrict__ mt, const int *__restrict__ msz,
-                                                      const double *__restrict__ s1, double s2,
-                                                      const double *__restrict__ gF, const double *__restrict__ pgF,
-                                                      int cap, double *__restrict__ dout, double *__restrict__ Sdiag,
-                                                      int small_cap /* blocks up to this size (0, 64 or 128) take the one-wave LDS path */) {
-    constexpr int PW = 32;
-    const int r = blockIdx.x;
-    const int m = msz[r];
-    if (m == 0) return;
-    const int hp = 32 * mt[r];
-    double *A = H + hoff[r];
-    const double sc = s1[r];
-    const double *g = gF + (int64_t)r * cap, *pg = pgF + (int64_t)r * cap;
-    extern __shared__ double sm[]; // dg[cap] | y[cap] | gg[cap] | Ul[32][33] | D[32][33]   (small blocks: L[64][65])
-    double *dg = sm, *y = sm + cap, *gg = sm + 2 * cap, *Ul = sm + 3 * cap, *D = Ul + PW * (PW + 1);
-    __shared__ int bad;
-    const int tid = threadIdx.x;
-    if (m <= small_cap) {
-        if (tid >= 64) return; // one wave, no workgroup barrier below
-        if (m <= 64) newton_small<1>(A, hp, m, sc, s2, g, pg, sm, dout + (int64_t)r * cap, Sdiag + r);
-        else newton_small<2>(A, hp, m, sc, s2, g, pg, sm, dout + (int64_t)r * cap, Sdiag + r);
-        return;
-    }
-    for (int i = tid; i < m; i += 256) gg[i] = s2 != 0.0 ? g[i] : 0.0;
-    __syncthreads();
-    auto a_at = [&](int i, int j) { return sc * A[(int64_t)i * hp + j] - s2 * gg[i] * gg[j]; }; // i >= j
-    double dmax = 0;
-    for (int i = tid; i < m; i += 256) dmax = fmax(dmax, fabs(a_at(i, i)));
-    for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
-    __shared__ double red[4];
-    if ((tid & 63) == 0) red[tid >> 6] = dmax;
-    __syncthreads();
-    dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-    if (tid == 0) Sdiag[r] = a_at(m - 1, m - 1);
-    double ridge = 0.0;
-    for (int attempt = 0; attempt < 10; ++attempt) {
-        if (tid == 0) bad = 0;
-        __syncthreads();
-        for (int c0 = 0; c0 < m && !bad; c0 += PW) {
-            const int pw = m - c0 < PW ? m - c0 : PW;
-            // the diagonal rows (c0 .. c0+pw-1) belong to the first chunk's threads 0 .. pw-1
-            for (int rb = c0; rb < m; rb += 256) {
-                const int i = rb + tid;
-                const bool valid = i < m;
-                double acc[PW];
-#pragma unroll
-                for (int c = 0; c < PW; ++c)
-                    acc[c] = (valid && c < pw && c0 + c <= i) ? a_at(i, c0 + c) + (i == c0 + c ? ridge : 0.0) : 0.0;
-                for (int kb = 0; kb < c0; kb += PW) {
-                    __syncthreads(); // Ul free
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int e = tid + 256 * q, kk = e >> 5, c = e & 31;
-                        Ul[kk * (PW + 1) + c] = c < pw ? A[(int64_t)(kb + kk) * hp + c0 + c] : 0.0;
-                    }
-                    __syncthreads();
-                    if (valid) {
-                        for (int kk = 0; kk < PW; ++kk) {
-                            const double u = A[(int64_t)(kb + kk) * hp + i];
-#pragma unroll
-                            for (int c = 0; c < PW; ++c) acc[c] = fma(-u, Ul[kk * (PW + 1) + c], acc[c]);
-                        }
-                    }
-                }
-                if (rb == c0) {
-                    // factor the diagonal block: rows c0+t, t < pw (threads of wave 0)
-                    __syncthreads();
-                    if (tid < PW) {
-#pragma unroll
-                        for (int c = 0; c < PW; ++c) D[tid * (PW + 1) + c] = acc[c];
-                    }
-                    __syncthreads();
-                    if (tid < 64) { // one wave, lanes >= pw idle
-                        const int t = tid;
-                        for (int c = 0; c < pw; ++c) {
-                            double x = 0.0;
-                            if (t >= c && t < pw) {
-                                x = D[t * (PW + 1) + c];
-                                for (int k = 0; k < c; ++k) x -= D[t * (PW + 1) + k] * D[c * (PW + 1) + k];
-                            }
-                            const double piv = __shfl(x, c); // row c's value = L[c][c]^2
-                            if (!(piv > 1e-300 * dmax) || !isfinite(piv)) {
-                                if (t == 0) bad = 1;
-                                break;
-                            }
-                            const double dgc = sqrt(piv);
-                            if (t == c) {
-                                D[t * (PW + 1) + c] = dgc;
-                                dg[c0 + c] = dgc;
-                            } else if (t > c && t < pw) {
-                                D[t * (PW + 1) + c] = x / dgc;
-                            }
-                        }
-                    }
-                    __syncthreads();
-                    if (bad) break;
-                }
-                if (valid) {
-                    if (i >= c0 + pw) { // triangular solve of this row against the diagonal block
-#pragma unroll
-                        for (int c = 0; c < PW; ++c) {
-                            if (c < pw) {
-                                double x = acc[c];
-#pragma unroll
-                                for (int k = 0; k < c; ++k) x = fma(-acc[k], D[c * (PW + 1) + k], x);
-                                acc[c] = x / D[c * (PW + 1) + c];
-                            }
-                        }
-                    } else { // a diagonal row: its entries are in D
-#pragma unroll
-                        for (int c = 0; c < PW; ++c) acc[c] = D[(i - c0) * (PW + 1) + c];
-                    }
-#pragma unroll
-                    for (int c = 0; c < PW; ++c)
-                        if (c < pw && i > c0 + c) A[(int64_t)(c0 + c) * hp + i] = acc[c]; // U[c0+c][i] = L[i][c0+c]
-                }
-            }
-            __syncthreads();
-        }
-        __syncthreads();
-        if (!bad) break;
-        __syncthreads();
-        ridge = ridge == 0.0 ? 1e-12 * fmax(dmax, 1e-300) : ridge * 100.0;
-    }
-    if (m <= 256) {
-        // Both triangular solves by ONE wave, the right-hand side in registers (index i in lane i & 63, register i >> 6),
-        // the rows of U = L^T streamed one step ahead (they do not depend on the solution, so their L2 latency hides):
-        // no workgroup barrier per column -- with working sets of a few dozen entries the 2 m barriers and dependent
-        // global reads of the general path below were most of this kernel's 0.45 ms.
-        if (tid < 64) {
-            const int l = tid;
-            auto urow = [&](int j, double (&u)[4]) { // U[j][i] = L[i][j], i > j
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = l + 64 * q;
-                    u[q] = (j < m && i > j && i < m) ? A[(int64_t)j * hp + i] : 0.0;
-                }
-            };
-            double yv[4], cur[4], nxt[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) yv[q] = l + 64 * q < m ? -pg[l + 64 * q] : 0.0;
-            // forward substitution L y = -pg, column by column
-            urow(0, cur);
-#pragma unroll
-            for (int jq = 0; jq < 4; ++jq) {
-                for (int jl = 0; jl < 64; ++jl) {
-                    const int j = jq * 64 + jl;
-                    if (j >= m) break;
-                    urow(j + 1, nxt);
-                    const double yj = __shfl(yv[jq], jl) / dg[j];
-                    if (l == jl) yv[jq] = yj;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        yv[q] = fma(-cur[q], yj, yv[q]); // cur is zero for i <= j
-                        cur[q] = nxt[q];
-                    }
-                }
-            }
-            // back substitution L^T d = y, row by row: d[j] = (y[j] - sum_{i > j} U[j][i] d[i]) / dg[j]
-            urow(m - 1, cur);
-#pragma unroll
-            for (int jq = 3; jq >= 0; --jq) {
-                for (int jl = 63; jl >= 0; --jl) {
-                    const int j = jq * 64 + jl;
-                    if (j >= m) continue;
-                    urow(j - 1 >= 0 ? j - 1 : m, nxt); // (row m: zeros)
-                    double part = 0.0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        part = fma(cur[q], yv[q], part); // entries i > j already hold d[i]
-                        cur[q] = nxt[q];
-                    }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-                    if (l == jl) yv[jq] = (yv[jq] - part) / dg[j];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (l + 64 * q < m) dout[(int64_t)r * cap + l + 64 * q] = bad ? 0.0 : yv[q];
-        }
-        return;
-    }
-    // forward substitution L y = -pg
-    for (int i = tid; i < m; i += 256) y[i] = -pg[i];
-    __syncthreads();
-    for (int j = 0; j < m; ++j) {
-        if (tid == 0) y[j] /= dg[j];
-        __syncthreads();
-        const double yj = y[j];
-        for (int i = j + 1 + tid; i < m; i += 256) y[i] -= A[(int64_t)j * hp + i] * yj;
-        __syncthreads();
-    }
-    // back substitution L^T d = y
-    for (int j = m - 1; j >= 0; --j) {
-        if (tid == 0) y[j] /= dg[j];
-        __syncthreads();
-        const double xj = y[j];
-        for (int i = tid; i < j; i += 256) y[i] -= A[(int64_t)i * hp + j] * xj; // L[j][i] = U[i][j]
-        __syncthreads();
-    }
-    for (int i = tid; i < m; i += 256) dout[(int64_t)r * cap + i] = bad ? 0.0 : y[i];
-}
-
-// ------------------------------------------------------------------------------------------
 // Inverse of a preconditioner tile (see gml_solver.hip, Newton-CG): A = sc * H_t - s2 g g^T on the tile's first m entries,
 // Cholesky A = L L^T in LDS (left-looking, one thread per row), L^-1 into the upper triangle (thread j owns column j of
 // L^-1, kept as row j above the diagonal), A^-1 = L^-T L^-1 written over the tile as a full symmetric matrix.
@@ -824,13 +517,268 @@ void launch_tile_inverse(int T, double *H, const long long *hoff, const int *vm,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Batched Newton solve on the device: for every row r, A d = -pg with
+//   A = s1[r] * H_r  -  s2 * gF gF^T        (s2 = 1 for logRISE: Hess log Z = Hess Z / Z - g g^T)
+// H_r is row r's ragged block (lower 32x32 tiles valid, pitch hp); Sdiag[r] = A[m-1][m-1] (the constant column, the Hessian's
+// diagonal scale).  Blocked right-looking Cholesky (round 3).
+//
+// One workgroup per row.  A = s1 H - s2 g g^T is read from the lower triangle of the block and never written, so a ridge
+// restart starts from it again; the factor goes to the strict upper triangle as U[k][i] = L[i][k] (row k = column k of L,
+// contiguous in i), its diagonal to LDS.  Per panel of 32 columns:
+//   (1) the 32 x 32 diagonal block -> LDS, factored by one wave, which also forward-solves the panel of the right-hand side;
+//   (2) every row below the panel solves its 32 entries against that block (one thread per row, the entries in registers,
+//       the block read from LDS as broadcasts) and leaves them in LDS (Lp) and in U;
+//   (3) the trailing matrix is updated from Lp alone, in 4 x 4 register tiles spread over the 256 threads -- first panel:
+//       read from the lower triangle, written to the upper; later panels: updated in place in the upper -- and so is the
+//       rest of the right-hand side: the forward substitution costs no pass of its own.
+// The back substitution walks the panels in reverse: 32 dot products of rows of U with the solved tail (coalesced, one wave
+// per 8 rows), the diagonal block back into LDS, one wave for the 32 x 32 triangular solve.
+// Why: rounds 1-2 had a left-looking panel Cholesky (every panel re-read all previous ones through L2, two barriers per 32 x 32
+// block, the diagonal block factored by 496 dependent LDS inner products) and a one-wave LDS path for small blocks (m dependent
+// column steps): 0.32 ms at 100 entries, 0.44 ms at 190, 0.68 ms at 250 for 128 rows (scripts/gpu_newton_ubench.py); this
+// one: 0.13 / 0.28 / 0.45 ms, 0.03 ms at 30 entries.  What is left is latency: three dependent global round trips and one
+// wave's 32 pivots per panel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_newton_chol(double *__restrict__ H, const long long *__restrict__ hoff, const int *__restrict__ mt,
+                                                     const int *__restrict__ msz, const double *__restrict__ s1, double s2,
+                                                     const double *__restrict__ gF, const double *__restrict__ pgF, int cap,
+                                                     double *__restrict__ dout, double *__restrict__ Sdiag, int mcap /* >= every msz */) {
+    constexpr int PW = 32, LP = PW + 1;
+    const int r = blockIdx.x;
+    const int m = msz[r];
+    if (m == 0) return;
+    const int hp = 32 * mt[r];
+    double *A = H + hoff[r];
+    const double sc = s1[r];
+    const double *g = gF + (int64_t)r * cap, *pg = pgF + (int64_t)r * cap;
+    extern __shared__ double sm[]; // dgw [mcap] | dg [mcap] | y [mcap] | gg [mcap] | Ld [32][33] | tmp [32] | Lp [mcap - 32 (>= 32)][33]
+    double *dgw = sm, *dg = sm + mcap, *y = sm + 2 * mcap, *gg = sm + 3 * mcap, *Ld = sm + 4 * mcap, *tmp = Ld + PW * LP, *Lp = tmp + PW;
+    __shared__ int bad;
+    __shared__ double red[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < m; i += 256) gg[i] = s2 != 0.0 ? g[i] : 0.0;
+    __syncthreads();
+    auto a_low = [&](int i, int j) { return sc * A[(int64_t)i * hp + j] - s2 * gg[i] * gg[j]; }; // i >= j: the matrix itself
+    double dmax = 0;
+    for (int i = tid; i < m; i += 256) dmax = fmax(dmax, fabs(a_low(i, i)));
+    for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
+    if (lane == 0) red[wave] = dmax;
+    __syncthreads();
+    dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (tid == 0) Sdiag[r] = a_low(m - 1, m - 1);
+    double ridge = 0.0;
+    bool ok = false;
+    for (int attempt = 0; attempt < 10 && !ok; ++attempt) {
+        for (int i = tid; i < m; i += 256) {
+            dgw[i] = a_low(i, i) + ridge;
+            y[i] = -pg[i];
+        }
+        if (tid == 0) bad = 0;
+        __syncthreads();
+        for (int c0 = 0; c0 < m; c0 += PW) {
+            const int pw = m - c0 < PW ? m - c0 : PW;
+            const bool first = c0 == 0;
+            // (1) diagonal block -> Ld (lower part; the working diagonal from dgw)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = tid + 256 * q, c = e >> 5, k = e & 31;
+                double v = 0.0;
+                if (c < pw && k < c) v = first ? a_low(c0 + c, c0 + k) : A[(int64_t)(c0 + k) * hp + c0 + c];
+                else if (c < pw && k == c) v = dgw[c0 + c];
+                Ld[c * LP + k] = v;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                // lane t holds row t of the block in registers; right-looking: column c is scaled, then every lane updates
+                // the rest of its row with L[k][c] shuffled in from lane k (independent FMAs: the dependent chain is the 32
+                // pivots, not the 496 inner products an LDS-resident left-looking sweep serialises)
+                const int t = lane & 31;
+                double v[PW];
+#pragma unroll
+                for (int k = 0; k < PW; ++k) v[k] = Ld[t * LP + k];
+                bool fail = false;
+#pragma unroll
+                for (int c = 0; c < PW; ++c) {
+                    if (c < pw && !fail) {
+                        const double piv = __shfl(v[c], c);
+                        if (!(piv > 1e-300 * dmax) || !isfinite(piv)) {
+                            fail = true;
+                        } else {
+                            // 1 / sqrt(piv): the hardware estimate + two Newton steps (a square root and a division in FP64
+                            // are ~40 instructions each, and the 32 pivots are this kernel's one sequential chain)
+                            double inv = __builtin_amdgcn_rsq(piv);
+                            inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+                            inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+                            const double dgc = piv * inv;
+                            v[c] = t == c ? dgc : v[c] * inv;
+                            const double ltc = t > c ? v[c] : 0.0;
+#pragma unroll
+                            for (int k = c + 1; k < PW; ++k) v[k] = fma(-ltc, __shfl(v[c], k), v[k]);
+                        }
+                    }
+                }
+                if (fail) {
+                    if (lane == 0) bad = 1;
+                } else {
+                    if (lane < pw) {
+#pragma unroll
+                        for (int k = 0; k < PW; ++k) Ld[t * LP + k] = k <= t ? v[k] : 0.0;
+                    }
+                    double dgt = 1.0;
+#pragma unroll
+                    for (int k = 0; k < PW; ++k)
+                        if (k == t) dgt = v[k];
+                    if (lane < pw) dg[c0 + t] = dgt;
+                    const double invd = 1.0 / dgt;
+                    tmp[t] = invd; // 1 / L_tt of this block, for the panel solve
+                    // forward substitution of the panel's right-hand side: lanes = rows of the block
+                    double yc = t < pw ? y[c0 + t] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < PW; ++k) {
+                        if (k < pw) {
+                            const double yk = __shfl(yc, k) * __shfl(invd, k);
+                            if (t == k) yc = yk;
+                            else if (t > k) yc = fma(-v[k], yk, yc);
+                        }
+                    }
+                    if (lane < pw) y[c0 + t] = yc;
+                }
+            }
+            __syncthreads();
+            if (!bad) { // the factored block's strict lower part -> U (the back substitution reads it from there)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = tid + 256 * q, c = e >> 5, k = e & 31;
+                    if (c < pw && k < c) A[(int64_t)(c0 + k) * hp + c0 + c] = Ld[c * LP + k];
+                }
+            }
+            if (bad) break;
+            const int r0 = c0 + pw, nt = m - r0; // trailing rows
+            if (nt <= 0) break;
+            // (2) panel solve: row i = r0 + a, a = tid, tid + 256
+            for (int a = tid; a < nt; a += 256) {
+                const int i = r0 + a;
+                double x[PW];
+#pragma unroll
+                for (int c = 0; c < PW; ++c) x[c] = c < pw ? (first ? a_low(i, c0 + c) : A[(int64_t)(c0 + c) * hp + i]) : 0.0;
+#pragma unroll
+                for (int c = 0; c < PW; ++c) {
+                    if (c < pw) {
+                        double v = x[c];
+#pragma unroll
+                        for (int k = 0; k < c; ++k) v = fma(-x[k], Ld[c * LP + k], v);
+                        x[c] = v * tmp[c];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < PW; ++c) {
+                    Lp[a * LP + c] = x[c];
+                    if (c < pw) A[(int64_t)(c0 + c) * hp + i] = x[c];
+                }
+            }
+            __syncthreads();
+            // (3) trailing update in 4 x 4 tiles (ib >= jb), and the rest of the right-hand side
+            const int nb = (nt + 3) >> 2, ntile = nb * (nb + 1) / 2;
+            for (int tile = tid; tile < ntile; tile += 256) {
+                int ib = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+                while ((ib + 1) * (ib + 2) / 2 <= tile) ++ib;
+                while (ib * (ib + 1) / 2 > tile) --ib;
+                const int jb = tile - ib * (ib + 1) / 2;
+                double acc[4][4], old[4][4]; // (the entries to be updated are requested first: their latency hides under the products)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        acc[a][b] = 0.0;
+                        const int ia = 4 * ib + a, jbb = 4 * jb + b;
+                        old[a][b] = (ia < nt && jbb < ia) ? (first ? a_low(r0 + ia, r0 + jbb) : A[(int64_t)(r0 + jbb) * hp + r0 + ia]) : 0.0;
+                    }
+                const double *li = Lp + (4 * ib) * LP, *lj = Lp + (4 * jb) * LP;
+                for (int c = 0; c < pw; ++c) {
+                    double va[4], vb[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        va[a] = li[a * LP + c];
+                        vb[a] = lj[a * LP + c];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[a][b] = fma(va[a], vb[b], acc[a][b]);
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int ia = 4 * ib + a, jbb = 4 * jb + b;
+                        if (ia >= nt || jbb > ia) continue;
+                        const int i = r0 + ia, j = r0 + jbb;
+                        if (i == j) dgw[i] -= acc[a][b];
+                        else A[(int64_t)j * hp + i] = old[a][b] - acc[a][b];
+                    }
+            }
+            for (int a = tid; a < nt; a += 256) {
+                double v = 0.0;
+                for (int c = 0; c < pw; ++c) v = fma(Lp[a * LP + c], y[c0 + c], v);
+                y[r0 + a] -= v;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        ok = !bad;
+        __syncthreads();
+        if (!ok) ridge = ridge == 0.0 ? 1e-12 * fmax(dmax, 1e-300) : ridge * 100.0;
+    }
+    if (!ok) {
+        for (int i = tid; i < m; i += 256) dout[(int64_t)r * cap + i] = 0.0;
+        return;
+    }
+    // back substitution L^T d = y, panels in reverse
+    for (int c0 = (m - 1) / PW * PW; c0 >= 0; c0 -= PW) {
+        const int pw = m - c0 < PW ? m - c0 : PW, r0 = c0 + pw;
+        // tmp[c] = sum_{i >= r0} L[i][c0 + c] d_i = sum_i U[c0 + c][i] y[i]
+        double ldv[4]; // (requested before the dot products: one round trip for both)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q, c = e >> 5, k = e & 31;
+            ldv[q] = (c < pw && k < c) ? A[(int64_t)(c0 + k) * hp + c0 + c] : 0.0;
+        }
+        for (int c = wave; c < pw; c += 4) {
+            double v = 0.0;
+            for (int i = r0 + lane; i < m; i += 64) v = fma(A[(int64_t)(c0 + c) * hp + i], y[i], v);
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) tmp[c] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;
+            Ld[(e >> 5) * LP + (e & 31)] = ldv[q];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int c = lane & 31;
+            double yc = c < pw ? y[c0 + c] - tmp[c] : 0.0;
+            for (int k = pw - 1; k >= 0; --k) { // d_k = y_k / L_kk; y_c -= L[c0 + k][c0 + c] d_k for c < k
+                const double dk = __shfl(yc, k) / dg[c0 + k];
+                if (c == k) yc = dk;
+                else if (c < k) yc = fma(-Ld[k * LP + c], dk, yc);
+            }
+            if (lane < pw) y[c0 + c] = yc;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < m; i += 256) dout[(int64_t)r * cap + i] = y[i];
+}
+
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
                          const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st, int maxm) {
-    // maxm: largest block of this call, as far as the host knows it (0 = unknown): picks the LDS the one-wave path needs
-    const int small_cap = maxm <= 0 ? 64 : (maxm <= 64 ? 64 : (maxm <= 128 ? 128 : 64));
-    const size_t lds = sizeof(double) * std::max<size_t>((size_t)3 * cap + 2 * 32 * 33, small_cap == 128 ? 128 * 129 : 64 * 65);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_newton_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_newton_solve, dim3((unsigned)R), dim3(256), lds, st, H, hoff, mt, msz, s1, s2, gF, pgF, cap, dout, Sdiag, small_cap);
+    // maxm: largest block of this call, as far as the host knows it (0 = unknown): sizes the LDS of a workgroup
+    int mcap = maxm <= 0 || maxm > cap ? cap : maxm;
+    mcap = (mcap + 31) / 32 * 32;
+    const size_t lds = sizeof(double) * ((size_t)4 * mcap + 32 * 33 + 32 + (size_t)std::max(mcap - 32, 32) * 33);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_newton_chol), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_newton_chol, dim3((unsigned)R), dim3(256), lds, st, H, hoff, mt, msz, s1, s2, gF, pgF, cap, dout, Sdiag, mcap);
 }
 
 } // namespace gml

@@ -1,6 +1,6 @@
-"""The batched Newton solve of the direction phase (k_newton_solve: A d = -pg on ragged symmetric positive definite blocks, one
-workgroup per row) against numpy, for every path it has: one-wave LDS blocks (<= 64, <= 128 entries), the panel Cholesky with
-single-wave triangular solves (<= 256) and with workgroup solves (<= 512); with and without the logRISE rank-one term."""
+"""The batched Newton solve of the direction phase (k_newton_chol: A d = -pg on ragged symmetric positive definite blocks, one
+workgroup per row, blocked right-looking Cholesky with panels of 32) against numpy: one panel, partial last panels, sizes around
+every multiple of 32 and 64 up to 512, mixed sizes in one launch; with and without the logRISE rank-one term."""
 import ctypes as C
 
 import numpy as np
