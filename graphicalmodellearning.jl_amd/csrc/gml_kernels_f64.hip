@@ -543,36 +543,61 @@ void launch_tile_inverse(int T, double *H, const long long *hoff, const int *vm,
 __global__ __launch_bounds__(256) void k_newton_chol(double *__restrict__ H, const long long *__restrict__ hoff, const int *__restrict__ mt,
                                                      const int *__restrict__ msz, const double *__restrict__ s1, double s2,
                                                      const double *__restrict__ gF, const double *__restrict__ pgF, int cap,
-                                                     double *__restrict__ dout, double *__restrict__ Sdiag, int mcap /* >= every msz */) {
+                                                     double *__restrict__ dout, double *__restrict__ Sdiag, int mcap /* >= every msz */,
+                                                     // re-solve on an orthant face (k_chol_faces), all three or none: only the rows with
+                                                     // redo[r] != 0; entries with fix != 0 keep the step dfix, the others solve
+                                                     // A_ff d_f = -pg_f - A_fx dfix_x
+                                                     const int *__restrict__ redo, const uint8_t *__restrict__ fix,
+                                                     const double *__restrict__ dfix) {
     constexpr int PW = 32, LP = PW + 1;
     const int r = blockIdx.x;
     const int m = msz[r];
-    if (m == 0) return;
+    if (m == 0 || (redo && !redo[r])) return;
     const int hp = 32 * mt[r];
     double *A = H + hoff[r];
     const double sc = s1[r];
     const double *g = gF + (int64_t)r * cap, *pg = pgF + (int64_t)r * cap;
-    extern __shared__ double sm[]; // dgw [mcap] | dg [mcap] | y [mcap] | gg [mcap] | Ld [32][33] | tmp [32] | Lp [mcap - 32 (>= 32)][33]
-    double *dgw = sm, *dg = sm + mcap, *y = sm + 2 * mcap, *gg = sm + 3 * mcap, *Ld = sm + 4 * mcap, *tmp = Ld + PW * LP, *Lp = tmp + PW;
+    extern __shared__ double sm[]; // dgw [mcap] | dg [mcap] | y [mcap] | gg [mcap] | fx [mcap] | Ld [32][33] | tmp [32] | Lp [mcap - 32 (>= 32)][33]
+    double *dgw = sm, *dg = sm + mcap, *y = sm + 2 * mcap, *gg = sm + 3 * mcap, *fx = sm + 4 * mcap, *Ld = sm + 5 * mcap, *tmp = Ld + PW * LP,
+           *Lp = tmp + PW;
     __shared__ int bad;
     __shared__ double red[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < m; i += 256) gg[i] = s2 != 0.0 ? g[i] : 0.0;
+    for (int i = tid; i < m; i += 256) {
+        gg[i] = s2 != 0.0 ? g[i] : 0.0;
+        fx[i] = fix && fix[(int64_t)r * cap + i] ? 1.0 : 0.0;
+    }
     __syncthreads();
-    auto a_low = [&](int i, int j) { return sc * A[(int64_t)i * hp + j] - s2 * gg[i] * gg[j]; }; // i >= j: the matrix itself
+    auto a_orig = [&](int i, int j) { return sc * A[(int64_t)i * hp + j] - s2 * gg[i] * gg[j]; }; // i >= j: the matrix itself
+    auto a_low = [&](int i, int j) { // ... with the fixed entries decoupled (unit diagonal)
+        if (fix && (fx[i] != 0.0 || fx[j] != 0.0)) return i == j ? 1.0 : 0.0;
+        return a_orig(i, j);
+    };
     double dmax = 0;
     for (int i = tid; i < m; i += 256) dmax = fmax(dmax, fabs(a_low(i, i)));
     for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
     if (lane == 0) red[wave] = dmax;
     __syncthreads();
     dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-    if (tid == 0) Sdiag[r] = a_low(m - 1, m - 1);
+    if (tid == 0 && !fix) Sdiag[r] = a_orig(m - 1, m - 1);
     double ridge = 0.0;
     bool ok = false;
     for (int attempt = 0; attempt < 10 && !ok; ++attempt) {
         for (int i = tid; i < m; i += 256) {
-            dgw[i] = a_low(i, i) + ridge;
-            y[i] = -pg[i];
+            dgw[i] = a_low(i, i) + (fx[i] != 0.0 ? 0.0 : ridge);
+            double v = -pg[i];
+            if (fix) {
+                if (fx[i] != 0.0) {
+                    v = dfix[(int64_t)r * cap + i];
+                } else {
+                    for (int j = 0; j < m; ++j)
+                        if (fx[j] != 0.0) {
+                            const double dj = dfix[(int64_t)r * cap + j];
+                            if (dj != 0.0) v -= (i >= j ? a_orig(i, j) : a_orig(j, i)) * dj;
+                        }
+                }
+            }
+            y[i] = v;
         }
         if (tid == 0) bad = 0;
         __syncthreads();
@@ -772,13 +797,15 @@ __global__ __launch_bounds__(256) void k_newton_chol(double *__restrict__ H, con
 }
 
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
-                         const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st, int maxm) {
+                         const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st, int maxm,
+                         const int *redo, const uint8_t *fix, const double *dfix) {
     // maxm: largest block of this call, as far as the host knows it (0 = unknown): sizes the LDS of a workgroup
     int mcap = maxm <= 0 || maxm > cap ? cap : maxm;
     mcap = (mcap + 31) / 32 * 32;
-    const size_t lds = sizeof(double) * ((size_t)4 * mcap + 32 * 33 + 32 + (size_t)std::max(mcap - 32, 32) * 33);
+    const size_t lds = sizeof(double) * ((size_t)5 * mcap + 32 * 33 + 32 + (size_t)std::max(mcap - 32, 32) * 33);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_newton_chol), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_newton_chol, dim3((unsigned)R), dim3(256), lds, st, H, hoff, mt, msz, s1, s2, gF, pgF, cap, dout, Sdiag, mcap);
+    hipLaunchKernelGGL(k_newton_chol, dim3((unsigned)R), dim3(256), lds, st, H, hoff, mt, msz, s1, s2, gF, pgF, cap, dout, Sdiag, mcap, redo, fix,
+                       dfix);
 }
 
 } // namespace gml

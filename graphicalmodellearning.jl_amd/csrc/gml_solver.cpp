@@ -182,6 +182,10 @@ struct Solver {
     // secant pairs of the Cholesky rows (k_secant): previous working set, x and g on it, the last two (s, y)
     int *dFprev = nullptr, *dMprev = nullptr, *dNpairs = nullptr;
     double *dXprev = nullptr, *dGprev = nullptr, *dSec = nullptr, *dYnoise = nullptr;
+    // orthant faces of the Cholesky rows (k_chol_faces): fixed entries of the working sets, their steps, rows to solve again
+    uint8_t *dFix = nullptr;
+    double *dDfix = nullptr;
+    int *dRedo = nullptr;
     // preconditioner tiles of the matrix-free rows (direction_blocks): control block, column lists, gradient entries
     static constexpr int kTile = 128;
     char *dTctl = nullptr;
@@ -320,6 +324,9 @@ int Solver::init() {
     HIPCHK(A.get(&dXprev, (size_t)Rp * capP));
     HIPCHK(A.get(&dGprev, (size_t)Rp * capP));
     HIPCHK(A.get(&dSec, (size_t)4 * Rp * capP)); // S[0], S[1], Y[0], Y[1]
+    HIPCHK(A.get(&dFix, (size_t)Rp * capP));
+    HIPCHK(A.get(&dDfix, (size_t)Rp * capP));
+    HIPCHK(A.get(&dRedo, (size_t)Rp));
     HIPCHK(hipMemsetAsync(dMprev, 0, sizeof(int) * Rp, st));
     HIPCHK(hipMemsetAsync(dNpairs, 0, sizeof(int) * Rp, st));
     HIPCHK(A.get(&dRes, (size_t)Scap));
@@ -900,6 +907,14 @@ int Solver::newton_blocks(const std::vector<int> &chol_rows) {
         fprintf(stderr, "[gml]   secant pairs in use: none %d rows, one %d, two %d\n", c[0], c[1], c[2]);
     }
     launch_newton_solve(dH, dHoff, dMt, dMt + 2 * R, dS1, s2, dgF, dpgF, (int)R, capP, dsol, dSdiag, st, maxm);
+    // orthant faces (as for the matrix-free rows, newton_cg_group): entries whose step the projection would clip are fixed
+    // there and the rows where they matter solve again for the others -- on the device, without a host round trip (the
+    // re-solve launches are no-ops for the rows that do not need them)
+    HIPCHK(hipMemsetAsync(dFix, 0, (size_t)Rp * capP, st));
+    for (int round = 0; round < face_rounds; ++round) {
+        launch_chol_faces(dRows, (int)chol_rows.size(), dFidx, dMt + 2 * R, capP, X, kind, Qp, dpgF, dsol, face_share, dFix, dDfix, dRedo, st);
+        launch_newton_solve(dH, dHoff, dMt, dMt + 2 * R, dS1, s2, dgF, dpgF, (int)R, capP, dsol, dSdiag, st, maxm, dRedo, dFix, dDfix);
+    }
     launch_scatter_dir(dRows, (int)chol_rows.size(), dFidx, dsol, dMt + 2 * R, capP, Qp, D, st);
     HIPCHK(hipGetLastError());
     return GML_OK;

@@ -197,6 +197,11 @@ __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, co
     // The Hessian blocks and the Cholesky work on whole 32-entry tiles: admit as many violators as fill the working set up
     // to a multiple of 32 rather than one entry into the next tile (support 1 + 64 violators = 65 entries would be three
     // tiles, 2.2x the Hessian work of the 64 that two tiles hold), as long as at least half of max_add still get in.
+    // A row with violators by the ten thousand has a dense optimum ahead of it (config 5 at the reference's default
+    // regulariser: 93 000 at the start, 7 000 in the solution): twice the entries per iteration until it goes matrix-free
+    // (13 -> 9 iterations of that phase, 36.6 -> 34.9 s on one box, the sparse-optimum run at c = 1.2 4.7 -> 3.7 s; four times as many
+    // lengthen the tail instead).
+    if (nviol > 16 * capW) max_add *= 2;
     {
         const int full = (nsupp + max_add) / 32 * 32;
         if (full - nsupp >= max_add / 2) max_add = full - nsupp;
@@ -423,6 +428,46 @@ void launch_secant(const int *drows, int nrows, const int *F, const int *msz, in
     if (nrows > 0)
         hipLaunchKernelGGL(k_secant, dim3((unsigned)nrows), dim3(256), 0, st, drows, F, msz, cap, X, Qp, gF, H, hoff, mt, s1, s2, ynoise, Fprev, mprev,
                            xprev, gprev, S, Y, npairs, pair_stride);
+}
+
+// ------------------------------------------------------------------------------------------
+// Orthant faces of the Cholesky rows (the gathered twin of k_pcg_faces): after the solve, the working-set entries whose step
+// leaves the face of the iterate's orthant -- a coordinate at zero moving with its pseudo-gradient, a non-zero one crossing
+// zero -- are fixed where the projection of the line search would put them (fix = 1, dfix = 0 resp. -x); when they carry
+// more than `share` of the predicted decrease the row is marked for a re-solve of the others (redo[r] = 1; k_newton_chol).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chol_faces(const int *__restrict__ rows, const int *__restrict__ F, const int *__restrict__ msz, int cap,
+                                                    const double *__restrict__ X, const uint8_t *__restrict__ kind, int64_t Qp,
+                                                    const double *__restrict__ pgF, const double *__restrict__ dsol, double share,
+                                                    uint8_t *__restrict__ fix, double *__restrict__ dfix, int *__restrict__ redo) {
+    const int r = rows[blockIdx.x], m = msz[r];
+    const int64_t base = (int64_t)r * cap;
+    __shared__ double red[4];
+    __shared__ int redi[4];
+    int nf = 0;
+    double mass = 0, total = 0;
+    for (int a = threadIdx.x; a < m; a += 256) {
+        if (fix[base + a]) continue;
+        const int c = F[base + a];
+        const double x = X[(int64_t)r * Qp + c], dc = dsol[base + a], pg = pgF[base + a];
+        total += fabs(pg * dc);
+        if (kind[(int64_t)r * Qp + c] != 2) continue;
+        if (x == 0.0 ? dc * pg > 0.0 : (x + dc) * x < 0.0) {
+            const double fixed = x == 0.0 ? 0.0 : -x;
+            mass += fabs(pg * (dc - fixed));
+            fix[base + a] = 1;
+            dfix[base + a] = fixed;
+            ++nf;
+        }
+    }
+    nf = block_sum_i(nf, redi);
+    mass = block_sum(mass, red);
+    total = block_sum(total, red);
+    if (threadIdx.x == 0) redo[r] = nf > 0 && mass > share * total;
+}
+void launch_chol_faces(const int *drows, int nrows, const int *F, const int *msz, int cap, const double *X, const uint8_t *kind, int64_t Qp,
+                       const double *pgF, const double *dsol, double share, uint8_t *fix, double *dfix, int *redo, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_chol_faces, dim3((unsigned)nrows), dim3(256), 0, st, drows, F, msz, cap, X, kind, Qp, pgF, dsol, share, fix, dfix, redo);
 }
 
 // ------------------------------------------------------------------------------------------
