@@ -1712,9 +1712,8 @@ extern "C" int gml_test_tile_precond(int T, int ntiles, const int *m, const doub
 
 // Test hook (not part of include/gml.h): the batched Newton solve on caller-given blocks -- A_r d_r = -pg_r for R symmetric positive
 // definite m_r x m_r blocks (row-major, m_r <= cap <= 512), exactly as gml_learn's direction phase calls it.  tests/test_gpu_newton_solve.py.
-extern "C" int gml_test_newton_solve(int R, const int *m, int cap, const double *blocks /* R x cap x cap, block r uses its leading m_r x m_r */,
-                                     const double *pg /* R x cap */, double s2, const double *g /* R x cap or NULL */, double *d_out /* R x cap */,
-                                     int device) {
+static int test_newton_solve(int R, const int *m, int cap, const double *blocks, const double *pg, double s2, const double *g, double *d_out,
+                             int device, const unsigned char *fix /* R x cap or NULL */, const double *dfix /* R x cap */) {
     HIPCHK(hipSetDevice(device));
     std::vector<long long> hoff((size_t)R + 1, 0);
     std::vector<int> mt((size_t)R);
@@ -1732,11 +1731,12 @@ extern "C" int gml_test_newton_solve(int R, const int *m, int cap, const double 
             for (int j = 0; j < m[r]; ++j) H[(size_t)hoff[r] + (size_t)i * hp + j] = blocks[((size_t)r * cap + i) * cap + j];
         for (int i = m[r]; i < hp; ++i) H[(size_t)hoff[r] + (size_t)i * hp + i] = 1.0; // padding: identity
     }
-    double *dH = nullptr, *dS1 = nullptr, *dG = nullptr, *dPg = nullptr, *dOut = nullptr, *dSd = nullptr;
+    double *dH = nullptr, *dS1 = nullptr, *dG = nullptr, *dPg = nullptr, *dOut = nullptr, *dSd = nullptr, *dDfix = nullptr;
     long long *dHoff = nullptr;
-    int *dMt = nullptr, *dM = nullptr;
+    int *dMt = nullptr, *dM = nullptr, *dRedo = nullptr;
+    uint8_t *dFix = nullptr;
     auto freeall = [&]() {
-        void *ptrs[] = {dH, dS1, dG, dPg, dOut, dSd, dHoff, dMt, dM};
+        void *ptrs[] = {dH, dS1, dG, dPg, dOut, dSd, dHoff, dMt, dM, dDfix, dRedo, dFix};
         for (void *q : ptrs)
             if (q) (void)dev_free(q);
     };
@@ -1764,11 +1764,31 @@ extern "C" int gml_test_newton_solve(int R, const int *m, int cap, const double 
     TCHK(hipMemcpy(dMt, mt.data(), sizeof(int) * R, hipMemcpyHostToDevice));
     TCHK(hipMemcpy(dM, m, sizeof(int) * R, hipMemcpyHostToDevice));
     TCHK(hipMemset(dOut, 0, sizeof(double) * R * cap));
-    launch_newton_solve(dH, dHoff, dMt, dM, dS1, s2, dG, dPg, R, cap, dOut, dSd, nullptr, maxm);
+    if (fix) { // the re-solve on an orthant face: every row is marked
+        std::vector<int> redo((size_t)R, 1);
+        TCHK(dev_malloc(&dFix, (size_t)R * cap));
+        TCHK(dev_malloc(&dDfix, sizeof(double) * R * cap));
+        TCHK(dev_malloc(&dRedo, sizeof(int) * R));
+        TCHK(hipMemcpy(dFix, fix, (size_t)R * cap, hipMemcpyHostToDevice));
+        TCHK(hipMemcpy(dDfix, dfix, sizeof(double) * R * cap, hipMemcpyHostToDevice));
+        TCHK(hipMemcpy(dRedo, redo.data(), sizeof(int) * R, hipMemcpyHostToDevice));
+    }
+    launch_newton_solve(dH, dHoff, dMt, dM, dS1, s2, dG, dPg, R, cap, dOut, dSd, nullptr, maxm, dRedo, dFix, dDfix);
     TCHK(hipGetLastError());
     TCHK(hipDeviceSynchronize());
     TCHK(hipMemcpy(d_out, dOut, sizeof(double) * R * cap, hipMemcpyDeviceToHost));
 #undef TCHK
     freeall();
     return GML_OK;
+}
+
+extern "C" int gml_test_newton_solve(int R, const int *m, int cap, const double *blocks /* R x cap x cap, block r uses its leading m_r x m_r */,
+                                     const double *pg /* R x cap */, double s2, const double *g /* R x cap or NULL */, double *d_out /* R x cap */,
+                                     int device) {
+    return test_newton_solve(R, m, cap, blocks, pg, s2, g, d_out, device, nullptr, nullptr);
+}
+// ... and the re-solve with some entries fixed (fix != 0: d = dfix there; the others solve A_ff d_f = -pg_f - A_fx dfix_x)
+extern "C" int gml_test_newton_solve_fixed(int R, const int *m, int cap, const double *blocks, const double *pg, double s2, const double *g,
+                                           const unsigned char *fix, const double *dfix, double *d_out, int device) {
+    return test_newton_solve(R, m, cap, blocks, pg, s2, g, d_out, device, fix, dfix);
 }

@@ -86,3 +86,43 @@ def test_tile_preconditioner_matches_numpy(T, logrise):
         scale = np.abs(want[t]).max()
         assert np.abs(z[t, :m] - want[t]).max() <= 1e-9 * scale, (t, m, np.abs(z[t, :m] - want[t]).max() / scale)
         assert (z[t, m:] == 0).all()
+
+
+@pytest.mark.parametrize("logrise", [False, True])
+def test_newton_resolve_with_fixed_entries_matches_numpy(logrise):
+    """The orthant-face re-solve of the Cholesky rows (k_newton_chol with fix / dfix): fixed entries keep their prescribed step, the
+    others solve A_ff d_f = -pg_f - A_fx dfix_x."""
+    L = _lib.lib()
+    L.gml_test_newton_solve_fixed.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int]
+    rng = np.random.default_rng(5 + logrise)
+    sizes = [3, 33, 64, 100, 190, 257, 512]
+    cap, R = 512, len(sizes)
+    blocks = np.zeros((R, cap, cap)); pg = np.zeros((R, cap)); g = np.zeros((R, cap)) if logrise else None
+    fix = np.zeros((R, cap), dtype=np.uint8); dfix = np.zeros((R, cap))
+    want = []
+    for r, m in enumerate(sizes):
+        X = rng.choice([-1.0, 1.0], size=(4 * m + 50, m)); h = rng.random(len(X))
+        A = (X * h[:, None]).T @ X / len(h)
+        gg = rng.normal(size=m) * 0.1 if logrise else np.zeros(m)
+        blocks[r, :m, :m] = A + np.outer(gg, gg)
+        pg[r, :m] = rng.normal(size=m)
+        if logrise:
+            g[r, :m] = gg
+        fx = rng.random(m) < 0.2
+        fx[0] = True  # (at least one fixed, and one with a non-zero step)
+        fix[r, :m] = fx
+        dfix[r, :m] = np.where(fx, np.where(rng.random(m) < 0.5, 0.0, rng.normal(size=m) * 0.01), 0.0)
+        dfix[r, 0] = 0.02
+        d = dfix[r, :m].copy()
+        fr = ~fx
+        if fr.any():
+            d[fr] = np.linalg.solve(A[np.ix_(fr, fr)], -pg[r, :m][fr] - A[np.ix_(fr, fx)] @ dfix[r, :m][fx])
+        want.append(d)
+    out = np.zeros((R, cap))
+    ms = np.array(sizes, dtype=np.int32)
+    _lib.check(L.gml_test_newton_solve_fixed(R, _lib._ptr(ms), cap, _lib._ptr(blocks), _lib._ptr(pg), 1.0 if logrise else 0.0, _lib._ptr(g),
+                                             _lib._ptr(fix), _lib._ptr(dfix), _lib._ptr(out), 0))
+    for r, m in enumerate(sizes):
+        scale = np.abs(want[r]).max()
+        assert np.abs(out[r, :m] - want[r]).max() <= 1e-9 * scale, (m, np.abs(out[r, :m] - want[r]).max() / scale)
