@@ -150,10 +150,20 @@ void launch_glauber(const int *dioff, const double *diw, const int *dooff, const
 
 // Batched Newton solve on the ragged Hessian blocks: A = s1[r]*H_r - s2*gF gF^T, A d = -pgF, in place
 // (Cholesky, ridge restart).  gF/pgF/dout are R x cap; Sdiag[r] = A[m-1][m-1].
+// faces: the orthant-face re-solves inside the kernel (working-set columns F [R][cap], iterates X [R][Qp] and their column kinds,
+// the share of the predicted decrease that triggers a re-solve, the number of re-solves); fix / dfix [R][cap]: entries fixed
+// from the start (tests).
+struct NewtonFaces {
+    const int *F = nullptr;
+    const double *X = nullptr;
+    const uint8_t *kind = nullptr;
+    int64_t Qp = 0;
+    double share = 0.05;
+    int rounds = 0;
+};
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
                          const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st, int maxm = 0,
-                         const int *redo = nullptr, const uint8_t *fix = nullptr, const double *dfix = nullptr);
-// (redo / fix / dfix: the re-solve of the rows whose step leaves its orthant face, see k_newton_chol and k_chol_faces)
+                         const NewtonFaces *faces = nullptr, const uint8_t *fix = nullptr, const double *dfix = nullptr);
 // Preconditioner tiles (T = 64 or 128): tile t holds the lower triangle of its T x T Hessian block at H + hoff[t] (pitch T);
 // A = s1[wrow[t]] * H_t - s2 * g g^T on its first vm[t] entries is replaced, in place, by its inverse (full symmetric matrix);
 // a block that is not positive definite even with a ridge becomes its inverse diagonal.

@@ -1764,16 +1764,13 @@ static int test_newton_solve(int R, const int *m, int cap, const double *blocks,
     TCHK(hipMemcpy(dMt, mt.data(), sizeof(int) * R, hipMemcpyHostToDevice));
     TCHK(hipMemcpy(dM, m, sizeof(int) * R, hipMemcpyHostToDevice));
     TCHK(hipMemset(dOut, 0, sizeof(double) * R * cap));
-    if (fix) { // the re-solve on an orthant face: every row is marked
-        std::vector<int> redo((size_t)R, 1);
+    if (fix) { // some entries fixed from the start
         TCHK(dev_malloc(&dFix, (size_t)R * cap));
         TCHK(dev_malloc(&dDfix, sizeof(double) * R * cap));
-        TCHK(dev_malloc(&dRedo, sizeof(int) * R));
         TCHK(hipMemcpy(dFix, fix, (size_t)R * cap, hipMemcpyHostToDevice));
         TCHK(hipMemcpy(dDfix, dfix, sizeof(double) * R * cap, hipMemcpyHostToDevice));
-        TCHK(hipMemcpy(dRedo, redo.data(), sizeof(int) * R, hipMemcpyHostToDevice));
     }
-    launch_newton_solve(dH, dHoff, dMt, dM, dS1, s2, dG, dPg, R, cap, dOut, dSd, nullptr, maxm, dRedo, dFix, dDfix);
+    launch_newton_solve(dH, dHoff, dMt, dM, dS1, s2, dG, dPg, R, cap, dOut, dSd, nullptr, maxm, nullptr, dFix, dDfix);
     TCHK(hipGetLastError());
     TCHK(hipDeviceSynchronize());
     TCHK(hipMemcpy(d_out, dOut, sizeof(double) * R * cap, hipMemcpyDeviceToHost));

@@ -544,33 +544,38 @@ __global__ __launch_bounds__(256) void k_newton_chol(double *__restrict__ H, con
                                                      const int *__restrict__ msz, const double *__restrict__ s1, double s2,
                                                      const double *__restrict__ gF, const double *__restrict__ pgF, int cap,
                                                      double *__restrict__ dout, double *__restrict__ Sdiag, int mcap /* >= every msz */,
-                                                     // re-solve on an orthant face (k_chol_faces), all three or none: only the rows with
-                                                     // redo[r] != 0; entries with fix != 0 keep the step dfix, the others solve
-                                                     // A_ff d_f = -pg_f - A_fx dfix_x
-                                                     const int *__restrict__ redo, const uint8_t *__restrict__ fix,
-                                                     const double *__restrict__ dfix) {
+                                                     // orthant faces (below): the working sets' columns, the iterates and their column
+                                                     // kinds, the share of the predicted decrease that triggers a re-solve, the number
+                                                     // of re-solves; F = NULL: none
+                                                     const int *__restrict__ F, const double *__restrict__ X, const uint8_t *__restrict__ kind,
+                                                     int64_t Qp, double share, int rounds,
+                                                     // entries fixed from the start (tests): fix != 0 keeps the step dfix
+                                                     const uint8_t *__restrict__ fix, const double *__restrict__ dfix) {
     constexpr int PW = 32, LP = PW + 1;
     const int r = blockIdx.x;
     const int m = msz[r];
-    if (m == 0 || (redo && !redo[r])) return;
+    if (m == 0) return;
     const int hp = 32 * mt[r];
     double *A = H + hoff[r];
     const double sc = s1[r];
     const double *g = gF + (int64_t)r * cap, *pg = pgF + (int64_t)r * cap;
-    extern __shared__ double sm[]; // dgw [mcap] | dg [mcap] | y [mcap] | gg [mcap] | fx [mcap] | Ld [32][33] | tmp [32] | Lp [mcap - 32 (>= 32)][33]
-    double *dgw = sm, *dg = sm + mcap, *y = sm + 2 * mcap, *gg = sm + 3 * mcap, *fx = sm + 4 * mcap, *Ld = sm + 5 * mcap, *tmp = Ld + PW * LP,
-           *Lp = tmp + PW;
+    extern __shared__ double sm[]; // dgw | dg | y | gg | fx | dfx [mcap each] | Ld [32][33] | tmp [32] | Lp [mcap - 32 (>= 32)][33]
+    double *dgw = sm, *dg = sm + mcap, *y = sm + 2 * mcap, *gg = sm + 3 * mcap, *fx = sm + 4 * mcap, *dfx = sm + 5 * mcap, *Ld = sm + 6 * mcap,
+           *tmp = Ld + PW * LP, *Lp = tmp + PW;
     __shared__ int bad;
     __shared__ double red[4];
+    __shared__ int redi[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bool masked = fix != nullptr || F != nullptr; // some entries may be fixed
     for (int i = tid; i < m; i += 256) {
         gg[i] = s2 != 0.0 ? g[i] : 0.0;
         fx[i] = fix && fix[(int64_t)r * cap + i] ? 1.0 : 0.0;
+        dfx[i] = fix ? dfix[(int64_t)r * cap + i] : 0.0;
     }
     __syncthreads();
     auto a_orig = [&](int i, int j) { return sc * A[(int64_t)i * hp + j] - s2 * gg[i] * gg[j]; }; // i >= j: the matrix itself
     auto a_low = [&](int i, int j) { // ... with the fixed entries decoupled (unit diagonal)
-        if (fix && (fx[i] != 0.0 || fx[j] != 0.0)) return i == j ? 1.0 : 0.0;
+        if (masked && (fx[i] != 0.0 || fx[j] != 0.0)) return i == j ? 1.0 : 0.0;
         return a_orig(i, j);
     };
     double dmax = 0;
@@ -579,22 +584,20 @@ __global__ __launch_bounds__(256) void k_newton_chol(double *__restrict__ H, con
     if (lane == 0) red[wave] = dmax;
     __syncthreads();
     dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-    if (tid == 0 && !fix) Sdiag[r] = a_orig(m - 1, m - 1);
+    if (tid == 0) Sdiag[r] = a_orig(m - 1, m - 1);
+    for (int face = 0;; ++face) { // (re-solves on an orthant face, see the end of the loop)
     double ridge = 0.0;
     bool ok = false;
     for (int attempt = 0; attempt < 10 && !ok; ++attempt) {
         for (int i = tid; i < m; i += 256) {
             dgw[i] = a_low(i, i) + (fx[i] != 0.0 ? 0.0 : ridge);
             double v = -pg[i];
-            if (fix) {
+            if (masked) {
                 if (fx[i] != 0.0) {
-                    v = dfix[(int64_t)r * cap + i];
+                    v = dfx[i];
                 } else {
                     for (int j = 0; j < m; ++j)
-                        if (fx[j] != 0.0) {
-                            const double dj = dfix[(int64_t)r * cap + j];
-                            if (dj != 0.0) v -= (i >= j ? a_orig(i, j) : a_orig(j, i)) * dj;
-                        }
+                        if (fx[j] != 0.0 && dfx[j] != 0.0) v -= (i >= j ? a_orig(i, j) : a_orig(j, i)) * dfx[j];
                 }
             }
             y[i] = v;
@@ -793,19 +796,65 @@ __global__ __launch_bounds__(256) void k_newton_chol(double *__restrict__ H, con
         }
         __syncthreads();
     }
+    // Orthant faces.  The line search projects the step onto the orthant of the iterate: an entry at zero may only move
+    // against its pseudo-gradient, a non-zero one not past zero.  Entries whose step leaves that face are fixed where the
+    // projection would put them (at zero: d = 0 resp. -x) and, when they carry more than `share` of the predicted decrease,
+    // the others are solved again -- with correlated statistics the unconstrained solution is full of moves that cancel each
+    // other, and clipping one of a pair leaves the other uncompensated (the matrix-free rows do the same: k_pcg_faces).
+    if (!F || face >= rounds) break;
+    int nf = 0;
+    double mass = 0, total = 0;
+    for (int a = tid; a < m; a += 256) {
+        if (fx[a] != 0.0) continue;
+        const int c = F[(int64_t)r * cap + a];
+        const double x = X[(int64_t)r * Qp + c], dc = y[a], pv = pg[a];
+        total += fabs(pv * dc);
+        if (kind[(int64_t)r * Qp + c] != 2) continue;
+        if (x == 0.0 ? dc * pv > 0.0 : (x + dc) * x < 0.0) {
+            const double fixed = x == 0.0 ? 0.0 : -x;
+            mass += fabs(pv * (dc - fixed));
+            fx[a] = 2.0; // candidate
+            dfx[a] = fixed;
+            ++nf;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        nf += __shfl_xor(nf, o);
+        mass += __shfl_xor(mass, o);
+        total += __shfl_xor(total, o);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        redi[wave] = nf;
+        red[wave] = mass;
+    }
+    __syncthreads();
+    nf = redi[0] + redi[1] + redi[2] + redi[3];
+    mass = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    if (lane == 0) red[wave] = total;
+    __syncthreads();
+    total = red[0] + red[1] + red[2] + red[3];
+    const bool again = nf > 0 && mass > share * total;
+    for (int a = tid; a < m; a += 256)
+        if (fx[a] == 2.0) fx[a] = again ? 1.0 : 0.0;
+    __syncthreads();
+    if (!again) break;
+    } // face
     for (int i = tid; i < m; i += 256) dout[(int64_t)r * cap + i] = y[i];
 }
 
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
                          const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st, int maxm,
-                         const int *redo, const uint8_t *fix, const double *dfix) {
+                         const NewtonFaces *faces, const uint8_t *fix, const double *dfix) {
     // maxm: largest block of this call, as far as the host knows it (0 = unknown): sizes the LDS of a workgroup
     int mcap = maxm <= 0 || maxm > cap ? cap : maxm;
     mcap = (mcap + 31) / 32 * 32;
-    const size_t lds = sizeof(double) * ((size_t)5 * mcap + 32 * 33 + 32 + (size_t)std::max(mcap - 32, 32) * 33);
+    const size_t lds = sizeof(double) * ((size_t)6 * mcap + 32 * 33 + 32 + (size_t)std::max(mcap - 32, 32) * 33);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_newton_chol), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_newton_chol, dim3((unsigned)R), dim3(256), lds, st, H, hoff, mt, msz, s1, s2, gF, pgF, cap, dout, Sdiag, mcap, redo, fix,
-                       dfix);
+    const NewtonFaces nf = faces ? *faces : NewtonFaces{};
+    hipLaunchKernelGGL(k_newton_chol, dim3((unsigned)R), dim3(256), lds, st, H, hoff, mt, msz, s1, s2, gF, pgF, cap, dout, Sdiag, mcap, nf.F, nf.X,
+                       nf.kind, nf.Qp, nf.share, nf.rounds, fix, dfix);
 }
 
 } // namespace gml

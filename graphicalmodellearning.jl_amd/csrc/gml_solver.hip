@@ -431,46 +431,6 @@ void launch_secant(const int *drows, int nrows, const int *F, const int *msz, in
 }
 
 // ------------------------------------------------------------------------------------------
-// Orthant faces of the Cholesky rows (the gathered twin of k_pcg_faces): after the solve, the working-set entries whose step
-// leaves the face of the iterate's orthant -- a coordinate at zero moving with its pseudo-gradient, a non-zero one crossing
-// zero -- are fixed where the projection of the line search would put them (fix = 1, dfix = 0 resp. -x); when they carry
-// more than `share` of the predicted decrease the row is marked for a re-solve of the others (redo[r] = 1; k_newton_chol).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_faces(const int *__restrict__ rows, const int *__restrict__ F, const int *__restrict__ msz, int cap,
-                                                    const double *__restrict__ X, const uint8_t *__restrict__ kind, int64_t Qp,
-                                                    const double *__restrict__ pgF, const double *__restrict__ dsol, double share,
-                                                    uint8_t *__restrict__ fix, double *__restrict__ dfix, int *__restrict__ redo) {
-    const int r = rows[blockIdx.x], m = msz[r];
-    const int64_t base = (int64_t)r * cap;
-    __shared__ double red[4];
-    __shared__ int redi[4];
-    int nf = 0;
-    double mass = 0, total = 0;
-    for (int a = threadIdx.x; a < m; a += 256) {
-        if (fix[base + a]) continue;
-        const int c = F[base + a];
-        const double x = X[(int64_t)r * Qp + c], dc = dsol[base + a], pg = pgF[base + a];
-        total += fabs(pg * dc);
-        if (kind[(int64_t)r * Qp + c] != 2) continue;
-        if (x == 0.0 ? dc * pg > 0.0 : (x + dc) * x < 0.0) {
-            const double fixed = x == 0.0 ? 0.0 : -x;
-            mass += fabs(pg * (dc - fixed));
-            fix[base + a] = 1;
-            dfix[base + a] = fixed;
-            ++nf;
-        }
-    }
-    nf = block_sum_i(nf, redi);
-    mass = block_sum(mass, red);
-    total = block_sum(total, red);
-    if (threadIdx.x == 0) redo[r] = nf > 0 && mass > share * total;
-}
-void launch_chol_faces(const int *drows, int nrows, const int *F, const int *msz, int cap, const double *X, const uint8_t *kind, int64_t Qp,
-                       const double *pgF, const double *dsol, double share, uint8_t *fix, double *dfix, int *redo, hipStream_t st) {
-    if (nrows > 0) hipLaunchKernelGGL(k_chol_faces, dim3((unsigned)nrows), dim3(256), 0, st, drows, F, msz, cap, X, kind, Qp, pgF, dsol, share, fix, dfix, redo);
-}
-
-// ------------------------------------------------------------------------------------------
 // Trial point of the projected (orthant-wise) line search: xt = P(x + alpha d), where a penalised coordinate that
 // would cross zero is clipped to it (orthant face: the sign of x, or of -pg at zero).  out: dd = pg . (xt - x) (the
 // directional derivative of F along the projected step), stepn = |xt - x|_1, l1t = lambda sum |xt_c|.
