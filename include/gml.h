@@ -59,7 +59,8 @@ typedef struct gml_opts {
     int32_t precision;   /* GML_PREC_* (default GML_PREC_AUTO)                               */
     int32_t max_working; /* cap on a node's Newton block (default = max = 512, multiple of 32); a
                             denser optimum is solved by cycling blocks (block Gauss-Seidel)    */
-    int32_t max_add;     /* new (violating) coordinates admitted per node per iteration (default 64) */
+    int32_t max_add;     /* new (violating) coordinates admitted per node per iteration (default 64; twice that while a node has
+                            more than 16 max_working violators: a dense optimum) */
     int32_t verbose;     /* 0 silent, 1 per-iteration line on stderr                        */
     int32_t hess_samples; /* Newton Hessians use the first hess_samples configurations (< 0 = all;
                             0 = adaptive: 32768 x (local nodes / nodes still active), so the
@@ -81,7 +82,8 @@ typedef struct gml_opts {
     int32_t reserved0;
     double cg_viol_frac; /* matrix-free rows admit, per iteration, the violators within this fraction of the largest
                             violation (default 0.5: full Newton steps throughout on dense optima)           */
-    double cg_eta;       /* CG stops at a residual reduced by min(cg_eta, sqrt(kkt)) (default 0.05)                         */
+    double cg_eta;       /* CG stops at a residual reduced by min(cg_eta, sqrt(kkt)) (default 0.05); rows that are still building
+                            their support (violators > 1/16 of the support) stop at 0.25                                   */
 } gml_opts;
 
 typedef struct gml_stats {
