@@ -1112,33 +1112,51 @@ __global__ __launch_bounds__(256) void k_make_hw(const int8_t *__restrict__ Vq, 
                                                  const int *__restrict__ rowcol /* row -> node */,
                                                  const int *__restrict__ vslot /* row -> slot of its V planes */,
                                                  const int *__restrict__ mt /* rows with mt[r] = 0 are skipped */, int64_t Kp,
-                                                 int64_t Hpitch, int64_t kstride, int form, int8_t *__restrict__ Hq,
+                                                 int64_t Hpitch, int64_t kstride, int64_t Kh, int form, int8_t *__restrict__ Hq,
                                                  long long *__restrict__ hS) {
+    // A thread owns 4 consecutive bytes of a 64-sample row piece: the V image and the weight planes share the byte order
+    // vq_pos() within a piece, and 4 consecutive positions are 4 consecutive samples, so the four limbs come in as four
+    // dwords and leave as four dwords (one byte per element and limb before: 4x the memory instructions).
     const int r = blockIdx.y;
     if (mt[r] == 0) return;
     const int u = rowcol[r], vs = vslot[r];
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;        // compact index
-    const int64_t k = (j >> 9) * kstride * 512 + (j & 511);          // the configuration it stands for
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; // (piece, dword)
+    const int64_t jc = (t >> 4) * 64;                            // compact index of the piece's first sample
+    const int p4 = (int)(t & 15) * 4;                            // byte position within the piece
     const int tile = r >> 5, rl = r & 31;
-    int mag = 0;
-    if (k < Kp) {
-        const int8_t *vq = Vq + vq_off(vs, 0, k, Kp);
-        const int q = (int)vq[0] + 256 * ((int)vq[32 * 64] + 256 * ((int)vq[64 * 64] + 256 * (int)vq[96 * 64]));
-        const int sgn = (Sb[(int64_t)u * (Kp >> 5) + (k >> 5)] >> (k & 31)) & 1u; // s_u^k = 1 - 2 sgn
-        mag = sgn ? q : -q;                                           // V = -w exp(-E) s: |V| = -q s >= 0
-        if (form == 2) {
-            const double t = tau[vs], a = (double)mag * t, wk = w[k];
-            mag = wk > 0 ? (int)rint(2.0 * a * (1.0 - a / (2.0 * wk)) / t) : 0;
+    long long sm = 0;
+    if (jc < Kh) {
+        const int64_t kc = (jc >> 9) * kstride * 512 + (jc & 511); // the configuration the piece starts at
+        // samples of the positions p4 .. p4 + 3: s = s0 .. s0 + 3 (inverse of vq_pos)
+        const int s0 = (((p4 >> 5) & 1) << 2) | (((p4 >> 2) & 3) << 3) | (((p4 >> 4) & 1) << 5);
+        unsigned q[4] = {0u, 0u, 0u, 0u};
+        unsigned sg = 0;
+        if (kc < Kp) {
+            const int8_t *vq = Vq + vq_off(vs, 0, kc, Kp) + p4; // (vq_pos(0) = 0: the piece's first byte)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) q[l] = *reinterpret_cast<const unsigned *>(vq + l * 32 * 64);
+            const int64_t k0 = kc + s0;
+            sg = (Sb[(int64_t)u * (Kp >> 5) + (k0 >> 5)] >> (k0 & 31)) & 15u; // s_u^k = 1 - 2 bit
         }
+        unsigned dgw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int qv = (int)(int8_t)(q[0] >> (8 * e)) + 256 * ((int)(int8_t)(q[1] >> (8 * e)) + 256 * ((int)(int8_t)(q[2] >> (8 * e)) + 256 * (int)(int8_t)(q[3] >> (8 * e))));
+            int mag = ((sg >> e) & 1u) ? qv : -qv; // V = -w exp(-E) s: |V| = -q s >= 0
+            if (form == 2) {
+                const double tt = tau[vs], a = (double)mag * tt, wk = kc < Kp ? w[kc + s0 + e] : 0.0;
+                mag = wk > 0 ? (int)rint(2.0 * a * (1.0 - a / (2.0 * wk)) / tt) : 0;
+            }
+            sm += mag;
+            const unsigned dg = ((unsigned)mag + 0x80808080u) ^ 0x80808080u;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) dgw[l] |= ((dg >> (8 * l)) & 0xffu) << (8 * e);
+        }
+        int8_t *hq = Hq + ((int64_t)tile * 128 + rl) * Hpitch + jc + p4;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) *reinterpret_cast<unsigned *>(hq + (int64_t)l * 32 * Hpitch) = dgw[l];
     }
-    const unsigned dg = ((unsigned)mag + 0x80808080u) ^ 0x80808080u;
-    int8_t *hq = Hq + ((int64_t)tile * 128 + rl) * Hpitch + (j & ~(int64_t)63) + vq_pos((int)(j & 63));
-    hq[0] = (int8_t)(dg & 0xff);
-    hq[32 * Hpitch] = (int8_t)((dg >> 8) & 0xff);
-    hq[64 * Hpitch] = (int8_t)((dg >> 16) & 0xff);
-    hq[96 * Hpitch] = (int8_t)((dg >> 24) & 0xff);
     // S = sum of the weights
-    long long sm = mag;
     for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
     __shared__ long long red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sm;
@@ -1476,8 +1494,8 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
     }
     I8CHK(hipMemsetAsync(w->H64, 0, sizeof(long long) * need, st));
     I8CHK(hipMemsetAsync(w->hS, 0, sizeof(long long) * Rp, st));
-    hipLaunchKernelGGL(k_make_hw, dim3((unsigned)(Kh / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Sb, d.w, w->sc[0].tau, dRowcol, dVslot,
-                       dFlag, d.Kp, pitch, kstride, form, w->Hq, w->hS);
+    hipLaunchKernelGGL(k_make_hw, dim3((unsigned)((Kh / 4 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Sb, d.w, w->sc[0].tau, dRowcol,
+                       dVslot, dFlag, d.Kp, pitch, kstride, Kh, form, w->Hq, w->hS);
     if (maxsmall > 0) launch_hess_blk<2>(w, d, dF, dMt, dHoff, R, cap, maxsmall, Kh, kstride, nsmall, st, tl);
     if (maxm > 4) { // (tiles hold at most 4 x 32 entries: only the rows' own blocks are in this size class)
         HessTiles rows_only = tl;
