@@ -1173,6 +1173,7 @@ __global__ __launch_bounds__(256) void k_build_mb(const unsigned *__restrict__ X
     *reinterpret_cast<uint2 *>(Mb + (c * nkk + kt) * 2) = v;
 }
 
+constexpr int kHessSmall = 4; // working sets of up to this many 32-entry tiles take the 2 x 2 kernel, larger ones the 2 x 4
 // Blocked kernel: a workgroup computes the tile block (rows 2a, 2a+1) x (columns BT b .. BT b + BT - 1) of one row's
 // working-set matrix (needed iff BT b <= 2a + 1: lower triangle) over one chunk of the compact index.  Per group of 8
 // steps (512 samples) it DMAs the 64 + 32 BT gathered rows x 64 B of bits and 4 x 512 B of weight limbs into a
@@ -1196,7 +1197,7 @@ __global__ __launch_bounds__(256, 2) void k_hess_bits_blk(const unsigned *__rest
     int8_t *eb = lds + NSG * STAGE;
     const int r = blockIdx.z + z0; // block: a row's working set (r < R0), or tile r - R0 of the matrix-free rows' preconditioner
     const int m = mt[r];
-    if (m == 0 || (m <= 4) != (BT == 2)) return; // one launch per size class
+    if (m == 0 || (m <= kHessSmall) != (BT == 2)) return; // one launch per size class
     // decode the block index: a = tile-row pair, b = group of BT tile columns, needed iff BT b <= 2a+1
     int a = 0, b = blockIdx.y;
     for (;;) {
@@ -1458,15 +1459,20 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
     int64_t nsmall = 0, nlarge = 0;
     for (int r = 0; r < R; ++r) {
         maxm = hMt[r] > maxm ? hMt[r] : maxm;
-        if (hMt[r] <= 4) maxsmall = hMt[r] > maxsmall ? hMt[r] : maxsmall;
-        if (hMt[r] > 4) ++nlarge;
+        if (hMt[r] <= kHessSmall) maxsmall = hMt[r] > maxsmall ? hMt[r] : maxsmall;
+        if (hMt[r] > kHessSmall) ++nlarge;
         else if (hMt[r] > 0) ++nsmall;
     }
     if (maxm > 16) return GML_EUNSUPPORTED;
+    const bool tiles_small = tl.T / 32 <= kHessSmall;
     if (tl.n > 0) { // the tiles: tl.n blocks of T / 32 <= 4 tiles each
         maxm = std::max(maxm, tl.T / 32);
-        maxsmall = std::max(maxsmall, tl.T / 32);
-        nsmall += tl.n;
+        if (tiles_small) {
+            maxsmall = std::max(maxsmall, tl.T / 32);
+            nsmall += tl.n;
+        } else {
+            nlarge += tl.n;
+        }
     }
     const int64_t pitch = d.Kp, Rp = (R + 31) / 32 * 32;
     if (Kh > pitch) Kh = pitch;
@@ -1496,12 +1502,10 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
     I8CHK(hipMemsetAsync(w->hS, 0, sizeof(long long) * Rp, st));
     hipLaunchKernelGGL(k_make_hw, dim3((unsigned)((Kh / 4 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Sb, d.w, w->sc[0].tau, dRowcol,
                        dVslot, dFlag, d.Kp, pitch, kstride, Kh, form, w->Hq, w->hS);
-    if (maxsmall > 0) launch_hess_blk<2>(w, d, dF, dMt, dHoff, R, cap, maxsmall, Kh, kstride, nsmall, st, tl);
-    if (maxm > 4) { // (tiles hold at most 4 x 32 entries: only the rows' own blocks are in this size class)
-        HessTiles rows_only = tl;
-        rows_only.n = 0;
-        launch_hess_blk<4>(w, d, dF, dMt, dHoff, R, cap, maxm, Kh, kstride, nlarge, st, rows_only);
-    }
+    HessTiles rows_only = tl; // (the tiles are all of one size class: the other launch covers the rows' own blocks only)
+    rows_only.n = 0;
+    if (maxsmall > 0) launch_hess_blk<2>(w, d, dF, dMt, dHoff, R, cap, maxsmall, Kh, kstride, nsmall, st, tiles_small ? tl : rows_only);
+    if (maxm > kHessSmall) launch_hess_blk<4>(w, d, dF, dMt, dHoff, R, cap, maxm, Kh, kstride, nlarge, st, tiles_small ? rows_only : tl);
     hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64, w->hS,
                        w->sc[0].tau, dVslot, dMt, dHoff, dH, 0, R, tl.wrow);
     const int tm = tl.T / 32;
