@@ -19,6 +19,7 @@ for it in range(40):
         if kind == 0 and it % 3 and it % 2:
             if ref is None: ref = out.copy()
             assert np.array_equal(ref, out)
+    gml._lib.trim_cache() if hasattr(gml, '_lib') else import_module('gml_amd._lib').trim_cache()  # (released blocks are cached by the library: hand them back before looking)
     free = torch.cuda.mem_get_info()[0]
     if it == 7: free0 = free  # the runtime's one-time allocations (code objects, pools) are in by now
     if it % 8 == 7: print(it, 'free GB %.3f (start %.3f)' % (free / 1e9, free0 / 1e9), flush=True)
