@@ -57,11 +57,11 @@ void launch_check_pm1(const int8_t *S, int64_t K, int64_t n, long long *bad, hip
 int64_t xtb_bytes(const DevProblem &d);
 
 // Byte offset of limb l of V[r][k] in the int8 limb image Vq of the fixed-point pass: images [node tile r/32][k/64]
-// of [4 limbs x 32 rows][64 B], contiguous (8 KB each); within a row the 64 samples of the step are stored in the
-// order vq_pos() (gml_bits.h), which the feature-major bit image shares, so the backward GEMM contracts position
-// against position.
-__host__ __device__ inline int64_t vq_off(int64_t r, int l, int64_t k, int64_t Kp) {
-    return ((((r >> 5) * (Kp >> 6) + (k >> 6)) * 4 + l) * 32 + (r & 31)) * 64 + vq_pos((int)(k & 63));
+// of [lbt limbs x 32 rows][64 B], contiguous (lbt = 4: 8 KB each, the i8x pass; 6: 12 KB, the i8w pass); within a row the
+// 64 samples of the step are stored in the order vq_pos() (gml_bits.h), which the feature-major bit image shares, so the
+// backward GEMM contracts position against position.
+__host__ __device__ inline int64_t vq_off(int64_t r, int l, int64_t k, int64_t Kp, int lbt = 4) {
+    return ((((r >> 5) * (Kp >> 6) + (k >> 6)) * lbt + l) * 32 + (r & 31)) * 64 + vq_pos((int)(k & 63));
 }
 
 // ---- int8-limb path --------------------------------------------------------------------------
@@ -93,10 +93,16 @@ struct I8Pass {
     int64_t kchunk, kpart; // hv: a split plan fixed by the caller (one operator for all the steps of a CG solve); 0 = plan here
     SlotResult *res;      // device [slots] or NULL: {f, tau, mmax} of every slot of the pass, written by its last kernel
     int lf;               // forward limb planes (3, 4, 5; 0 = the default, 5; 2 for Hessian-vector directions): 8 lf - 2 significant bits of theta
+    bool wide;            // the FP64-grade pass (precision i8w): theta in 7 limb planes (54 bits), V in 6 (47 bits), FP64 exp;
+                          // the workspace then holds 6-plane V images, of which Hessians and Hessian-vector passes read the top 4
 };
 void i8_split_plan(const DevProblem &d, int ngroups, int ksub, int64_t *kchunk, int64_t *kpart, int *nsplit);
 int i8_pass(void **ws, const DevProblem &d, int64_t slot_capacity, const I8Pass &a, hipStream_t st, hipEvent_t *ev /* [3] or NULL */,
             std::string *err);
+// Unit of SlotResult.mmax in multiples of SlotResult.tau, and the largest |V| / tau the planes hold, for a pass of the given width:
+// (mmax + 1) * i8_mmax_unit * tau bounds max_k |V_k|; a caller-imposed scale is bound / i8_vdiv.
+inline double i8_mmax_unit(bool wide) { return wide ? 65536.0 : 1.0; }
+inline double i8_vdiv(bool wide) { return wide ? 1.400e14 : 2130000000.0; }
 void i8_free(void *ws);
 // per-slot results of the last pass of the given kind (device pointers)
 void i8_slot_results(void *ws, int hv, const double **tau, const unsigned **mmax);

@@ -1260,7 +1260,8 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
     if (ms)
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     double *dOvr = nullptr;
-    if (precision == GML_PREC_I8X) {
+    const bool wide = precision == GML_PREC_I8W;
+    if (gml_is_i8(precision)) {
         if (tau_ovr) {
             HIPCHK(dev_malloc(&dOvr, sizeof(double) * Rp));
             HIPCHK(hipMemcpyAsync(dOvr, tau_ovr->data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
@@ -1279,6 +1280,7 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
         a.F = p->dF;
         a.G = p->dG;
         a.tauovr = dOvr;
+        a.wide = wide;
         rc = gml::i8_pass(&p->i8ws, p->d, W, a, st, ms ? ev : nullptr, &err);
         if (rc) {
             if (dOvr) (void)dev_free(dOvr);
@@ -1302,7 +1304,7 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
         HIPCHK(hipMemcpyAsync(p->hG + ra * Qp, p->dG + ra * Qp, sizeof(double) * (rb - ra) * Qp, hipMemcpyDeviceToHost, st));
     std::vector<double> tauh;
     std::vector<unsigned> mmaxh;
-    const bool i8exp = precision == GML_PREC_I8X && form != GML_RPLE;
+    const bool i8exp = gml_is_i8(precision) && form != GML_RPLE;
     if (i8exp) {
         const double *tau = nullptr;
         const unsigned *mm = nullptr;
@@ -1344,11 +1346,11 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
         for (int64_t r = 0; r < R; ++r)
             if (act[r] && mmaxh[r] < (1u << 23)) {
                 again[r] = 1;
-                ovr[r] = ((double)mmaxh[r] + 1.0) * tauh[r] * (1.0 + 1e-12) / 2130000000.0;
+                ovr[r] = ((double)mmaxh[r] + 1.0) * gml::i8_mmax_unit(wide) * tauh[r] * (1.0 + 1e-12) / gml::i8_vdiv(wide);
                 ++nagain;
             }
         if (nagain > 0) {
-            if (depth >= 6) return fail(GML_EUNSUPPORTED, "precision i8x: the weights exp(-E) of a row underflow its fixed-point range; use precision f64");
+            if (depth >= 6) return fail(GML_EUNSUPPORTED, "precision i8x / i8w: the weights exp(-E) of a row underflow its fixed-point range; use precision f64");
             return device_pass(p, rs, again, theta, form, precision, want_grad, f, g, stats, nullptr, &ovr, depth + 1);
         }
     }
@@ -1533,7 +1535,12 @@ extern "C" int gml_bench_pass_resident(gml_problem *p, int formulation, int prec
     for (int g = 0; g < ngroups || (npad % 4); ++g, ++npad) p->hCtl[2 * W + g] = g < ngroups ? g : -1;
     HIPCHK(hipMemcpyAsync(p->dTheta, p->hTh, sizeof(double) * Rp * Qp, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(p->dSrow, p->hCtl, sizeof(int) * (2 * W + npad), hipMemcpyHostToDevice, st));
-    if (precision != GML_PREC_I8X) {
+    {
+        const int asked = precision;
+        precision = gml_resolve_precision(p, asked);
+        if (precision < 0) return fail(GML_EINVAL, "unknown precision %d", asked);
+    }
+    if (!gml_is_i8(precision)) {
         rc = gml_ensure_f64(p, p->ws_rows);
         if (rc) return rc;
     }
@@ -1541,7 +1548,7 @@ extern "C" int gml_bench_pass_resident(gml_problem *p, int formulation, int prec
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     for (int s = 0; s < warmup + steps; ++s) {
         hipEvent_t *e3 = s >= warmup ? ev.data() + (size_t)3 * (s - warmup) : nullptr;
-        if (precision == GML_PREC_I8X) {
+        if (gml_is_i8(precision)) {
             std::string err;
             gml::I8Pass a{};
             a.theta = p->dTheta;
@@ -1555,6 +1562,7 @@ extern "C" int gml_bench_pass_resident(gml_problem *p, int formulation, int prec
             a.want_grad = true;
             a.F = p->dF;
             a.G = p->dG;
+            a.wide = precision == GML_PREC_I8W;
             rc = gml::i8_pass(&p->i8ws, p->d, W, a, st, e3, &err);
             if (rc) return fail(rc, "%s", err.c_str());
         } else {
@@ -1573,7 +1581,7 @@ extern "C" int gml_bench_pass_resident(gml_problem *p, int formulation, int prec
     HIPCHK(hipMemcpyAsync(p->hF, p->dF, sizeof(double) * Rp, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(p->hG, p->dG, sizeof(double) * Rp * Qp, hipMemcpyDeviceToHost, st));
     std::vector<unsigned> mm;
-    if (precision == GML_PREC_I8X && formulation != GML_RPLE) {
+    if (gml_is_i8(precision) && formulation != GML_RPLE) {
         mm.resize((size_t)Rp);
         const double *tau_ = nullptr;
         const unsigned *mm_ = nullptr;

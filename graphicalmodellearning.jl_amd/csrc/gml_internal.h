@@ -64,8 +64,10 @@ void gml_build_layout(const gml_problem *p, int64_t u, NodeLayout &L);
 // the whole problem, not on the rows of one call or one shard: the arithmetic does not depend on the GPU count); -1: unknown value
 inline int gml_resolve_precision(const gml_problem *p, int precision) {
     if (precision == GML_PREC_AUTO) return (double)p->K * (double)p->P * (double)p->n <= 268435456.0 ? GML_PREC_F64 : GML_PREC_I8X;
-    return precision == GML_PREC_F64 || precision == GML_PREC_I8X ? precision : -1;
+    return precision == GML_PREC_F64 || precision == GML_PREC_I8X || precision == GML_PREC_I8W ? precision : -1;
 }
+// the int8-limb precisions (fixed point on the matrix cores: slots, limb planes, tracked scales)
+inline bool gml_is_i8(int precision) { return precision == GML_PREC_I8X || precision == GML_PREC_I8W; }
 
 // handles for several node ranges / devices from one host histogram: packed once, the bits copied to every device
 int gml_create_parts(const void *samples, int dtype, int64_t K, int64_t n, int64_t ld, int col_major, int order,

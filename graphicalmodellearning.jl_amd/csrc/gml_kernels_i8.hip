@@ -25,44 +25,12 @@
 // to 0/1 bytes in registers: sum_c q_c x_c = sum_c q_c - 2 sum_c q_c b_c.  An int8 image of it would
 // make the kernel L2->LDS bandwidth bound (measured: 98 MAC per loaded byte against the ~140 the CU
 // needs); with bits the loop loads 12 KB instead of 26.6 KB per 64-column step.
-#include "../../include/gml.h"
-#include "gml_dev.h"
-#include "gml_bits.h"
+#include "gml_i8.h"
 #include <algorithm>
 #include <string>
 #include <type_traits>
 
 namespace gml {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-
-constexpr int LB = 4; // limbs of V (30 significant bits relative to the per-node bound)
-
-// per-slot scalars of one kind of pass (objective/gradient passes, Hessian-vector passes)
-struct SlotScalars {
-    double *sigma = nullptr, *tau = nullptr, *invtau = nullptr;
-    long long *qconst = nullptr, *csum = nullptr, *asum = nullptr;
-    unsigned *mmax = nullptr; // largest |V| / tau seen per slot in the last pass (dynamic-range check)
-};
-
-// Workspace of the int8-limb passes.  Everything is indexed by SLOT: a pass evaluates the node rows its caller lists
-// in consecutive slots (32 slots = one MFMA node tile), so that the tiles it runs are full whatever subset of the
-// rows is still active; `srow` maps a slot to the row of the caller's Theta / G arrays.
-struct I8Ws {
-    int64_t slots = 0; // capacity (multiple of 32)
-    int LF = 5;        // limb planes the Tq buffer is sized for
-    int8_t *Tq = nullptr, *Vq = nullptr, *Uq = nullptr; // Uq: the V-like limb planes of Hessian-vector passes (on first use)
-    int32_t *Gacc = nullptr; // [gplanes][slots * LB][Qfp]: one set of i32 gradient accumulators per 2^24 configurations
-    int gplanes = 1;
-    SlotScalars sc[2]; // [0] objective/gradient passes, [1] Hessian-vector passes
-    double *tauovr = nullptr; // per-slot tau imposed by the caller (tracked scale, rescaled re-run), 0 = derive from the bound
-    // working-set Hessian on the int8 cores (indexed by ROW of the caller's arrays)
-    int64_t hKh = 0, hrows = 0, hcap_elems = 0;
-    int8_t *Hq = nullptr;   // limb planes of the Hessian weights over the compact (sub-sampled) index
-    unsigned *Mb = nullptr; // row-major twin of Xtb (gathered-row DMA of the Hessian kernel), built on first use
-    long long *hS = nullptr, *H64 = nullptr;
-};
 
 // ------------------------------------------------------------------------------------------
 // quantise Theta rows into limb planes.  One workgroup per node row.
@@ -74,28 +42,48 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
                                                      const int *__restrict__ vmap, const double *__restrict__ tauV,
                                                      int8_t *__restrict__ Tq, double *__restrict__ sigma,
                                                      double *__restrict__ tau, double *__restrict__ invtau,
-                                                     long long *__restrict__ qconst, const double *__restrict__ tauovr) {
+                                                     long long *__restrict__ qconst, const double *__restrict__ tauovr,
+                                                     double vdiv /* largest |V| / tau the planes of this pass hold */,
+                                                     double vsrc_scale /* hv: unit of the V planes read, in multiples of tauV */) {
     const int r = slot0 + blockIdx.x; // slot
     if (rowcol[r] < 0) return;
     const double *th = Theta + (int64_t)srow[r] * Qp;
     __shared__ double red[256];
+    __shared__ double red1[256];
     const int tid = threadIdx.x;
-    double mx = 0.0;
-    for (int64_t c = tid; c < Qfp; c += 256) mx = fmax(mx, fabs(th[c]));
-    if (tid == 0) mx = fmax(mx, fabs(th[cconst]));
+    double mx = 0.0, s1 = 0.0;
+    for (int64_t c = tid; c < Qfp; c += 256) {
+        mx = fmax(mx, fabs(th[c]));
+        if (LF > 5) s1 += fabs(th[c]);
+    }
+    if (tid == 0) {
+        mx = fmax(mx, fabs(th[cconst]));
+        if (LF > 5) s1 += fabs(th[cconst]);
+    }
     red[tid] = mx;
+    red1[tid] = s1;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
+        if (tid < s) {
+            red[tid] = fmax(red[tid], red[tid + s]);
+            if (LF > 5) red1[tid] += red1[tid + s];
+        }
         __syncthreads();
     }
     mx = red[0];
+    s1 = red1[0];
     __syncthreads();
     // sigma = 2^(ex - (8LF-2)) with mx < 2^ex  =>  |q| <= 2^(8LF-2)
     int ex = 0;
     if (mx > 0) (void)frexp(mx, &ex);
-    const double sg = ldexp(1.0, ex - (8 * LF - 2));
-    const double isg = ldexp(1.0, (8 * LF - 2) - ex);
+    int sx = ex - (8 * LF - 2);
+    if (LF > 5) { // 54-bit digits: keep sum_c |q_c| below 2^61, so that every integer sum of the pass fits 64 bits
+        int e1 = 0;
+        if (s1 > 0) (void)frexp(s1 * 1.0000001, &e1); // sum |theta| < 2^e1
+        if (e1 - 61 > sx) sx = e1 - 61;
+    }
+    const double sg = ldexp(1.0, sx);
+    const double isg = ldexp(1.0, -sx);
     const int tile = r >> 5, rl = r & 31;
     const int64_t nk = Qfp >> 6;
     double sabs = 0.0;
@@ -141,7 +129,7 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
             // ample for the matrix-free Newton-CG that stops at a 5 % residual; the factor 1.01 keeps |u| inside the
             // +-32639 of two balanced digits)
             const double pn = (emax > 0.0 ? emax : 1.0) * (hv == 2 ? 65536.0 * 1.01 : 1.0);
-            t = tauV[vmap[r]] * pn;
+            t = tauV[vmap[r]] * vsrc_scale * pn;
             it = 1.0 / pn;
         } else {
             const double B = (form == 2) ? 2.0 * wmax : wmax * exp(emax); // bound on |V|
@@ -150,7 +138,7 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
             // The bound exp(sum|theta|) can exceed the largest actual |V| by many orders of magnitude (dense
             // theta); the caller then re-runs the row with tau taken from the largest |V| the first pass saw, and
             // the solver passes max|V| of its previous pass times exp(||step||_1), which bounds the new weights.
-            t = B * (1.0 + 1e-12) / 2130000000.0;
+            t = B * (1.0 + 1e-12) / vdiv;
             if (tauovr && tauovr[r] > 0.0 && tauovr[r] < t) t = tauovr[r]; // a tighter rigorous scale from the caller
             it = 1.0 / t;
         }
@@ -159,30 +147,6 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
         tau[r] = t;
         invtau[r] = it;
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// shared GEMM pieces: LDS tiles of [rows][64 bytes] with the 16-byte slots XOR-swizzled by
-// (row>>2)&3, which makes the ds_read_b128 fragment reads (lane = row) conflict-free.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lds_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
-
-#define MFMA_I8(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8((a), (b), (c), 0, 0, 0)
-
-// exp(x) for |x| < 700 to ~1e-15 relative: 2^(n/64) table (in LDS) times a degree-6 polynomial
-__device__ __forceinline__ double exp_tab(double x, const double *__restrict__ tab) {
-    const double t = rint(x * 92.33248261689366);      // 64/ln2
-    double r = fma(t, -0.01083042469326756, x);          // ln2/64, high part (low 21 bits zero: t*hi exact)
-    r = fma(t, -2.9815858269852933e-12, r);                 // low part
-    double p = 1.3888888888888889e-03;  // 1/720
-    p = fma(p, r, 8.3333333333333332e-03);
-    p = fma(p, r, 4.1666666666666664e-02);
-    p = fma(p, r, 1.6666666666666666e-01);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    const int n = (int)t;
-    return ldexp(tab[n & 63] * p, n >> 6);
 }
 
 // V / tau of one element of the exp forms: -s rint(w/tau exp(-s E) + dither), E = s Ea.  Ea to 3e-10 relative before
@@ -229,8 +193,6 @@ __device__ __forceinline__ int vq_exp(double Ea, unsigned sb, double wk32, unsig
 // address instead.  Three stages: the loads of tile kt+2 are issued right after the barrier that
 // retires tile kt-1, and stay in flight across two compute phases (counted vmcnt, raw s_barrier).
 // ------------------------------------------------------------------------------------------
-typedef const __attribute__((address_space(1))) void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
 
 template <int NP>
 __device__ __forceinline__ void ring_issue(const int8_t *const (&src)[NP], int64_t off, int8_t *stage_base, int wave,
@@ -426,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     // Hessian-vector forms only: the limb planes of V written by the rows' last objective pass, the slot that holds
     // them for each slot of this pass, and their scales
     const int8_t *__restrict__ Vsrc, const int *__restrict__ vmap, const double *__restrict__ tauV,
+    int vsrc_lbt /* planes of a source image */, int vsrc_pl0 /* first of the 4 planes read */, double vsrc_scale /* their unit / tauV */,
     // sub-sampled passes (Hessian-vector products over a part of the configurations): compact sample tile t stands for the
     // tile (t / part_tiles) * chunk_tiles + t % part_tiles -- the first part_tiles tiles of every split-K chunk of the
     // backward kernel.  chunk_tiles == part_tiles: every configuration.
@@ -588,8 +551,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     double tvh = 0.0;
     if (HV && active) {
         const int vs = vmap[r];
-        vsrc = Vsrc + vq_off(vs, 0, k0 + wave * 64, Kp) + h * 32;
-        tvh = tauV[vs];
+        vsrc = Vsrc + vq_off(vs, vsrc_pl0, k0 + wave * 64, Kp, vsrc_lbt) + h * 32;
+        tvh = tauV[vs] * vsrc_scale;
     }
     long long cs = 0, as = 0;
     double fp = 0.0;
@@ -926,17 +889,19 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
 // the chunk's slabs of Vq and of the bit image are fetched from HBM once and shared through that XCD's L2.
 // ------------------------------------------------------------------------------------------
 template <int TM /* node tiles per workgroup: 1 (4 waves, two workgroups per CU) or 2 (8 waves) */,
-          int NL /* limb planes of Vq that are non-zero: 4, or 2 for the products of a 2-limb Hessian-vector pass (TM = 1) */>
+          int NL /* limb planes of Vq multiplied: 4; 2 for the products of a 2-limb Hessian-vector pass; 3 for one half of the
+                    6 planes of the i8w pass (TM = 1) */>
 __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
     const int8_t *__restrict__ Vq, const unsigned *__restrict__ Xtb, const int *__restrict__ groups, int ngroups_t,
     int nNt, int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit, int32_t *__restrict__ Gacc,
     int chunks_per_plane /* split-K chunks that share one set of i32 accumulators (<= 2^24 configurations: |sum| < 2^31) */,
     int64_t plane_stride /* elements between the accumulator sets */,
-    int64_t kpart /* configurations of every chunk that take part (== kchunk: all; less: sub-sampled Hessian-vector products) */) {
+    int64_t kpart /* configurations of every chunk that take part (== kchunk: all; less: sub-sampled Hessian-vector products) */,
+    int lbt /* limb planes of a Vq image (and of the accumulator rows of a node tile) */, int pl0 /* first plane multiplied */) {
     constexpr int NW = 4 * TM;
     constexpr int AR = 128 * TM, NPIECE = 8 * TM + 2, STAGE = NPIECE * 1024, NS = 4;
-    constexpr int WMT = NL, WNT = 2; // wave tile 128 (64) x 64: MFMA tile i <-> limb plane i of the node tile
-    static_assert(NL == 4 || (NL == 2 && TM == 1), "the 2-limb form exists for 4-wave workgroups");
+    constexpr int WMT = NL, WNT = 2; // wave tile 128 (96, 64) x 64: MFMA tile i <-> limb plane pl0 + i of the node tile
+    static_assert(NL == 4 || ((NL == 2 || NL == 3) && TM == 1), "the 2- and 3-limb forms exist for 4-wave workgroups");
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lr = lane & 31, h = lane >> 5;
@@ -956,21 +921,24 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
 
     // 8*TM + 2 pieces over 4*TM waves: waves 0 and 1 load three (the third is a piece of bits), the others two.
     // NL = 2: only the four pieces of limb planes 0 and 1 (rows 0..63 of the image) + the bits: two per wave.
+    // NL = 3: the six pieces of three planes + the bits: two per wave.
     const bool three = NL == 4 && wave < 2;
     const int8_t *src[3];
     int adv[3], dst[3];
+    const int img = lbt * 2048; // bytes of a Vq image
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         int pc = wave + NW * j; // piece of the full stage image: 0 .. 8 TM - 1 rows of Vq, then the bits
         if (NL == 2) pc = j == 0 ? wave : 8 * TM + (wave & 1);
+        if (NL == 3) pc = wave + 4 * j < 6 ? wave + 4 * j : 8 * TM + ((wave + 4 * j - 6) & 1);
         dst[j] = pc * 1024;
         if (pc < 8 * TM) {
             int tl = tiles[pc >> 3];
             if (tl < 0) tl = tiles[0];
             const int row = (pc & 7) * 16 + (lane >> 2);
             const int slot = (lane & 3) ^ ((row >> 2) & 3);
-            src[j] = Vq + ((int64_t)tl * nkk + kt0) * 8192 + row * 64 + slot * 16;
-            adv[j] = 8192;
+            src[j] = Vq + ((int64_t)tl * nkk + kt0) * img + (pl0 * 32 + row) * 64 + slot * 16;
+            adv[j] = img;
         } else {
             const int pb = pc < NPIECE ? pc - 8 * TM : 0;
             src[j] = reinterpret_cast<const int8_t *>(Xtb) + ((int64_t)(2 * nt + pb) * nkk + kt0) * 1024 + lane * 16;
@@ -1035,7 +1003,7 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int mrow = (grow & 127) + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    atomicAdd(&Gacc[((int64_t)tl * 128 + mrow) * Qfp + c], acc[i][jn][e]);
+                    atomicAdd(&Gacc[((int64_t)tl * lbt * 32 + pl0 * 32 + mrow) * Qfp + c], acc[i][jn][e]);
                 }
             }
         }
@@ -1113,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_make_hw(const int8_t *__restrict__ Vq, 
                                                  const int *__restrict__ vslot /* row -> slot of its V planes */,
                                                  const int *__restrict__ mt /* rows with mt[r] = 0 are skipped */, int64_t Kp,
                                                  int64_t Hpitch, int64_t kstride, int64_t Kh, int form, int8_t *__restrict__ Hq,
-                                                 long long *__restrict__ hS) {
+                                                 long long *__restrict__ hS, int vlbt, int vpl0, double vscale) {
     // A thread owns 4 consecutive bytes of a 64-sample row piece: the V image and the weight planes share the byte order
     // vq_pos() within a piece, and 4 consecutive positions are 4 consecutive samples, so the four limbs come in as four
     // dwords and leave as four dwords (one byte per element and limb before: 4x the memory instructions).
@@ -1132,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_make_hw(const int8_t *__restrict__ Vq, 
         unsigned q[4] = {0u, 0u, 0u, 0u};
         unsigned sg = 0;
         if (kc < Kp) {
-            const int8_t *vq = Vq + vq_off(vs, 0, kc, Kp) + p4; // (vq_pos(0) = 0: the piece's first byte)
+            const int8_t *vq = Vq + vq_off(vs, vpl0, kc, Kp, vlbt) + p4; // (vq_pos(0) = 0: the piece's first byte)
 #pragma unroll
             for (int l = 0; l < 4; ++l) q[l] = *reinterpret_cast<const unsigned *>(vq + l * 32 * 64);
             const int64_t k0 = kc + s0;
@@ -1143,8 +1111,9 @@ __global__ __launch_bounds__(256) void k_make_hw(const int8_t *__restrict__ Vq, 
         for (int e = 0; e < 4; ++e) {
             const int qv = (int)(int8_t)(q[0] >> (8 * e)) + 256 * ((int)(int8_t)(q[1] >> (8 * e)) + 256 * ((int)(int8_t)(q[2] >> (8 * e)) + 256 * (int)(int8_t)(q[3] >> (8 * e))));
             int mag = ((sg >> e) & 1u) ? qv : -qv; // V = -w exp(-E) s: |V| = -q s >= 0
+            if (mag < 0) mag = 0; // (cannot happen: the top four planes of a 6-plane image are V / 65536 tau rounded to nearest, same sign or 0)
             if (form == 2) {
-                const double tt = tau[vs], a = (double)mag * tt, wk = kc < Kp ? w[kc + s0 + e] : 0.0;
+                const double tt = tau[vs] * vscale, a = (double)mag * tt, wk = kc < Kp ? w[kc + s0 + e] : 0.0;
                 mag = wk > 0 ? (int)rint(2.0 * a * (1.0 - a / (2.0 * wk)) / tt) : 0;
             }
             sm += mag;
@@ -1334,7 +1303,7 @@ __global__ __launch_bounds__(256) void k_hess_i8_fin(const long long *__restrict
                                                      const double *__restrict__ tau, const int *__restrict__ vslot,
                                                      const int *__restrict__ mt,
                                                      const long long *__restrict__ hoff, double *__restrict__ H, int y0, int R0,
-                                                     const int *__restrict__ trow) {
+                                                     const int *__restrict__ trow, double vscale) {
     const int r = blockIdx.y + y0;
     const int wr = r < R0 ? r : trow[r - R0];
     const int m = mt[r] * 32;
@@ -1344,7 +1313,7 @@ __global__ __launch_bounds__(256) void k_hess_i8_fin(const long long *__restrict
     if ((j >> 5) > (i >> 5)) return;
     const long long *Hr = H64 + hoff[r];
     const long long T = Hr[(int64_t)i * m + j], Ti = Hr[(int64_t)i * m + i], Tj = Hr[(int64_t)j * m + j];
-    H[hoff[r] + (int64_t)i * m + j] = tau[vslot[wr]] * (double)(hS[wr] - 2 * Ti - 2 * Tj + 4 * T);
+    H[hoff[r] + (int64_t)i * m + j] = tau[vslot[wr]] * vscale * (double)(hS[wr] - 2 * Ti - 2 * Tj + 4 * T);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1373,26 +1342,37 @@ void i8_free(void *p) {
     for (void *q : ptrs)
         if (q) (void)dev_free(q);
     for (auto &sc : w->sc) {
-        void *qs[] = {sc.sigma, sc.tau, sc.invtau, sc.qconst, sc.csum, sc.asum, sc.mmax};
+        void *qs[] = {sc.sigma, sc.tau, sc.invtau, sc.qconst, sc.csum, sc.asum, sc.csum2, sc.asum2, sc.mmax};
         for (void *q : qs)
             if (q) (void)dev_free(q);
     }
     delete w;
 }
 
-static int i8_ensure(void **wsp, const DevProblem &d, int64_t slots, std::string *err) {
+// `wide`: 1 = the workspace must hold 6-plane V images and 7 planes of Theta (objective passes of precision i8w), 0 = 4 / 5
+// (i8x), -1 = whatever it holds (Hessian-vector passes: they read the V planes that are there and write Uq)
+static int i8_ensure(void **wsp, const DevProblem &d, int64_t slots, int wide, hipStream_t st, std::string *err) {
     I8Ws *w = static_cast<I8Ws *>(*wsp);
-    if (w && w->slots >= slots) return GML_OK;
-    if (w) i8_free(w);
+    if (w && w->slots >= slots && (wide < 0 || (w->LBT == LBW) == (wide == 1))) return GML_OK;
+    if (w) {
+        // blocks go back to the library's cache, which hands them to the next caller without waiting: nothing of this
+        // stream may still be using them
+        (void)hipStreamSynchronize(st);
+        i8_free(w);
+    }
     *wsp = nullptr;
     w = new I8Ws();
     *wsp = w; // owned by the handle from here on: a failed allocation below is released by i8_free
+    if (wide == 1) {
+        w->LF = LFW;
+        w->LBT = LBW;
+    }
     I8CHK(dev_malloc(&w->Tq, (size_t)slots * w->LF * d.Qfp));
-    I8CHK(dev_malloc(&w->Vq, (size_t)slots * LB * d.Kp));
+    I8CHK(dev_malloc(&w->Vq, (size_t)slots * w->LBT * d.Kp));
     // i32 accumulators of the backward GEMM hold |sum_k v_k b_k| <= 128 K: exact up to 2^24 configurations per set
     // (beyond 2^24: sets of <= 2^23 configurations + the slack of whole split-K chunks, see i8_pass)
     w->gplanes = d.Kp <= ((int64_t)1 << 24) ? 1 : (int)((d.Kp + ((int64_t)1 << 23) - 1) >> 23);
-    I8CHK(dev_malloc(&w->Gacc, sizeof(int32_t) * (size_t)w->gplanes * slots * LB * d.Qfp));
+    I8CHK(dev_malloc(&w->Gacc, sizeof(int32_t) * (size_t)w->gplanes * slots * w->LBT * d.Qfp));
     for (auto &sc : w->sc) {
         I8CHK(dev_malloc(&sc.sigma, sizeof(double) * slots));
         I8CHK(dev_malloc(&sc.tau, sizeof(double) * slots));
@@ -1400,11 +1380,13 @@ static int i8_ensure(void **wsp, const DevProblem &d, int64_t slots, std::string
         I8CHK(dev_malloc(&sc.qconst, sizeof(long long) * slots));
         I8CHK(dev_malloc(&sc.csum, sizeof(long long) * slots));
         I8CHK(dev_malloc(&sc.asum, sizeof(long long) * slots));
+        I8CHK(dev_malloc(&sc.csum2, sizeof(long long) * slots));
+        I8CHK(dev_malloc(&sc.asum2, sizeof(long long) * slots));
         I8CHK(dev_malloc(&sc.mmax, sizeof(unsigned) * slots));
     }
     I8CHK(dev_malloc(&w->tauovr, sizeof(double) * slots));
-    I8CHK(hipMemset(w->Tq, 0, (size_t)slots * w->LF * d.Qfp));
-    I8CHK(hipMemset(w->Vq, 0, (size_t)slots * LB * d.Kp));
+    I8CHK(hipMemsetAsync(w->Tq, 0, (size_t)slots * w->LF * d.Qfp, st));
+    I8CHK(hipMemsetAsync(w->Vq, 0, (size_t)slots * w->LBT * d.Kp, st));
     w->slots = slots;
     return GML_OK;
 }
@@ -1501,17 +1483,17 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
     I8CHK(hipMemsetAsync(w->H64, 0, sizeof(long long) * need, st));
     I8CHK(hipMemsetAsync(w->hS, 0, sizeof(long long) * Rp, st));
     hipLaunchKernelGGL(k_make_hw, dim3((unsigned)((Kh / 4 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Sb, d.w, w->sc[0].tau, dRowcol,
-                       dVslot, dFlag, d.Kp, pitch, kstride, Kh, form, w->Hq, w->hS);
+                       dVslot, dFlag, d.Kp, pitch, kstride, Kh, form, w->Hq, w->hS, w->LBT, w->vpl0(), w->vscale());
     HessTiles rows_only = tl; // (the tiles are all of one size class: the other launch covers the rows' own blocks only)
     rows_only.n = 0;
     if (maxsmall > 0) launch_hess_blk<2>(w, d, dF, dMt, dHoff, R, cap, maxsmall, Kh, kstride, nsmall, st, tiles_small ? tl : rows_only);
     if (maxm > kHessSmall) launch_hess_blk<4>(w, d, dF, dMt, dHoff, R, cap, maxm, Kh, kstride, nlarge, st, tiles_small ? rows_only : tl);
     hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64, w->hS,
-                       w->sc[0].tau, dVslot, dMt, dHoff, dH, 0, R, tl.wrow);
+                       w->sc[0].tau, dVslot, dMt, dHoff, dH, 0, R, tl.wrow, w->vscale());
     const int tm = tl.T / 32;
     for (int64_t y0 = 0; y0 < tl.n; y0 += 8192)
         hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((tm * 32 * tm * 32 + 255) / 256), (unsigned)std::min<int64_t>(8192, tl.n - y0)), dim3(256),
-                           0, st, w->H64, w->hS, w->sc[0].tau, dVslot, dMt, dHoff, dH, (int)(R + y0), R, tl.wrow);
+                           0, st, w->H64, w->hS, w->sc[0].tau, dVslot, dMt, dHoff, dH, (int)(R + y0), R, tl.wrow, w->vscale());
     I8CHK(hipGetLastError());
     return GML_OK;
 }
@@ -1519,12 +1501,15 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
 // one launch zeroes every accumulator of a pass over the slots [slot0, slot0 + ns): slot sums, maxima, f, and the i32
 // gradient planes of those slots' tiles
 __global__ __launch_bounds__(256) void k_zero_pass(long long *__restrict__ csum, long long *__restrict__ asum,
+                                                   long long *__restrict__ csum2, long long *__restrict__ asum2,
                                                    unsigned *__restrict__ mmax, double *__restrict__ f, int slot0, int ns,
                                                    v4i *__restrict__ gacc, int64_t ngacc, int nplanes, int64_t plane_stride4) {
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
     if (i0 < ns) {
         csum[slot0 + i0] = 0;
         asum[slot0 + i0] = 0;
+        csum2[slot0 + i0] = 0;
+        asum2[slot0 + i0] = 0;
         mmax[slot0 + i0] = 0;
         if (f) f[slot0 + i0] = 0.0;
     }
@@ -1556,7 +1541,8 @@ static void launch_fwd4(const FwdLaunch &a) {
     const int grid = ((ntk + 7) / 8) * 8 * a.ngroups; // one workgroup per (sample tile, node tile); see the kernel's block mapping
     hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE, UNIW>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.w->Tq, a.rowcol, a.groups,
                        a.ngroups, d.w, a.sc->sigma, a.sc->qconst, a.sc->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, a.Vout,
-                       a.sc->csum, a.sc->asum, a.F, a.sc->mmax, a.w->Vq, a.vmap, a.w->sc[0].tau, a.chunk_tiles, a.part_tiles);
+                       a.sc->csum, a.sc->asum, a.F, a.sc->mmax, a.w->Vq, a.vmap, a.w->sc[0].tau, a.w->LBT, a.w->vpl0(), a.w->vscale(),
+                       a.chunk_tiles, a.part_tiles);
 }
 
 template <int LF, int FORM, bool WANTF, bool WIDE>
@@ -1608,16 +1594,17 @@ void i8_split_plan(const DevProblem &d, int ngroups, int ksub, int64_t *kchunk_o
 
 // One pass of the int8-limb operator over the slots the caller lists (I8Pass, gml_dev.h).
 int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass &a, hipStream_t st, hipEvent_t *ev, std::string *err) {
-    int rc = i8_ensure(wsp, d, slot_capacity, err);
+    const int hv = a.hv ? (a.hv == 2 ? 2 : 1) : 0; // 2: Hessian-vector products in 2 backward limbs
+    const bool wide = a.wide && !hv;                // (Hessian-vector passes are 31-bit passes whatever the workspace holds)
+    int rc = i8_ensure(wsp, d, slot_capacity, hv ? -1 : (wide ? 1 : 0), st, err);
     if (rc) return rc;
     I8Ws *w = static_cast<I8Ws *>(*wsp);
-    int LF = a.lf ? a.lf : 5;
+    int LF = wide ? LFW : (a.lf ? a.lf : 5);
     if (LF > w->LF) LF = w->LF;
     if (a.ngroups + 1 > 65536 || a.slot1 > w->slots || a.slot0 % 32 || a.slot1 % 32) {
         if (err) *err = "bad slot range";
         return GML_EINVAL;
     }
-    const int hv = a.hv ? (a.hv == 2 ? 2 : 1) : 0; // 2: Hessian-vector products in 2 backward limbs
     if (hv && !w->Uq) {
         I8CHK(dev_malloc(&w->Uq, (size_t)w->slots * LB * d.Kp));
         I8CHK(hipMemsetAsync(w->Uq, 0, (size_t)w->slots * LB * d.Kp, st));
@@ -1625,18 +1612,21 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     const SlotScalars &sc = w->sc[hv ? 1 : 0];
     const int ns = a.slot1 - a.slot0;
     const bool grad = a.want_grad || hv;
-    int32_t *gacc0 = w->Gacc + (int64_t)a.slot0 * LB * d.Qfp;
-    const int64_t gplane_stride = (int64_t)w->slots * LB * d.Qfp;
-    hipLaunchKernelGGL(k_zero_pass, dim3(1024), dim3(256), 0, st, sc.csum, sc.asum, sc.mmax, a.F, a.slot0, ns, reinterpret_cast<v4i *>(gacc0),
-                       grad ? (int64_t)ns * LB * d.Qfp / 4 : 0, w->gplanes, gplane_stride / 4);
+    const int lbg = wide ? LBW : LB; // limb planes of this pass's V and of its gradient accumulators
+    int32_t *gacc0 = w->Gacc + (int64_t)a.slot0 * lbg * d.Qfp;
+    const int64_t gplane_stride = (int64_t)w->slots * lbg * d.Qfp;
+    hipLaunchKernelGGL(k_zero_pass, dim3(1024), dim3(256), 0, st, sc.csum, sc.asum, sc.csum2, sc.asum2, sc.mmax, a.F, a.slot0, ns,
+                       reinterpret_cast<v4i *>(gacc0), grad ? (int64_t)ns * lbg * d.Qfp / 4 : 0, w->gplanes, gplane_stride / 4);
 #define QUANT(LFV)                                                                                                                    \
     hipLaunchKernelGGL((k_quant_theta<LFV>), dim3(ns), dim3(256), 0, st, a.theta, a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.cconst,   \
-                       d.wmax, a.form, hv, a.vmap, w->sc[0].tau, w->Tq, sc.sigma, sc.tau, sc.invtau, sc.qconst, a.tauovr)
+                       d.wmax, a.form, hv, a.vmap, w->sc[0].tau, w->Tq, sc.sigma, sc.tau, sc.invtau, sc.qconst, a.tauovr,             \
+                       wide ? kVdiv6 : kVdiv4, w->vscale())
     if (LF < 3 && !hv) LF = 3; // 2 limbs exist for the directions of Hessian-vector passes only
     switch (LF) {
     case 2: QUANT(2); break;
     case 3: QUANT(3); break;
     case 4: QUANT(4); break;
+    case 7: QUANT(7); break;
     default: QUANT(5);
     }
 #undef QUANT
@@ -1656,18 +1646,27 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     }
     const int ksub = kpart < kchunk ? (int)(kchunk / kpart) : 1;
     if (ev) I8CHK(hipEventRecord(ev[0], st));
-    FwdLaunch fl{(int)(kchunk / 256), (int)(kpart / 256), 0, w, &d, &sc, a.rowcol, a.groups, a.vmap, a.ngroups, a.F, hv ? w->Uq : w->Vq, st};
-    fl.ntk = ksub > 1 ? nsplit * fl.part_tiles : (int)(d.Kp / 256);
-    if (ksub == 1) fl.chunk_tiles = fl.part_tiles = 1; // (every tile: no remapping)
-    switch (LF) {
-    // with the gradient requested, f comes out of the backward GEMM for free (column u of row u)
-    case 2: // (Hessian-vector forms only)
-        if (a.form == 2) launch_fwd2<2, 4, false>(fl);
-        else launch_fwd2<2, 3, false>(fl);
-        break;
-    case 3: launch_fwd<3>(fl, a.form, !a.want_grad, hv); break;
-    case 4: launch_fwd<4>(fl, a.form, !a.want_grad, hv); break;
-    default: launch_fwd<5>(fl, a.form, !a.want_grad, hv);
+    if (wide) {
+        FwdWArgs fw{&d, w->Tq, &sc, a.rowcol, a.groups, a.ngroups, a.form, !a.want_grad, a.F, w->Vq, st};
+        launch_fwd_i8w(fw);
+    } else {
+        FwdLaunch fl{(int)(kchunk / 256), (int)(kpart / 256), 0, w, &d, &sc, a.rowcol, a.groups, a.vmap, a.ngroups, a.F, hv ? w->Uq : w->Vq, st};
+        fl.ntk = ksub > 1 ? nsplit * fl.part_tiles : (int)(d.Kp / 256);
+        if (ksub == 1) fl.chunk_tiles = fl.part_tiles = 1; // (every tile: no remapping)
+        if (!hv && w->LBT != LB) {
+            if (err) *err = "a 31-bit objective pass on a workspace of 6-plane V images";
+            return GML_EINVAL;
+        }
+        switch (LF) {
+        // with the gradient requested, f comes out of the backward GEMM for free (column u of row u)
+        case 2: // (Hessian-vector forms only)
+            if (a.form == 2) launch_fwd2<2, 4, false>(fl);
+            else launch_fwd2<2, 3, false>(fl);
+            break;
+        case 3: launch_fwd<3>(fl, a.form, !a.want_grad, hv); break;
+        case 4: launch_fwd<4>(fl, a.form, !a.want_grad, hv); break;
+        default: launch_fwd<5>(fl, a.form, !a.want_grad, hv);
+        }
     }
     if (ev) I8CHK(hipEventRecord(ev[1], st));
     if (grad) {
@@ -1677,19 +1676,29 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
         const int grid = ((nsplit + 7) / 8) * 8 * T;
         const int shmem = 4 * (8 * TM + 2) * 1024;
         const int8_t *Vin = hv ? w->Uq : w->Vq;
-        if (hv == 2) {
+        if (wide) { // the two halves of the 6 planes: two launches of the 3-plane form
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+            for (int half = 0; half < 2; ++half)
+                hipLaunchKernelGGL((k_bwd_i8<1, 3>), dim3(grid), dim3(256), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
+                                   nsplit, w->Gacc, cpp, gplane_stride, kpart, LBW, 3 * half);
+        } else if (hv == 2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
             hipLaunchKernelGGL((k_bwd_i8<1, 2>), dim3(grid), dim3(256), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
-                               nsplit, w->Gacc, cpp, gplane_stride, kpart);
+                               nsplit, w->Gacc, cpp, gplane_stride, kpart, LB, 0);
         } else {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
             hipLaunchKernelGGL((k_bwd_i8<1, 4>), dim3(grid), dim3(256), shmem, st, Vin, d.Xtb, a.groups, ngt, nNt, d.Qfp, d.Kp, kchunk,
-                               nsplit, w->Gacc, cpp, gplane_stride, kpart);
+                               nsplit, w->Gacc, cpp, gplane_stride, kpart, LB, 0);
         }
     }
     if (ev) I8CHK(hipEventRecord(ev[2], st));
-    hipLaunchKernelGGL(k_finalize_i8, dim3((unsigned)((d.Qp + 255) / 256), (unsigned)ns), dim3(256), 0, st, w->Gacc, sc.tau, sc.csum, sc.asum,
-                       a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.Qf, d.cconst, a.form, grad ? 1 : 0, hv, a.G, a.F, w->gplanes, gplane_stride, sc.mmax, a.res);
+    if (wide)
+        launch_finalize_i8w(w->Gacc, sc, a.srow, a.rowcol, a.slot0, ns, d.Qp, d.Qfp, d.Qf, d.cconst, a.form, grad ? 1 : 0, a.G, a.F, w->gplanes,
+                            gplane_stride, a.res, st);
+    else
+        hipLaunchKernelGGL(k_finalize_i8, dim3((unsigned)((d.Qp + 255) / 256), (unsigned)ns), dim3(256), 0, st, w->Gacc, sc.tau, sc.csum, sc.asum,
+                           a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.Qf, d.cconst, a.form, grad ? 1 : 0, hv, a.G, a.F, w->gplanes, gplane_stride,
+                           sc.mmax, a.res);
     I8CHK(hipGetLastError());
     return GML_OK;
 }

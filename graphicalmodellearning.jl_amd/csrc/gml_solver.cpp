@@ -289,7 +289,7 @@ int Solver::init() {
     // slots of the int8-limb workspace: every active row of a pass in its own slot, the passes of one iteration in
     // disjoint ranges (their V planes feed the next Hessians).  Objective-only passes (line-search trials whose V planes
     // nobody reads) run in a scratch range above the main one.
-    Smain = o.precision == GML_PREC_I8X ? Rp + gml_round_up(std::max<int64_t>(R / 2, 96), 32) + 64 : Rp + 64;
+    Smain = gml_is_i8(o.precision) ? Rp + gml_round_up(std::max<int64_t>(R / 2, 96), 32) + 64 : Rp + 64;
     Scap = Smain + Rp;
     {
         size_t freeb = 0, totalb = 0;
@@ -374,11 +374,11 @@ int Solver::init() {
     dref.assign((size_t)R, 0.0);
     stepn.assign((size_t)R, 0.0);
 
-    if (o.precision == GML_PREC_I8X && o.polish >= 0) {
+    if (gml_is_i8(o.precision) && o.polish >= 0) {
         size_t freeb = 0, totalb = 0;
         if (dev_mem_info(&freeb, &totalb) == hipSuccess) {
             const double need_b = (d.Xs ? 0.0 : 2.0 * (double)d.Kp * (double)Qp) + (p->dV && p->dVrows >= Rp ? 0.0 : 8.0 * (double)Rp * (double)d.Kp) +
-                                  8.0 * (double)nd + 4.0 * (double)Scap * d.Kp /* the i8 workspace still to come */;
+                                  8.0 * (double)nd + (o.precision == GML_PREC_I8W ? 6.0 : 4.0) * (double)Scap * d.Kp /* the i8 workspace still to come */;
             can_polish = need_b < 0.8 * (double)freeb;
         }
     }
@@ -424,8 +424,9 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
     const int64_t np = gml_round_up(n, 32);
     std::vector<double> fh, tauh;
     std::vector<unsigned> mmh;
-    const bool track = pp == GML_PREC_I8X && formulation != GML_RPLE;
-    if (pp == GML_PREC_I8X) {
+    const bool track = gml_is_i8(pp) && formulation != GML_RPLE;
+    const bool wide = pp == GML_PREC_I8W;
+    if (gml_is_i8(pp)) {
         // slots of this pass: a fresh consecutive range, or (re-run of some rows of a pass with a tighter scale: ovr_in)
         // the slots those rows already hold -- a re-run must not claim new slots, it could wrap around and overwrite
         // planes of its own pass
@@ -487,7 +488,7 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
             rowcol[q] = (int)(p->node0 + r);
             if (ovr_in) ovr[q] = (*ovr_in)[r];
             else if (track && vref[r] > 0.0)
-                ovr[q] = vref[r] * std::exp(dref[r] + (at_trial ? stepn[r] : 0.0)) * (1.0 + 1e-6) / 2130000000.0;
+                ovr[q] = vref[r] * std::exp(dref[r] + (at_trial ? stepn[r] : 0.0)) * (1.0 + 1e-6) / i8_vdiv(wide);
         }
         {
             int k = 0;
@@ -512,6 +513,7 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         a.tauovr = rebase(reinterpret_cast<const double *>(dPass + ioff), lo);
         a.res = dRes;
         a.lf = o.limbs_fwd;
+        a.wide = wide;
         std::string err;
         int rc = i8_pass(&p->i8ws, d, Scap, a, st, nullptr, &err);
         if (rc) return fail(rc, "%s", err.c_str());
@@ -572,14 +574,14 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
     std::vector<double> ovr2;
     for (int64_t a = 0; a < n; ++a) {
         const int r = rows[a];
-        const double fv = pp == GML_PREC_I8X ? fh[a] : fh[r];
+        const double fv = gml_is_i8(pp) ? fh[a] : fh[r];
         // f64: summation rounding.  int8 limbs: every V_rk is rounded to a multiple of tau_r with a dither that is
         // equidistributed over the samples, so the errors (each within one unit, standard deviation 0.41 tau) add like a
         // random walk: 8 sigma of sqrt(K) terms (the worst case K * tau is never approached).
         double noise = 1e-13 * std::max(1.0, std::fabs(fv));
         if (track) {
             noise += 3.3 * std::sqrt((double)p->K) * tauh[a];
-            const double vmax = ((double)mmh[a] + 1.0) * tauh[a]; // rigorous bound on max_k |V_rk|
+            const double vmax = ((double)mmh[a] + 1.0) * i8_mmax_unit(wide) * tauh[a]; // rigorous bound on max_k |V_rk|
             vref[r] = vmax;
             dref[r] = at_trial ? stepn[r] : 0.0; // distance from the current iterate to the point just evaluated
             // Dynamic range: tau_r was derived from a bound; when the largest |V_rk| actually seen is more than 8 bits
@@ -587,7 +589,7 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
             if (mmh[a] < (1u << 23)) {
                 if (ovr2.empty()) ovr2.assign((size_t)R, 0.0);
                 again.push_back(r);
-                ovr2[r] = vmax * (1.0 + 1e-12) / 2130000000.0;
+                ovr2[r] = vmax * (1.0 + 1e-12) / i8_vdiv(wide);
             }
         }
         if (formulation == GML_LOGRISE) { // f = log Z, g = grad Z / Z   (:279)
@@ -696,7 +698,7 @@ int Solver::start_polish(bool *started) {
     std::vector<int> fl;
     for (int64_t r = 0; r < R; ++r)
         if (atfloor[r] && !(std::min(best[r], kkt[r]) <= o.tol)) fl.push_back((int)r);
-    if (!(prec == GML_PREC_I8X && can_polish && !fl.empty())) return GML_OK;
+    if (!(gml_is_i8(prec) && can_polish && !fl.empty())) return GML_OK;
     if (gml_ensure_f64(p, Rp) != GML_OK) return GML_OK; // does not fit after all: the rows stay as they are (reported not converged)
     prec = GML_PREC_F64;
     stall_cap = 10;
@@ -743,12 +745,12 @@ int Solver::refresh_stale() {
 // set of a Cholesky row; for a matrix-free row the tiles of its block-diagonal preconditioner (gml_solver.hip), inverted here.
 // One upload carries the control block of the rows, one that of the tiles.
 int Solver::direction_blocks(const std::vector<int> &cg_rows) {
-    if (!cg_rows.empty() && prec != GML_PREC_I8X) {
+    if (!cg_rows.empty() && !gml_is_i8(prec)) {
         // FP64 phase: the curvature weights of the matrix-free rows' Hessian-vector products and preconditioner tiles come from
         // an int8-limb objective pass at the same iterate (those run on the int8 cores either way; only the curvature is
         // approximate)
         std::vector<double> tf((size_t)R), tz((size_t)R, 1.0), tn((size_t)R);
-        RCCHK(run_pass(cg_rows, X, nullptr, false, false, tf, tz, tn, nullptr, 0, GML_PREC_I8X));
+        RCCHK(run_pass(cg_rows, X, nullptr, false, false, tf, tz, tn, nullptr, 0, gml_is_i8(o.precision) ? o.precision : GML_PREC_I8X));
     }
     // layout of the block: mt [R] | node [R] | msz of the Cholesky rows [R] | (unused) [R] | vslot [R] | hoff [R+1] |
     // s1 [Rp] | ynoise [Rp] | s1cg [Rp]
@@ -789,7 +791,7 @@ int Solver::direction_blocks(const std::vector<int> &cg_rows) {
         vmV.resize((size_t)ntiles);
         wrowV.resize((size_t)ntiles);
         hflag.assign((size_t)R, 0);
-        const bool rows_i8 = prec == GML_PREC_I8X; // (FP64 phase: the rows' blocks come from launch_hess_f64, not from this call)
+        const bool rows_i8 = gml_is_i8(prec); // (FP64 phase: the rows' blocks come from launch_hess_f64, not from this call)
         for (int64_t r = 0; r < R; ++r) {
             mtV[r] = rows_i8 ? mt2[r] : 0;
             hoffV[r] = hoff[r];
@@ -810,7 +812,7 @@ int Solver::direction_blocks(const std::vector<int> &cg_rows) {
         HIPCHK(A.get(&dH, (size_t)dH_elems));
     }
     for (int64_t r = 0; r < R; ++r) {
-        const bool needs_planes = (prec == GML_PREC_I8X && mt2[r] > 0) || (ntiles > 0 && iscg[r] && !done[r]);
+        const bool needs_planes = (gml_is_i8(prec) && mt2[r] > 0) || (ntiles > 0 && iscg[r] && !done[r]);
         if (needs_planes && (vslot[r] < 0 || vslot[r] >= Scap || owner[vslot[r]] != r || vstale[r]))
             return fail(GML_EHIP, "internal: row %lld enters the Hessian without valid V planes (slot %d, owner %d, stale %d)", (long long)r,
                         vslot[r], vslot[r] >= 0 && vslot[r] < Scap ? owner[vslot[r]] : -2, (int)vstale[r]);
@@ -862,13 +864,13 @@ int Solver::direction_blocks(const std::vector<int> &cg_rows) {
     }
     HIPCHK(hipMemsetAsync(dH, 0, sizeof(double) * htotal, st));
     trace("hessian");
-    if (prec == GML_PREC_I8X || ntiles > 0) {
+    if (gml_is_i8(prec) || ntiles > 0) {
         std::string err;
         const int hrc = i8_hessian(p->i8ws, d, dMt + R, dVslot, dFidx, dMtV, ntiles > 0 ? mtV.data() : mt2, dHoffV, htotal, (int)R, capP, formulation, Kh,
                                    kstride, dH, st, &err, ntiles > 0 ? &tl : nullptr);
         if (hrc) return fail(hrc, "%s", err.empty() ? "int8 Hessian: working set above 512 entries" : err.c_str());
     }
-    if (prec != GML_PREC_I8X) launch_hess_f64(d, p->dV, dMt + R, dFidx, dMt, dHoff, (int)R, capP, formulation, Kh, kstride, dH, st);
+    if (!gml_is_i8(prec)) launch_hess_f64(d, p->dV, dMt + R, dFidx, dMt, dHoff, (int)R, capP, formulation, Kh, kstride, dH, st);
     if (ntiles > 0) {
         trace("tile inverses");
         launch_tile_inverse(T, dH, dHoffV + R, dVm, dWrow, dS1, formulation == GML_LOGRISE ? 1.0 : 0.0, dgV, ntiles, st);
@@ -1152,7 +1154,7 @@ int Solver::line_search() {
                 if (!full) accepted_fwd[r] = 1; // (its V planes still belong to the old iterate)
                 need[r] = 0;
             } else {
-                if (prec != GML_PREC_I8X) {
+                if (!gml_is_i8(prec)) {
                     vstale[r] = 1; // the FP64 path's V is indexed by row: every trial overwrites it
                 } else if (full) { // the planes just written belong to the rejected point: back to those of the iterate, if they survive
                     const int pv = vprev[r];

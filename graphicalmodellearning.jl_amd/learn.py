@@ -96,7 +96,7 @@ def learn(samples, formulation=None, method=None):
     if method.distributed and method.node_range is not None:
         raise ValueError("HIP: distributed=True derives the node range from the rank; node_range must not be given")
     if method.precision not in _lib.PRECISIONS:
-        raise ValueError(f"HIP: unknown precision {method.precision!r} (use 'auto', 'i8x' or 'f64')")
+        raise ValueError(f"HIP: unknown precision {method.precision!r} (use 'auto', 'i8x', 'i8w' or 'f64')")
     world, rank = 1, 0
     if method.distributed:
         import torch.distributed as dist

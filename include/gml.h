@@ -44,6 +44,11 @@ extern "C" {
 #define GML_PREC_F64 0   /* FP64 MFMA (v_mfma_f64_16x16x4_f64)                             */
 #define GML_PREC_I8X 1   /* fixed point on v_mfma_i32_*_i8: Theta in 38-bit and V in 31-bit int8 limbs (V rounded
                             with a dither), integer GEMMs without further rounding: f, grad to ~1e-9 relative      */
+#define GML_PREC_I8W 3   /* FP64-grade fixed point on the same int8 matrix cores: Theta in 54-bit (7 limb planes; entries within a
+                            factor two of a row's largest are exact), V in dithered 47-bit int8 limbs (6 planes), exp in FP64,
+                            integer GEMMs without further rounding: f, grad agree with a Float64 evaluation (:191-208) to the
+                            1e-12 the GML_PREC_F64 path is held to, at ~6x its speed.  gml_learn builds its Hessians and
+                            Hessian-vector products from the top 31 bits of the same V planes                              */
 #define GML_PREC_AUTO 2  /* GML_PREC_I8X, except for problems so small (samples x parameters x spins <= 2^28: a
                             property of the problem, not of the call or of the node shard) that every kernel is
                             launch-bound either way: those run in FP64, which needs fewer iterations near tight
