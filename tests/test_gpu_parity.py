@@ -14,13 +14,15 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 synthetic = __import__("importlib").import_module("gml_amd.synthetic")
 FORMS = ["RISE", "logRISE", "RPLE"]
-PRECS = ["f64", "i8x"]
+PRECS = ["f64", "i8x", "i8w"]
+EXACT = ("f64", "i8w")  # held to the tolerances of Float64 arithmetic: the FP64-MFMA path and the FP64-grade int8-limb path
 # objective/gradient tolerances: FP64 path = rounding only; int8-limb path = dithered 31-bit quantisation of
 # V relative to the per-node scale (errors ~ sqrt(K) * 2^-31 * scale: <1e-7 on the tiny, very non-uniform
 # mvt histogram whose few rows carry very different counts, ~2e-10 on benchmark-like inputs)
-FTOL = {"f64": 1e-12, "i8x": 1e-7}
-GTOL = {"f64": 1e-12, "i8x": 1e-7}
-SOLTOL = {"f64": 1e-9, "i8x": 1e-7}
+# (i8w: 54-bit Theta, dithered 47-bit V, FP64 exp -- the same 1e-12 as the FP64 path)
+FTOL = {"f64": 1e-12, "i8x": 1e-7, "i8w": 1e-12}
+GTOL = {"f64": 1e-12, "i8x": 1e-7, "i8w": 1e-12}
+SOLTOL = {"f64": 1e-9, "i8x": 1e-7, "i8w": 1e-9}
 
 
 def hist_from_spins(spins):
@@ -82,11 +84,11 @@ def test_objgrad_multibody_matches_oracle():
 def test_learn_abc_goldens(name, form, prec):
     # runtests.jl:68-80 -- default regularisers, symmetrised
     s = load_csv(f"{name}_samples.csv")
-    tol = 1e-11 if prec == "f64" else 1e-7
+    tol = 1e-11 if prec in EXACT else 1e-7
     m = gml.HIP(tol=tol, precision=prec)
     R = gml.learn(s, getattr(gml, form)(), m)
     G = load_csv(f"{name}_{form}_learned.csv")
-    assert np.abs(R - G).max() <= (5e-8 if prec == "f64" else 3e-7)
+    assert np.abs(R - G).max() <= (5e-8 if prec in EXACT else 3e-7)
     assert np.linalg.norm(R - G) / np.linalg.norm(G) <= 1e-6
     R0, _, _ = O.learn_pair(s, form, c=DEFAULT_C[form], symmetrize=True)
     assert np.abs(R - R0).max() <= SOLTOL[prec]
@@ -175,7 +177,7 @@ def test_learn_synthetic_block_ising_vs_oracle(prec):
     hist = hist_from_spins(spins)
     R0, kkt0, _ = O.learn_pair(hist, "RISE", c=0.4, symmetrize=False, tol=1e-13)
     with gml.Problem(spins=spins) as p:
-        out, kkt, st = p.learn("RISE", 0.4, tol=1e-12 if prec == "f64" else 2e-9, precision=prec)
+        out, kkt, st = p.learn("RISE", 0.4, tol=1e-12 if prec in EXACT else 2e-9, precision=prec)
     assert st["not_converged"] == 0
     assert np.linalg.norm(out - R0) / np.linalg.norm(R0) <= 1e-6
     assert np.abs(out - R0).max() / np.abs(R0).max() <= 1e-6
@@ -204,7 +206,7 @@ def test_c2_config_kkt_certificate(prec):
     n, K = 256, 100000
     spins, J = synthetic.block_ising(n, K, block=16, seed=0)
     with gml.Problem(spins=spins) as p:
-        tol = 1e-10 if prec == "f64" else 1e-9
+        tol = 1e-10 if prec in EXACT else 1e-9
         out, kkt, st = p.learn("RISE", 0.4, tol=tol, precision=prec)
     assert st["not_converged"] == 0 and kkt.max() <= tol
     lam = O.lam(0.4, n, K)
@@ -216,7 +218,7 @@ def test_c2_config_kkt_certificate(prec):
         pen = np.arange(n) != u
         pg = np.where(x > 0, g[a] + lam, np.where(x < 0, g[a] - lam, np.sign(g[a]) * np.maximum(np.abs(g[a]) - lam, 0)))
         pg[~pen] = g[a][~pen]
-        assert np.abs(pg).max() <= (1e-9 if prec == "f64" else 5e-9)
+        assert np.abs(pg).max() <= (1e-9 if prec in EXACT else 5e-9)
     sym = 0.5 * (out + out.T)
     assert np.abs(sym - J).max() <= 0.1  # ground truth recovered
 
@@ -282,6 +284,9 @@ def test_resident_timing_hook_returns_the_operator_output():
         km, f1, g1 = p.bench_pass_resident("RISE", J[64:192], steps=3, warmup=1, precision="i8x", want_output=True)
         f0, g0 = p.objgrad("RISE", np.arange(64, 192), J[64:192], precision="i8x")
         assert np.array_equal(f0, f1) and np.array_equal(g0, g1) and km["device_ms_per_pass"] > 0
+        km, f1, g1 = p.bench_pass_resident("RISE", J[64:192], steps=3, warmup=1, precision="i8w", want_output=True)
+        f0, g0 = p.objgrad("RISE", np.arange(64, 192), J[64:192], precision="i8w")
+        assert np.array_equal(f0, f1) and np.array_equal(g0, g1) and km["device_ms_per_pass"] > 0
         km, f1, g1 = p.bench_pass_resident("logRISE", J[64:192], steps=2, warmup=0, precision="f64", want_output=True)
         f0, g0 = p.objgrad("logRISE", np.arange(64, 192), J[64:192], precision="f64")
         assert np.abs(f0 - f1).max() <= 1e-12 and np.abs(g0 - g1).max() <= 1e-12  # FP64 atomics: order-dependent sums
@@ -324,10 +329,10 @@ def test_histogram_collisions_zero_counts_and_row_order(prec):
     ghosts[:, 1:] *= -1
     messy = np.vstack([split, ghosts, rest])
     messy = messy[rng.permutation(len(messy))]
-    tol = 1e-11 if prec == "f64" else 1e-9
+    tol = 1e-11 if prec in EXACT else 1e-9
     A = gml.learn(h, gml.RISE(0.4, False), gml.HIP(tol=tol, precision=prec))
     B = gml.learn(messy, gml.RISE(0.4, False), gml.HIP(tol=tol, precision=prec))
-    assert np.abs(A - B).max() <= (1e-9 if prec == "f64" else 1e-7)
+    assert np.abs(A - B).max() <= (1e-9 if prec in EXACT else 1e-7)
     R0, _, _ = O.learn_pair(h, "RISE", c=0.4, symmetrize=False)
     assert np.abs(B - R0).max() <= SOLTOL[prec]
 
@@ -736,3 +741,102 @@ def test_more_than_2_pow_24_configurations_default_precision():
             r = np.where(x != 0, g[a] + lam * np.sign(x) * pen, np.sign(g[a]) * np.maximum(np.abs(g[a]) - lam * pen, 0))
             assert np.abs(r).max() <= 5e-8
         assert np.abs(0.5 * (out[:32, :32] + out[:32, :32].T) - J[:32, :32]).max() < 0.02
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# precision i8w: the int8-limb pass at the width of the reference's Float64 arithmetic (54-bit Theta, 47-bit V, FP64 exp)
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [512, 1024])
+def test_i8w_matches_oracle_and_fp64_path_at_1e12(n):
+    # headline-width problems (8 / 16 column steps in each of the forward kernel's two sweeps, 2 / 4 column tiles in the two
+    # 3-plane backward launches): FP64 tolerance against the oracle and against the FP64-MFMA path, every formulation
+    K = 6000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=11)
+    rng = np.random.default_rng(3)
+    theta = J + rng.normal(scale=0.02, size=J.shape) * (rng.random(J.shape) < 0.1)
+    nodes = np.arange(n)
+    some = np.array([0, 1, n // 2 + 3, n - 1])
+    with gml.Problem(spins=spins) as p:
+        for form in FORMS:
+            fw, gw = p.objgrad(form, nodes, theta, precision="i8w")
+            f64, g64 = p.objgrad(form, nodes, theta, precision="f64")
+            assert np.abs(fw - f64).max() <= 1e-12 * max(1.0, np.abs(f64).max()) and np.abs(gw - g64).max() <= 1e-12
+            fo, go = O.objgrad_nodes(form, None, spins, some, theta[some])
+            assert np.abs(fw[some] - fo).max() <= 1e-12 * max(1.0, np.abs(fo).max()) and np.abs(gw[some] - go).max() <= 1e-12
+
+
+def test_i8w_deterministic_shard_independent_and_linear_in_counts():
+    # like the i8x pass: integer GEMMs, integer atomics -- two runs, any node sharding and doubled counts give the same bits
+    n, K = 256, 50000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=5)
+    theta = J.copy()
+    with gml.Problem(spins=spins) as p:
+        f1, g1 = p.objgrad("RISE", np.arange(n), theta, precision="i8w")
+        f2, g2 = p.objgrad("RISE", np.arange(n), theta, precision="i8w")
+        fa, ga = p.objgrad("RISE", np.arange(n), theta, precision="f64")
+    assert np.array_equal(f1, f2) and np.array_equal(g1, g2)
+    assert np.abs(f1 / fa - 1).max() <= 1e-12 and np.abs(g1 - ga).max() <= 1e-12
+    with gml.Problem(spins=spins, node_range=(100, 164)) as p:
+        f3, g3 = p.objgrad("RISE", np.array([7, 130, 255]), theta[[7, 130, 255]], precision="i8w")
+    assert np.array_equal(f3, f1[[7, 130, 255]]) and np.array_equal(g3, g1[[7, 130, 255]])
+    with gml.Problem(counts=2 * np.ones(K), spins=spins) as p:
+        fc, gc = p.objgrad("RISE", np.arange(n), theta, precision="i8w")
+    assert np.array_equal(fc, f1) and np.array_equal(gc, g1)
+
+
+def test_i8w_dense_theta_dynamic_range():
+    # sum|theta| ~ 40, 80: the weights exp(-E) of a row spread over tens of e-folds.  47 bits relative to the largest weight
+    # keep what the 31 bits of i8x lose: K / 2^48 relative to f at worst (coherent rounding), against K / 2^32
+    n, K = 100, 30000
+    spins, J = synthetic.block_ising(n, K, block=10, seed=4)
+    rng = np.random.default_rng(0)
+    nodes = np.arange(n)
+    with gml.Problem(spins=spins) as p:
+        for scale in (0.5, 1.0):
+            theta = rng.normal(scale=scale, size=(n, n))
+            fw, gw = p.objgrad("RISE", nodes, theta, precision="i8w")
+            f64, g64 = p.objgrad("RISE", nodes, theta, precision="f64")
+            tol = max(K / 2.0**48, 1e-12)
+            assert np.abs(fw / f64 - 1).max() <= tol
+            assert (np.abs(gw - g64) / np.abs(f64)[:, None]).max() <= tol
+            lw, _ = p.objgrad("logRISE", nodes, theta, precision="i8w")
+            l64, _ = p.objgrad("logRISE", nodes, theta, precision="f64")
+            assert np.abs(lw - l64).max() <= tol
+
+
+def test_i8w_multibody_narrow_and_wide_column_counts():
+    # order 3: 666 columns (int32 pairing of the limb accumulators) and 67 896 columns (every plane through FP64)
+    spins, terms = synthetic.block_multibody(36, 20000, block=12, seed=3)
+    rng = np.random.default_rng(1)
+    hist = np.column_stack([np.ones(len(spins), dtype=np.int64), spins.astype(np.int64)])
+    with gml.Problem(spins=spins, order=3) as p:
+        theta = rng.normal(scale=0.05, size=(36, p.P))
+        fw, gw = p.objgrad("RISE", np.arange(36), theta, precision="i8w")
+    for u in (0, 17, 35):
+        fo, go = O.objgrad_multi(hist, 3, u, theta[u])
+        assert abs(fw[u] / fo - 1) <= 1e-12 and np.abs(gw[u] - go).max() <= 1e-11 * fo
+    n, K = 368, 2048
+    rng = np.random.default_rng(12)
+    spins = np.where(rng.random((K, n)) < 0.9, 1, -1).astype(np.int8)
+    with gml.Problem(spins=spins, order=3) as p:
+        theta = np.full((2, p.P), 1.0e-4)
+        theta[1] = -theta[1]
+        nodes = np.array([0, 367])
+        fw, gw = p.objgrad("RISE", nodes, theta, precision="i8w")
+    fo, go = O.objgrad_multi3_nodes(None, spins, nodes, theta)
+    assert np.abs(fw / fo - 1).max() <= 1e-11 and (np.abs(gw - go) / fo[:, None]).max() <= 1e-11
+
+
+def test_i8w_learn_uses_top_planes_for_curvature_and_matches_fp64_solve():
+    # gml_learn at precision i8w: objective and gradient from the 47-bit planes, Hessian blocks and Hessian-vector products
+    # from their top four; same optimum as the FP64 path, and the matrix-free rows (block cap below the support) converge too
+    n, K = 192, 30000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=14)
+    with gml.Problem(spins=spins) as p:
+        a, ka, sa = p.learn("RISE", 0.1, tol=1e-11, precision="i8w", max_iter=200)
+        b, kb, sb = p.learn("RISE", 0.1, tol=1e-11, precision="f64", max_iter=200)
+        c, kc, sc = p.learn("RISE", 0.1, tol=1e-10, precision="i8w", max_working=64, max_iter=200)
+    assert sa["not_converged"] == 0 and sb["not_converged"] == 0 and sc["not_converged"] == 0 and sa["polished"] == 0
+    assert sc["hv_evals"] > 0
+    assert np.abs(a - b).max() <= 1e-9 and np.abs(c - b).max() <= 1e-8
+    assert ((a == 0) == (b == 0)).all()
