@@ -14,11 +14,13 @@ With N > 1 and no WORLD_SIZE in the environment this process only launches
 relays rank 0's line; under torchrun each rank takes the nodes [rank*n/N, (rank+1)*n/N) of the SAME
 problem (strong scaling; no collective on the data path, one RCCL all-gather of the learned rows).
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel: algorithmic flops /
-HIP-event time vs the MFMA peak of the arithmetic type), "f64" (the same pass on the FP64-MFMA path),
-"cpu_baseline" (the CPU oracle's blocked restatement timed on this box's host cores on a bounded
-sample, plus CPU learn() wall-clock at config 2 and an extrapolation to this config), and the
-learn() wall-clock of this config.
+Prints ONE JSON line (rank 0).  The headline (`value`, `ms_per_step`, `dtype`, `roofline`, `learn_wall_s`) is measured at
+precision "i8w": the int8 matrix cores at the width of the reference's Float64 arithmetic (Theta in 54-bit, the weights in
+47-bit int8 limbs, exp in FP64; tests/test_gpu_parity.py holds it to the same 1e-12 as the FP64-MFMA path, and this run
+re-checks it against that path and against the CPU oracle).  Extra objects: "f64" (the same pass on the FP64-MFMA path),
+"i8x" (the 38/31-bit accelerated mode that learn() uses by default), "cpu_baseline" (the CPU oracle's blocked restatement
+timed on this box's host cores on a bounded sample: all threads and one thread; CPU learn() wall-clock at config 2 and at
+this config), the learn() wall-clock of this config at all three precisions, and one pass over a weighted histogram.
 """
 import argparse
 import json
@@ -34,8 +36,13 @@ sys.path.insert(0, ROOT)
 # dense MFMA peaks (flop/s or op/s).  i8 / bf16: /opt/skills/guides/MI355X_MICROARCH.md (bf16
 # ~2.5 PF dense, i8 = 2x bf16 per clock).  FP64: AMD datasheet (78.6 TF matrix = vector); the local
 # guide lists no FP64 figure.
-PEAKS = {"f64": 78.6e12, "i8x": 5.0e15}
-KERNELS = {"f64": {"fwd": "k_fwd_f64", "bwd": "k_bwd_f64"}, "i8x": {"fwd": "k_fwd_i8", "bwd": "k_bwd_i8"}}
+PEAKS = {"f64": 78.6e12, "i8x": 5.0e15, "i8w": 5.0e15}
+KERNELS = {"f64": {"fwd": "k_fwd_f64", "bwd": "k_bwd_f64"}, "i8x": {"fwd": "k_fwd_i8", "bwd": "k_bwd_i8"},
+           "i8w": {"fwd": "k_fwd_i8w", "bwd": "k_bwd_i8<1, 3>"}}
+# int8 digit-plane products issued per algorithmic product (forward: planes of Theta, backward: planes of V)
+LIMBS = {"i8x": {"fwd": 5, "bwd": 4}, "i8w": {"fwd": 7, "bwd": 6}}
+PMC_FILES = {"i8w": ("r4_i8w_pmc_traffic.json",), "i8x": ("r3_i8x_pmc_traffic.json", "r2_i8x_pmc_traffic.json")}
+KERNEL_SOURCES = {"i8w": "gml_kernels_i8w.hip", "i8x": "gml_kernels_i8.hip"}
 
 
 def parse_args():
@@ -46,11 +53,16 @@ def parse_args():
     ap.add_argument("--spins", dest="n", type=int, default=1024, help="number of spins n (not --n: torchrun's own parser would call that an ambiguous abbreviation)")
     ap.add_argument("--samples", type=int, default=1000000)
     ap.add_argument("--block", type=int, default=16)
-    ap.add_argument("--precision", default=os.environ.get("GML_BENCH_PRECISION", "i8x"), choices=["f64", "i8x"],
-                    help="i8x: int8-limb MFMA pass (default, fastest); f64: FP64 MFMA pass")
+    ap.add_argument("--precision", default=os.environ.get("GML_BENCH_PRECISION", "i8w"), choices=["f64", "i8x", "i8w"],
+                    help="arithmetic of the headline: i8w = FP64-grade int8-limb pass (default); i8x = 38/31-bit int8-limb pass; "
+                         "f64 = FP64 MFMA pass")
     ap.add_argument("--no-learn", action="store_true", help="skip the full learn() wall-clock leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-f64", action="store_true", help="skip the FP64-path leg")
+    ap.add_argument("--no-i8x", action="store_true", help="skip the i8x (accelerated mode) leg")
+    ap.add_argument("--no-weighted", action="store_true", help="skip the weighted-histogram pass")
+    ap.add_argument("--cpu-learn-max-s", type=float, default=100.0, help="run the CPU learn() of THIS config in full when the "
+                                                                           "measured CPU rate predicts at most this many seconds")
     ap.add_argument("--no-host-learn", action="store_true", help="skip learn() from an 8.2 GB host Matrix{Int64}")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the timed CPU objective/gradient sample")
     ap.add_argument("--cpu-learn-full", action="store_true", help="run the CPU learn() of THIS config in full instead of extrapolating")
@@ -98,14 +110,15 @@ def pass_roofline(km, K, P, nloc, precision):
           # of the instruction class issued)
           "frac_fwd": flops_kernel / (km["fwd_ms"] * 1e-3) / peak, "frac_bwd": flops_kernel / (km["bwd_ms"] * 1e-3) / peak,
           "frac_pass": 2 * flops_kernel / (km["device_ms_per_pass"] * 1e-3) / peak}
-    if precision == "i8x":
-        # the int8-limb pass issues LF forward + 4 backward digit-plane products per algorithmic one
-        LF = 5  # forward limb planes of the objective passes (gml_opts.limbs_fwd default)
-        limbs = {"fwd": LF, "bwd": 4}[dom]
+    if precision in LIMBS:
+        limbs = LIMBS[precision][dom]
         rf["limb_products"] = limbs
         rf["mfma_issue_frac"] = limbs * achieved / peak
         rf["note"] = ("achieved counts algorithmic flops once; the kernel issues limb_products int8 MFMA products per "
                       "algorithmic product (fixed point), so frac <= 1/limb_products")
+        if precision == "i8w":
+            rf["note"] += ("; the backward GEMM of i8w runs as two launches of the 3-plane kernel (bwd_ms = both), the forward "
+                           "kernel as one launch sweeping the columns twice (4 + 3 planes)")
     return rf, dom
 
 
@@ -211,18 +224,26 @@ def main():
     # measured with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same command (separate passes;
     # scripts/gpu_profile.sh) is reported from the committed summary, labelled with its file.  gfx950 correction per
     # MI355X_MICROARCH.md: FETCH_SIZE counts half the bytes of 16-B/lane loads -> doubled.
-    if args.precision == "i8x" and (n, K, world) == (1024, 1000000, 1):
-        for fn in ("r3_i8x_pmc_traffic.json", "r2_i8x_pmc_traffic.json"):
+    # algorithmic bytes of an all-node pass = the spins once (bit-packed) + 8 K of weights + 16 n_loc P
+    # (Theta in, G out); what this implementation moves on top (both operand images, the limb planes of V out and back) is
+    # reported apart as traffic_impl.
+    roofline["bytes_alg_per_pass"] = K * n / 8.0 + 8.0 * K + 16.0 * nloc * n
+    if args.precision in LIMBS:
+        roofline["traffic_impl_per_pass"] = 2.0 * K * n / 8.0 + 2.0 * LIMBS[args.precision]["bwd"] * K * nloc
+        roofline["traffic_impl_note"] = ("bytes this implementation must move per pass: the two operand bit images (K n / 8 each) and the "
+                                         "%d int8 limb planes of V written by the forward and read by the backward kernel"
+                                         % LIMBS[args.precision]["bwd"])
+    if args.precision in PMC_FILES and (n, K, world) == (1024, 1000000, 1):
+        for fn in PMC_FILES[args.precision]:
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
-                kn = [k for k in pm if KERNELS["i8x"][dom] in k][0]
+                kn = [k for k in pm if KERNELS[args.precision][dom].split("<")[0] in k][0]
                 roofline["traffic"] = (2.0 * pm[kn]["FETCH_SIZE_KB"] + pm[kn]["WRITE_SIZE_KB"]) * 1024.0
-                roofline["traffic_note"] = ("bytes per launch from profiles/%s (2*FETCH_SIZE + WRITE_SIZE, KB; a separate rocprofv3 "
-                                            "--pmc run of this command, not this run); algorithmic bytes per launch: %.3g (bit image "
-                                            "K*n/8 + the 4 int8 limb planes of V, 4*K*n_loc)" % (fn, K * n / 8.0 + 4.0 * K * nloc))
+                roofline["traffic_note"] = ("HBM bytes per launch of %s from profiles/%s (2*FETCH_SIZE + WRITE_SIZE, KB; a separate "
+                                            "rocprofv3 --pmc run of this command, not this run)" % (kn, fn))
                 # were the counters taken on the kernels that ran just now?
                 import hashlib
-                ksrc = os.path.join(ROOT, "graphicalmodellearning.jl_amd", "csrc", "gml_kernels_i8.hip")
+                ksrc = os.path.join(ROOT, "graphicalmodellearning.jl_amd", "csrc", KERNEL_SOURCES[args.precision])
                 sha = pm.get("_kernel_source_sha256")
                 roofline["traffic_kernels_match"] = (None if sha is None else
                                                      sha == hashlib.sha256(open(ksrc, "rb").read()).hexdigest())
@@ -234,35 +255,48 @@ def main():
     extra = {"per_rank_ms_per_step": [e / args.steps * 1e3 for e in per_rank],
              # spread of the timed passes on this rank (HIP events around every pass, device time)
              "step_ms_min": float(step[0]), "step_ms_median": float(np.median(step)), "step_ms_max": float(step[-1])}
-    if world > 1:
-        extra["collective_backend"] = dist.get_backend() + (" (RCCL)" if backend == "nccl" else " (ranks share a GPU: host tensors)")
-        extra["collective_ranks"] = dist.get_world_size()
+    def gather_list(x):
+        """one float per rank -> list over ranks (rank order)"""
+        return max_over_ranks(x)[1]
 
-    # ---- the FP64-MFMA path on the same workload (fewer steps: ~85 ms each) ----------------------------------
-    f64 = None
-    if not args.no_f64 and args.precision == "i8x":
-        s64 = max(3, min(20, args.steps // 10))
-        e64, _, km64, f64_res, g64_res = timed("f64", s64, 1)
-        rf64, _ = pass_roofline(km64, K, n, nloc, "f64")
-        f64 = {"value": n * s64 / e64, "unit": "node-evals/s", "steps": s64, "ms_per_step": e64 / s64 * 1e3, "dtype": "f64",
-               "roofline": rf64,
-               "i8x_vs_f64_max_abs_grad_diff": float(np.abs(g64_res - g_res).max()),
-               "i8x_vs_f64_max_rel_f_diff": float(np.abs(f_res / f64_res - 1).max())}
+    extra["collective_backend"] = (dist.get_backend() + (" (RCCL)" if backend == "nccl" else " (ranks share a GPU: host tensors)")) if world > 1 else "none (1 rank)"
+    extra["collective_ranks"] = world
+    extra["devices_visible"] = ndev
+
+    # ---- the other arithmetics on the same workload ------------------------------------------------------------------
+    # f64: the FP64-MFMA path (fewer steps: ~85 ms each); i8x: the 38/31-bit int8-limb pass (learn()'s default)
+    others = {}
+    for prec, skip, nsteps in (("f64", args.no_f64, max(3, min(20, args.steps // 10))), ("i8x", args.no_i8x, max(3, min(50, args.steps // 4))),
+                               ("i8w", True, 0)):
+        if skip or prec == args.precision:
+            continue
+        e_o, _, km_o, f_o, g_o = timed(prec, nsteps, 1)
+        rf_o, _ = pass_roofline(km_o, K, n, nloc, prec)
+        others[prec] = {"value": n * nsteps / e_o, "unit": "node-evals/s", "steps": nsteps, "ms_per_step": e_o / nsteps * 1e3, "dtype": prec,
+                        "roofline": rf_o,
+                        "max_abs_grad_diff_vs_headline": float(np.abs(g_o - g_res).max()),
+                        "max_rel_f_diff_vs_headline": float(np.abs(f_res / f_o - 1).max())}
+    f64 = others.get("f64")
 
     # ---- learn() wall-clock of this config ---------------------------------------------------------------------
     out = None
-    if not args.no_learn:
-        # three runs, the median reported (every run listed): a run now and then carries a one-off stall of the
-        # allocator or of a lazily loaded code object that has nothing to do with the path
+    STKEYS = ("iterations", "passes", "forward_passes", "node_evals", "max_kkt", "not_converged", "t_pass", "t_hess", "t_host", "polished")
+
+    def learn_leg(prec, nruns):
+        # nruns runs, the median reported (every run listed): a run now and then carries a one-off stall of the allocator or of
+        # a lazily loaded code object that has nothing to do with the path
         runs = []
-        for _ in range(3):
+        for _ in range(nruns):
             sync()
             t0 = time.perf_counter()
-            out, kkt, st = prob.learn("RISE", 0.4, tol=1e-9, precision=args.precision, raise_on_fail=False)
+            o_, kkt_, st_ = prob.learn("RISE", 0.4, tol=1e-9, precision=prec, raise_on_fail=False)
             sync()
-            runs.append((max_over_ranks(time.perf_counter() - t0), st))
-        runs_s = [r[0][0] for r in runs]
-        (t_learn, learn_per_rank), st = sorted(runs, key=lambda r: r[0][0])[1]
+            runs.append((max_over_ranks(time.perf_counter() - t0), st_, o_))
+        (t_, per_rank_), st_, o_ = sorted(runs, key=lambda r: r[0][0])[len(runs) // 2]
+        return t_, per_rank_, st_, o_, [r[0][0] for r in runs]
+
+    if not args.no_learn:
+        t_learn, learn_per_rank, st, out, runs_s = learn_leg(args.precision, 3)
         extra["learn_wall_runs_s"] = runs_s
         if world > 1:
             # final gather of the row blocks over RCCL/xGMI (the only collective of the path)
@@ -274,10 +308,16 @@ def main():
             torch.cuda.synchronize()
             extra["gather_s"] = time.perf_counter() - tg
             full = allb.reshape(n, n).cpu().numpy()
+            # stragglers among the node shards: iterations, passes and evaluated rows of every rank
+            extra["learn_per_rank_iterations"] = [int(v) for v in gather_list(st["iterations"])]
+            extra["learn_per_rank_passes"] = [int(v) for v in gather_list(st["passes"])]
+            extra["learn_per_rank_node_evals"] = [int(v) for v in gather_list(st["node_evals"])]
+            extra["learn_per_rank_t_pass_s"] = gather_list(st["t_pass"])
+            extra["learn_per_rank_t_hess_s"] = gather_list(st["t_hess"])
         else:
             full = out
         sym_err = float(np.abs(0.5 * (full + full.T) - J).max())
-        extra.update({"learn_wall_s": t_learn, "learn_per_rank_s": learn_per_rank, "learn_create_s": t_create,
+        extra.update({"learn_wall_s": t_learn, "learn_precision": args.precision, "learn_per_rank_s": learn_per_rank, "learn_create_s": t_create,
                       "learn_iterations": st["iterations"], "learn_passes": st["passes"],
                       "learn_forward_passes": st["forward_passes"], "learn_node_evals": st["node_evals"],
                       "learn_max_kkt": st["max_kkt"], "learn_not_converged": st["not_converged"],
@@ -286,6 +326,14 @@ def main():
                       # the solver drives the same resident pass function the timed region above calls
                       "learn_pass_node_evals_per_s": st["node_evals"] / max(st["t_pass"], 1e-9) * world,
                       "max_err_vs_true_model": sym_err})
+        # the same solve in the other arithmetics: the reference's own (FP64 MFMA throughout, one run) and the accelerated mode
+        for prec, skip, nruns in (("f64", args.no_f64, 1), ("i8x", args.no_i8x, 3), ("i8w", True, 0)):
+            if skip or prec == args.precision:
+                continue
+            t_o, _, st_o, out_o, runs_o = learn_leg(prec, nruns)
+            extra["learn_wall_s_" + prec] = t_o
+            extra["learn_" + prec] = dict({k: st_o[k] for k in STKEYS}, runs_s=runs_o,
+                                          max_abs_diff_vs_headline_solution=float(np.abs(out_o - out).max()))
 
     # ---- learn() from a HOST histogram: what a `learn(samples, RISE(), HIP())` caller pays (pack + upload +
     # solve + gather + symmetrise).  The samples as the reference holds them: a column-major Matrix{Int64}, K x (1+n)
@@ -326,17 +374,44 @@ def main():
         else:
             extra["learn_from_host"] = {"skipped": "needs %.0f GB of host memory, %.0f available" % (1.5 * need_gb + 8, avail_gb)}
 
+    # ---- one pass over a WEIGHTED histogram (rank 0 of a 1-GPU run only): non-uniform counts take the weight-loading template
+    # of the forward kernel (UNIW = false); the timed region above runs the uniform-weight one (every count equal) -----------
+    spins = None
+    if rank == 0 and world == 1 and not (args.no_cpu and args.no_weighted):
+        spins = prob.spins()  # the K x n configurations the GPU path works on
+    if spins is not None and not args.no_weighted:
+        counts_w = 1.0 + (np.arange(K) % 3)
+        with gml.Problem(counts=counts_w, spins=spins, device=device) as pw:
+            sw = max(3, min(20, args.steps // 10))
+            pw.bench_pass_resident("RISE", theta, steps=2, warmup=0, precision=args.precision)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            kmw = pw.bench_pass_resident("RISE", theta, steps=sw, warmup=0, precision=args.precision)
+            torch.cuda.synchronize()
+            ew = time.perf_counter() - t0
+        extra["ms_per_step_weighted"] = ew / sw * 1e3
+        extra["weighted"] = {"counts": "1 + (k mod 3)", "steps": sw, "fwd_ms": kmw["fwd_ms"], "bwd_ms": kmw["bwd_ms"],
+                             "device_ms_per_pass": kmw["device_ms_per_pass"], "value": n * sw / ew, "unit": "node-evals/s"}
+
     # ---- CPU baseline (rank 0 of a 1-GPU run only) -----------------------------------------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import oracle as O
         hc = O.host_cpus()
-        cores = hc["threads"]
+        threads = hc["threads"]
+        cpu_model, phys = "unknown", None
         try:
-            cpu_model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+            info = open("/proc/cpuinfo").read().split("\n\n")
+            cpu_model = [ln.split(":", 1)[1].strip() for ln in info[0].splitlines() if ln.startswith("model name")][0]
+            allowed = os.sched_getaffinity(0)
+            ids = set()
+            for blk in info:
+                kv = {ln.split(":", 1)[0].strip(): ln.split(":", 1)[1].strip() for ln in blk.splitlines() if ":" in ln}
+                if "processor" in kv and int(kv["processor"]) in allowed:
+                    ids.add((kv.get("physical id", "0"), kv.get("core id", kv["processor"])))
+            phys = len(ids)
         except Exception:
-            cpu_model = "unknown"
-        spins = prob.spins()  # the K x n configurations the GPU path works on
+            pass
         # (1) objective/gradient rate: the oracle's blocked FP64 restatement (32 nodes share one sweep over the spins,
         # OpenMP over node blocks x sample chunks, all host threads), on a bounded sample of nodes at full K and n
         nodes = (np.arange(32, dtype=np.int64) * (n // 32)) % n
@@ -352,16 +427,29 @@ def main():
         # parity spot check of the timed GPU operator against the oracle on the same rows
         f_gpu, g_gpu = prob.objgrad("RISE", nodes, J[nodes], precision=args.precision)
         assert np.array_equal(g_gpu, g_res[nodes]) and np.array_equal(f_gpu, f_res[nodes]), "timed passes != operator output"
-        cpu = {"value": nn / t_cpu, "unit": "node-evals/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
-               "cpus_visible": hc["visible"], "cgroup_cpu_quota": hc["quota"],
+        # ... and ONE thread: the per-node-evaluation time of the same code (one block of 32 nodes, a quarter of the samples,
+        # scaled: the sweep is linear in K)
+        O.lib().gml_oracle_set_threads(1)
+        k1 = max(4096, K // 4)
+        t0 = time.perf_counter()
+        O.objgrad_nodes("RISE", None, spins[:k1], nodes[:32], J[nodes[:32]])
+        t_one = (time.perf_counter() - t0) * (K / k1)
+        O.lib().gml_oracle_set_threads(threads)
+        cpu = {"value": nn / t_cpu, "unit": "node-evals/s", "cores": threads, "threads": threads, "cpu_model": cpu_model, "kind": "port",
+               "cpus_visible": hc["visible"], "cgroup_cpu_quota": hc["quota"], "physical_cores_visible": phys,
+               "cores_note": "`cores` = the OpenMP threads actually used (= `threads`; the contract's field); the container may use "
+                             "`cgroup_cpu_quota` CPUs' worth of time out of `cpus_visible` logical CPUs (`physical_cores_visible` "
+                             "physical cores); thread count = 2 x quota, the measured optimum on this box class",
                "sample": f"{nn} node evaluations (nodes spread over 0..{n - 1}) at full K={K}, n={n}; oracle/gml_oracle_fast.c "
-                         f"gml_oracle_objgrad_nodes: FP64, 32-node blocks share one sweep over the spins, OpenMP with {cores} threads "
-                         f"(the container's cgroup quota is {hc['quota']:g} CPUs of {hc['visible']} visible; thread count = 2 x quota)",
+                         f"gml_oracle_objgrad_nodes: FP64, 32-node blocks share one sweep over the spins, OpenMP with {threads} threads",
                "seconds": t_cpu, "gflops": 4.0 * K * n * nn / t_cpu / 1e9,
+               "ms_per_node_eval_all_threads": t_cpu / nn * 1e3,
+               "single_thread": {"ms_per_node_eval": t_one / 32 * 1e3, "value": 32 / t_one, "unit": "node-evals/s", "gflops": 4.0 * K * n * 32 / t_one / 1e9,
+                                 "sample": f"32 node evaluations (one block) over {k1} of the {K} configurations, one thread, scaled to K"},
                "parity_max_abs_grad_diff": float(np.abs(g_gpu - g_cpu).max()),
                "parity_max_rel_f_diff": float(np.abs(f_gpu / f_cpu - 1).max())}
         # (2) CPU learn() wall-clock, same method (batched working-set Newton), same tolerance:
-        #     config 2 (n=256, K=1e5) in full on both sides; this config extrapolated from the measured rate unless asked
+        #     config 2 (n=256, K=1e5) in full on both sides; this config in full when the measured rate predicts it fits the budget
         J2 = synthetic.block_ising_model(256, block=16, seed=0)
         with gml.Problem(model=J2, num_samples=100000, seed=0, device=device) as p2:
             t0 = time.perf_counter()
@@ -376,19 +464,22 @@ def main():
                            "cpu_max_kkt": float(ck2.max()), "gpu_max_kkt": float(k2.max()),
                            "max_abs_diff_cpu_vs_gpu": float(np.abs(c2 - o2).max())}
         if not args.no_learn:
-            if args.cpu_learn_full:
+            t_pred = extra["learn_node_evals"] / cpu["value"]
+            if args.cpu_learn_full or t_pred <= args.cpu_learn_max_s:
                 t0 = time.perf_counter()
                 c3, ck3, cs3 = O.learn_pair_fast(None, spins, "RISE", c=0.4, tol=1e-9)
                 t_cpu3 = time.perf_counter() - t0
                 cpu["learn_this_config"] = {"cpu_s": t_cpu3, "gpu_s": extra["learn_wall_s"], "speedup": t_cpu3 / extra["learn_wall_s"],
-                                            "kind": "measured", "cpu_max_kkt": float(ck3.max()),
-                                            "max_abs_diff_cpu_vs_gpu": float(np.abs(c3 - out).max())}
+                                            "kind": "measured", "cpu_max_kkt": float(ck3.max()), "cpu_passes": cs3["passes"],
+                                            "cpu_node_evals": cs3["node_evals"], "predicted_s": t_pred,
+                                            "max_abs_diff_cpu_vs_gpu": float(np.abs(c3 - out).max()),
+                                            "rel_frobenius_diff_cpu_vs_gpu": float(np.linalg.norm(c3 - out) / np.linalg.norm(c3))}
             else:
-                t_cpu3 = extra["learn_node_evals"] / cpu["value"]
-                cpu["learn_this_config"] = {"cpu_s": t_cpu3, "gpu_s": extra["learn_wall_s"], "speedup": t_cpu3 / extra["learn_wall_s"],
-                                            "kind": "extrapolated: the GPU run's node evaluations / the measured CPU rate "
-                                                    "(Hessians and solves not counted); --cpu-learn-full measures it"}
-        del spins
+                cpu["learn_this_config"] = {"cpu_s": t_pred, "gpu_s": extra["learn_wall_s"], "speedup": t_pred / extra["learn_wall_s"],
+                                            "kind": "extrapolated: the GPU run's node evaluations / the measured CPU rate (Hessians and "
+                                                    "solves not counted), because that predicts more than --cpu-learn-max-s = %g s; "
+                                                    "--cpu-learn-full measures it" % args.cpu_learn_max_s}
+    del spins
 
     if rank == 0:
         line = {"metric": "obj/grad evals/sec (RISE, n=%d spins, %d samples)" % (n, K), "value": value,
@@ -400,16 +491,21 @@ def main():
                                        % (n, args.block, K),
                            "n": n, "samples": K, "nodes_per_gpu": nloc, "parallelism": "node-shard x%d" % world,
                            "sample_and_pack_s": t_create},
-                "roofline": roofline, "f64": f64, "cpu_baseline": cpu}
+                "roofline": roofline, "f64": f64, "i8x": others.get("i8x"), "cpu_baseline": cpu}
         if f64 is not None:
-            # the reference computes in Float64: the precision-equal throughput of the same pass, at top level
+            # the same pass on the FP64 matrix cores (the reference's arithmetic, instruction for instruction)
             line.update({"value_f64": f64["value"], "ms_per_step_f64": f64["ms_per_step"], "roofline_f64": f64["roofline"]})
-        if args.precision == "i8x":
-            line["precision_note"] = ("dtype i8x = fixed point on the int8 matrix cores: Theta in 38-bit, V in dithered 31-bit int8 limbs, "
-                                      "integer GEMMs exact; f and grad differ from the FP64 evaluation by ~0.4*sqrt(K)*2^-31 of the "
-                                      "largest weight (this run: see f64.i8x_vs_f64_* and cpu_baseline.parity_*; tests hold 1e-7 where "
-                                      "the FP64 path holds 1e-12); north_star tolerance 1e-6 on the learned couplings. value_f64 is the "
-                                      "same pass in the reference's own arithmetic (FP64 MFMA).")
+        if others.get("i8x") is not None:
+            line.update({"value_i8x": others["i8x"]["value"], "ms_per_step_i8x": others["i8x"]["ms_per_step"]})
+        notes = {"i8w": "dtype i8w = fixed point on the int8 matrix cores at the width of Float64: Theta in 54-bit int8 limbs (entries within a "
+                        "factor two of a row's largest exact, the rest to 2^-55 of it), the weights V in dithered 47-bit limbs, exp in FP64, "
+                        "integer GEMMs exact.  f and grad agree with the FP64-MFMA path and with the CPU oracle to the 1e-12 that path is held "
+                        "to (tests/test_gpu_parity.py: FTOL/GTOL; this run: f64.max_*_diff_vs_headline, cpu_baseline.parity_*).",
+                 "i8x": "dtype i8x = fixed point on the int8 matrix cores: Theta in 38-bit, V in dithered 31-bit int8 limbs, integer GEMMs exact; "
+                        "f and grad differ from the FP64 evaluation by ~0.4*sqrt(K)*2^-31 of the largest weight (tests hold 1e-7 where the FP64 "
+                        "and i8w paths hold 1e-12); north_star tolerance 1e-6 on the learned couplings.",
+                 "f64": "dtype f64 = FP64 MFMA (v_mfma_f64_16x16x4_f64) throughout."}
+        line["precision_note"] = notes[args.precision]
         line.update(extra)
         print(json.dumps(line))
     prob.close()
