@@ -106,6 +106,8 @@ inline double i8_vdiv(bool wide) { return wide ? 1.400e14 : 2130000000.0; }
 void i8_free(void *ws);
 // per-slot results of the last pass of the given kind (device pointers)
 void i8_slot_results(void *ws, int hv, const double **tau, const unsigned **mmax);
+// the limb planes of V of the workspace (device pointer, bytes): the kernel-timing experiments read per-workgroup timestamps from it
+void i8_vq_buffer(void *ws, const int8_t **vq, int64_t *bytes, const DevProblem &d);
 // Extra blocks of a Hessian call: the preconditioner tiles of the matrix-free rows.  Block R + t (t < n) is the T x T Hessian of
 // the T columns F[t T ..] under the weights of row wrow[t]; the caller's mt / hoff arrays cover R + n blocks (mt = T / 32 for a
 // tile).  hflag [R]: rows whose weights are needed (those with a working set, and those with tiles).

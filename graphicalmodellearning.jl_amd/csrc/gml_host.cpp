@@ -1797,3 +1797,17 @@ extern "C" int gml_test_newton_solve_fixed(int R, const int *m, int cap, const d
                                            const unsigned char *fix, const double *dfix, double *d_out, int device) {
     return test_newton_solve(R, m, cap, blocks, pg, s2, g, d_out, device, fix, dfix);
 }
+
+// Experiment hook (not part of include/gml.h): bytes [off, off + bytes) of the V limb planes of the handle's int8 workspace.  The
+// timing builds of the forward kernels (scripts/build_variant.sh ... -DABL_TIMING) leave per-workgroup timestamps there.
+extern "C" int gml_debug_read_vq(gml_problem *p, int64_t off, int64_t bytes, void *out) {
+    if (!p || !out) return fail(GML_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(p->device));
+    const int8_t *vq = nullptr;
+    int64_t total = 0;
+    gml::i8_vq_buffer(p->i8ws, &vq, &total, p->d);
+    if (!vq || off < 0 || off + bytes > total) return fail(GML_EINVAL, "range outside the %lld bytes of V planes", (long long)total);
+    HIPCHK(hipStreamSynchronize(p->st));
+    HIPCHK(hipMemcpy(out, vq + off, (size_t)bytes, hipMemcpyDeviceToHost));
+    return GML_OK;
+}

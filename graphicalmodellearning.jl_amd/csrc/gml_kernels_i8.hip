@@ -1335,6 +1335,12 @@ void i8_slot_results(void *p, int hv, const double **tau, const unsigned **mmax)
     *mmax = w ? w->sc[hv ? 1 : 0].mmax : nullptr;
 }
 
+void i8_vq_buffer(void *p, const int8_t **vq, int64_t *bytes, const DevProblem &d) {
+    I8Ws *w = static_cast<I8Ws *>(p);
+    *vq = w ? w->Vq : nullptr;
+    *bytes = w ? (int64_t)w->slots * w->LBT * d.Kp : 0;
+}
+
 void i8_free(void *p) {
     I8Ws *w = static_cast<I8Ws *>(p);
     if (!w) return;

@@ -45,6 +45,14 @@ __device__ __forceinline__ void digits6(double yr, unsigned &dl, unsigned &dh) {
     dh = (unsigned)(v >> 32);
 }
 
+// One LDS-DMA instruction with the address split the way the hardware takes it: a wave-uniform 64-bit base in scalar registers,
+// a 32-bit per-lane offset, the (wave-uniform) LDS destination in M0.  (Through __builtin_amdgcn_global_load_lds the compiler
+// folds the lane offset into loop-invariant 64-bit VECTOR pointers, one pair per instruction of the stage: 18 registers this
+// kernel does not have.)
+__device__ __forceinline__ void dma16(const int8_t *ubase, int voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_addr) : "memory"); // (M0 is reserved: the compiler never keeps a value in it)
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -108,39 +116,65 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
     const int8_t *const gX = reinterpret_cast<const int8_t *>(Xb) + (int64_t)(2 * st) * nk * 1024;
     const int8_t *const gT = Tq + (int64_t)mytile * nk * BRT * 64;
     const int nst = (nk + DSW - 1) / DSW; // ring stages per sweep; global stage gs < nst: sweep A, else sweep B
-    auto issue = [&](int gs) {
-        int8_t *stage_base = lds + (gs % NSW) * STAGEW;
-        const bool sweepA = gs < nst;
-        const int ks = sweepA ? gs : gs - nst;
-        const int pps = sweepA ? PA : PB, row0 = sweepA ? 0 : 32 * LFA;
+    // per DMA instruction of this wave (wave-uniform, scalar registers): source of step 0, bytes per step, step within the
+    // stage, destination within the stage
+    const int8_t *baseA[NLA], *baseB[NLB];
+    int advA[NLA], advB[NLB], subA[NLA], subB[NLB], dstA[NLA], dstB[NLB];
+    bool bitsA[NLA], bitsB[NLB];
+    auto plan = [&](int sp, int pps, int row0, const int8_t *&base, int &adv, int &sub, int &dst, bool &bits) {
+        sub = sp / pps;
+        const int pc = sp - sub * pps;
+        dst = sub * STEPW + pc * 1024;
+        bits = pc < 2;
+        base = bits ? gX + (int64_t)pc * nk * 1024 : gT + (row0 + (pc - 2) * 16) * 64;
+        adv = bits ? 1024 : BRT * 64;
+    };
 #pragma unroll
-        for (int j = 0; j < NLA; ++j) {
-            if (j == NLA - 1 && !sweepA) break; // (wave-uniform)
-            const int sp = wave + 4 * j, sub = sp / pps, pc = sp - sub * pps;
-            int kt = DSW * ks + sub;
-            kt = kt < nk ? kt : nk - 1; // (a step beyond the last one: the last one again, so that every stage counts the same loads)
-            const int8_t *src = pc < 2 ? gX + ((int64_t)pc * nk + kt) * 1024 + voffX
-                                       : gT + ((int64_t)kt * BRT + row0 + (pc - 2) * 16) * 64 + voffT;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(stage_base + sub * STEPW + pc * 1024), 16, 0, 0);
+    for (int j = 0; j < NLA; ++j) plan(wave + 4 * j, PA, 0, baseA[j], advA[j], subA[j], dstA[j], bitsA[j]);
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) plan(wave + 4 * j, PB, 32 * LFA, baseB[j], advB[j], subB[j], dstB[j], bitsB[j]);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int8_t *)lds;
+    auto issue = [&](int gs) {
+        const unsigned stage_base = lds0 + (gs % NSW) * STAGEW;
+        if (gs < nst) {
+#pragma unroll
+            for (int j = 0; j < NLA; ++j) {
+                int kt = DSW * gs + subA[j];
+                kt = kt < nk ? kt : nk - 1; // (a step beyond the last one: the last one again, so that every stage counts the same loads)
+                dma16(baseA[j] + (int64_t)(kt * advA[j]), bitsA[j] ? voffX : voffT, stage_base + dstA[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NLB; ++j) {
+                int kt = DSW * (gs - nst) + subB[j];
+                kt = kt < nk ? kt : nk - 1;
+                dma16(baseB[j] + (int64_t)(kt * advB[j]), bitsB[j] ? voffX : voffT, stage_base + dstB[j]);
+            }
         }
     };
 
-    // the epilogue's per-lane inputs are fetched now, so that their latency hides under the GEMM
+    // what the fold between the sweeps needs is fetched now, so that the latency hides under the GEMM; the inputs of the pointwise
+    // arithmetic (sign bits, 1 / tau) are fetched behind sweep B -- registers are what this kernel is short of, and the
+    // co-resident workgroup covers the wait
     const int r = mytile * 32 + lr;
     const int rc = rowcol[r];
     const bool active = rc >= 0;
-    unsigned sgn[WM]; // the node's sign bits for this wave's 64 samples, shifted so that bit 8g + j is this lane's sample 8g + 4h + j
-#pragma unroll
-    for (int i = 0; i < WM; ++i) sgn[i] = active ? (Sb[(int64_t)rc * (Kp >> 5) + ((k0 + wave * 64) >> 5) + i] >> (4 * h)) : 0u;
-    const int64_t left = Kreal - (k0 + wave * 64 + 4 * h);
-    const int nreal = left > 64 ? 64 : (left < 0 ? 0 : (int)left);
     const double sg = active ? sigma[r] : 0.0;
     const long long qc = active ? qconst[r] : 0; // C0 = sum_c q_c + q_const: the energy of the all-(+1) configuration / sigma
-    const double it = active ? invtau[r] : 0.0;
     // C0 = c_lo + 2^32 c_hi with 0 <= c_lo < 2^32: both halves, and everything combined with them below, are exact in FP64
     const double c_lo = (double)(unsigned)(qc & 0xffffffffll), c_hi = (double)(qc >> 32);
     const double us0 = c_lo * sg, m2s = -2.0 * sg, sgT = sg * 4294967296.0;
+#ifdef ABL_EARLY_INPUTS
+    unsigned sgn[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) sgn[i] = active ? (Sb[(int64_t)rc * (Kp >> 5) + ((k0 + wave * 64) >> 5) + i] >> (4 * h)) : 0u;
+    const double it = active ? invtau[r] : 0.0;
+#endif
 
+#ifdef ABL_TIMING
+    unsigned long long tst[6];
+    tst[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     __builtin_amdgcn_s_setprio(1);
     const int ntot = 2 * nst;
 #pragma unroll
@@ -196,6 +230,9 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
         v16i acc[WM][LFA];
         gemm_stage(0, 0, std::true_type{}, acc); // nk >= 1: Qfp >= 64
         for (int ks = 1; ks < nst; ++ks) gemm_stage(ks, ks, std::false_type{}, acc);
+#ifdef ABL_TIMING
+        tst[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -210,13 +247,35 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
                     alo = fma((double)p1, 65536.0, (double)p0);
                 }
                 us[i][e] = fma(alo, m2s, us0);
+                // (pinned here: left alone, the compiler sinks the whole fold behind sweep B and keeps the 128 accumulators of
+                // sweep A alive under the 96 of sweep B)
+                asm volatile("" : "+v"(us[i][e]));
             }
     }
     // ---- sweep B: digit planes 4..6
+#ifdef ABL_TIMING
+    tst[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     v16i acc[WM][LFB];
     gemm_stage(nst, 0, std::true_type{}, acc);
+#ifndef ABL_ONESWEEP
     for (int ks = 1; ks < nst; ++ks) gemm_stage(nst + ks, ks, std::false_type{}, acc);
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_s_setprio(0);
+#ifdef ABL_TIMING
+    tst[3] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+#ifndef ABL_EARLY_INPUTS
+    unsigned sgn[WM]; // the node's sign bits for this wave's 64 samples, shifted so that bit 8g + j is this lane's sample 8g + 4h + j
+#pragma unroll
+    for (int i = 0; i < WM; ++i) sgn[i] = active ? (Sb[(int64_t)rc * (Kp >> 5) + ((k0 + wave * 64) >> 5) + i] >> (4 * h)) : 0u;
+    const double it = active ? invtau[r] : 0.0;
+#endif
+    const int64_t left = Kreal - (k0 + wave * 64 + 4 * h);
+    const int nreal = left > 64 ? 64 : (left < 0 ? 0 : (int)left);
 
     // ---- epilogue ----------------------------------------------------------------------------
     // lane <-> node row (lr), register e <-> sample (e&3) + 8*(e>>2) + 4*h within the 32-sample tile; the Vq image stores a
@@ -230,9 +289,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
     const int wleft = (int)((Kreal - kw) < 64 ? (Kreal - kw) : 64); // wave-uniform: real samples among this wave's 64
     int csl[LBW] = {0, 0, 0, 0, 0, 0};
     unsigned long long as64 = 0;
-    double ymax = 0.0, fp = 0.0;
+    int ymax_hi = 0; // high word of the largest 2^32 (|V| / tau + dither): non-negative doubles order like their bit patterns
+    double fp = 0.0;
 
-    // a_hi = sum_{l>=4} 256^(l-4) C_l of element (i, e), as the exact FP64 value t = c_hi - 2 a_hi
+    // a_hi = sum_{l>=4} 256^(l-4) C_l of element (i, e), as the exact FP64 value t = c_hi - 2 a_hi; then
+    // E / s = sigma (t 2^32 + (c_lo - 2 a_lo)) with ONE rounding.  Done for all 32 elements of the lane at once: the 96
+    // accumulators and the 64 registers of `us` become 64 registers of energies before the pointwise arithmetic starts.
     auto thi = [&](int i, int e) -> double {
         double ahi;
         if (WIDE) {
@@ -257,6 +319,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
         }
     };
 
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) us[i][e] = fma(thi(i, e), sgT, us[i][e]);
+    __builtin_amdgcn_sched_barrier(0);
+
     if constexpr (FORM == 0) {
         // Exp forms: the arithmetic is laid out in layers of 8 independent instructions (two 4-sample groups), fenced by
         // sched_barriers, as in k_fwd_i8 -- a wave in its epilogue then issues back to back instead of waiting out the latency
@@ -270,18 +338,20 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
             for (int hg = 0; hg < 2; ++hg) {
                 double Ea[8], tm[8], x[8], tj0[8], yy[8], pp[8], wk[8];
                 int mneg[8], nn[8];
-                // A: E = sigma (t 2^32 + (c_lo - 2 a_lo)), one rounding
-#pragma unroll
-                for (int q = 0; q < 8; ++q) Ea[q] = thi(i, 8 * hg + q);
-                SB;
+                // A: the energies, the sign bits, the weights
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int pos = 8 * (2 * hg + (q >> 2)) + (q & 3);
-                    Ea[q] = fma(Ea[q], sgT, us[i][8 * hg + q]);
+                    Ea[q] = us[i][8 * hg + q];
                     asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mneg[q]) : "v"(nsg), "n"(pos)); // -1 iff s = +1
                     if (!UNIW) wk[q] = w[kw + i * 32 + 8 * (2 * hg + (q >> 2)) + 4 * h + (q & 3)];
                 }
                 SB;
+#ifdef ABL_NOEPI
+#pragma unroll
+                for (int q = 0; q < 8; ++q) yy[q] = fma(fabs(Ea[q]), 1.0e21, 3.0e21);
+                if (false) {
+#endif
                 // B: x = -s E, n = rint(64 x / ln2), r = x - n ln2 / 64 (two-part constant)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -331,6 +401,9 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
                 SB;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) yy[q] = fma(UNIW ? wk32 : 4294967296.0 * (wk[q] * it), x[q], yy[q]);
+#ifdef ABL_NOEPI
+                }
+#endif
                 if (UNIW && wleft < 64) { // the last sample tile: padding samples carry no weight
                     asm volatile("; padding samples" ::: "memory");
 #pragma unroll
@@ -341,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
                 // E: sign, rounding to the 48-bit integer, 6 balanced digits, 4 samples x 6 planes byte transpose
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    ymax = fmax(ymax, yy[q]);
+                    ymax_hi = max(ymax_hi, __double2hiint(yy[q]));
                     if (WANTF) {
                         const double ya = yy[q] + MAGIC32; // |V| / tau >= 0 rounded: its integer sits in the low 48 bits
                         as64 += (((unsigned long long)((unsigned)__double2hiint(ya) & 0xffffu)) << 32) | (unsigned)__double2loint(ya);
@@ -359,7 +432,11 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef ABL_NOSTORE
+            if (active && pl[0][0] == 0x12345678 && pl[5][3] == 0x1234567) {
+#else
             if (active) {
+#endif
 #pragma unroll
                 for (int lb = 0; lb < LBW; ++lb) *reinterpret_cast<v4i *>(vimg + lb * 32 * 64 + i * 16) = pl[lb];
             }
@@ -376,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int e = 4 * g + j;
-                    const double Ea = fma(thi(i, e), sgT, us[i][e]);
+                    const double Ea = us[i][e];
                     const double dith = (double)(int)(dh0 + (unsigned)(i * 32 + 8 * g + j) * GOLD) * 2.3283064365386963e-10; // [-1/2, 1/2)
                     const bool neg = ((sgn[i] >> (8 * g + j)) & 1u) != 0; // s_u^k = -1
                     const double wk0 = UNIW ? (i * 32 + 8 * g + j < nreal ? wuni : 0.0) : w[kk + j];
@@ -410,6 +487,15 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
             }
         }
     }
+#ifdef ABL_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tst[4] = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && wave == 0 && active) { // 100 MHz ticks: start, end of sweep A, of the fold, of sweep B, of the epilogue (stores landed)
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(Vq + vq_off(mytile * 32, 0, k0, Kp, LBW));
+        for (int q = 0; q < 5; ++q) o[q] = tst[q];
+        o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) /* HW_ID */;
+    }
+#endif
     // per-slot sums: sum_k V (two halves), sum_k |V| (objective-only passes), max_k |V| >> 16
     long long cs_lo = (long long)csl[0] + 256ll * csl[1] + 65536ll * csl[2];
     long long cs_hi = (long long)csl[3] + 256ll * csl[4] + 65536ll * csl[5];
@@ -427,8 +513,9 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
                 atomicAdd(reinterpret_cast<unsigned long long *>(&asum2[r]), as64 >> 32);
             }
         }
-        ymax = fmax(ymax, __shfl_xor(ymax, 32));
-        // ymax = 2^32 max(|V| / tau + dither): in units of 2^16 tau, rounded down
+        ymax_hi = max(ymax_hi, __shfl_xor(ymax_hi, 32));
+        // the high word + 1 bounds 2^32 max(|V| / tau + dither) from above (to 2^-20 relative); in units of 2^16 tau
+        const double ymax = __hiloint2double(ymax_hi + 1, 0);
         const unsigned mxu = (unsigned)fmin(ymax * 3.5527136788005009e-15 /* 2^-48 */, 4294967295.0);
         if (active && h == 0) atomicMax(&mmax[r], mxu);
     } else {

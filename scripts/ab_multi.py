@@ -6,7 +6,7 @@ for rnd in range(int(os.environ.get("AB_ROUNDS", "3"))):
     for tag, path in libs:
         env = dict(os.environ)
         if path: env["GML_LIB_OVERRIDE"] = path
-        out = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "3", "--no-cpu", "--no-learn", "--no-f64"], env=env,
+        out = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "3", "--no-cpu", "--no-learn", "--no-f64", "--no-i8x", "--no-weighted"] + os.environ.get("AB_ARGS", "").split(), env=env,
                              capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
