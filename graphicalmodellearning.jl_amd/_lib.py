@@ -135,6 +135,14 @@ def trim_cache():
     return int(L.gml_trim_cache())
 
 
+def set_cache_limit(bytes_per_device):
+    """Cap of that cache per device (gml_set_cache_limit): 0 = keep nothing, < 0 = the default (a quarter of the device)."""
+    L = lib()
+    L.gml_set_cache_limit.restype = None
+    L.gml_set_cache_limit.argtypes = [C.c_int64]
+    L.gml_set_cache_limit(int(bytes_per_device))
+
+
 def pack_histogram(samples):
     """Host-only (gml_pack_histogram): histogram matrix -> (sign_bits [n][words] uint32, counts [K] float64, M)."""
     L = lib()
@@ -156,10 +164,19 @@ class Problem:
         (gml_problem_create_sampled_hist: sorted and run-length encoded on the device), not one row per draw."""
         L = lib()
         h = C.c_void_p()
+        if histogram and (samples is not None or spins is not None or packed is not None):
+            raise GMLError(GML_EINVAL, "histogram=True applies to handles sampled on the device (model= or terms=)")
         if histogram and model is not None and terms is None:
-            m = np.asarray(model, dtype=np.float64)  # matrix -> terms: fields on the diagonal, couplings above it (models.jl:105-134)
-            terms = {(i + 1,): m[i, i] for i in range(m.shape[0]) if m[i, i] != 0.0}
-            terms.update({(i + 1, j + 1): m[i, j] for i in range(m.shape[0]) for j in range(i + 1, m.shape[0]) if m[i, j] != 0.0})
+            # matrix -> terms exactly as gml_problem_create_sampled lists them (row by row, j <= i: the same seed then gives the
+            # same draws), with its symmetry check (models.jl:105-134: the matrix of a FactorGraph is symmetric)
+            m = np.asarray(model, dtype=np.float64)
+            if m.ndim != 2 or m.shape[0] != m.shape[1] or not np.array_equal(m, m.T):
+                raise GMLError(GML_EINVAL, "the model matrix is not symmetric")
+            terms = {}
+            for i in range(m.shape[0]):
+                for j in range(i + 1):
+                    if m[i, j] != 0.0:
+                        terms[(j + 1, i + 1) if j < i else (i + 1,)] = m[i, j]
             n, model = m.shape[0], None
             if not terms:
                 terms = {(1,): 0.0}

@@ -19,11 +19,17 @@ struct Block {
     size_t bytes;
     int device;
 };
+struct Cached {
+    void *p;
+    unsigned long long seq; // order of release: the oldest block goes first when room is needed
+};
 struct Cache {
     std::mutex mu;
     std::unordered_map<void *, Block> live;                 // blocks handed out
-    std::map<int, std::multimap<size_t, void *>> free_;     // device -> size -> cached blocks
+    std::map<int, std::multimap<size_t, Cached>> free_;     // device -> size -> cached blocks
     std::map<int, size_t> cached, limit;                    // bytes cached / allowed per device
+    unsigned long long seq = 0;
+    long long user_limit = -1;                              // gml_set_cache_limit: bytes per device, 0 = no caching, -1 = a quarter of the device
 };
 Cache &cache() {
     static Cache *c = new Cache(); // leaked on purpose: the HIP runtime may be gone before static destructors run
@@ -34,7 +40,7 @@ constexpr size_t kMinCached = (size_t)1 << 20; // smaller blocks are not worth k
 size_t release_device(Cache &c, int dev) { // caller holds the lock and has the device current
     size_t n = 0;
     for (auto &kv : c.free_[dev]) {
-        (void)hipFree(kv.second);
+        (void)hipFree(kv.second.p);
         n += kv.first;
     }
     c.free_[dev].clear();
@@ -54,7 +60,7 @@ hipError_t dev_malloc_bytes(void **out, size_t bytes) {
     auto &fl = c.free_[dev];
     auto it = fl.find(bytes);
     if (it != fl.end()) {
-        *out = it->second;
+        *out = it->second.p;
         fl.erase(it);
         c.cached[dev] -= bytes;
         c.live[*out] = {bytes, dev};
@@ -70,7 +76,11 @@ hipError_t dev_malloc_bytes(void **out, size_t bytes) {
     return e;
 }
 
-hipError_t dev_free(void *p) {
+// A cached block is handed to the next caller of the same size on ANY stream or thread without further waiting, so nothing
+// may still be using it when it enters the cache.  hipFree gave that guarantee implicitly (it synchronises the device);
+// dev_free keeps it by synchronising the block's device before the block is cached.  Callers that release many blocks at
+// once (the solver's arena, a handle's workspace) synchronise once themselves and use dev_free_synced.
+static hipError_t free_impl(void *p, bool synced) {
     if (!p) return hipSuccess;
     Cache &c = cache();
     std::lock_guard<std::mutex> lock(c.mu);
@@ -79,6 +89,14 @@ hipError_t dev_free(void *p) {
     const Block b = it->second;
     c.live.erase(it);
     if (b.bytes < kMinCached) return hipFree(p);
+    if (!synced) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != b.device) (void)hipSetDevice(b.device);
+        const hipError_t es = hipDeviceSynchronize();
+        if (cur != b.device) (void)hipSetDevice(cur);
+        if (es != hipSuccess) return hipFree(p); // a failed device: do not recycle anything it may still own
+    }
     if (!c.limit.count(b.device)) {
         size_t freeb = 0, total = 0;
         int cur = 0;
@@ -87,11 +105,26 @@ hipError_t dev_free(void *p) {
         c.limit[b.device] = hipMemGetInfo(&freeb, &total) == hipSuccess ? total / 4 : 0;
         (void)hipSetDevice(cur);
     }
-    if (c.cached[b.device] + b.bytes > c.limit[b.device]) return hipFree(p);
-    c.free_[b.device].emplace(b.bytes, p);
+    const size_t lim = c.user_limit >= 0 ? (size_t)c.user_limit : c.limit[b.device];
+    if (b.bytes > lim) return hipFree(p);
+    // room for the newcomer: the blocks released longest ago go back to the driver first (one-off sizes -- a sort's scratch, a
+    // raw upload -- do not squat in the cache)
+    auto &fl = c.free_[b.device];
+    while (c.cached[b.device] + b.bytes > lim && !fl.empty()) {
+        auto oldest = fl.begin();
+        for (auto jt = fl.begin(); jt != fl.end(); ++jt)
+            if (jt->second.seq < oldest->second.seq) oldest = jt;
+        (void)hipFree(oldest->second.p);
+        c.cached[b.device] -= oldest->first;
+        fl.erase(oldest);
+    }
+    fl.emplace(b.bytes, Cached{p, c.seq++});
     c.cached[b.device] += b.bytes;
     return hipSuccess;
 }
+
+hipError_t dev_free(void *p) { return free_impl(p, false); }
+hipError_t dev_free_synced(void *p) { return free_impl(p, true); }
 
 size_t dev_cached_bytes(int device) {
     Cache &c = cache();
@@ -124,6 +157,16 @@ size_t dev_trim_cache() {
     return n;
 }
 
+void dev_set_cache_limit(long long bytes) {
+    Cache &c = cache();
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        c.user_limit = bytes < 0 ? -1 : bytes;
+    }
+    if (bytes == 0) (void)dev_trim_cache();
+}
+
 } // namespace gml
 
 extern "C" int64_t gml_trim_cache(void) { return (int64_t)gml::dev_trim_cache(); }
+extern "C" void gml_set_cache_limit(int64_t bytes_per_device) { gml::dev_set_cache_limit((long long)bytes_per_device); }

@@ -10,7 +10,8 @@ namespace gml {
 // Device memory of the library (gml_alloc.cpp): freed blocks of >= 1 MB are kept per device and size for the next handle of
 // the same shape (a hipMalloc of a multi-GB block after a hipFree sporadically takes a second).
 hipError_t dev_malloc_bytes(void **out, size_t bytes);
-hipError_t dev_free(void *p);
+hipError_t dev_free(void *p);        // synchronises the block's device before the block can be handed out again (as hipFree does)
+hipError_t dev_free_synced(void *p); // the caller has synchronised the device (or every stream that touched the block) itself
 hipError_t dev_mem_info(size_t *free_bytes, size_t *total_bytes); // free = the driver's + the cache's
 size_t dev_trim_cache();
 template <typename T> inline hipError_t dev_malloc(T **out, size_t bytes) { return dev_malloc_bytes(reinterpret_cast<void **>(out), bytes); }

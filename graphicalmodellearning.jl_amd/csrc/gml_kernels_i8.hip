@@ -1344,13 +1344,14 @@ void i8_vq_buffer(void *p, const int8_t **vq, int64_t *bytes, const DevProblem &
 void i8_free(void *p) {
     I8Ws *w = static_cast<I8Ws *>(p);
     if (!w) return;
+    (void)hipDeviceSynchronize(); // once for all the blocks below (dev_free_synced)
     void *ptrs[] = {w->Tq, w->Vq, w->Uq, w->Gacc, w->tauovr, w->Hq, w->hS, w->H64, w->Mb};
     for (void *q : ptrs)
-        if (q) (void)dev_free(q);
+        if (q) (void)dev_free_synced(q);
     for (auto &sc : w->sc) {
         void *qs[] = {sc.sigma, sc.tau, sc.invtau, sc.qconst, sc.csum, sc.asum, sc.csum2, sc.asum2, sc.mmax};
         for (void *q : qs)
-            if (q) (void)dev_free(q);
+            if (q) (void)dev_free_synced(q);
     }
     delete w;
 }

@@ -43,8 +43,19 @@ namespace {
 struct Arena {
     std::vector<void *> ptrs;
     ~Arena() {
+        // also reached by the early returns of a failed solve, with kernels possibly still queued on the blocks: wait once,
+        // then the blocks may go back to the library's cache (which hands them out without waiting)
+        if (!ptrs.empty()) (void)hipDeviceSynchronize();
         for (void *q : ptrs)
-            if (q) (void)dev_free(q);
+            if (q) (void)dev_free_synced(q);
+    }
+    // give one block back before the arena dies (regrown buffers)
+    void release(void *q) {
+        for (auto &x : ptrs)
+            if (x == q && q) {
+                (void)dev_free(q);
+                x = nullptr;
+            }
     }
     template <typename T> hipError_t get(T **out, size_t count) {
         *out = nullptr;
@@ -808,7 +819,18 @@ int Solver::direction_blocks(const std::vector<int> &cg_rows) {
         }
     }
     if (htotal > dH_elems) {
+        // regrown: the superseded block goes back now (a long solve of rows that keep admitting violators would otherwise hold
+        // every earlier size until gml_learn returns), and the new size is checked against what the device has left
+        A.release(dH);
+        dH = nullptr;
         dH_elems = htotal + htotal / 4;
+        size_t freeb = 0, totalb = 0;
+        HIPCHK(dev_mem_info(&freeb, &totalb));
+        if (8.0 * (double)dH_elems > 0.95 * (double)freeb) {
+            if (8.0 * (double)htotal > 0.95 * (double)freeb)
+                return fail(GML_ENOMEM, "Hessian blocks of %.1f GB do not fit in %.1f GB free HBM (lower max_working)", 8.0 * htotal / 1e9, freeb / 1e9);
+            dH_elems = htotal;
+        }
         HIPCHK(A.get(&dH, (size_t)dH_elems));
     }
     for (int64_t r = 0; r < R; ++r) {
@@ -831,10 +853,13 @@ int Solver::direction_blocks(const std::vector<int> &cg_rows) {
         // control block of the tiles: hoffV [NV] | t0 [R] | mtV [NV] | vm [ntiles] | wrow [ntiles] | hflag [R]
         const size_t tb = sizeof(long long) * (NV + R) + sizeof(int) * (NV + 2 * ntiles + R);
         if (tb > dTctl_bytes) {
+            A.release(dTctl);
             dTctl_bytes = tb + tb / 4;
             HIPCHK(A.get(&dTctl, dTctl_bytes));
         }
         if (ntiles > tile_cap) {
+            A.release(dFV);
+            A.release(dgV);
             tile_cap = ntiles + ntiles / 4;
             HIPCHK(A.get(&dFV, (size_t)tile_cap * T));
             HIPCHK(A.get(&dgV, (size_t)tile_cap * T));

@@ -125,6 +125,10 @@ def learn(samples, formulation=None, method=None):
     method.stats["kkt"] = kkt
 
     if method.distributed and world > 1:
+        # the ranks may share a GPU with each other and share it with torch's allocator (the gather below): hand the blocks the
+        # library keeps for the next handle back to the driver before anybody else needs the memory
+        if solve is _local_solve_hip:
+            _lib.trim_cache()
         P = out.shape[1]
         out = _gather_rows(out, n, P, method)
         node_range = (0, n)

@@ -220,6 +220,10 @@ void gml_problem_destroy(gml_problem *p);
  * ROCm 7 a hipMalloc of a multi-GB block after a hipFree sporadically takes 0.4-1.3 s, several times the headline solve.
  * gml_trim_cache() returns all of it to the driver; the return value is the number of bytes released. */
 int64_t gml_trim_cache(void);
+/* Cap of that cache in bytes per device: 0 = keep nothing (every release goes back to the driver: for processes that share a GPU
+ * with other allocators -- a framework's caching allocator, other ranks), < 0 = the default, a quarter of the device's memory.
+ * When a release does not fit, the blocks released longest ago are returned to the driver first. */
+void gml_set_cache_limit(int64_t bytes_per_device);
 
 /* sizes: n, K (rows given), M = sum(counts) (:79), P = parameters per node
  * (n for order 2; sum_{p<=order} C(n-1,p-1) in general), local node range */

@@ -370,12 +370,10 @@ static void node_hessian(int form, int64_t K, int64_t n, const double *counts, d
  * set, Cholesky, projected backtracking (Armijo, then monotone-KKT acceptance at the FP64 noise floor).
  * stats[0] = Newton iterations, [1] = batched passes, [2] = node evaluations.  Returns the worst KKT.
  * ---------------------------------------------------------------------------------------- */
-double gml_oracle_learn_pair_fast(int form, int64_t K, int64_t n, const double *counts, const int8_t *spins, int64_t node0,
-                                  int64_t node1, double c, double tol, int max_iter, double *out, double *kkt_out,
-                                  double *stats) {
+static double learn_ids(int form, int64_t K, int64_t n, const double *counts, const int8_t *spins, const int64_t *ids_in,
+                        int64_t R, double c, double tol, int max_iter, double *out, double *kkt_out, double *stats) {
     const double M = sum_counts(counts, K);
     const double lam = gml_oracle_lambda(c, n, M);
-    const int64_t R = node1 - node0;
     const int max_add = 64;
     double *X = calloc((size_t)(R * n), sizeof(double)), *G = calloc((size_t)(R * n), sizeof(double));
     double *Xt = calloc((size_t)(R * n), sizeof(double)), *Gtr = calloc((size_t)(R * n), sizeof(double));
@@ -388,7 +386,7 @@ double gml_oracle_learn_pair_fast(int form, int64_t K, int64_t n, const double *
     double *gpack = malloc(sizeof(double) * (size_t)(R * n));
     double npass = 0, nevals = 0;
     for (int64_t r = 0; r < R; ++r) {
-        ids[r] = node0 + r;
+        ids[r] = ids_in[r];
         best[r] = INFINITY;
         kkt[r] = INFINITY;
     }
@@ -584,4 +582,24 @@ double gml_oracle_learn_pair_fast(int form, int64_t K, int64_t n, const double *
     free(done); free(stall); free(pack); free(fpack); free(gpack);
     free(Wm); free(Wall); free(Dall); free(PGall); free(Fobj); free(dd); free(alpha); free(need);
     return worst;
+}
+
+/* the node loop of learn (:161) over the range [node0, node1) ... */
+double gml_oracle_learn_pair_fast(int form, int64_t K, int64_t n, const double *counts, const int8_t *spins, int64_t node0,
+                                  int64_t node1, double c, double tol, int max_iter, double *out, double *kkt_out,
+                                  double *stats) {
+    const int64_t R = node1 - node0;
+    int64_t *ids = malloc(sizeof(int64_t) * (size_t)(R > 0 ? R : 1));
+    for (int64_t r = 0; r < R; ++r) ids[r] = node0 + r;
+    const double w = learn_ids(form, K, n, counts, spins, ids, R, c, tol, max_iter, out, kkt_out, stats);
+    free(ids);
+    return w;
+}
+
+/* ... and over a list of nodes (row r of `out` = node nodes[r]): the full-size parity tests solve a sample of the nodes of a
+ * problem whose every node the oracle cannot solve in seconds */
+double gml_oracle_learn_nodes_fast(int form, int64_t K, int64_t n, const double *counts, const int8_t *spins, const int64_t *nodes,
+                                   int64_t nnodes, double c, double tol, int max_iter, double *out, double *kkt_out,
+                                   double *stats) {
+    return learn_ids(form, K, n, counts, spins, nodes, nnodes, c, tol, max_iter, out, kkt_out, stats);
 }

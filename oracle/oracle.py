@@ -52,6 +52,8 @@ def lib():
         L.gml_oracle_objgrad_multi3_nodes.argtypes = [i64, i64, p, p, p, i64, p, p, p]
         L.gml_oracle_learn_pair_fast.restype = dbl
         L.gml_oracle_learn_pair_fast.argtypes = [C.c_int, i64, i64, p, p, i64, i64, dbl, dbl, C.c_int, p, p, p]
+        L.gml_oracle_learn_nodes_fast.restype = dbl
+        L.gml_oracle_learn_nodes_fast.argtypes = [C.c_int, i64, i64, p, p, p, i64, dbl, dbl, C.c_int, p, p, p]
         L.gml_oracle_set_threads.restype = None
         L.gml_oracle_set_threads.argtypes = [C.c_int]
         L.gml_oracle_set_threads(host_cpus()["threads"])
@@ -169,6 +171,24 @@ def learn_pair_fast(counts, spins, form="RISE", c=None, node_range=None, tol=1e-
     st = np.zeros(3)
     lib().gml_oracle_learn_pair_fast(FORMS[form], K, n, None if counts is None else _ptr(counts), _ptr(spins), n0, n1, float(c),
                                      float(tol), int(max_iter), _ptr(out), _ptr(kkt), _ptr(st))
+    return out, kkt, {"iterations": int(st[0]), "passes": int(st[1]), "node_evals": int(st[2])}
+
+
+def learn_nodes_fast(counts, spins, nodes, form="RISE", c=None, tol=1e-9, max_iter=100):
+    """learn_pair_fast for a LIST of nodes (row r = node nodes[r]): the full-size parity tests solve a sample of the nodes."""
+    defaults = {"RISE": 0.4, "logRISE": 0.8, "RPLE": 0.2}
+    if c is None:
+        c = defaults[form]
+    spins = np.ascontiguousarray(spins, dtype=np.int8)
+    K, n = spins.shape
+    nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+    if counts is not None:
+        counts = np.ascontiguousarray(counts, dtype=np.float64)
+    out = np.zeros((len(nodes), n))
+    kkt = np.zeros(len(nodes))
+    st = np.zeros(3)
+    lib().gml_oracle_learn_nodes_fast(FORMS[form], K, n, None if counts is None else _ptr(counts), _ptr(spins), _ptr(nodes), len(nodes), float(c),
+                                      float(tol), int(max_iter), _ptr(out), _ptr(kkt), _ptr(st))
     return out, kkt, {"iterations": int(st[0]), "passes": int(st[1]), "node_evals": int(st[2])}
 
 
