@@ -16,8 +16,8 @@ for d in dirs:
 # the kernels the counters belong to: bench.py compares this with the source it runs and says so when they differ
 import hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "graphicalmodellearning.jl_amd", "csrc", "gml_kernels_i8.hip")
+src = os.path.join(root, "graphicalmodellearning.jl_amd", "csrc", os.environ.get("PMC_KERNEL_SOURCE", "gml_kernels_i8w.hip"))
 summary = {k: v for k, v in res.items() if k.startswith("gml::")}
 summary["_kernel_source_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
 json.dump(summary, open(out, "w"), indent=1)
-print(json.dumps({k: v for k, v in res.items() if "fwd_i8" in k or "bwd_i8" in k}, indent=1))
+print(json.dumps({k: v for k, v in res.items() if "fwd_i8" in k or "bwd_i8" in k or "_f64" in k}, indent=1))
