@@ -437,6 +437,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
 #else
             if (active) {
 #endif
+                // (holding tile 0's dwords back until tile 1 is packed, so that a lane's neighbouring 16-byte pieces go out
+                // together, and double-buffered B fragments in the GEMM loops, were measured: no change -- DESIGN.md)
 #pragma unroll
                 for (int lb = 0; lb < LBW; ++lb) *reinterpret_cast<v4i *>(vimg + lb * 32 * 64 + i * 16) = pl[lb];
             }
