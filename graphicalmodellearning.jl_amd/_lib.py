@@ -377,6 +377,12 @@ class MultiProblem:
         check(lib().gml_multi_part_stats(self._h, arr))
         return [a.asdict() for a in arr]
 
+    def diag(self):
+        """how the RCCL communicators came about and which path the last gather took (gml_multi_diag)"""
+        buf = C.create_string_buffer(256)
+        check(lib().gml_multi_diag(self._h, buf, 256))
+        return buf.value.decode()
+
     def gather_kind(self):
         buf = C.create_string_buffer(32)
         check(lib().gml_multi_info(self._h, None, None, None, None, None, buf))

@@ -58,6 +58,7 @@ struct gml_multi {
     double M = 0;
     std::vector<Rccl::comm_t> comm; // one per part when RCCL is usable for this device list
     char gather_kind[32] = "host";
+    std::string rccl_note;          // how the communicators came about (gml_multi_diag): a first 8-GPU run must be diagnosable
     std::vector<gml_stats> last;    // per-part statistics of the last gml_multi_learn
 };
 
@@ -95,9 +96,19 @@ extern "C" int gml_multi_create(const void *samples, int dtype, int64_t K, int64
     std::vector<int> uniq(m->device);
     std::sort(uniq.begin(), uniq.end());
     const bool distinct = std::adjacent_find(uniq.begin(), uniq.end()) == uniq.end();
-    if (distinct && rccl().ok) {
+    if (!rccl().ok) {
+        m->rccl_note = "librccl not loadable (dlopen): gathers use peer copies";
+    } else if (!distinct) {
+        m->rccl_note = "the device list repeats a GPU: gathers use peer copies (RCCL refuses two ranks on one device)";
+    } else {
         m->comm.assign((size_t)ndev, nullptr);
-        if (rccl().CommInitAll(m->comm.data(), ndev, devices) != 0) m->comm.clear(); // fall back to peer copies
+        const int e = rccl().CommInitAll(m->comm.data(), ndev, devices);
+        if (e != 0) {
+            m->comm.clear(); // fall back to peer copies
+            m->rccl_note = std::string("ncclCommInitAll failed (") + (rccl().GetErrorString ? rccl().GetErrorString(e) : "?") + "): gathers use peer copies";
+        } else {
+            m->rccl_note = "RCCL communicators ready: " + std::to_string(ndev) + " ranks, one per GPU";
+        }
     }
     *out = m;
     return GML_OK;
@@ -111,6 +122,36 @@ extern "C" int gml_multi_info(const gml_multi *m, int64_t *n, int64_t *K, double
     if (P) *P = m->P;
     if (ndev) *ndev = (int)m->part.size();
     if (gather_kind) std::strcpy(gather_kind, m->gather_kind);
+    return GML_OK;
+}
+
+// Diagnostics of the collective path (not needed for results): how the RCCL communicators of this handle came about, and which
+// path the last dev_out gather took.
+extern "C" int gml_multi_diag(const gml_multi *m, char *buf, int nbuf) {
+    if (!m || !buf || nbuf < 1) return fail(GML_EINVAL, "NULL argument");
+    const std::string s = m->rccl_note + "; last gather: " + m->gather_kind;
+    std::strncpy(buf, s.c_str(), (size_t)nbuf - 1);
+    buf[nbuf - 1] = 0;
+    return GML_OK;
+}
+
+// Test hook (not part of include/gml.h): build RCCL communicators for this handle's device list even when it repeats a GPU, so
+// that the error path of the collective set-up can be exercised on a 1-GPU box: RCCL refuses, and the refusal must come back as a
+// clean GML_EHIP carrying ncclGetErrorString's text.  (Should an RCCL build accept the list, the communicators are kept and the
+// next dev_out gather takes the all-gather path.)
+extern "C" int gml_test_multi_force_rccl(gml_multi *m) {
+    if (!m) return fail(GML_EINVAL, "handle is NULL");
+    if (!rccl().ok) return fail(GML_EUNSUPPORTED, "librccl not loadable");
+    if (!m->comm.empty()) return GML_OK;
+    const int ndev = (int)m->device.size();
+    m->comm.assign((size_t)ndev, nullptr);
+    const int e = rccl().CommInitAll(m->comm.data(), ndev, m->device.data());
+    if (e != 0) {
+        m->comm.clear();
+        m->rccl_note = std::string("ncclCommInitAll failed (") + (rccl().GetErrorString ? rccl().GetErrorString(e) : "?") + ")";
+        return fail(GML_EHIP, "ncclCommInitAll over %d ranks failed: %s", ndev, rccl().GetErrorString ? rccl().GetErrorString(e) : "?");
+    }
+    m->rccl_note = "RCCL communicators forced on a device list that repeats a GPU";
     return GML_OK;
 }
 

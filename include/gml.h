@@ -311,6 +311,9 @@ int gml_multi_info(const gml_multi *m, int64_t *n, int64_t *K, double *M, int64_
 int gml_multi_learn(gml_multi *m, int formulation, double regularizer_c, const gml_opts *opts, double *out, double *kkt,
                     gml_stats *stats, double **dev_out);
 int gml_multi_part_stats(const gml_multi *m, gml_stats *parts);
+/* diagnostics of the collective path, as text (nbuf >= 160 holds it): whether librccl was loaded, whether ncclCommInitAll succeeded
+ * (with ncclGetErrorString's text when not) and which path the last dev_out gather took */
+int gml_multi_diag(const gml_multi *m, char *buf, int nbuf);
 void gml_multi_destroy(gml_multi *m);
 
 /* Timing hook for the benchmark: runs `steps` full objective+gradient passes over the local

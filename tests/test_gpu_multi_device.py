@@ -65,3 +65,28 @@ def test_multi_rejects_bad_device_lists():
         gml.MultiProblem(hist, [])
     with pytest.raises(gml.GMLError):
         gml.MultiProblem(hist, [0, 99])
+
+
+def test_multi_collective_setup_is_diagnosable_and_fails_cleanly():
+    # What can be checked of the RCCL path on one GPU: (1) a single part builds a real communicator and says so; (2) a device
+    # list that repeats a GPU is told apart and falls back to peer copies; (3) forcing ncclCommInitAll on the repeated list --
+    # which RCCL refuses -- comes back as GML_EHIP carrying ncclGetErrorString's text, not as a crash or a hang, and the handle
+    # keeps working afterwards.  (Several DISTINCT devices run for the first time on the driver's 8-GPU box.)
+    from gml_amd import _lib
+    import ctypes as C
+    spins, J = synthetic.block_ising(32, 4000, block=16, seed=23)
+    hist = _hist(spins)
+    with gml.MultiProblem(hist, [0]) as m:
+        assert "RCCL communicators ready: 1 ranks" in m.diag()
+    with gml.MultiProblem(hist, [0, 0]) as m:
+        assert "repeats a GPU" in m.diag() and "peer copies" in m.diag()
+        L = _lib.lib()
+        L.gml_test_multi_force_rccl.argtypes = [C.c_void_p]
+        rc = L.gml_test_multi_force_rccl(m._h)
+        if rc != 0:
+            assert rc == _lib.GML_EHIP
+            msg = L.gml_last_error().decode()
+            assert "ncclCommInitAll" in msg and len(msg) > len("ncclCommInitAll over 2 ranks failed: ")
+            assert "ncclCommInitAll failed" in m.diag()
+        out, kkt, st = m.learn("RISE", 0.4, tol=1e-9)  # the handle still solves (host gather)
+        assert st["not_converged"] == 0
