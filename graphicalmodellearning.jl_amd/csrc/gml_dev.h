@@ -23,19 +23,19 @@ template <typename T> inline hipError_t dev_malloc(T **out, size_t bytes) { retu
 //   Xtb                backward operand: the same matrix feature-major, piece layout of k_build_xtb
 //   keys [Qf][ko]      spins of every statistic column (-1 = unused slot): column c = prod of its spins = XOR of sign bits
 //   w   [Kp]     f64   c_k / M   (samples[k,1]/num_samples, GraphicalModelLearning.jl:170)
-//   Xs [Kp][Qp], Xt [Qp][Kp] int8   byte images, built on first use by the FP64 path only
+//   Xt [Qp][Kp] int8   feature-major byte image, built on first use by the FP64 path only (rows gathered by its Hessian kernel)
 // Columns 0..n-1 are the single spins, then pairs (i<j) in lexicographic order, ... (multi-body, :94-108); column
 // `cconst` is the empty key (constant 1: the node's field).  Column Qp-1 is always a zero (padding) column.
 struct DevProblem {
     int64_t K, Kp, n;
     int64_t Qf, Qfp;  // statistic columns [0,Qf), zero padded to Qfp (multiple of 64)
     int64_t cconst;   // column of the constant statistic (= Qfp)
-    int64_t Qp;       // row pitch of Xs / number of rows of Xt (= Qfp + 64)
+    int64_t Qp;       // row pitch of the parameter arrays / number of rows of Xt (= Qfp + 64)
     unsigned *Sb;
     unsigned *Xb, *Xtb;
     int32_t *keys;
     int ko;
-    int8_t *Xs, *Xt;
+    int8_t *Xt;
     double *w;
     double wmax;      // max_k w_k
     double wuni;      // the common weight when all K samples weigh the same (counts all equal), else 0

@@ -295,7 +295,7 @@ static int prob_layout(gml_problem *p) {
             } while (next_comb(idx, p->n));
         }
     }
-    d.Xs = d.Xt = nullptr; // FP64 path only, built on first use (ensure_f64)
+    d.Xt = nullptr; // FP64 path only, built on first use (ensure_f64)
     HIPCHK(dev_malloc(&d.Sb, (size_t)p->n * (d.Kp / 8)));
     HIPCHK(dev_malloc(&d.keys, sizeof(int32_t) * p->gkeys.size()));
     HIPCHK(dev_malloc(&d.Xb, (size_t)d.Kp * (d.Qfp / 8)));
@@ -1097,7 +1097,7 @@ extern "C" void gml_problem_destroy(gml_problem *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->st) (void)hipStreamSynchronize(p->st);
-    void *ptrs[] = {p->d.Xs, p->d.Xt, p->d.Sb, p->d.keys, p->d.Xb, p->d.Xtb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dSrow};
+    void *ptrs[] = {p->d.Xt, p->d.Sb, p->d.keys, p->d.Xb, p->d.Xtb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dSrow};
     for (void *q : ptrs)
         if (q) (void)dev_free(q);
     void *hptrs[] = {p->hTh, p->hG, p->hF, p->hCtl, p->stage};
@@ -1182,18 +1182,15 @@ static int ensure_ws(gml_problem *p, int64_t rows) { return gml_ensure_ws(p, row
 int gml_ensure_f64(gml_problem *p, int64_t vrows) {
     DevProblem &d = p->d;
     size_t freeb = 0, totalb = 0;
-    if (!d.Xs) {
+    if (!d.Xt) { // feature-major byte image: the rows the FP64 Hessian kernel gathers (the GEMM kernels read the bit images)
         HIPCHK(dev_mem_info(&freeb, &totalb));
-        if (2.0 * (double)d.Kp * d.Qp > 0.9 * (double)freeb)
-            return fail(GML_EUNSUPPORTED, "the FP64 path needs two %.1f GB byte images of the design matrix: use precision i8x",
+        if ((double)d.Kp * d.Qp > 0.9 * (double)freeb)
+            return fail(GML_EUNSUPPORTED, "the FP64 path needs a %.1f GB byte image of the design matrix: use precision i8x or i8w",
                         (double)d.Kp * d.Qp / 1e9);
         HIPCHK(dev_malloc(&d.Xt, (size_t)d.Kp * d.Qp));
-        HIPCHK(dev_malloc(&d.Xs, (size_t)d.Kp * d.Qp));
         HIPCHK(hipMemsetAsync(d.Xt, 0, (size_t)d.Kp * d.Qp, p->st));
-        HIPCHK(hipMemsetAsync(d.Xs, 0, (size_t)d.Kp * d.Qp, p->st));
         launch_expand_xt(d, d.Xt, p->st);
         HIPCHK(hipMemsetAsync(d.Xt + d.cconst * d.Kp, 1, (size_t)p->K, p->st)); // the constant statistic
-        launch_transpose_i8(d.Xt, d.cconst + 1, p->K, d.Kp, d.Xs, d.Qp, p->st);
     }
     vrows = round_up(vrows, 32);
     if (!p->dV || p->dVrows < vrows) {

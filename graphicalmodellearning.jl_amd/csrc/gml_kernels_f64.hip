@@ -1,5 +1,6 @@
-// FP64 device path of the learn() hot path: packing kernels + the three FP64-MFMA kernels
-// (energies+pointwise, gradient, working-set Hessian).  gfx950 only.
+// FP64 device path of the learn() hot path: packing kernels, the working-set Hessian on FP64 MFMA, the batched Newton /
+// preconditioner solves.  (The two GEMM-shaped kernels -- energies + pointwise, gradient -- live in gml_kernels_f64gemm.hip.)
+// gfx950 only.
 //
 // Math restated from /root/reference/src/GraphicalModelLearning.jl:
 //   energy   E_rk = s_u^k * sum_c Theta[r][c] * X[k][c]          (:162 + :170 inner sum)
@@ -119,170 +120,6 @@ __device__ __forceinline__ void load8b(const int8_t *p, double (&d)[8]) {
         d[s] = (double)(int)(int8_t)((u.x >> (8 * s)) & 0xff);
         d[4 + s] = (double)(int)(int8_t)((u.y >> (8 * s)) & 0xff);
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// forward: energies + pointwise.  Wave tile: 32 rows (nodes) x 64 samples.
-// grid.x = Kp/64, grid.y = ceil(Rp/128); 4 waves = 4 x 32 rows on the same 64 samples.
-// Lane (li = lane&15, q = lane>>4) feeds MFMA step s of a 32-deep block with the element at
-// contraction index 8q+s for both operands (a fixed permutation of the contraction order).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fwd_f64(const double *__restrict__ Theta,
-                                                 const int8_t *__restrict__ Xs,
-                                                 const int8_t *__restrict__ Xt,
-                                                 const int *__restrict__ rowcol,
-                                                 const int *__restrict__ groups,
-                                                 const double *__restrict__ w, int64_t Qp,
-                                                 int64_t Kp, int form, double *__restrict__ V,
-                                                 double *__restrict__ fsum) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int li = lane & 15, q = lane >> 4;
-    const int grp = groups[blockIdx.y * 4 + wave]; // 32-row group handled by this wave (-1: none)
-    if (grp < 0) return;
-    const int r0 = grp * 32;
-    const int64_t k0 = (int64_t)blockIdx.x * 64;
-
-    v4d acc[2][4];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (v4d){0, 0, 0, 0};
-
-    const double *arow[2];
-    const int8_t *brow[4];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) arow[mi] = Theta + (int64_t)(r0 + 16 * mi + li) * Qp + 8 * q;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) brow[ni] = Xs + (k0 + 16 * ni + li) * Qp + 8 * q;
-
-    for (int64_t t0 = 0; t0 < Qp; t0 += 32) {
-        double a[2][8], b[4][8];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) load8d(arow[mi] + t0, a[mi]);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) load8b(brow[ni] + t0, b[ni]);
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MFMA_F64(a[mi][s], b[ni][s], acc[mi][ni]);
-    }
-
-    // epilogue: lane holds C[r = r0+16mi+q+4j][k = k0+16ni+li]
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = r0 + 16 * mi + q + 4 * j;
-            const int rc = rowcol[r];
-            double fpart = 0.0;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int64_t k = k0 + 16 * ni + li;
-                double val = 0.0;
-                if (rc >= 0) {
-                    const double wk = w[k];
-                    const double s = (double)(int)Xt[(int64_t)rc * Kp + k];
-                    const double E = s * acc[mi][ni][j];
-                    if (form == 2) { // RPLE (:317)
-                        const double t = -2.0 * E;
-                        const double sp = t > 0 ? t + log1p(exp(-t)) : log1p(exp(t));
-                        const double sg = 1.0 / (1.0 + exp(2.0 * E));
-                        fpart += wk * sp;
-                        val = -2.0 * wk * sg * s; // d/dE of w log(1+exp(-2E)), times s
-                    } else { // RISE (:196) / logRISE Z (:279)
-                        const double e = wk * exp(-E);
-                        fpart += e;
-                        val = -e * s; // partial_obj (:204) times the node's sign
-                    }
-                }
-                if (rc >= 0) V[(int64_t)r * Kp + k] = val; // inactive rows keep their previous V
-            }
-            // reduce over the 16 lanes sharing this row (li = 0..15)
-            fpart += __shfl_xor(fpart, 1);
-            fpart += __shfl_xor(fpart, 2);
-            fpart += __shfl_xor(fpart, 4);
-            fpart += __shfl_xor(fpart, 8);
-            if (li == 0 && rc >= 0) unsafeAtomicAdd(&fsum[r], fpart);
-        }
-    }
-}
-
-void launch_fwd_f64(const DevProblem &P, const double *Theta, const int *rowcol, const int *groups,
-                    int ngroups4, int form, double *V, double *fsum, hipStream_t st) {
-    dim3 grid((unsigned)(P.Kp / 64), (unsigned)(ngroups4 / 4));
-    hipLaunchKernelGGL(k_fwd_f64, grid, dim3(256), 0, st, Theta, P.Xs, P.Xt, rowcol, groups, P.w, P.Qp, P.Kp,
-                       form, V, fsum);
-}
-
-// ------------------------------------------------------------------------------------------
-// backward: G[r][c] += sum_k V[r][k] * Xt[c][k].  Wave tile 32 rows x 64 columns; the 4 waves
-// of a workgroup share the 32 rows (V is fetched once per workgroup, the other waves hit L1/L2)
-// and take 4 adjacent 64-column tiles.  grid = (ceil(Qp/256), Rp/32, nsplit); split-K partial
-// sums are combined with f64 atomics.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bwd_f64(const double *__restrict__ V,
-                                                 const int8_t *__restrict__ Xt,
-                                                 const int *__restrict__ groups, int64_t Qp,
-                                                 int64_t Kp, int64_t kchunk, double *__restrict__ G) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int li = lane & 15, q = lane >> 4;
-    const int r0 = groups[blockIdx.y] * 32;
-    const int64_t c0 = (int64_t)blockIdx.x * 256 + wave * 64;
-    if (c0 >= Qp) return;
-    const int64_t kb = (int64_t)blockIdx.z * kchunk;
-    const int64_t ke = (kb + kchunk < Kp) ? kb + kchunk : Kp;
-
-    v4d acc[2][4];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (v4d){0, 0, 0, 0};
-    const double *arow[2];
-    const int8_t *brow[4];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) arow[mi] = V + (int64_t)(r0 + 16 * mi + li) * Kp + 8 * q;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) brow[ni] = Xt + (c0 + 16 * ni + li) * Kp + 8 * q;
-
-    for (int64_t t0 = kb; t0 < ke; t0 += 32) {
-        double a[2][8], b[4][8];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) load8d(arow[mi] + t0, a[mi]);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) load8b(brow[ni] + t0, b[ni]);
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MFMA_F64(a[mi][s], b[ni][s], acc[mi][ni]);
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = r0 + 16 * mi + q + 4 * j;
-                const int64_t c = c0 + 16 * ni + li;
-                unsafeAtomicAdd(&G[(int64_t)r * Qp + c], acc[mi][ni][j]);
-            }
-}
-
-void launch_bwd_f64(const DevProblem &P, const double *V, const int *groups, int ngroups, double *G,
-                    hipStream_t st) {
-    const unsigned gx = (unsigned)((P.Qp + 255) / 256), gy = (unsigned)ngroups;
-    int64_t nsplit = (4096 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
-    const int64_t maxsplit = P.Kp / 1024 > 0 ? P.Kp / 1024 : 1;
-    if (nsplit > maxsplit) nsplit = maxsplit;
-    if (nsplit < 1) nsplit = 1;
-    int64_t kchunk = (P.Kp + nsplit - 1) / nsplit;
-    kchunk = (kchunk + 31) / 32 * 32;
-    nsplit = (P.Kp + kchunk - 1) / kchunk;
-    dim3 grid(gx, gy, (unsigned)nsplit);
-    hipLaunchKernelGGL(k_bwd_f64, grid, dim3(256), 0, st, V, P.Xt, groups, P.Qp, P.Kp, kchunk, G);
 }
 
 // ------------------------------------------------------------------------------------------

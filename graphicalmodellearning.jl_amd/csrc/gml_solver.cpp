@@ -388,7 +388,7 @@ int Solver::init() {
     if (gml_is_i8(o.precision) && o.polish >= 0) {
         size_t freeb = 0, totalb = 0;
         if (dev_mem_info(&freeb, &totalb) == hipSuccess) {
-            const double need_b = (d.Xs ? 0.0 : 2.0 * (double)d.Kp * (double)Qp) + (p->dV && p->dVrows >= Rp ? 0.0 : 8.0 * (double)Rp * (double)d.Kp) +
+            const double need_b = (d.Xt ? 0.0 : (double)d.Kp * (double)Qp) + (p->dV && p->dVrows >= Rp ? 0.0 : 8.0 * (double)Rp * (double)d.Kp) +
                                   8.0 * (double)nd + (o.precision == GML_PREC_I8W ? 6.0 : 4.0) * (double)Scap * d.Kp /* the i8 workspace still to come */;
             can_polish = need_b < 0.8 * (double)freeb;
         }
