@@ -42,7 +42,7 @@ KERNELS = {"f64": {"fwd": "k_fwd_f64", "bwd": "k_bwd_f64"}, "i8x": {"fwd": "k_fw
 # int8 digit-plane products issued per algorithmic product (forward: planes of Theta, backward: planes of V)
 LIMBS = {"i8x": {"fwd": 5, "bwd": 4}, "i8w": {"fwd": 7, "bwd": 6}}
 PMC_FILES = {"i8w": ("r4_i8w_pmc_traffic.json",), "i8x": ("r3_i8x_pmc_traffic.json", "r2_i8x_pmc_traffic.json")}
-KERNEL_SOURCES = {"i8w": "gml_kernels_i8w.hip", "i8x": "gml_kernels_i8.hip"}
+KERNEL_SOURCES = {"i8w": "gml_kernels_i8w.hip", "i8x": "gml_i8_fwd.hip"}
 
 
 def parse_args():

@@ -19,7 +19,7 @@ template <typename T> inline hipError_t dev_malloc(T **out, size_t bytes) { retu
 // Device-resident problem data (all padded, padding is zero).  The samples are stored as ONE BIT per entry:
 //   Sb  [n][Kp/32]     sign bits of the spins, spin-major, natural order (bit j of word w <-> sample 32w + j; set <=> -1)
 //   Xb                 forward operand of the int8 path: the design matrix sample-major, in the piece layout of
-//                      k_build_xb (gml_kernels_i8.hip)
+//                      k_build_xb (gml_i8_pack.hip)
 //   Xtb                backward operand: the same matrix feature-major, piece layout of k_build_xtb
 //   keys [Qf][ko]      spins of every statistic column (-1 = unused slot): column c = prod of its spins = XOR of sign bits
 //   w   [Kp]     f64   c_k / M   (samples[k,1]/num_samples, GraphicalModelLearning.jl:170)
@@ -66,7 +66,7 @@ __host__ __device__ inline int64_t vq_off(int64_t r, int l, int64_t k, int64_t K
 }
 
 // ---- int8-limb path --------------------------------------------------------------------------
-// One pass of the fixed-point operator (gml_kernels_i8.hip).  The rows to evaluate are listed in consecutive SLOTS
+// One pass of the fixed-point operator (gml_i8_pass.hip).  The rows to evaluate are listed in consecutive SLOTS
 // (32 slots = one MFMA node tile; slot0, slot1 multiples of 32), so the tiles that run are full whatever subset of the
 // caller's rows is active; all per-slot arrays (and the limb planes of V the Hessians are built from) live in the
 // workspace, indexed by slot.

@@ -4,7 +4,7 @@
 // reference (pairwise :162, multi-body :94-104), the batched working-set Newton solver that
 // replaces the reference's per-node Ipopt solve (:164-181), and the orchestration of the
 // device passes.  All arithmetic over the K configurations happens in HIP kernels
-// (gml_kernels_f64.hip, gml_kernels_i8.hip); there is no CPU fallback for it.
+// (gml_kernels_f64*.hip, gml_i8_*.hip, gml_kernels_i8w.hip); there is no CPU fallback for it.
 #include "gml_internal.h"
 #include "gml_solver.h"
 #include "gml_pack.h"

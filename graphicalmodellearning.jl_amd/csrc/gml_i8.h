@@ -1,9 +1,40 @@
-// Shared pieces of the int8-limb kernels (gml_kernels_i8.hip: the 38/31-bit pass "i8x", Hessians, Hessian-vector forms;
-// gml_kernels_i8w.hip: the FP64-grade 54/47-bit pass "i8w").  Internal, device side.
+// Exact fixed-point device pass of the learn() hot path on the int8 matrix cores (gfx950,
+// v_mfma_i32_32x32x32_i8).
+//
+// Idea: the statistics are +-1 (GraphicalModelLearning.jl:162, :107), so both contractions of
+// the objective/gradient pass,
+//     A[r][k] = sum_c Theta[r][c] X[k][c]        (energies, inner sum of :170 / :196)
+//     G[r][c] = sum_k V[r][k]     X[k][c]        (gradient, :205-207)
+// become EXACT integer GEMMs once the real operand is written in balanced base-256 digits
+// ("limbs"):  Theta[r][c] = sigma_r * sum_l 256^l t_l[r][c],  V[r][k] = tau_r * sum_l 256^l v_l[r][k],
+// t_l, v_l in [-128,127].  Each limb plane is one int8 operand of the i8 MFMA (2x the bf16
+// rate), the i32 accumulators cannot overflow (|sum| <= 128 * 2^24), and the limb planes are
+// recombined in int64 / FP64 exactly.  The only roundings are the two quantisations (sigma_r,
+// sigma_r is a power of two, tau_r = bound/2.13e9, chosen per node: 8*LF-2 resp. 31 significant bits), so the result is
+// deterministic and independent of tiling, split-K order and GPU count.
+//
+// Layout of the limb planes ("planar tiles"): rows are grouped by 32-node tile `t` and limb `l`:
+//   Tq image (t, kt) = [LF*32 rows][64 B]: row l*32 + rl holds limb l of node row t*32+rl, columns
+//                      [64kt, 64kt+64); images are contiguous (t major)            (forward B operand)
+//   Vq image (t, k/64) = [LB*32 rows][64 B]: row l*32 + rl holds limb l of V row t*32+rl, samples
+//                      [64(k/64), +64); images are contiguous (t major), see vq_off()  (backward A operand)
+// so that a wave's 32x32 MFMA tiles of the different limbs share lane <-> node and
+// register <-> sample, and the limbs combine lane-locally.
+//
+// The +-1 operand of the forward GEMM is kept as ONE BIT per entry (Xb, bit set <=> -1) and expanded
+// to 0/1 bytes in registers: sum_c q_c x_c = sum_c q_c - 2 sum_c q_c b_c.  An int8 image of it would
+// make the kernel L2->LDS bandwidth bound (measured: 98 MAC per loaded byte against the ~140 the CU
+// needs); with bits the loop loads 12 KB instead of 26.6 KB per 64-column step.
+//
+// Files: gml_i8_pack.hip (bit images, quantisation of Theta), gml_i8_fwd.hip (forward kernel of the 38/31-bit pass "i8x" and of the
+// Hessian-vector forms), gml_i8_bwd.hip (backward kernel, finalisation), gml_i8_hess.hip (working-set Hessians),
+// gml_kernels_i8w.hip (forward kernel and finalisation of the FP64-grade 54/47-bit pass "i8w"), gml_i8_pass.hip (workspace and
+// the orchestration of a pass).  This header: what they share.  Internal, device side.
 #pragma once
 #include "../../include/gml.h"
 #include "gml_dev.h"
 #include "gml_bits.h"
+#include <string>
 
 namespace gml {
 
@@ -58,6 +89,18 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * 64 + ((
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
+// LDS-DMA ring shared by the GEMM kernels: wait until at most `ahead` later stages of NP loads each are in flight, then the
+// workgroup barrier (counted vmcnt, raw s_barrier)
+template <int NP>
+__device__ __forceinline__ void ring_wait_ahead(int ahead) {
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+
 // exp(x) for |x| < 700 to ~1e-15 relative: 2^(n/64) table (in LDS) times a degree-6 polynomial
 __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ tab) {
     const double t = rint(x * 92.33248261689366);      // 64/ln2
@@ -73,6 +116,40 @@ __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ t
     const int n = (int)t;
     return ldexp(tab[n & 63] * p, n >> 6);
 }
+
+#define I8CHK(expr)                                                                                   \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            if (err) *err = std::string(#expr) + " failed: " + hipGetErrorString(e_);                 \
+            return e_ == hipErrorOutOfMemory ? GML_ENOMEM : GML_EHIP;                                 \
+        }                                                                                             \
+    } while (0)
+
+// ---- launchers across the kernel files ----------------------------------------------------------------------------------
+// gml_i8_pack.hip
+void launch_quant_theta(int LF, int ns, const I8Pass &a, const DevProblem &d, int hv, const double *tauV, int8_t *Tq, const SlotScalars &sc,
+                        double vdiv, double vsrc_scale, hipStream_t st);
+// gml_i8_fwd.hip
+struct FwdLaunch {
+    int chunk_tiles, part_tiles, ntk; // sample tiles: per backward chunk, of them taking part, compact count
+    const I8Ws *w;
+    const DevProblem *d;
+    const SlotScalars *sc;
+    const int *rowcol, *groups, *vmap;
+    int ngroups;
+    double *F;
+    int8_t *Vout;
+    hipStream_t st;
+};
+void launch_fwd_i8(const FwdLaunch &a, int LF, int form, bool wantf, int hv);
+// gml_i8_bwd.hip
+void launch_zero_pass(const SlotScalars &sc, double *F, int slot0, int ns, int32_t *gacc0, int64_t ngacc4, int nplanes, int64_t plane_stride4,
+                      hipStream_t st);
+void launch_bwd_i8(int NL, const int8_t *Vin, const DevProblem &d, const int *groups, int ngt, int nNt, int64_t kchunk, int nsplit, int32_t *Gacc,
+                   int cpp, int64_t plane_stride, int64_t kpart, int lbt, int pl0, hipStream_t st);
+void launch_finalize_i8(const int32_t *Gacc, const SlotScalars &sc, const int *srow, const int *rowcol, int slot0, int ns, const DevProblem &d,
+                        int form, int want_grad, int hv, double *G, double *F, int nplanes, int64_t plane_stride, SlotResult *res, hipStream_t st);
 
 // ---- the FP64-grade pass (gml_kernels_i8w.hip) ---------------------------------------------------------------------------
 struct FwdWArgs {

@@ -45,7 +45,7 @@ struct gml_problem {
     int *hCtl = nullptr; // pinned twin of the control block: srow | rowcol | groups
     int *dSrow = nullptr, *dRowcol = nullptr, *dGroups = nullptr;
     double *hTh = nullptr, *hG = nullptr, *hF = nullptr; // pinned staging (ws_rows x Qp, ws_rows)
-    // int8-limb path workspace (gml_kernels_i8.hip, allocated lazily)
+    // int8-limb path workspace (gml_i8_pass.hip, allocated lazily)
     void *i8ws = nullptr;
     // pinned staging arena of the solver's small control / scalar transfers (gml_solver.cpp), allocated on first use
     char *stage = nullptr;

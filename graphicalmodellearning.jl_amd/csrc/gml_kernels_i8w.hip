@@ -1,5 +1,5 @@
 // FP64-grade fixed-point pass of the learn() hot path on the int8 matrix cores (gfx950, v_mfma_i32_32x32x32_i8): precision
-// "i8w".  Same idea as gml_kernels_i8.hip -- the statistics are +-1 (GraphicalModelLearning.jl:162, :107), so the two
+// "i8w".  Same idea as the i8x pass (gml_i8.h) -- the statistics are +-1 (GraphicalModelLearning.jl:162, :107), so the two
 // contractions of the objective/gradient pass (:196, :205-207) are exact integer GEMMs once the real operand is written in
 // balanced base-256 digits -- carried to the width of the reference's Float64 arithmetic:
 //   Theta[r][c] = sigma_r * q,  q an integer of 54 bits in 7 digit planes (sigma_r a power of two: the entries within a factor

@@ -338,7 +338,7 @@ def test_histogram_collisions_zero_counts_and_row_order(prec):
 
 
 def _quantise_like_device(theta, LF=5):
-    # gml_kernels_i8.hip k_quant_theta: sigma = 2^(ex-(8LF-2)), max|theta_r| < 2^ex
+    # gml_i8_pack.hip k_quant_theta: sigma = 2^(ex-(8LF-2)), max|theta_r| < 2^ex
     mx = np.abs(theta).max(1)
     ex = np.where(mx > 0, np.frexp(mx)[1], 0)
     sg = np.ldexp(1.0, ex - (8 * LF - 2))
