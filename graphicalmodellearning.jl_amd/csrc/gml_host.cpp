@@ -1335,13 +1335,16 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
     }
     if (i8exp) {
         // Dynamic range of the fixed-point V: tau_r was derived from the bound w_max exp(sum_j |theta_rj|).  When
-        // the largest |V_rk| actually seen is more than 8 bits below that bound (dense theta), re-run the row with
+        // the largest |V_rk| actually seen is more than 8 bits (i8w: 4 bits) below that bound (dense theta), re-run the row with
         // tau_r taken from it: (mmax + 1) tau bounds every |V_rk| rigorously, so the re-run cannot overflow.
         std::vector<uint8_t> again((size_t)R, 0);
         std::vector<double> ovr((size_t)Rp, 0.0);
         int64_t nagain = 0;
+        // (the FP64-grade pass is stricter: it is re-run as soon as four of its 47 bits would go unused, so that its error stays
+        // at 2^-43 of the largest weight whatever the bound was)
+        const unsigned mm_min = wide ? (1u << 27) : (1u << 23);
         for (int64_t r = 0; r < R; ++r)
-            if (act[r] && mmaxh[r] < (1u << 23)) {
+            if (act[r] && mmaxh[r] < mm_min) {
                 again[r] = 1;
                 ovr[r] = ((double)mmaxh[r] + 1.0) * gml::i8_mmax_unit(wide) * tauh[r] * (1.0 + 1e-12) / gml::i8_vdiv(wide);
                 ++nagain;

@@ -26,7 +26,7 @@ const libgml = get(ENV, "LIBGML_HIP", "libgml_hip.so")
 const GML_OK, GML_ENOTCONV = Cint(0), Cint(2)
 const GML_RISE, GML_LOGRISE, GML_RPLE = Cint(0), Cint(1), Cint(2)
 const GML_I64, GML_F64 = Cint(2), Cint(3)
-const GML_PREC_F64, GML_PREC_I8X, GML_PREC_AUTO = Cint(0), Cint(1), Cint(2)
+const GML_PREC_F64, GML_PREC_I8X, GML_PREC_AUTO, GML_PREC_I8W = Cint(0), Cint(1), Cint(2), Cint(3)
 
 struct GmlOpts                      # struct gml_opts
     tol::Cdouble; max_iter::Int32; precision::Int32; max_working::Int32; max_add::Int32
@@ -51,7 +51,9 @@ end
 GMLMethod that solves every node-wise problem on MI355X through libgml_hip (same fields and defaults as the Python
 twin, graphicalmodellearning.jl_amd/formulations.py).
 `precision = :auto` (default) is `:i8x` except for launch-bound sizes, which run in FP64; `:i8x` is the int8-limb fixed-point pass; rows it cannot bring below `tol` are finished on the
-FP64 path unless `polish = false`; `:f64` runs FP64 MFMA throughout.  `devices = 0:7` shards the nodes over several
+FP64 path unless `polish = false`; `:i8w` is the same int8 matrix-core pass at the width of Float64 (theta in 54-bit, the weights in
+47-bit limbs, exp in FP64: objective and gradient to the 1e-12 the FP64 path is held to, about 1.5x the time of `:i8x`); `:f64` runs
+FP64 MFMA throughout.  `devices = 0:7` shards the nodes over several
 GPUs of this node from this one process (gml_multi_*: one handle and one host thread per GPU inside the library, the
 row blocks are written straight into the result matrix).
 """
@@ -76,8 +78,9 @@ HIP(; tol=1e-9, precision=:auto, device=0, devices=nothing, max_iter=100, max_wo
 function precision_id(s::Symbol)
     s == :auto && return GML_PREC_AUTO
     s == :i8x && return GML_PREC_I8X
+    s == :i8w && return GML_PREC_I8W
     s == :f64 && return GML_PREC_F64
-    throw(ArgumentError("HIP: unknown precision :$s (use :auto, :i8x or :f64)"))   # as the C ABI and the Python twin do
+    throw(ArgumentError("HIP: unknown precision :$s (use :auto, :i8x, :i8w or :f64)"))   # as the C ABI and the Python twin do
 end
 
 gmlopts(m::HIP) = Ref(GmlOpts(m.tol, m.max_iter, precision_id(m.precision), m.max_working, m.max_add,

@@ -59,8 +59,8 @@ static int layout(void) {
     /* the constants of the .jl file */
     printf("const GML_OK %d\nconst GML_ENOTCONV %d\nconst GML_RISE %d\nconst GML_LOGRISE %d\nconst GML_RPLE %d\n", GML_OK, GML_ENOTCONV, GML_RISE,
            GML_LOGRISE, GML_RPLE);
-    printf("const GML_I64 %d\nconst GML_F64 %d\nconst GML_PREC_F64 %d\nconst GML_PREC_I8X %d\nconst GML_PREC_AUTO %d\n", GML_I64, GML_F64,
-           GML_PREC_F64, GML_PREC_I8X, GML_PREC_AUTO);
+    printf("const GML_I64 %d\nconst GML_F64 %d\nconst GML_PREC_F64 %d\nconst GML_PREC_I8X %d\nconst GML_PREC_AUTO %d\nconst GML_PREC_I8W %d\n", GML_I64,
+           GML_F64, GML_PREC_F64, GML_PREC_I8X, GML_PREC_AUTO, GML_PREC_I8W);
     return 0;
 }
 
