@@ -1310,7 +1310,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     {
         // (auto: launch-bound sizes gain nothing from the int8 path and converge in fewer FP64 iterations)
         const int asked = o.precision;
-        o.precision = gml_resolve_precision(p, asked);
+        o.precision = gml_resolve_precision(p, asked, o.tol > 0 ? o.tol : 1e-9);
         if (o.precision < 0) return fail(GML_EINVAL, "unknown precision %d", asked);
     }
     HIPCHK(hipSetDevice(p->device));

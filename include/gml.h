@@ -52,7 +52,8 @@ extern "C" {
 #define GML_PREC_AUTO 2  /* GML_PREC_I8X, except for problems so small (samples x parameters x spins <= 2^28: a
                             property of the problem, not of the call or of the node shard) that every kernel is
                             launch-bound either way: those run in FP64, which needs fewer iterations near tight
-                            tolerances (README example: 1.2 ms against 5.5).  Never GML_EUNSUPPORTED for a
+                            tolerances (README example: 1.2 ms against 5.5), and except for solves with tol < 2e-10, which
+                            take GML_PREC_I8W (the 31-bit weights would stall at their noise floor).  Never GML_EUNSUPPORTED for a
                             valid histogram: beyond 2^24 configurations the int8 path keeps one set of i32
                             gradient accumulators per 2^23 configurations and adds them in int64             */
 

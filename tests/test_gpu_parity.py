@@ -840,3 +840,19 @@ def test_i8w_learn_uses_top_planes_for_curvature_and_matches_fp64_solve():
     assert sc["hv_evals"] > 0
     assert np.abs(a - b).max() <= 1e-9 and np.abs(c - b).max() <= 1e-8
     assert ((a == 0) == (b == 0)).all()
+
+
+def test_auto_precision_takes_the_wide_limbs_for_tight_tolerances():
+    # precision "auto" at a benchmark-like size: tol >= 2e-10 -> i8x; tighter -> i8w, which reaches 1e-11 without the FP64 polish the
+    # 31-bit weights need on ill-conditioned problems (test_learn_mvt_goldens)
+    spins, J = synthetic.block_ising(64, 200000, block=8, seed=2)
+    with gml.Problem(spins=spins) as p:
+        a, ka, sa = p.learn("RISE", 0.4, tol=1e-11)
+        w, kw, sw = p.learn("RISE", 0.4, tol=1e-11, precision="i8w")
+        x, kx, sx = p.learn("RISE", 0.4, tol=1e-11, precision="i8x")
+    assert np.array_equal(a, w) and sa["passes"] == sw["passes"] and sa["polished"] == 0 and ka.max() <= 1e-11
+    assert np.abs(x - w).max() <= 1e-9
+    with gml.Problem(spins=spins) as p:  # ... and the default tolerance stays on the 38/31-bit pass
+        b, _, sb = p.learn("RISE", 0.4)
+        c, _, sc = p.learn("RISE", 0.4, precision="i8x")
+    assert np.array_equal(b, c) and sb["passes"] == sc["passes"]
