@@ -730,6 +730,8 @@ def test_more_than_2_pow_24_configurations_default_precision():
         fo, go = O.objgrad_nodes("RISE", None, spins, nodes, J[nodes])
         assert np.abs(f8 / fo - 1).max() <= 1e-8
         assert np.abs(g8 - go).max() <= 1e-8
+        fw, gw = p.objgrad("RISE", nodes, J[nodes], precision="i8w")  # the wide limbs: two halves x one set of accumulators per 2^23
+        assert np.abs(fw / fo - 1).max() <= 2e-11 and np.abs(gw - go).max() <= 1e-12  # (f: the oracle's own summation over 1.7e7 terms)
         out, kkt, st = p.learn("RISE", 0.4, tol=1e-8)  # default (auto) precision
         assert st["not_converged"] == 0
         lam = 0.4 * np.sqrt(np.log(n * n / 0.05) / K)
