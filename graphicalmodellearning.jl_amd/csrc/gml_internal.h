@@ -79,5 +79,14 @@ int gml_create_parts(const void *samples, int dtype, int64_t K, int64_t n, int64
                      const std::vector<std::pair<int64_t, int64_t>> &ranges, const std::vector<int> &devices,
                      std::vector<gml_problem *> &parts);
 
+// shared between the host files (gml_host.cpp: core; gml_ingest.cpp; gml_sampled.cpp; gml_operator.cpp)
+int64_t gml_binom(int64_t n, int64_t k);
+bool gml_next_comb(std::vector<int> &idx, int64_t n);
+void gml_node_cols(const gml_problem *p, int64_t u, std::vector<int32_t> &cols);
+int gml_check_create_args(int64_t K, int64_t n, int order, int64_t node0, int64_t node1, int device);
+gml_problem *gml_new_problem(int64_t K, int64_t n, double M, int order, int64_t node0, int64_t node1, int device);
+int gml_create_from_device_bytes(gml_problem *p, int8_t *dbytes, bool spin_major, int64_t ld, const double *counts, gml_problem **out,
+                                 bool dedupe = false);
+
 int gml_ensure_ws(gml_problem *p, int64_t rows);
 int gml_ensure_f64(gml_problem *p, int64_t vrows); // byte images + V [vrows][Kp] of the FP64 path

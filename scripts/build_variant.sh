@@ -9,7 +9,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CS=$ROOT/graphicalmodellearning.jl_amd/csrc
 mkdir -p $ROOT/gpurun_ab /tmp/variant_$TAG
 OBJS=""
-for o in gml_pack.o gml_alloc.o gml_host.o gml_solver_host.o gml_multi.o gml_kernels_f64.o gml_kernels_f64gemm.o gml_i8_pack.o gml_i8_fwd.o gml_i8_bwd.o gml_i8_hess.o gml_i8_pass.o gml_kernels_i8w.o gml_solver.o gml_sampler.o gml_dedupe.o; do
+for o in gml_pack.o gml_alloc.o gml_host.o gml_ingest.o gml_sampled.o gml_operator.o gml_testhooks.o gml_solver_host.o gml_multi.o gml_kernels_f64.o gml_kernels_f64gemm.o gml_i8_pack.o gml_i8_fwd.o gml_i8_bwd.o gml_i8_hess.o gml_i8_pass.o gml_kernels_i8w.o gml_solver.o gml_sampler.o gml_dedupe.o; do
   src=${o%.o}.hip
   if [[ " $FILES " == *" $src "* ]]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -fno-slp-vectorize $FLAGS -c $CS/$src -o /tmp/variant_$TAG/$o
