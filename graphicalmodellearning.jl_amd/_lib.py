@@ -33,7 +33,7 @@ class Opts(C.Structure):
                 ("max_working", C.c_int32), ("max_add", C.c_int32), ("verbose", C.c_int32),
                 ("hess_samples", C.c_int32), ("polish", C.c_int32), ("max_cg", C.c_int32),
                 ("limbs_fwd", C.c_int32), ("hv_limbs_fwd", C.c_int32), ("hv_limbs_bwd", C.c_int32), ("debug_row", C.c_int32),
-                ("hv_subsample", C.c_int32), ("reserved0", C.c_int32), ("cg_viol_frac", C.c_double), ("cg_eta", C.c_double)]
+                ("hv_subsample", C.c_int32), ("coarse", C.c_int32), ("cg_viol_frac", C.c_double), ("cg_eta", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -304,7 +304,7 @@ class Problem:
 
     def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="auto", max_working=512, max_add=64,
               verbose=0, hess_samples=0, polish=True, max_cg=0, limbs_fwd=0, hv_limbs_fwd=0, hv_limbs_bwd=0, debug_row=0,
-              hv_subsample=0, cg_viol_frac=0.0, cg_eta=0.0, out_ptr=None, raise_on_fail=True):
+              hv_subsample=0, cg_viol_frac=0.0, cg_eta=0.0, coarse=True, out_ptr=None, raise_on_fail=True):
         L = lib()
         o = Opts()
         L.gml_default_opts(C.byref(o))
@@ -315,6 +315,8 @@ class Problem:
         o.max_cg = int(max_cg)
         o.limbs_fwd, o.hv_limbs_fwd, o.hv_limbs_bwd, o.debug_row = int(limbs_fwd), int(hv_limbs_fwd), int(hv_limbs_bwd), int(debug_row)
         o.cg_viol_frac, o.cg_eta, o.hv_subsample = float(cg_viol_frac), float(cg_eta), int(hv_subsample)
+        # precision i8w: early iterations in the cheap 30 / 23-bit form of the pass (True), never (False), or until KKT 10^-coarse
+        o.coarse = (0 if coarse else -1) if isinstance(coarse, bool) else int(coarse)
         R = self.node1 - self.node0
         out = None
         if out_ptr is None:

@@ -96,6 +96,9 @@ struct I8Pass {
     int lf;               // forward limb planes (3, 4, 5; 0 = the default, 5; 2 for Hessian-vector directions): 8 lf - 2 significant bits of theta
     bool wide;            // the FP64-grade pass (precision i8w): theta in 7 limb planes (54 bits), V in 6 (47 bits), FP64 exp;
                           // the workspace then holds 6-plane V images, of which Hessians and Hessian-vector passes read the top 4
+    bool coarse;          // wide only: the cheap form of the pass for iterates far from the optimum -- the top four planes of theta
+                          // (30 bits), V in three planes (dithered 23 bits): one forward sweep and one backward launch instead of two.
+                          // SlotResult.tau stays the unit of the 47-bit planes; the values are multiples of 2^24 tau
 };
 void i8_split_plan(const DevProblem &d, int ngroups, int ksub, int64_t *kchunk, int64_t *kpart, int *nsplit);
 int i8_pass(void **ws, const DevProblem &d, int64_t slot_capacity, const I8Pass &a, hipStream_t st, hipEvent_t *ev /* [3] or NULL */,

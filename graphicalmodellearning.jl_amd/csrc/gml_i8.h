@@ -52,6 +52,7 @@ constexpr double kVdiv4 = 2130000000.0, kVdiv6 = 1.400e14;
 struct SlotScalars {
     double *sigma = nullptr, *tau = nullptr, *invtau = nullptr;
     long long *qconst = nullptr, *csum = nullptr, *asum = nullptr;
+    long long *qconst2 = nullptr; // i8w: the constant of the coarse form (the number the top four planes of Theta spell)
     long long *csum2 = nullptr, *asum2 = nullptr; // i8w: the high halves (sum of the planes 3..5; sum of |V| >> 32)
     unsigned *mmax = nullptr; // largest |V| / tau seen per slot in the last pass (i8w: >> 16) (dynamic-range check)
 };
@@ -159,6 +160,7 @@ struct FwdWArgs {
     const int *rowcol, *groups;
     int ngroups, form;
     bool want_f; // objective only: sum |V| per slot (with the gradient, f comes out of the backward GEMM)
+    bool coarse; // the 30 / 23-bit form of the pass: the top four planes of Theta, V to three planes (planes 3..5; plane 2 zero)
     double *F;   // RPLE: the FP64 sum of the objective terms per slot
     int8_t *Vq;
     hipStream_t st;
@@ -166,6 +168,6 @@ struct FwdWArgs {
 void launch_fwd_i8w(const FwdWArgs &a);
 void launch_finalize_i8w(const int32_t *Gacc, const SlotScalars &sc, const int *srow, const int *rowcol, int slot0, int ns, int64_t Qp,
                          int64_t Qfp, int64_t Qf, int64_t cconst, int form, int want_grad, double *G, double *f, int nplanes,
-                         int64_t plane_stride, SlotResult *res, hipStream_t st);
+                         int64_t plane_stride, SlotResult *res, bool coarse, hipStream_t st);
 
 } // namespace gml

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
                                                      const int *__restrict__ vmap, const double *__restrict__ tauV,
                                                      int8_t *__restrict__ Tq, double *__restrict__ sigma,
                                                      double *__restrict__ tau, double *__restrict__ invtau,
-                                                     long long *__restrict__ qconst, const double *__restrict__ tauovr,
+                                                     long long *__restrict__ qconst, long long *__restrict__ qconst2, const double *__restrict__ tauovr,
                                                      double vdiv /* largest |V| / tau the planes of this pass hold */,
                                                      double vsrc_scale /* hv: unit of the V planes read, in multiples of tauV */) {
     const int r = slot0 + blockIdx.x; // slot
@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
     const int64_t nk = Qfp >> 6;
     double sabs = 0.0;
     long long ssum = 0; // sum_c q_c: the energy of the all-(+1) configuration (the forward GEMM runs on b = [x = -1])
+    long long shi = 0;  // (7 planes) the same sum for the number the top four planes alone spell: q_hi = q / 2^24 rounded to nearest
     for (int64_t c = tid; c < Qfp; c += 256) {
         long long q = (long long)rint(th[c] * isg);
         sabs += fabs((double)q);
@@ -202,28 +203,38 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
         int8_t *img = Tq + ((((int64_t)tile * nk + (c >> 6)) * LF) * 32 + rl) * 64 + (c & 63);
 #pragma unroll
         for (int l = 0; l < LF; ++l) {
+            if (LF > 5 && l == 3) shi += q; // what is left after three balanced digits
             const long long dgt = ((q + 128) & 255) - 128;
             q = (q - dgt) >> 8;
             img[l * 32 * 64] = (int8_t)dgt;
         }
     }
-    long long q0 = 0;
+    long long q0 = 0, q0hi = 0;
     if (tid == 0) {
         q0 = (long long)rint(th[cconst] * isg);
         sabs += fabs((double)q0);
+        if (LF > 5) {
+            long long q = q0;
+            for (int l = 0; l < 3; ++l) q = (q - (((q + 128) & 255) - 128)) >> 8;
+            q0hi = q;
+        }
     }
     __shared__ long long redl[256];
+    __shared__ long long redh[256];
     red[tid] = sabs;
     redl[tid] = ssum;
+    redh[tid] = shi;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (tid < s) {
             red[tid] += red[tid + s];
             redl[tid] += redl[tid + s];
+            if (LF > 5) redh[tid] += redh[tid + s];
         }
         __syncthreads();
     }
     q0 += redl[0];
+    q0hi += redh[0];
     if (tid == 0) {
         // |E| <= sigma * sum|q|  (|X| <= 1)
         const double emax = red[0] * sg;
@@ -251,6 +262,7 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
         }
         sigma[r] = sg;
         qconst[r] = q0;
+        if (LF > 5) qconst2[r] = q0hi;
         tau[r] = t;
         invtau[r] = it;
     }
@@ -261,7 +273,7 @@ void launch_quant_theta(int LF, int ns, const I8Pass &a, const DevProblem &d, in
                         double vdiv, double vsrc_scale, hipStream_t st) {
 #define QUANT(LFV)                                                                                                                    \
     hipLaunchKernelGGL((k_quant_theta<LFV>), dim3(ns), dim3(256), 0, st, a.theta, a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.cconst,   \
-                       d.wmax, a.form, hv, a.vmap, tauV, Tq, sc.sigma, sc.tau, sc.invtau, sc.qconst, a.tauovr, vdiv, vsrc_scale)
+                       d.wmax, a.form, hv, a.vmap, tauV, Tq, sc.sigma, sc.tau, sc.invtau, sc.qconst, sc.qconst2, a.tauovr, vdiv, vsrc_scale)
     switch (LF) {
     case 2: QUANT(2); break;
     case 3: QUANT(3); break;

@@ -27,7 +27,7 @@ void i8_free(void *p) {
     for (void *q : ptrs)
         if (q) (void)dev_free_synced(q);
     for (auto &sc : w->sc) {
-        void *qs[] = {sc.sigma, sc.tau, sc.invtau, sc.qconst, sc.csum, sc.asum, sc.csum2, sc.asum2, sc.mmax};
+        void *qs[] = {sc.sigma, sc.tau, sc.invtau, sc.qconst, sc.qconst2, sc.csum, sc.asum, sc.csum2, sc.asum2, sc.mmax};
         for (void *q : qs)
             if (q) (void)dev_free_synced(q);
     }
@@ -63,6 +63,7 @@ static int i8_ensure(void **wsp, const DevProblem &d, int64_t slots, int wide, h
         I8CHK(dev_malloc(&sc.tau, sizeof(double) * slots));
         I8CHK(dev_malloc(&sc.invtau, sizeof(double) * slots));
         I8CHK(dev_malloc(&sc.qconst, sizeof(long long) * slots));
+        I8CHK(dev_malloc(&sc.qconst2, sizeof(long long) * slots));
         I8CHK(dev_malloc(&sc.csum, sizeof(long long) * slots));
         I8CHK(dev_malloc(&sc.asum, sizeof(long long) * slots));
         I8CHK(dev_malloc(&sc.csum2, sizeof(long long) * slots));
@@ -105,6 +106,7 @@ void i8_split_plan(const DevProblem &d, int ngroups, int ksub, int64_t *kchunk_o
 int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass &a, hipStream_t st, hipEvent_t *ev, std::string *err) {
     const int hv = a.hv ? (a.hv == 2 ? 2 : 1) : 0; // 2: Hessian-vector products in 2 backward limbs
     const bool wide = a.wide && !hv;                // (Hessian-vector passes are 31-bit passes whatever the workspace holds)
+    const bool coarse = wide && a.coarse && a.form != GML_RPLE;
     int rc = i8_ensure(wsp, d, slot_capacity, hv ? -1 : (wide ? 1 : 0), st, err);
     if (rc) return rc;
     I8Ws *w = static_cast<I8Ws *>(*wsp);
@@ -143,7 +145,7 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     const int ksub = kpart < kchunk ? (int)(kchunk / kpart) : 1;
     if (ev) I8CHK(hipEventRecord(ev[0], st));
     if (wide) {
-        FwdWArgs fw{&d, w->Tq, &sc, a.rowcol, a.groups, a.ngroups, a.form, !a.want_grad, a.F, w->Vq, st};
+        FwdWArgs fw{&d, w->Tq, &sc, a.rowcol, a.groups, a.ngroups, a.form, !a.want_grad, coarse, a.F, w->Vq, st};
         launch_fwd_i8w(fw);
     } else {
         FwdLaunch fl{(int)(kchunk / 256), (int)(kpart / 256), 0, w, &d, &sc, a.rowcol, a.groups, a.vmap, a.ngroups, a.F, hv ? w->Uq : w->Vq, st};
@@ -162,8 +164,8 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
         // cpp chunks each: cpp * kchunk < (Kp + kchunk) / gplanes + kchunk <= 2^23 + 1.5 * 2^22 < 2^24, so |sum| < 2^31
         const int cpp = (nsplit + w->gplanes - 1) / w->gplanes;
         const int8_t *Vin = hv ? w->Uq : w->Vq;
-        if (wide) { // the two halves of the 6 planes: two launches of the 3-plane form
-            for (int half = 0; half < 2; ++half)
+        if (wide) { // the two halves of the 6 planes: two launches of the 3-plane form (coarse passes: the high half only)
+            for (int half = coarse ? 1 : 0; half < 2; ++half)
                 launch_bwd_i8(3, Vin, d, a.groups, ngt, nNt, kchunk, nsplit, w->Gacc, cpp, gplane_stride, kpart, LBW, 3 * half, st);
         } else {
             launch_bwd_i8(hv == 2 ? 2 : 4, Vin, d, a.groups, ngt, nNt, kchunk, nsplit, w->Gacc, cpp, gplane_stride, kpart, LB, 0, st);
@@ -172,7 +174,7 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     if (ev) I8CHK(hipEventRecord(ev[2], st));
     if (wide)
         launch_finalize_i8w(w->Gacc, sc, a.srow, a.rowcol, a.slot0, ns, d.Qp, d.Qfp, d.Qf, d.cconst, a.form, grad ? 1 : 0, a.G, a.F, w->gplanes,
-                            gplane_stride, a.res, st);
+                            gplane_stride, a.res, coarse, st);
     else
         launch_finalize_i8(w->Gacc, sc, a.srow, a.rowcol, a.slot0, ns, d, a.form, grad ? 1 : 0, hv, a.G, a.F, w->gplanes, gplane_stride, a.res, st);
     I8CHK(hipGetLastError());

@@ -61,11 +61,14 @@ __device__ __forceinline__ void dma16(const int8_t *ubase, int voff, unsigned ld
 // V -> 6 balanced digits -> the planes of the wave's Vq image.  Workgroup = 4 waves along the samples: 256 samples x one
 // 32-node tile; block mapping, ring and fragment handling as in k_fwd_i8.
 // ------------------------------------------------------------------------------------------
-template <int FORM /* 0: exp forms (RISE, logRISE), 2: RPLE */, bool WANTF, bool WIDE /* more than 32768 statistics columns */, bool UNIW>
+template <int FORM /* 0: exp forms (RISE, logRISE), 2: RPLE */, bool WANTF, bool WIDE /* more than 32768 statistics columns */, bool UNIW,
+          bool COARSE /* sweep A only: Theta from its top four planes (30 bits), V in three planes (dithered 23 bits: planes 3..5, plane 2
+                         zero) -- the cheap form of the pass for iterates far from the optimum (exp forms) */>
 __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
     const unsigned *__restrict__ Xb, const unsigned *__restrict__ Sb, const int8_t *__restrict__ Tq, const int *__restrict__ rowcol,
     const int *__restrict__ groups, int ngroups, const double *__restrict__ w, const double *__restrict__ sigma,
-    const long long *__restrict__ qconst, const double *__restrict__ invtau, int64_t Kp, int ntiles_k, int nk /* 64-column steps */,
+    const long long *__restrict__ qconst, const long long *__restrict__ qconst2, const double *__restrict__ invtau, int64_t Kp, int ntiles_k,
+    int nk /* 64-column steps */,
     double wuni, int64_t Kreal, int8_t *__restrict__ Vq, long long *__restrict__ csum, long long *__restrict__ csum2,
     long long *__restrict__ asum, long long *__restrict__ asum2, double *__restrict__ fsum, unsigned *__restrict__ mmax) {
     constexpr int WM = 2; // 32-sample MFMA tiles per wave
@@ -130,9 +133,9 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
         adv = bits ? 1024 : BRT * 64;
     };
 #pragma unroll
-    for (int j = 0; j < NLA; ++j) plan(wave + 4 * j, PA, 0, baseA[j], advA[j], subA[j], dstA[j], bitsA[j]);
+    for (int j = 0; j < NLA; ++j) plan(wave + 4 * j, PA, 32 * LFB, baseA[j], advA[j], subA[j], dstA[j], bitsA[j]); // planes 3..6
 #pragma unroll
-    for (int j = 0; j < NLB; ++j) plan(wave + 4 * j, PB, 32 * LFA, baseB[j], advB[j], subB[j], dstB[j], bitsB[j]);
+    for (int j = 0; j < NLB; ++j) plan(wave + 4 * j, PB, 0, baseB[j], advB[j], subB[j], dstB[j], bitsB[j]);        // planes 0..2
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int8_t *)lds;
     auto issue = [&](int gs) {
         const unsigned stage_base = lds0 + (gs % NSW) * STAGEW;
@@ -160,10 +163,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
     const int rc = rowcol[r];
     const bool active = rc >= 0;
     const double sg = active ? sigma[r] : 0.0;
-    const long long qc = active ? qconst[r] : 0; // C0 = sum_c q_c + q_const: the energy of the all-(+1) configuration / sigma
-    // C0 = c_lo + 2^32 c_hi with 0 <= c_lo < 2^32: both halves, and everything combined with them below, are exact in FP64
-    const double c_lo = (double)(unsigned)(qc & 0xffffffffll), c_hi = (double)(qc >> 32);
-    const double us0 = c_lo * sg, m2s = -2.0 * sg, sgT = sg * 4294967296.0;
+    // C0 = sum_c q_c + q_const: the energy of the all-(+1) configuration / sigma.  C0 = c_lo + 2^24 c_hi with 0 <= c_lo < 2^24: both
+    // halves, and everything combined with them below, are exact in FP64.  The coarse form has its own constant: the sum of the
+    // numbers the top four planes spell (q / 2^24 rounded to nearest, entry by entry).
+    const long long qc = active ? (COARSE ? qconst2[r] : qconst[r]) : 0;
+    const double c_lo = COARSE ? 0.0 : (double)(unsigned)(qc & 0xffffffll), c_hi = COARSE ? (double)qc : (double)(qc >> 24);
+    const double sgT = sg * 16777216.0, us0 = c_hi * sgT, m2sT = -2.0 * sgT;
 #ifdef ABL_EARLY_INPUTS
     unsigned sgn[WM];
 #pragma unroll
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
     tst[0] = __builtin_amdgcn_s_memrealtime();
 #endif
     __builtin_amdgcn_s_setprio(1);
-    const int ntot = 2 * nst;
+    const int ntot = COARSE ? nst : 2 * nst; // (the ring of a coarse pass ends with sweep A)
 #pragma unroll
     for (int s = 0; s < NSW - 1; ++s)
         if (s < ntot) issue(s);
@@ -224,7 +229,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
         }
     };
 
-    // ---- sweep A: digit planes 0..3, folded into us = sigma (c_lo - 2 a_lo), a_lo = sum_{l<4} 256^l C_l (exact: |.| < 2^53 sigma)
+    // ---- sweep A: digit planes 3..6, folded into us = sigma 2^24 (c_hi - 2 a_hi), a_hi = sum_{l>=3} 256^(l-3) C_l (exact: an integer
+    // below 2^53 times a power of two)
     double us[WM][16];
     {
         v16i acc[WM][LFA];
@@ -237,32 +243,50 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                double alo;
+                double ahi;
                 if (WIDE) {
-                    alo = (double)acc[i][3][e];
+                    ahi = (double)acc[i][3][e];
 #pragma unroll
-                    for (int l = 2; l >= 0; --l) alo = fma(alo, 256.0, (double)acc[i][l][e]);
+                    for (int l = 2; l >= 0; --l) ahi = fma(ahi, 256.0, (double)acc[i][l][e]);
                 } else { // |acc_l| <= 128 Qfp <= 2^22: pairs in int32
                     const int p0 = acc[i][0][e] + (acc[i][1][e] << 8), p1 = acc[i][2][e] + (acc[i][3][e] << 8);
-                    alo = fma((double)p1, 65536.0, (double)p0);
+                    ahi = fma((double)p1, 65536.0, (double)p0);
                 }
-                us[i][e] = fma(alo, m2s, us0);
+                us[i][e] = fma(ahi, m2sT, us0);
                 // (pinned here: left alone, the compiler sinks the whole fold behind sweep B and keeps the 128 accumulators of
                 // sweep A alive under the 96 of sweep B)
                 asm volatile("" : "+v"(us[i][e]));
             }
     }
-    // ---- sweep B: digit planes 4..6
 #ifdef ABL_TIMING
     tst[2] = __builtin_amdgcn_s_memrealtime();
 #endif
-    v16i acc[WM][LFB];
-    gemm_stage(nst, 0, std::true_type{}, acc);
+    if constexpr (!COARSE) {
+        // ---- sweep B: digit planes 0..2; E / s = sigma (c_lo - 2 a_lo) + us with ONE rounding (c_lo - 2 a_lo is an exact integer).
+        // Done for all 32 elements of the lane at once: the 96 accumulators and the 64 registers of `us` become 64 registers of
+        // energies before the pointwise arithmetic starts.
+        v16i acc[WM][LFB];
+        gemm_stage(nst, 0, std::true_type{}, acc);
 #ifndef ABL_ONESWEEP
-    for (int ks = 1; ks < nst; ++ks) gemm_stage(nst + ks, ks, std::false_type{}, acc);
+        for (int ks = 1; ks < nst; ++ks) gemm_stage(nst + ks, ks, std::false_type{}, acc);
 #else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                double alo;
+                if (WIDE) {
+                    alo = fma((double)acc[i][2][e], 256.0, (double)acc[i][1][e]);
+                    alo = fma(alo, 256.0, (double)acc[i][0][e]);
+                } else {
+                    alo = fma((double)acc[i][2][e], 65536.0, (double)(acc[i][0][e] + (acc[i][1][e] << 8)));
+                }
+                us[i][e] = fma(fma(alo, -2.0, c_lo), sg, us[i][e]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __builtin_amdgcn_s_setprio(0);
 #ifdef ABL_TIMING
     tst[3] = __builtin_amdgcn_s_memrealtime();
@@ -282,7 +306,9 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
     // step's samples in the order vq_pos() (gml_bits.h): this lane's 16 samples of tile i are 16 contiguous bytes per plane.
     int8_t *vimg = Vq + vq_off(mytile * 32 + lr, 0, k0 + wave * 64, Kp, LBW) + h * 32;
     const int64_t kw = k0 + wave * 64; // first sample of this wave
-    const double wk32 = 4294967296.0 * (wuni * it); // 2^32 w / tau
+    // 2^32 w / tau; a coarse pass rounds V to multiples of 2^24 tau (the same dither, one step up)
+    const double wscale = COARSE ? 256.0 : 4294967296.0; // 2^32 / 2^24
+    const double wk32 = wscale * (wuni * it);
     const unsigned dh0 = (unsigned)rc * 0x85EBCA6Bu + (unsigned)(kw + 4 * h) * 0x9E3779B9u; // dither: see k_fwd_i8
     constexpr double MAGIC = 6755399441055744.0, MAGIC32 = 6755399441055744.0 * 4294967296.0;
     constexpr unsigned GOLD = 0x9E3779B9u;
@@ -292,21 +318,19 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
     int ymax_hi = 0; // high word of the largest 2^32 (|V| / tau + dither): non-negative doubles order like their bit patterns
     double fp = 0.0;
 
-    // a_hi = sum_{l>=4} 256^(l-4) C_l of element (i, e), as the exact FP64 value t = c_hi - 2 a_hi; then
-    // E / s = sigma (t 2^32 + (c_lo - 2 a_lo)) with ONE rounding.  Done for all 32 elements of the lane at once: the 96
-    // accumulators and the 64 registers of `us` become 64 registers of energies before the pointwise arithmetic starts.
-    auto thi = [&](int i, int e) -> double {
-        double ahi;
-        if (WIDE) {
-            ahi = fma((double)acc[i][2][e], 256.0, (double)acc[i][1][e]);
-            ahi = fma(ahi, 256.0, (double)acc[i][0][e]);
-        } else {
-            ahi = fma((double)acc[i][2][e], 65536.0, (double)(acc[i][0][e] + (acc[i][1][e] << 8)));
-        }
-        return fma(ahi, -2.0, c_hi);
-    };
     // digits of 4 consecutive samples -> one dword per plane, and the plane sums
     auto pack4 = [&](const unsigned (&dl)[4], const unsigned (&dhh)[4], v4i (&pl)[LBW], int slot) {
+        if (COARSE) { // the three digits of the 23-bit value go to the planes 3..5; plane 2 reads zero (the consumers of the top four)
+#pragma unroll
+            for (int lb = 0; lb < 3; ++lb) {
+                const unsigned sel = ((4u + lb) << 8) | (unsigned)lb;
+                const unsigned pk = __builtin_amdgcn_perm(__builtin_amdgcn_perm(dl[3], dl[2], sel), __builtin_amdgcn_perm(dl[1], dl[0], sel), 0x05040100u);
+                pl[3 + lb][slot] = (int)pk;
+                csl[3 + lb] = __builtin_amdgcn_sdot4((int)pk, 0x01010101, csl[3 + lb], false);
+            }
+            pl[2][slot] = 0;
+            return;
+        }
 #pragma unroll
         for (int lb = 0; lb < LBW; ++lb) {
             const unsigned bsel = (unsigned)(lb & 3);
@@ -318,12 +342,6 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
             csl[lb] = __builtin_amdgcn_sdot4((int)pk, 0x01010101, csl[lb], false);
         }
     };
-
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) us[i][e] = fma(thi(i, e), sgT, us[i][e]);
-    __builtin_amdgcn_sched_barrier(0);
 
     if constexpr (FORM == 0) {
         // Exp forms: the arithmetic is laid out in layers of 8 independent instructions (two 4-sample groups), fenced by
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
                 for (int q = 0; q < 8; ++q) x[q] = fma(tj0[q], pp[q], tj0[q]); // exp(-E)
                 SB;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) yy[q] = fma(UNIW ? wk32 : 4294967296.0 * (wk[q] * it), x[q], yy[q]);
+                for (int q = 0; q < 8; ++q) yy[q] = fma(UNIW ? wk32 : wscale * (wk[q] * it), x[q], yy[q]);
 #ifdef ABL_NOEPI
                 }
 #endif
@@ -440,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
                 // (holding tile 0's dwords back until tile 1 is packed, so that a lane's neighbouring 16-byte pieces go out
                 // together, and double-buffered B fragments in the GEMM loops, were measured: no change -- DESIGN.md)
 #pragma unroll
-                for (int lb = 0; lb < LBW; ++lb) *reinterpret_cast<v4i *>(vimg + lb * 32 * 64 + i * 16) = pl[lb];
+                for (int lb = COARSE ? 2 : 0; lb < LBW; ++lb) *reinterpret_cast<v4i *>(vimg + lb * 32 * 64 + i * 16) = pl[lb];
             }
         }
     } else { // RPLE (:317): f = w log(1 + exp(-2E)), V = -2 w s / (1 + exp(2E)), E = s Ea
@@ -504,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
     cs_lo += __shfl_xor(cs_lo, 32);
     cs_hi += __shfl_xor(cs_hi, 32);
     if (active && h == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(&csum[r]), (unsigned long long)cs_lo);
+        if (!COARSE) atomicAdd(reinterpret_cast<unsigned long long *>(&csum[r]), (unsigned long long)cs_lo);
         atomicAdd(reinterpret_cast<unsigned long long *>(&csum2[r]), (unsigned long long)cs_hi);
     }
     if (FORM == 0) {
@@ -518,7 +536,9 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
         ymax_hi = max(ymax_hi, __shfl_xor(ymax_hi, 32));
         // the high word + 1 bounds 2^32 max(|V| / tau + dither) from above (to 2^-20 relative); in units of 2^16 tau
         const double ymax = __hiloint2double(ymax_hi + 1, 0);
-        const unsigned mxu = (unsigned)fmin(ymax * 3.5527136788005009e-15 /* 2^-48 */, 4294967295.0);
+        // (coarse: ymax bounds 2^32 |V| / (2^24 tau); reported in the same unit, rounded up to the next multiple of 2^24 tau)
+        const unsigned mxu = COARSE ? (((unsigned)fmin(ymax * 2.3283064365386963e-10 /* 2^-32 */, 8388606.0) + 1u) << 8)
+                                    : (unsigned)fmin(ymax * 3.5527136788005009e-15 /* 2^-48 */, 4294967295.0);
         if (active && h == 0) atomicMax(&mmax[r], mxu);
     } else {
         fp += __shfl_xor(fp, 32);
@@ -535,7 +555,8 @@ __global__ __launch_bounds__(256) void k_finalize_i8w(const int32_t *__restrict_
                                                       const int *__restrict__ srow, const int *__restrict__ rowcol, int slot0, int64_t Qp,
                                                       int64_t Qfp, int64_t Qf, int64_t cconst, int form, int want_grad,
                                                       double *__restrict__ G, double *__restrict__ f, int nplanes, int64_t plane_stride,
-                                                      const unsigned *__restrict__ mmax, SlotResult *__restrict__ res) {
+                                                      const unsigned *__restrict__ mmax, SlotResult *__restrict__ res,
+                                                      int coarse /* only the high half carries the values: multiples of 2^24 tau */) {
     const int r = slot0 + blockIdx.y;
     if (rowcol[r] < 0) return;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -544,20 +565,22 @@ __global__ __launch_bounds__(256) void k_finalize_i8w(const int32_t *__restrict_
     auto gcol = [&](int64_t col) -> double {
         long long s[2] = {0, 0};
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
+        for (int half = 0; half < 2; ++half) {
+            if (coarse && half == 0) continue;
 #pragma unroll
             for (int l = 2; l >= 0; --l) {
                 long long a = 0;
                 for (int pl = 0; pl < nplanes; ++pl) a += (long long)Gacc[pl * plane_stride + ((int64_t)(tile * LBW + 3 * half + l) * 32 + rl) * Qfp + col];
                 s[half] = s[half] * 256 + a;
             }
-        return fma((double)(csum2[r] - 2 * s[1]), 16777216.0, (double)(csum[r] - 2 * s[0]));
+        }
+        return fma((double)(csum2[r] - 2 * s[1]), 16777216.0, coarse ? 0.0 : (double)(csum[r] - 2 * s[0]));
     };
     if (c == 0) {
         double fv = f ? f[r] : 0.0; // RPLE: the forward kernel's FP64 sum
         if (form != 2) {
             if (want_grad) fv = -t * gcol(rowcol[r]); // f = sum_k w exp(-E) = -sum_k V_k s_k = -G[r][u]
-            else fv = t * fma((double)asum2[r], 4294967296.0, (double)asum[r]);
+            else fv = t * (coarse ? 16777216.0 : 1.0) * fma((double)asum2[r], 4294967296.0, (double)asum[r]);
             f[r] = fv;
         }
         if (res) res[r] = SlotResult{fv, t, mmax[r], 0u};
@@ -565,28 +588,37 @@ __global__ __launch_bounds__(256) void k_finalize_i8w(const int32_t *__restrict_
     if (!want_grad || c >= Qp) return;
     double v = 0.0;
     if (c < Qf) v = t * gcol(c);
-    else if (c == cconst) v = t * fma((double)csum2[r], 16777216.0, (double)csum[r]);
+    else if (c == cconst) v = t * fma((double)csum2[r], 16777216.0, coarse ? 0.0 : (double)csum[r]);
     G[(int64_t)srow[r] * Qp + c] = v;
 }
 
 void launch_finalize_i8w(const int32_t *Gacc, const SlotScalars &sc, const int *srow, const int *rowcol, int slot0, int ns, int64_t Qp,
                          int64_t Qfp, int64_t Qf, int64_t cconst, int form, int want_grad, double *G, double *f, int nplanes,
-                         int64_t plane_stride, SlotResult *res, hipStream_t st) {
+                         int64_t plane_stride, SlotResult *res, bool coarse, hipStream_t st) {
     hipLaunchKernelGGL(k_finalize_i8w, dim3((unsigned)((Qp + 255) / 256), (unsigned)ns), dim3(256), 0, st, Gacc, sc.tau, sc.csum, sc.csum2,
-                       sc.asum, sc.asum2, srow, rowcol, slot0, Qp, Qfp, Qf, cconst, form, want_grad, G, f, nplanes, plane_stride, sc.mmax, res);
+                       sc.asum, sc.asum2, srow, rowcol, slot0, Qp, Qfp, Qf, cconst, form, want_grad, G, f, nplanes, plane_stride, sc.mmax, res,
+                       coarse ? 1 : 0);
+}
+
+template <int FORM, bool WANTF, bool WIDE, bool UNIW, bool COARSE>
+static void launch_fwd_w5(const FwdWArgs &a) {
+    constexpr int shmem = RINGW + 512 + 1024; // ring + exp, log tables
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8w<FORM, WANTF, WIDE, UNIW, COARSE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
+    const DevProblem &d = *a.d;
+    const int ntk = (int)(d.Kp / 256);
+    const int grid = ((ntk + 7) / 8) * 8 * a.ngroups; // one workgroup per (sample tile, node tile)
+    hipLaunchKernelGGL((k_fwd_i8w<FORM, WANTF, WIDE, UNIW, COARSE>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.Tq, a.rowcol, a.groups,
+                       a.ngroups, d.w, a.sc->sigma, a.sc->qconst, a.sc->qconst2, a.sc->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, a.Vq,
+                       a.sc->csum, a.sc->csum2, a.sc->asum, a.sc->asum2, a.F, a.sc->mmax);
 }
 
 template <int FORM, bool WANTF, bool WIDE, bool UNIW>
 static void launch_fwd_w4(const FwdWArgs &a) {
-    constexpr int shmem = RINGW + 512 + 1024; // ring + exp, log tables
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8w<FORM, WANTF, WIDE, UNIW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              shmem); // per device: set on every launch
-    const DevProblem &d = *a.d;
-    const int ntk = (int)(d.Kp / 256);
-    const int grid = ((ntk + 7) / 8) * 8 * a.ngroups; // one workgroup per (sample tile, node tile)
-    hipLaunchKernelGGL((k_fwd_i8w<FORM, WANTF, WIDE, UNIW>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.Tq, a.rowcol, a.groups, a.ngroups,
-                       d.w, a.sc->sigma, a.sc->qconst, a.sc->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, a.Vq, a.sc->csum, a.sc->csum2,
-                       a.sc->asum, a.sc->asum2, a.F, a.sc->mmax);
+    if constexpr (FORM == 0) {
+        if (a.coarse) return launch_fwd_w5<FORM, WANTF, WIDE, UNIW, true>(a);
+    }
+    launch_fwd_w5<FORM, WANTF, WIDE, UNIW, false>(a);
 }
 
 template <int FORM, bool WANTF, bool WIDE>

@@ -163,6 +163,10 @@ struct Solver {
     int maxcg = 16, hv_lf = 2, hv_lb = 2;
     int64_t dbg_row = 0, worst_row = 0;
     const double t_begin = gml_now_s();
+    // precision i8w: the passes run in their coarse form (30-bit theta, 23-bit weights) until the first active row comes within
+    // coarse_thr of its optimum, then at full width for the rest of the solve
+    bool coarse_on = false;
+    double coarse_thr = 1e-7;
     int prec = GML_PREC_I8X; // arithmetic of the passes: switches to FP64 for the rows the int8 path leaves above tol ("polish")
     bool can_polish = false;
     int stall_cap = 10;
@@ -296,6 +300,8 @@ int Solver::init() {
     dir_time.st = st;
     stats.lambda = lambda;
     prec = o.precision;
+    coarse_on = o.precision == GML_PREC_I8W && o.coarse >= 0 && formulation != GML_RPLE;
+    if (o.coarse > 0) coarse_thr = std::pow(10.0, -(double)o.coarse); // (tuning: the KKT residual at which the coarse phase ends)
 
     // slots of the int8-limb workspace: every active row of a pass in its own slot, the passes of one iteration in
     // disjoint ranges (their V planes feed the next Hessians).  Objective-only passes (line-search trials whose V planes
@@ -525,6 +531,7 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         a.res = dRes;
         a.lf = o.limbs_fwd;
         a.wide = wide;
+        a.coarse = wide && coarse_on;
         std::string err;
         int rc = i8_pass(&p->i8ws, d, Scap, a, st, nullptr, &err);
         if (rc) return fail(rc, "%s", err.c_str());
@@ -591,7 +598,7 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         // random walk: 8 sigma of sqrt(K) terms (the worst case K * tau is never approached).
         double noise = 1e-13 * std::max(1.0, std::fabs(fv));
         if (track) {
-            noise += 3.3 * std::sqrt((double)p->K) * tauh[a];
+            noise += 3.3 * std::sqrt((double)p->K) * tauh[a] * (wide && coarse_on ? 16777216.0 : 1.0); // (coarse: multiples of 2^24 tau)
             const double vmax = ((double)mmh[a] + 1.0) * i8_mmax_unit(wide) * tauh[a]; // rigorous bound on max_k |V_rk|
             vref[r] = vmax;
             dref[r] = at_trial ? stepn[r] : 0.0; // distance from the current iterate to the point just evaluated
@@ -1268,7 +1275,31 @@ int Solver::iterate(double *out, double *kkt_out) {
     int it = 0;
     for (it = 0; it < o.max_iter; ++it) {
         int64_t nactive = 0;
+        const std::vector<uint8_t> done_before = coarse_on ? done : std::vector<uint8_t>();
         RCCHK(select(it, &nactive));
+        if (coarse_on) {
+            // A gradient of the coarse form (30-bit theta, 23-bit weights) must not certify anything: as soon as a row comes within
+            // coarse_thr of its optimum -- or is declared converged -- by such a gradient, the coarse phase ends for good, those rows
+            // are evaluated again at full width where they stand, their best-iterate records start over, and the selection is redone.
+            const double thr = std::max(coarse_thr, 100.0 * o.tol);
+            std::vector<int> low;
+            for (int64_t r = 0; r < R; ++r)
+                if (!done_before[r] && !(kkt[r] > thr)) low.push_back((int)r);
+            if (!low.empty()) {
+                coarse_on = false;
+                if (o.verbose) fprintf(stderr, "[gml] it %3d: %zu rows within %.1e of their optimum: the passes switch from the coarse form to full width\n", it, low.size(), thr);
+                const double inf = INFINITY;
+                for (int r : low) {
+                    done[r] = 0;
+                    atfloor[r] = 0;
+                    best[r] = INFINITY;
+                    Fbest[r] = INFINITY;
+                    HIPCHK(stg.h2d(dBest + r, &inf, sizeof(double)));
+                }
+                RCCHK(run_pass(low, X, G, true, false, f, Z, fn, nullptr, 0, prec));
+                RCCHK(select(it, &nactive));
+            }
+        }
         if (nactive == 0) {
             bool polishing = false;
             RCCHK(start_polish(&polishing));

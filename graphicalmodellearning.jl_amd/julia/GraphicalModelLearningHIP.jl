@@ -32,7 +32,7 @@ struct GmlOpts                      # struct gml_opts
     tol::Cdouble; max_iter::Int32; precision::Int32; max_working::Int32; max_add::Int32
     verbose::Int32; hess_samples::Int32; polish::Int32; max_cg::Int32
     limbs_fwd::Int32; hv_limbs_fwd::Int32; hv_limbs_bwd::Int32; debug_row::Int32   # 0 = the library's defaults
-    hv_subsample::Int32; reserved0::Int32
+    hv_subsample::Int32; coarse::Int32
     cg_viol_frac::Cdouble; cg_eta::Cdouble
 end
 

@@ -49,7 +49,7 @@ static int layout(void) {
     OFF(gml_opts, tol); OFF(gml_opts, max_iter); OFF(gml_opts, precision); OFF(gml_opts, max_working); OFF(gml_opts, max_add);
     OFF(gml_opts, verbose); OFF(gml_opts, hess_samples); OFF(gml_opts, polish); OFF(gml_opts, max_cg);
     OFF(gml_opts, limbs_fwd); OFF(gml_opts, hv_limbs_fwd); OFF(gml_opts, hv_limbs_bwd); OFF(gml_opts, debug_row);
-    OFF(gml_opts, hv_subsample); OFF(gml_opts, reserved0);
+    OFF(gml_opts, hv_subsample); OFF(gml_opts, coarse);
     OFF(gml_opts, cg_viol_frac); OFF(gml_opts, cg_eta);
     printf("sizeof gml_stats %zu\n", sizeof(gml_stats));
     OFF(gml_stats, iterations); OFF(gml_stats, passes); OFF(gml_stats, forward_passes); OFF(gml_stats, hessian_passes);
@@ -115,7 +115,7 @@ static int run(const char *samples_csv, const char *learned_csv, double c, int s
     o.hess_samples = 0;
     o.polish = 0;
     o.max_cg = 0;
-    o.limbs_fwd = o.hv_limbs_fwd = o.hv_limbs_bwd = o.debug_row = o.hv_subsample = o.reserved0 = 0;
+    o.limbs_fwd = o.hv_limbs_fwd = o.hv_limbs_bwd = o.debug_row = o.hv_subsample = o.coarse = 0;
     o.cg_viol_frac = o.cg_eta = 0.0;
     gml_stats st;
     memset(&st, 0xEE, sizeof st); /* Ref{GmlStats}() is uninitialised memory */
