@@ -20,7 +20,9 @@ import gml_amd as gml  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 syn = __import__("importlib").import_module("gml_amd.synthetic")
-PEAK = {"i8x": 5.0e15, "f64": 78.6e12}  # dense MFMA op/s (bench.py)
+PEAK = {"i8x": 5.0e15, "i8w": 5.0e15, "f64": 78.6e12}  # dense MFMA op/s (bench.py)
+PREC = "i8x"   # --precision i8w: every device leg at the FP64-grade limbs (round 4: the arithmetic of the bench headline)
+VPLANES = {"i8x": 4, "i8w": 6}
 HBM = 8.0e12
 
 
@@ -33,15 +35,16 @@ def cpu_info():
     return {"nproc": os.cpu_count(), "cpu_model": model, "cgroup_cpu_quota": hc["quota"], "oracle_threads": hc["threads"]}
 
 
-def roof(K, P, nloc, pass_ms, prec="i8x", n_spins=None):
+def roof(K, P, nloc, pass_ms, prec=None, n_spins=None):
     """t_roof = max(bytes_alg / BW_peak, flops_alg / F_peak) with the ALGORITHMIC figures -- 4 K P flops per node
     evaluation; spins read once (bit-packed: K n / 8 B) + 8 K B of weights + 16 n_loc P B of Theta in / G out.  What THIS
     implementation moves on top of that (the int8 limb planes of V: written by the forward, read by the backward kernel) is
     reported apart as traffic_impl, never folded into the roofline."""
+    prec = prec or PREC
     n_spins = n_spins or P
     flops = 4.0 * K * P * nloc
     bytes_alg = K * n_spins / 8.0 + 8.0 * K + 16.0 * nloc * P
-    traffic_impl = 2 * K * P / 8.0 + 2 * 4.0 * K * nloc  # both operand bit images + the V planes out and back in
+    traffic_impl = 2 * K * P / 8.0 + 2.0 * VPLANES.get(prec, 4) * K * nloc  # both operand bit images + the V planes out and back in
     t_roof = max(bytes_alg / HBM, flops / PEAK[prec])
     return {"flops_alg_per_pass": flops, "bytes_alg_per_pass": bytes_alg, "traffic_impl_per_pass": traffic_impl, "t_roof_ms": t_roof * 1e3,
             "pass_ms": pass_ms, "roofline_frac": t_roof * 1e3 / pass_ms, "bound": "mfma" if flops / PEAK[prec] >= bytes_alg / HBM else "hbm",
@@ -59,7 +62,7 @@ def pairwise(name, desc, J, K, form, c, seed, node_range=None, sample_nodes=4, c
     n0, n1 = node_range or (0, n)
     rec = {"config": desc, "n": n, "K": K, "formulation": f"{form}({c})", "seed": seed,
            # learn() at the library default: "auto" = the int8-limb path, FP64 for launch-bound sizes (config 1)
-           "precision": "auto -> " + ("f64" if K * n * n <= 2 ** 28 else "i8x"), "tol": tol,
+           "precision": ("auto -> f64" if K * n * n <= 2 ** 28 else ("auto -> i8x" if PREC == "i8x" else PREC)), "tol": tol,
            "node_range": [n0, n1], "n_gpus": 1, **cpu_info()}
     t0 = time.time()
     prob = gml.Problem(hist, node_range=node_range) if hist is not None else \
@@ -68,13 +71,18 @@ def pairwise(name, desc, J, K, form, c, seed, node_range=None, sample_nodes=4, c
     with prob as p:
         K = p.K
         t0 = time.time()
-        out, kkt, st = p.learn(form, c, tol=tol, raise_on_fail=False)
+        small = K * n * n <= 2 ** 28
+        out, kkt, st = p.learn(form, c, tol=tol, raise_on_fail=False, precision="auto" if (small or PREC == "i8x") else PREC)
         rec["learn_s"] = time.time() - t0
+        if not small:  # a second solve on the warm handle (the first one of a process also pays for the workspace allocation)
+            t0 = time.time()
+            p.learn(form, c, tol=tol, raise_on_fail=False, precision="auto" if PREC == "i8x" else PREC)
+            rec["learn_warm_s"] = time.time() - t0
         rec.update({"lambda": st["lambda_"], "iterations": st["iterations"], "passes": st["passes"],
                     "forward_passes": st["forward_passes"], "hessian_passes": st["hessian_passes"], "node_evals": st["node_evals"],
                     "max_kkt": st["max_kkt"], "not_converged": st["not_converged"], "polished": st["polished"],
                     "t_pass": st["t_pass"], "t_hess": st["t_hess"], "t_host": st["t_host"]})
-        km = p.bench_pass_resident(form, out, steps=10, warmup=2, precision="i8x")
+        km = p.bench_pass_resident(form, out, steps=10, warmup=2, precision=PREC)
         km = {k: v for k, v in km.items() if k != "step_ms"}
         rec["pass"] = {**km, **roof(K, n, n1 - n0, km["device_ms_per_pass"])}
         rec["ingest"] = p.ingest_times()
@@ -82,7 +90,7 @@ def pairwise(name, desc, J, K, form, c, seed, node_range=None, sample_nodes=4, c
         some = np.unique(np.linspace(n0, n1 - 1, sample_nodes).astype(np.int64))
         rng = np.random.default_rng(0)
         th = out[some - n0] + rng.normal(scale=0.02, size=(len(some), n)) * (rng.random((len(some), n)) < 0.05)
-        f8, g8 = p.objgrad(form, some, th, precision="i8x")
+        f8, g8 = p.objgrad(form, some, th, precision=PREC)
         spins = p.spins()
     counts = None if hist is None else np.ascontiguousarray(hist[:, 0], dtype=np.float64)
     t0 = time.time()
@@ -118,13 +126,13 @@ def pairwise(name, desc, J, K, form, c, seed, node_range=None, sample_nodes=4, c
 def c5(name, K=1000000, n=512, c=1.2, seed=5, tol=1e-8, max_iter=100):
     terms = syn.block_multibody_terms(n, block=16, seed=0)
     rec = {"config": "multi-body (3-spin) model, multiRISE/ISODUS order 3", "n": n, "K": K, "formulation": f"multiRISE({c}, true, 3)",
-           "seed": seed, "precision": "i8x", "tol": tol, "n_gpus": 1, **cpu_info()}
+           "seed": seed, "precision": PREC, "tol": tol, "n_gpus": 1, **cpu_info()}
     t0 = time.time()
     with gml.Problem(terms=terms, n=n, num_samples=K, seed=seed, order=3) as p:
         rec["create_s"] = time.time() - t0
         rec["P_per_node"] = P = p.P
         t0 = time.time()
-        out, kkt, st = p.learn("RISE", c, tol=tol, precision="i8x", max_iter=max_iter, raise_on_fail=False)
+        out, kkt, st = p.learn("RISE", c, tol=tol, precision=PREC, max_iter=max_iter, raise_on_fail=False)
         rec["learn_s"] = time.time() - t0
         rec.update({"lambda": st["lambda_"], "iterations": st["iterations"], "passes": st["passes"], "forward_passes": st["forward_passes"],
                     "hessian_and_hv_passes": st["hessian_passes"], "hv_node_evals": st["hv_evals"],
@@ -132,16 +140,16 @@ def c5(name, K=1000000, n=512, c=1.2, seed=5, tol=1e-8, max_iter=100):
                     "t_pass": st["t_pass"], "t_hess": st["t_hess"], "t_host": st["t_host"],
                     "nnz_per_node_max": int((out != 0).sum(1).max()), "nnz_per_node_mean": float((out != 0).sum(1).mean())})
         try:
-            km = p.bench_pass_resident("RISE", out, steps=2, warmup=1, precision="i8x")
+            km = p.bench_pass_resident("RISE", out, steps=2, warmup=1, precision=PREC)
         except gml.GMLError:  # dense theta: some rows need the rescaled re-run, which the host-pointer pass performs
-            km = p.bench_pass("RISE", out, steps=2, warmup=1, precision="i8x")
+            km = p.bench_pass("RISE", out, steps=2, warmup=1, precision=PREC)
             km["device_ms_per_pass"] = km["pass_ms"]
             km["note"] = "kernel times of the first (bound-scaled) pass of gml_bench_pass; the rescaled re-run of some rows is extra"
         km = {k: v for k, v in km.items() if k != "step_ms"}
         rec["pass"] = {**km, **roof(K, P, n, km["device_ms_per_pass"], n_spins=n)}
         rec["node_evals_per_s"] = n / (km["device_ms_per_pass"] * 1e-3)
         some = np.array([0, n - 1])
-        f8, g8 = p.objgrad("RISE", some, out[some], precision="i8x")
+        f8, g8 = p.objgrad("RISE", some, out[some], precision=PREC)
         keys0 = p.multi_keys(0)
         spins = p.spins()
     t0 = time.time()
@@ -165,11 +173,15 @@ def c5(name, K=1000000, n=512, c=1.2, seed=5, tol=1e-8, max_iter=100):
 
 
 def main():
+    global PREC
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    rnd = "r3"
+    rnd = "r4"
     if "--round" in sys.argv:
         rnd = sys.argv[sys.argv.index("--round") + 1]
         args = [a for a in args if a != rnd]
+    if "--precision" in sys.argv:
+        PREC = sys.argv[sys.argv.index("--precision") + 1]
+        args = [a for a in args if a != PREC]
     which = args or ["c1", "c2", "c3", "c4", "c5", "c5d"]
     out_dir = os.path.join(ROOT, "gpurun_out", "configs")
     os.makedirs(out_dir, exist_ok=True)
@@ -203,7 +215,7 @@ def main():
             G = np.loadtxt(os.path.join(ROOT, "tests", "golden", "a_RISE_learned.csv"), delimiter=",")
             rec["note"] = "golden a_RISE_learned.csv is reproduced by tests/test_gpu_parity.py::test_learn_abc_goldens (<= 5e-8)"
             rec["golden_shape"] = list(G.shape)
-        path = os.path.join(out_dir, f"{rnd}_{name}.json")
+        path = os.path.join(out_dir, f"{rnd}_{name}" + ("" if PREC == "i8x" else "_" + PREC) + ".json")
         json.dump(rec, open(path, "w"), indent=1)
         print(name, json.dumps({k: rec[k] for k in ("learn_s", "node_evals_per_s", "speedup_learn_vs_cpu", "parity") if k in rec}), flush=True)
 
