@@ -96,9 +96,11 @@ struct I8Pass {
     int lf;               // forward limb planes (3, 4, 5; 0 = the default, 5; 2 for Hessian-vector directions): 8 lf - 2 significant bits of theta
     bool wide;            // the FP64-grade pass (precision i8w): theta in 7 limb planes (54 bits), V in 6 (47 bits), FP64 exp;
                           // the workspace then holds 6-plane V images, of which Hessians and Hessian-vector passes read the top 4
-    bool coarse;          // wide only: the cheap form of the pass for iterates far from the optimum -- the top four planes of theta
-                          // (30 bits), V in three planes (dithered 23 bits): one forward sweep and one backward launch instead of two.
-                          // SlotResult.tau stays the unit of the 47-bit planes; the values are multiples of 2^24 tau
+    bool coarse;          // the cheap form of an objective pass (exp forms) for iterates far from the optimum.  wide: the top four
+                          // planes of theta (30 bits), V in three planes (dithered 23 bits): one forward sweep and one backward launch
+                          // instead of two; SlotResult.tau stays the unit of the 47-bit planes, the values are multiples of 2^24 tau.
+                          // i8x: theta in 4 limb planes (30 bits), V in the planes 1..3 (23 bits, multiples of 2^8 tau), a 3-plane
+                          // backward launch
 };
 void i8_split_plan(const DevProblem &d, int ngroups, int ksub, int64_t *kchunk, int64_t *kpart, int *nsplit);
 int i8_pass(void **ws, const DevProblem &d, int64_t slot_capacity, const I8Pass &a, hipStream_t st, hipEvent_t *ev /* [3] or NULL */,
@@ -107,6 +109,8 @@ int i8_pass(void **ws, const DevProblem &d, int64_t slot_capacity, const I8Pass 
 // (mmax + 1) * i8_mmax_unit * tau bounds max_k |V_k|; a caller-imposed scale is bound / i8_vdiv.
 inline double i8_mmax_unit(bool wide) { return wide ? 65536.0 : 1.0; }
 inline double i8_vdiv(bool wide) { return wide ? 1.400e14 : 2130000000.0; }
+// unit of the values of a coarse pass, in multiples of SlotResult.tau (the noise of f and grad scales with it)
+inline double i8_coarse_unit(bool wide) { return wide ? 16777216.0 : 256.0; }
 void i8_free(void *ws);
 // per-slot results of the last pass of the given kind (device pointers)
 void i8_slot_results(void *ws, int hv, const double **tau, const unsigned **mmax);

@@ -142,6 +142,7 @@ struct FwdLaunch {
     double *F;
     int8_t *Vout;
     hipStream_t st;
+    bool coarse = false; // exp forms, LF = 4: V to multiples of 2^8 tau (planes 1..3)
 };
 void launch_fwd_i8(const FwdLaunch &a, int LF, int form, bool wantf, int hv);
 // gml_i8_bwd.hip

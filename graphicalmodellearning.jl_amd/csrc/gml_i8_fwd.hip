@@ -55,6 +55,8 @@ __device__ __forceinline__ int vq_exp(double Ea, unsigned sb, double wk32, unsig
 template <int LF, int FORM /* 0: exp forms (RISE, logRISE), 2: RPLE; Hessian-vector products: 3 (exp forms), 4 (RPLE) */,
           bool WANTF,
           bool WIDE /* more than 32768 statistics columns: |acc_l| <= 128 Qfp no longer leaves room for the int32 pairing */,
+          bool COARSE /* exp forms: V rounded to multiples of 2^8 tau (dithered 23 bits: planes 1..3, plane 0 zero), for the cheap early
+                         passes of a solve (with LF = 4 and a 3-plane backward launch) */,
           bool UNIW /* every real sample has the weight wuni (all counts equal): no weight loads.  A template parameter, not
                        a run-time test: a branch per element would put each of the epilogue's 32 dependent chains (range
                        reduction -> table read -> polynomial -> rounding) into its own basic block and serialise them */>
@@ -238,7 +240,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     double fp = 0.0;
     int mx = 0;
     const int64_t kw = k0 + wave * 64; // first sample of this wave
-    const double sgq0 = sg * q0, wk32 = 4294967296.0 * (wuni * it); // 2^32 w / tau (vq_exp)
+    constexpr double WSCALE = COARSE ? 16777216.0 : 4294967296.0; // 2^32 w / tau (vq_exp), 2^24 for the coarse form
+    const double sgq0 = sg * q0, wk32 = WSCALE * (wuni * it);
     double sg2 = -2.0 * sg;
     // dither of the V rounding: golden-ratio (Weyl) sequence in the global sample index, offset per node --
     // independent of tiling, node sharding and compaction, so results stay bit-identical across GPU counts
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                 for (int q = 0; q < 8; ++q) x[q] = fma(tj0[q], x[q], tj0[q]); // exp(-E)
                 SB;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) yy[q] = fma(UNIW ? wk32 : 4294967296.0 * (wk[q] * it), x[q], yy[q]);
+                for (int q = 0; q < 8; ++q) yy[q] = fma(UNIW ? wk32 : WSCALE * (wk[q] * it), x[q], yy[q]);
                 SB;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) mag[q] = (unsigned)__double2loint(yy[q] + MAGIC32); // >= 0: y > -2^31
@@ -388,11 +391,11 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
                     for (int j = 0; j < 4; ++j) {
                         const int q = 4 * gg + j;
                         mxu = mag[q] > mxu ? mag[q] : mxu;
-                        if (WANTF) as += (long long)mag[q];
+                        if (WANTF) as += COARSE ? (long long)mag[q] << 8 : (long long)mag[q];
                         // V / tau = -s |V| / tau = (mag ^ m) - m, then the 4 balanced digits (v + CB) ^ CB: one v_xad
                         unsigned tq;
                         asm("v_xad_u32 %0, %1, %2, %3" : "=v"(tq) : "v"(mag[q]), "v"(mneg[q]), "v"(CB - (unsigned)mneg[q]));
-                        dj[j] = tq ^ CB;
+                        dj[j] = COARSE ? (tq ^ CB) << 8 : tq ^ CB; // (coarse: the three digits of the 23-bit value in the planes 1..3)
                     }
 #pragma unroll
                     for (int lb = 0; lb < LB; ++lb) {
@@ -416,6 +419,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
         as += __shfl_xor(as, 32);
         const unsigned mo = (unsigned)__shfl_xor((int)mxu, 32);
         mxu = mo > mxu ? mo : mxu;
+        if (COARSE) mxu = (mxu + 1u) << 8; // in units of tau, rounded up to the next multiple of 2^8 tau
         if (active && h == 0) {
             atomicAdd(reinterpret_cast<unsigned long long *>(&csum[r]), (unsigned long long)cs);
             if (WANTF) atomicAdd(reinterpret_cast<unsigned long long *>(&asum[r]), (unsigned long long)as);
@@ -560,19 +564,27 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     }
 }
 
-template <int LF, int FORM, bool WANTF, bool WIDE, bool UNIW>
-static void launch_fwd4(const FwdLaunch &a) {
+template <int LF, int FORM, bool WANTF, bool WIDE, bool UNIW, bool COARSE>
+static void launch_fwd5(const FwdLaunch &a) {
     constexpr int STAGE = 2 * (2 + 2 * LF) * 1024; // two 64-column steps per ring stage, three stages
     constexpr int shmem = 3 * STAGE + 512 + 1024;   // ring + exp, log tables
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF, WIDE, UNIW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd_i8<LF, FORM, WANTF, WIDE, COARSE, UNIW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem); // per device: set on every launch
     const DevProblem &d = *a.d;
     const int ntk = a.ntk;
     const int grid = ((ntk + 7) / 8) * 8 * a.ngroups; // one workgroup per (sample tile, node tile); see the kernel's block mapping
-    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE, UNIW>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.w->Tq, a.rowcol, a.groups,
+    hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE, COARSE, UNIW>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.w->Tq, a.rowcol, a.groups,
                        a.ngroups, d.w, a.sc->sigma, a.sc->qconst, a.sc->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, a.Vout,
                        a.sc->csum, a.sc->asum, a.F, a.sc->mmax, a.w->Vq, a.vmap, a.w->sc[0].tau, a.w->LBT, a.w->vpl0(), a.w->vscale(),
                        a.chunk_tiles, a.part_tiles);
+}
+
+template <int LF, int FORM, bool WANTF, bool WIDE, bool UNIW>
+static void launch_fwd4(const FwdLaunch &a) {
+    if constexpr (LF == 4 && FORM == 0) {
+        if (a.coarse) return launch_fwd5<LF, FORM, WANTF, WIDE, UNIW, true>(a);
+    }
+    launch_fwd5<LF, FORM, WANTF, WIDE, UNIW, false>(a);
 }
 
 template <int LF, int FORM, bool WANTF, bool WIDE>

@@ -106,11 +106,11 @@ void i8_split_plan(const DevProblem &d, int ngroups, int ksub, int64_t *kchunk_o
 int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass &a, hipStream_t st, hipEvent_t *ev, std::string *err) {
     const int hv = a.hv ? (a.hv == 2 ? 2 : 1) : 0; // 2: Hessian-vector products in 2 backward limbs
     const bool wide = a.wide && !hv;                // (Hessian-vector passes are 31-bit passes whatever the workspace holds)
-    const bool coarse = wide && a.coarse && a.form != GML_RPLE;
+    const bool coarse = !hv && a.coarse && a.form != GML_RPLE; // the cheap form of an objective pass, either width
     int rc = i8_ensure(wsp, d, slot_capacity, hv ? -1 : (wide ? 1 : 0), st, err);
     if (rc) return rc;
     I8Ws *w = static_cast<I8Ws *>(*wsp);
-    int LF = wide ? LFW : (a.lf ? a.lf : 5);
+    int LF = wide ? LFW : (coarse ? 4 : (a.lf ? a.lf : 5));
     if (LF > w->LF) LF = w->LF;
     if (a.ngroups + 1 > 65536 || a.slot1 > w->slots || a.slot0 % 32 || a.slot1 % 32) {
         if (err) *err = "bad slot range";
@@ -149,6 +149,7 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
         launch_fwd_i8w(fw);
     } else {
         FwdLaunch fl{(int)(kchunk / 256), (int)(kpart / 256), 0, w, &d, &sc, a.rowcol, a.groups, a.vmap, a.ngroups, a.F, hv ? w->Uq : w->Vq, st};
+        fl.coarse = coarse;
         fl.ntk = ksub > 1 ? nsplit * fl.part_tiles : (int)(d.Kp / 256);
         if (ksub == 1) fl.chunk_tiles = fl.part_tiles = 1; // (every tile: no remapping)
         if (!hv && w->LBT != LB) {
@@ -167,6 +168,8 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
         if (wide) { // the two halves of the 6 planes: two launches of the 3-plane form (coarse passes: the high half only)
             for (int half = coarse ? 1 : 0; half < 2; ++half)
                 launch_bwd_i8(3, Vin, d, a.groups, ngt, nNt, kchunk, nsplit, w->Gacc, cpp, gplane_stride, kpart, LBW, 3 * half, st);
+        } else if (coarse) { // the planes 1..3 carry the 23-bit value (plane 0 is zero, its accumulators stay zero)
+            launch_bwd_i8(3, Vin, d, a.groups, ngt, nNt, kchunk, nsplit, w->Gacc, cpp, gplane_stride, kpart, LB, 1, st);
         } else {
             launch_bwd_i8(hv == 2 ? 2 : 4, Vin, d, a.groups, ngt, nNt, kchunk, nsplit, w->Gacc, cpp, gplane_stride, kpart, LB, 0, st);
         }

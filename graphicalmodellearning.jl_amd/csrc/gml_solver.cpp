@@ -300,7 +300,9 @@ int Solver::init() {
     dir_time.st = st;
     stats.lambda = lambda;
     prec = o.precision;
-    coarse_on = o.precision == GML_PREC_I8W && o.coarse >= 0 && formulation != GML_RPLE;
+    // (launch-bound problems gain nothing from cheaper passes and pay for the re-evaluation at the switch: config 2 takes 16 + 3
+    // passes instead of 13 + 2)
+    coarse_on = gml_is_i8(o.precision) && o.coarse >= 0 && formulation != GML_RPLE && (double)p->K * (double)Qp * (double)R >= 17179869184.0;
     if (o.coarse > 0) coarse_thr = std::pow(10.0, -(double)o.coarse); // (tuning: the KKT residual at which the coarse phase ends)
 
     // slots of the int8-limb workspace: every active row of a pass in its own slot, the passes of one iteration in
@@ -531,7 +533,7 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         a.res = dRes;
         a.lf = o.limbs_fwd;
         a.wide = wide;
-        a.coarse = wide && coarse_on;
+        a.coarse = coarse_on;
         std::string err;
         int rc = i8_pass(&p->i8ws, d, Scap, a, st, nullptr, &err);
         if (rc) return fail(rc, "%s", err.c_str());
@@ -598,7 +600,7 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         // random walk: 8 sigma of sqrt(K) terms (the worst case K * tau is never approached).
         double noise = 1e-13 * std::max(1.0, std::fabs(fv));
         if (track) {
-            noise += 3.3 * std::sqrt((double)p->K) * tauh[a] * (wide && coarse_on ? 16777216.0 : 1.0); // (coarse: multiples of 2^24 tau)
+            noise += 3.3 * std::sqrt((double)p->K) * tauh[a] * (coarse_on ? i8_coarse_unit(wide) : 1.0); // (coarse: multiples of 2^24 / 2^8 tau)
             const double vmax = ((double)mmh[a] + 1.0) * i8_mmax_unit(wide) * tauh[a]; // rigorous bound on max_k |V_rk|
             vref[r] = vmax;
             dref[r] = at_trial ? stepn[r] : 0.0; // distance from the current iterate to the point just evaluated

@@ -85,10 +85,12 @@ typedef struct gml_opts {
                             spread over the whole histogram (the gradient always uses all of them, so only the convergence
                             rate is affected).  0 = automatic: as many as keep >= 32 configurations per working-set entry,
                             at most 8; 1 = every configuration                                                             */
-    int32_t coarse;      /* precision i8w only: 0 = while every active node is farther than max(1e-7, 100 tol) (KKT) from its optimum the passes run in
-                            their cheap form -- theta from its top four limb planes (30 bits), the weights in three planes (dithered
-                            23 bits): one forward sweep and one backward launch instead of two -- and switch to the full 54 / 47 bits
-                            for the rest of the solve (default); -1 = every pass at full width; e > 0: the coarse phase ends at 10^-e */
+    int32_t coarse;      /* int8-limb precisions, exp forms: 0 = while every active node is farther than max(1e-7, 100 tol) (KKT) from its
+                            optimum the passes run in a cheap form -- theta in 30 bits (i8w: its top four limb planes, one forward sweep
+                            instead of two; i8x: four limb planes instead of five), the weights in three limb planes (dithered 23 bits),
+                            one 3-plane backward launch -- and at full width for the rest of the solve, starting with a re-evaluation of
+                            the rows that ended the phase: a coarse gradient certifies nothing (default); -1 = every pass at full width;
+                            e > 0: the coarse phase ends at 10^-e                                                                  */
     double cg_viol_frac; /* matrix-free rows admit, per iteration, the violators within this fraction of the largest
                             violation (default 0.5: full Newton steps throughout on dense optima)           */
     double cg_eta;       /* CG stops at a residual reduced by min(cg_eta, sqrt(kkt)) (default 0.05); rows that are still building

@@ -860,11 +860,11 @@ def test_auto_precision_takes_the_wide_limbs_for_tight_tolerances():
     assert np.array_equal(b, c) and sb["passes"] == sc["passes"]
 
 
-def test_i8w_coarse_early_passes_do_not_change_the_answer():
-    # gml_opts.coarse: precision i8w runs its passes in the 30 / 23-bit form (one forward sweep, one backward launch) while every
+def test_coarse_early_passes_do_not_change_the_answer():
+    # gml_opts.coarse: the int8-limb precisions run their passes in the 30 / 23-bit form (one forward sweep, one backward launch) while every
     # active node is far from its optimum and at full width afterwards: same optimum, same iteration count +- 1, and the rows are
     # certified at full width (the KKT residuals reported come from 54 / 47-bit gradients)
-    n, K = 256, 100000
+    n, K = 512, 200000  # (above the size below which the coarse phase is not used at all: samples x columns x rows >= 2^34)
     spins, J = synthetic.block_ising(n, K, block=16, seed=3)
     lam = O.lam(0.4, n, K)
     with gml.Problem(spins=spins) as p:
@@ -872,7 +872,11 @@ def test_i8w_coarse_early_passes_do_not_change_the_answer():
         b, kb, sb = p.learn("RISE", 0.4, tol=1e-10, precision="i8w", coarse=False)
         c, kc, sc = p.learn("logRISE", 0.8, tol=1e-10, precision="i8w", coarse=True)
         d, kd, sd = p.learn("logRISE", 0.8, tol=1e-10, precision="i8w", coarse=False)
+        e, ke, se = p.learn("RISE", 0.4, tol=1e-9, precision="i8x", coarse=True)
+        g, kg, sg = p.learn("RISE", 0.4, tol=1e-9, precision="i8x", coarse=False)
     assert sa["not_converged"] == 0 and sb["not_converged"] == 0 and abs(sa["iterations"] - sb["iterations"]) <= 1
+    assert sa["passes"] != sb["passes"] or sa["t_pass"] != sb["t_pass"]  # (the two runs did differ)
     assert np.abs(a - b).max() <= 1e-9 and ((a == 0) == (b == 0)).all()
     assert sc["not_converged"] == 0 and np.abs(c - d).max() <= 1e-9
-    assert _kkt_from_oracle(spins, a, [0, 100, 255], lam) <= 1e-9
+    assert se["not_converged"] == 0 and sg["not_converged"] == 0 and np.abs(e - g).max() <= 5e-9 and abs(se["iterations"] - sg["iterations"]) <= 1
+    assert _kkt_from_oracle(spins, a, [0, 100, 511], lam) <= 1e-9 and _kkt_from_oracle(spins, e, [0, 100, 511], lam) <= 5e-9
