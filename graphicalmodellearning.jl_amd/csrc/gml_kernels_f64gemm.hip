@@ -4,8 +4,8 @@
 //   gradient  G[r][c] = sum_k V[r][k] x[k][c]                                      (:205-207)
 // Round-4 form.  The +-1 operand comes from the BIT images the int8 kernels use (Xb sample-major, Xtb feature-major: one dword per
 // lane and 32-deep block, expanded to +-1.0 by two integer instructions per element) -- the two 1-GB byte images of rounds 1-3
-// are gone from these kernels.  A workgroup is 8 waves that share the FP64 operand and split the +-1 side: 32 rows x 1024
-// samples (forward) / 32 rows x 1024 columns (backward), wave tile 32 x 128 = 16 MFMA tiles, 128 accumulator registers.  With
+// are gone from these kernels.  The waves of a workgroup share the FP64 operand and split the +-1 side: 4 waves = 32 rows x 512
+// samples (forward) / 8 waves = 32 rows x 1024 columns (backward), wave tile 32 x 128 = 16 MFMA tiles, 128 accumulator registers.  With
 // every column of a row group in ONE workgroup the backward kernel reads V from HBM once per pass (8.2 GB at the headline size;
 // the round-1 kernel re-read it once per 256-column block: 61 GB fetched per launch), and a 32-deep block carries 128 MFMAs of
 // 64 cycles each per wave against 16 + 8 loads: the kernels need no LDS staging, and a barrier only now and then.
@@ -34,13 +34,18 @@ constexpr int NT = 8; // 16-wide MFMA tiles of the +-1 side per wave (wave tile 
 } // namespace
 
 // ------------------------------------------------------------------------------------------
-// forward.  grid = (Kp / 1024, listed row groups); workgroup = 8 waves x 128 samples of one 32-row group.
+// forward.  grid = (Kp / 512, listed row groups); workgroup = 4 waves x 128 samples of one 32-row group.
 // Lane (li = lane & 15, q = lane >> 4) feeds MFMA step s of a 32-column block with the element at contraction index 8 q + s
 // of both operands: Theta[row li][.. + 8 q + s] (8 consecutive doubles) and, from the lane's dword (sample li, step kt,
 // half h = q >> 1) of the Xb image, the bit of column 64 kt + 32 g + 8 q + s: bit 4 g + 2 (q & 1) + (s >> 2) + 8 (s & 3)
 // (gml_bits.h: xb_col).  The constant statistic (column cconst, x = 1) is added in the epilogue.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 1) void k_fwd_f64(const double *__restrict__ Theta, const unsigned *__restrict__ Xb,
+// Forward workgroups are 4 waves (32 rows x 512 samples), two per CU: the epilogue of one -- 64 exp per lane and the V stores, with
+// no matrix work -- then runs beside the other's GEMM loop (8-wave workgroups, one per CU: 36.7 ms; 4-wave: 32.7 ms).
+#ifndef F64_FWD_WAVES
+#define F64_FWD_WAVES 4
+#endif
+__global__ __launch_bounds__(64 * F64_FWD_WAVES, 8 / F64_FWD_WAVES) void k_fwd_f64(const double *__restrict__ Theta, const unsigned *__restrict__ Xb,
                                                     const unsigned *__restrict__ Sb, const int *__restrict__ rowcol,
                                                     const int *__restrict__ groups, const double *__restrict__ w, int64_t Qp,
                                                     int64_t cconst, int64_t Kp, int nk, int form, double *__restrict__ V,
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(512, 1) void k_fwd_f64(const double *__restrict__ T
     const int grp = groups[blockIdx.y]; // 32-row group of this workgroup (-1: padding of the list)
     if (grp < 0) return;
     const int r0 = grp * 32;
-    const int64_t k0 = (int64_t)blockIdx.x * 1024 + wave * 128; // this wave's 128 samples: one 128-sample piece of Xb
+    const int64_t k0 = (int64_t)blockIdx.x * (128 * F64_FWD_WAVES) + wave * 128; // this wave's 128 samples: one 128-sample piece of Xb
     if (k0 >= Kp) return;
 
     v4d acc[2][NT];
@@ -132,8 +137,8 @@ __global__ __launch_bounds__(512, 1) void k_fwd_f64(const double *__restrict__ T
 
 void launch_fwd_f64(const DevProblem &P, const double *Theta, const int *rowcol, const int *groups, int ngroups4, int form, double *V,
                     double *fsum, hipStream_t st) {
-    dim3 grid((unsigned)((P.Kp + 1023) / 1024), (unsigned)ngroups4);
-    hipLaunchKernelGGL(k_fwd_f64, grid, dim3(512), 0, st, Theta, P.Xb, P.Sb, rowcol, groups, P.w, P.Qp, P.cconst, P.Kp, (int)(P.Qfp / 64), form,
+    dim3 grid((unsigned)((P.Kp + 128 * F64_FWD_WAVES - 1) / (128 * F64_FWD_WAVES)), (unsigned)ngroups4);
+    hipLaunchKernelGGL(k_fwd_f64, grid, dim3(64 * F64_FWD_WAVES), 0, st, Theta, P.Xb, P.Sb, rowcol, groups, P.w, P.Qp, P.cconst, P.Kp, (int)(P.Qfp / 64), form,
                        V, fsum);
 }
 
