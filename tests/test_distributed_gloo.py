@@ -101,3 +101,12 @@ def test_bench_two_ranks_on_the_gpu_box():
     assert line["n_gpus"] == 2 and line["config"]["nodes_per_gpu"] == 128 and len(line["per_rank_ms_per_step"]) == 2
     assert line["value"] > 0 and line["learn_not_converged"] == 0 and line["max_err_vs_true_model"] < 0.1
     assert line["collective_ranks"] == 2 and "gather_s" in line
+    # the headline is measured in arithmetic as wide as the reference's Float64 (the int8 limbs at 54 / 47 bits), the other two
+    # arithmetics ride along, and a first multi-GPU run is diagnosable from the line alone
+    assert line["dtype"] == "i8w" and line["learn_precision"] == "i8w"
+    assert line["f64"]["max_abs_grad_diff_vs_headline"] <= 1e-12 and line["f64"]["max_rel_f_diff_vs_headline"] <= 1e-12
+    assert line["value_f64"] > 0 and line["value_i8x"] > 0 and line["learn_wall_s_f64"] > 0 and line["learn_wall_s_i8x"] > 0
+    for key in ("collective_backend", "devices_visible", "learn_per_rank_s", "learn_per_rank_iterations", "learn_per_rank_passes",
+                "learn_per_rank_node_evals", "learn_per_rank_t_pass_s", "learn_per_rank_t_hess_s"):
+        assert key in line, key
+    assert len(line["learn_per_rank_iterations"]) == 2
