@@ -14,8 +14,9 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("prec", ["f64", "i8w"])  # (the Julia operator file binds i8w: FP64-grade, several times the FP64-MFMA rate)
 @pytest.mark.parametrize("name", ["a", "c"])
-def test_external_first_order_solver_reproduces_the_goldens(name):
+def test_external_first_order_solver_reproduces_the_goldens(name, prec):
     s = load_csv(f"{name}_samples.csv")
     n = s.shape[1] - 1
     lam = O.lam(0.4, n, s[:, 0].sum())
@@ -29,7 +30,7 @@ def test_external_first_order_solver_reproduces_the_goldens(name):
                 nonlocal calls
                 calls += 1
                 x = v[:n] - v[n:]
-                f, g = p.objgrad("RISE", np.array([u]), x[None, :], precision="f64")  # ONE node evaluation per call
+                f, g = p.objgrad("RISE", np.array([u]), x[None, :], precision=prec)  # ONE node evaluation per call
                 return f[0] + lam * (pen * (v[:n] + v[n:])).sum(), np.concatenate([g[0] + lam * pen, -g[0] + lam * pen])
 
             bounds = [(None, None) if j == u else (0, None) for j in range(n)] + [(0, 0) if j == u else (0, None) for j in range(n)]
@@ -52,11 +53,11 @@ def test_operator_one_row_calls_equal_the_batched_call():
     rng = np.random.default_rng(0)
     th = rng.normal(scale=0.2, size=(n, n))
     with gml.Problem(s) as p:
-        for prec in ("f64", "i8x"):
+        for prec in ("f64", "i8x", "i8w"):
             fb, gb = p.objgrad("RISE", np.arange(n), th, precision=prec)
             for u in range(n):
                 f1, g1 = p.objgrad("RISE", np.array([u]), th[u][None, :], precision=prec)
-                if prec == "i8x":
+                if prec != "f64":  # (integer arithmetic: bit for bit)
                     assert f1[0] == fb[u] and np.array_equal(g1[0], gb[u])
                 else:
                     assert abs(f1[0] - fb[u]) <= 1e-14 and np.abs(g1[0] - gb[u]).max() <= 1e-14
