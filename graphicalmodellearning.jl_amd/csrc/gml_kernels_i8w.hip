@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
                 SB;
 #ifdef ABL_NOEPI
 #pragma unroll
-                for (int q = 0; q < 8; ++q) yy[q] = fma(fabs(Ea[q]), 1.0e21, 3.0e21);
+                for (int q = 0; q < 8; ++q) yy[q] = fma(fabs(Ea[q]), 1.0e21, 2.0e23);
                 if (false) {
 #endif
                 // B: x = -s E, n = rint(64 x / ln2), r = x - n ln2 / 64 (two-part constant)
