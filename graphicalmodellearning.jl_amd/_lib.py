@@ -283,7 +283,7 @@ class Problem:
         check(lib().gml_multi_keys(self._h, int(u), _ptr(keys)))
         return [tuple(int(v) for v in row if v >= 0) for row in keys]
 
-    def objgrad(self, formulation, nodes, theta, precision="f64", want_grad=True):
+    def objgrad(self, formulation, nodes, theta, precision="auto", want_grad=True):
         nodes = np.ascontiguousarray(nodes, dtype=np.int64)
         theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(len(nodes), -1)
         f = np.zeros(len(nodes))

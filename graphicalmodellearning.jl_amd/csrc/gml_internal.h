@@ -62,12 +62,13 @@ void gml_build_layout(const gml_problem *p, int64_t u, NodeLayout &L);
 
 // GML_PREC_AUTO -> the int8-limb path, or FP64 where samples x parameters x nodes is launch-bound either way (decided on
 // the whole problem, not on the rows of one call or one shard: the arithmetic does not depend on the GPU count); -1: unknown value
-// (tol: the KKT tolerance of a solve, 0 for operator calls.  Below 2e-10 the 38/31-bit pass would stall at the noise floor of its
-// gradient and finish on the FP64-MFMA path; the 54/47-bit pass gets there directly, ~8x faster than FP64 MFMA)
+// (tol: the KKT tolerance of a solve, 0 for operator calls.  Operator calls -- gml_objgrad_batch is what an external solver registers
+// in place of the reference's Float64 obj / grad pair -- take the FP64-grade limbs.  Solves below 2e-10 too: the 38/31-bit pass would
+// stall at the noise floor of its gradient and finish on the FP64-MFMA path, the 54/47-bit pass gets there directly)
 inline int gml_resolve_precision(const gml_problem *p, int precision, double tol = 0.0) {
     if (precision == GML_PREC_AUTO) {
         if ((double)p->K * (double)p->P * (double)p->n <= 268435456.0) return GML_PREC_F64;
-        return tol > 0.0 && tol < 2e-10 ? GML_PREC_I8W : GML_PREC_I8X;
+        return tol <= 0.0 || tol < 2e-10 ? GML_PREC_I8W : GML_PREC_I8X;
     }
     return precision == GML_PREC_F64 || precision == GML_PREC_I8X || precision == GML_PREC_I8W ? precision : -1;
 }

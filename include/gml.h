@@ -49,7 +49,8 @@ extern "C" {
                             integer GEMMs without further rounding: f, grad agree with a Float64 evaluation (:191-208) to the
                             1e-12 the GML_PREC_F64 path is held to, at ~6x its speed.  gml_learn builds its Hessians and
                             Hessian-vector products from the top 31 bits of the same V planes                              */
-#define GML_PREC_AUTO 2  /* GML_PREC_I8X, except for problems so small (samples x parameters x spins <= 2^28: a
+#define GML_PREC_AUTO 2  /* gml_objgrad_batch (the pair an external solver registers in place of the reference's Float64 obj / grad):
+                            GML_PREC_I8W.  gml_learn: GML_PREC_I8X, except for problems so small (samples x parameters x spins <= 2^28: a
                             property of the problem, not of the call or of the node shard) that every kernel is
                             launch-bound either way: those run in FP64, which needs fewer iterations near tight
                             tolerances (README example: 1.2 ms against 5.5), and except for solves with tol < 2e-10, which

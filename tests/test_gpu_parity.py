@@ -725,12 +725,12 @@ def test_more_than_2_pow_24_configurations_default_precision():
         spins = p.spins()
         nodes = np.array([3, 40])
         f8, g8 = p.objgrad("RISE", nodes, J[nodes], precision="i8x")
-        fa, ga = p.objgrad("RISE", nodes, J[nodes], precision="auto")
-        assert np.array_equal(f8, fa) and np.array_equal(g8, ga)  # auto = the int8 path at this size
+        fa, ga = p.objgrad("RISE", nodes, J[nodes], precision="auto")  # operator calls: auto = the FP64-grade limbs at this size
         fo, go = O.objgrad_nodes("RISE", None, spins, nodes, J[nodes])
         assert np.abs(f8 / fo - 1).max() <= 1e-8
         assert np.abs(g8 - go).max() <= 1e-8
         fw, gw = p.objgrad("RISE", nodes, J[nodes], precision="i8w")  # the wide limbs: two halves x one set of accumulators per 2^23
+        assert np.array_equal(fw, fa) and np.array_equal(gw, ga)
         assert np.abs(fw / fo - 1).max() <= 2e-11 and np.abs(gw - go).max() <= 1e-12  # (f: the oracle's own summation over 1.7e7 terms)
         out, kkt, st = p.learn("RISE", 0.4, tol=1e-8)  # default (auto) precision
         assert st["not_converged"] == 0
