@@ -13,7 +13,7 @@ for n, K, blk, seed in cases:
     spins, J = syn.block_ising(n, K, block=blk, seed=seed)
     with gml.Problem(spins=spins) as p:
         for form, c in [('RISE', 0.4), ('RISE', 0.1), ('RISE', 1.5), ('logRISE', 0.8), ('logRISE', 0.2), ('RPLE', 0.2), ('RPLE', 1.0)]:
-            for prec in (['i8x', 'f64'] if n <= 200 else ['i8x']):
+            for prec in (['i8x', 'i8w', 'f64'] if n <= 200 else ['i8x', 'i8w']):
                 t0 = time.time()
                 out, kkt, st = p.learn(form, c, tol=1e-9, precision=prec, raise_on_fail=False)
                 flag = '' if st['not_converged'] == 0 else '  <-- NOT CONVERGED'
@@ -28,7 +28,7 @@ for n, N in [(10, 200000), (14, 2000000)]:
     hist = syn.enumerate_sample(m, N, seed=3)
     with gml.Problem(hist) as p:
         for form, c in [('RISE', 0.4), ('RISE', 1.5), ('logRISE', 0.8), ('RPLE', 0.2)]:
-            for prec in ('i8x', 'f64'):
+            for prec in ('i8x', 'i8w', 'f64'):
                 out, kkt, st = p.learn(form, c, tol=1e-9, precision=prec, raise_on_fail=False)
                 flag = '' if st['not_converged'] == 0 else '  <-- NOT CONVERGED'
                 bad += st['not_converged'] != 0
@@ -36,7 +36,7 @@ for n, N in [(10, 200000), (14, 2000000)]:
 spins, terms = syn.block_multibody(36, 100000, block=12, seed=2)
 with gml.Problem(spins=spins, order=3) as p:
     for c in (0.2, 0.4, 1.5):
-        for prec in ('i8x', 'f64'):
+        for prec in ('i8x', 'i8w', 'f64'):
             out, kkt, st = p.learn('RISE', c, tol=1e-9, precision=prec, raise_on_fail=False)
             flag = '' if st['not_converged'] == 0 else '  <-- NOT CONVERGED'
             bad += st['not_converged'] != 0
@@ -51,8 +51,9 @@ for a in range(Lx):
             J[(min(i, j) + 1, max(i, j) + 1)] = float(rng.uniform(0.1, 0.6) * rng.choice([-1, 1]))
 with gml.Problem(terms=J, n=n, num_samples=400000, seed=2, mcmc_sweeps=80) as p:
     for form, c in [('RISE', 0.4), ('RISE', 0.1), ('RISE', 1.5), ('logRISE', 0.8), ('RPLE', 0.2)]:
-        out, kkt, st = p.learn(form, c, tol=1e-9, precision='i8x', raise_on_fail=False)
+      for prec in ('i8x', 'i8w'):
+        out, kkt, st = p.learn(form, c, tol=1e-9, precision=prec, raise_on_fail=False)
         flag = '' if st['not_converged'] == 0 else '  <-- NOT CONVERGED'
         bad += st['not_converged'] != 0
-        print(f"lattice 24x24 {form}({c}) i8x: it {st['iterations']} passes {st['passes']}+{st['forward_passes']} kkt {st['max_kkt']:.2e} nnz {int((out != 0).sum(1).max())}{flag}", flush=True)
+        print(f"lattice 24x24 {form}({c}) {prec}: it {st['iterations']} passes {st['passes']}+{st['forward_passes']} kkt {st['max_kkt']:.2e} nnz {int((out != 0).sum(1).max())}{flag}", flush=True)
 print('failures:', bad)
