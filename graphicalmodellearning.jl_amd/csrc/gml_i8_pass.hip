@@ -107,6 +107,11 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     const int hv = a.hv ? (a.hv == 2 ? 2 : 1) : 0; // 2: Hessian-vector products in 2 backward limbs
     const bool wide = a.wide && !hv;                // (Hessian-vector passes are 31-bit passes whatever the workspace holds)
     const bool coarse = !hv && a.coarse && a.form != GML_RPLE; // the cheap form of an objective pass, either width
+    if (wide && d.Qfp > ((int64_t)1 << 21)) {
+        // the partial sums sum_c q_c b_c over 4 digit planes (|q| < 2^31) are folded in FP64: exact below 2^53, i.e. up to 2^21 columns
+        if (err) *err = "precision i8w holds at most 2^21 statistics columns: use precision i8x";
+        return GML_EUNSUPPORTED;
+    }
     int rc = i8_ensure(wsp, d, slot_capacity, hv ? -1 : (wide ? 1 : 0), st, err);
     if (rc) return rc;
     I8Ws *w = static_cast<I8Ws *>(*wsp);
