@@ -68,7 +68,7 @@ void gml_build_layout(const gml_problem *p, int64_t u, NodeLayout &L);
 inline int gml_resolve_precision(const gml_problem *p, int precision, double tol = 0.0) {
     if (precision == GML_PREC_AUTO) {
         if ((double)p->K * (double)p->P * (double)p->n <= 268435456.0) return GML_PREC_F64;
-        return tol <= 0.0 || tol < 2e-10 ? GML_PREC_I8W : GML_PREC_I8X;
+        return (tol <= 0.0 || tol < 2e-10) && p->d.Qfp <= ((int64_t)1 << 21) ? GML_PREC_I8W : GML_PREC_I8X; // (i8w: up to 2^21 columns)
     }
     return precision == GML_PREC_F64 || precision == GML_PREC_I8X || precision == GML_PREC_I8W ? precision : -1;
 }
