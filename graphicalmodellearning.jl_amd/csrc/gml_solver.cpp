@@ -1285,11 +1285,16 @@ int Solver::iterate(double *out, double *kkt_out) {
             // are evaluated again at full width where they stand, their best-iterate records start over, and the selection is redone.
             const double thr = std::max(coarse_thr, 100.0 * o.tol);
             std::vector<int> low;
+            bool dense = false; // a row has gone matrix-free: a dense optimum, whose many more iterations gain nothing from cheaper early
+                                // passes (config 5 at the default regulariser: 52 iterations instead of 39 for the same wall-clock)
+            for (int64_t r = 0; r < R; ++r) dense |= !done[r] && iscg[r];
             for (int64_t r = 0; r < R; ++r)
-                if (!done_before[r] && !(kkt[r] > thr)) low.push_back((int)r);
+                if (!done_before[r] && (dense ? !done[r] || !(kkt[r] > thr) : !(kkt[r] > thr))) low.push_back((int)r);
             if (!low.empty()) {
                 coarse_on = false;
-                if (o.verbose) fprintf(stderr, "[gml] it %3d: %zu rows within %.1e of their optimum: the passes switch from the coarse form to full width\n", it, low.size(), thr);
+                if (o.verbose)
+                    fprintf(stderr, "[gml] it %3d: %s: the passes switch from the coarse form to full width (%zu rows re-evaluated)\n", it,
+                            dense ? "rows have gone matrix-free (dense optimum)" : "rows have come within the coarse threshold of their optimum", low.size());
                 const double inf = INFINITY;
                 for (int r : low) {
                     done[r] = 0;
