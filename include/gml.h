@@ -84,8 +84,11 @@ typedef struct gml_opts {
     int32_t debug_row;   /* local row traced on stderr when verbose >= 2 (default 0)                                       */
     int32_t hv_subsample; /* the Hessian-vector products of the matrix-free rows run over 1/hv_subsample of the configurations,
                             spread over the whole histogram (the gradient always uses all of them, so only the convergence
-                            rate is affected).  0 = automatic: as many as keep >= 32 configurations per working-set entry,
-                            at most 8; 1 = every configuration                                                             */
+                            rate is affected).  0 = automatic: rows still admitting their support: as many as keep >= 32
+                            configurations per working-set entry, at most 8; rows with their support final: every configuration
+                            for the first two steps of a solve, 1/2 from step 2, 1/8 from step 4 on (inexact Krylov: the later a
+                            step, the less accurate its product needs to be).  1 = every configuration, always.  n > 1: the
+                            admitting rows over 1/n, the others over every configuration                                     */
     int32_t coarse;      /* int8-limb precisions, exp forms: 0 = while every active node is farther than max(1e-7, 100 tol) (KKT) from its
                             optimum the passes run in a cheap form -- theta in 30 bits (i8w: its top four limb planes, one forward sweep
                             instead of two; i8x: four limb planes instead of five), the weights in three limb planes (dithered 23 bits),
