@@ -228,7 +228,7 @@ struct Solver {
     void trace(const char *name) {
         if (o.verbose >= 3) {
             (void)stg.sync();
-            fprintf(stderr, "[gml]     stage %s (last error: %s)\n", name, hipGetErrorString(hipGetLastError()));
+            fprintf(stderr, "[gml]     stage %s at %.4f s (last error: %s)\n", name, gml_now_s() - t_begin, hipGetErrorString(hipGetLastError()));
             fflush(stderr);
         }
     }
@@ -1337,7 +1337,9 @@ int Solver::iterate(double *out, double *kkt_out) {
                 if (!done[r]) maxm = std::max(maxm, msz[r]);
             set_kh(nactive, maxm);
         }
+        trace("refresh");
         RCCHK(refresh_stale());
+        trace("refreshed");
         std::vector<int> chol_rows, cg_rows;
         for (int64_t r = 0; r < R; ++r)
             if (!done[r]) (iscg[r] ? cg_rows : chol_rows).push_back((int)r);
@@ -1345,6 +1347,7 @@ int Solver::iterate(double *out, double *kkt_out) {
         RCCHK(direction_blocks(cg_rows));
         RCCHK(newton_blocks(chol_rows));
         RCCHK(newton_cg(cg_rows));
+        trace("directions done");
         dir_time.mark();
         RCCHK(line_search());
     }

@@ -207,8 +207,9 @@ __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, co
         if (full - nsupp >= max_add / 2) max_add = full - nsupp;
     }
     // threshold of the max_add largest violators: bisection on the float pattern of |pg| (monotone as unsigned)
+    // (a support that alone exceeds capW makes the row matrix-free whatever the threshold: no search -- 31 sweeps of the row)
     unsigned thr = 0;
-    if (addv && nviol > max_add) {
+    if (addv && nviol > max_add && nsupp <= capW) {
         unsigned lo = 0, hi = 0x7f800000u; // invariant: count(v >= lo) > max_add >= count(v >= hi)
         while (hi - lo > 1) {
             const unsigned mid = lo + (hi - lo) / 2;
