@@ -483,6 +483,24 @@ def test_newton_cg_reduced_limbs_reach_the_same_optimum():
     assert _kkt_from_oracle(spins, dflt, [0, 50, 191], lam) <= 5e-9
 
 
+def test_newton_cg_relaxed_products_reach_the_same_optimum():
+    # Rows whose support is final solve their Newton system with every configuration in the first two CG steps and with 1/2, then
+    # 1/8 of them in the later ones (inexact Krylov, gml_solver.cpp newton_cg_group); hv_subsample = 1 keeps every product exact.
+    # Same (unique) optimum either way, certified by the oracle's gradient, and no more Newton iterations than a few.
+    n, K = 192, 30000
+    spins, J = synthetic.block_ising(n, K, block=16, seed=7)
+    lam = O.lam(0.05, n, K)
+    with gml.Problem(spins=spins) as p:
+        relaxed, _, st_r = p.learn("RISE", 0.05, tol=1e-9, precision="i8x", max_working=128, max_iter=200)
+        exact, _, st_e = p.learn("RISE", 0.05, tol=1e-9, precision="i8x", max_working=128, max_iter=200, hv_subsample=1)
+    assert st_r["not_converged"] == 0 and st_e["not_converged"] == 0
+    assert st_r["hessian_passes"] > 0 and st_e["hessian_passes"] > 0  # the matrix-free path really ran
+    assert np.abs(relaxed - exact).max() <= 1e-7
+    assert ((relaxed != 0) == (exact != 0)).all()
+    assert st_r["iterations"] <= st_e["iterations"] + 4
+    assert _kkt_from_oracle(spins, relaxed, [0, 50, 191], lam) <= 5e-9
+
+
 def test_multibody_dense_optimum_matrix_free_newton_cg():
     # multiRISE at the reference's default regulariser on a multi-body problem: lambda comes from n^2, not from the number of
     # parameters (:86), so the optimum is dense (a sizeable share of the P noise coefficients exceed lambda).  Reduced n;
