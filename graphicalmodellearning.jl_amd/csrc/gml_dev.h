@@ -116,6 +116,14 @@ void i8_free(void *ws);
 void i8_slot_results(void *ws, int hv, const double **tau, const unsigned **mmax);
 // the limb planes of V of the workspace (device pointer, bytes): the kernel-timing experiments read per-workgroup timestamps from it
 void i8_vq_buffer(void *ws, const int8_t **vq, int64_t *bytes, const DevProblem &d);
+// Hessian-vector products of a few matrix-free rows over their working sets only, bit-identical to an i8_pass with hv = 2 and two
+// forward limbs (gml_hv_sparse.hip).  rows / node / vslot [nrows]: local row, its spin, the slot of its V planes; nw, t0 (indexed by
+// local row): size and first tile of the row's list of working-set columns in FV (tiles of T entries); wcap >= every listed nw,
+// <= 65536; buf: i8_hv_sparse_bytes(d, nrows, wcap) bytes of device scratch.  Exp forms (RISE, logRISE), statistics of <= 2 spins.
+size_t i8_hv_sparse_bytes(const DevProblem &d, int nrows, int64_t wcap);
+int i8_hv_sparse(void *ws, const DevProblem &d, int nrows, const int *rows, const int *node, const int *vslot, const long long *t0, const int *nw,
+                 const int *FV, int T, int64_t wcap, const double *P, double *Hout, int64_t kchunk, int64_t kpart, void *buf, hipStream_t st,
+                 std::string *err);
 // Extra blocks of a Hessian call: the preconditioner tiles of the matrix-free rows.  Block R + t (t < n) is the T x T Hessian of
 // the T columns F[t T ..] under the weights of row wrow[t]; the caller's mt / hoff arrays cover R + n blocks (mt = T / 32 for a
 // tile).  hflag [R]: rows whose weights are needed (those with a working set, and those with tiles).

@@ -203,6 +203,14 @@ struct Solver {
     size_t dTctl_bytes = 0;
     int *dFV = nullptr, *dVm = nullptr, *dWrow = nullptr, *dLive = nullptr;
     double *dgV = nullptr;
+    // the last rows' Hessian-vector products on the vector ALUs over their working sets only (gml_hv_sparse.hip)
+    const long long *dT0m = nullptr; // first tile of each local row's working-set list (device; direction_blocks)
+    int *dNw = nullptr;              // |W| by local row
+    void *dHvsBuf = nullptr;
+    size_t hvs_bytes = 0;
+    bool hv_sparse = true;
+    double hv_sparse_ratio = g_hv_sparse_ratio; // sparse when sum |W| of the live rows < ratio * columns * node tiles of the GEMM pass
+    int64_t n_hv_sparse = 0;
     int64_t tile_cap = 0, ntiles = 0, tile_base = 0; // capacity of dFV / dgV in tiles; tiles of this iteration; offset of the first in dH
 
     // ---- host state (scalars per row) ------------------------------------------------------------------------------------
@@ -885,6 +893,7 @@ int Solver::direction_blocks(const std::vector<int> &cg_rows) {
         HIPCHK(stg.h2d(dTctl, tblk.data(), tb));
         dHoffV = reinterpret_cast<long long *>(dTctl);
         const long long *dT0 = dHoffV + NV;
+        dT0m = dT0;
         dMtV = reinterpret_cast<int *>(dTctl + sizeof(long long) * (NV + R));
         dVm = dMtV + NV;
         dWrow = dVm + ntiles;
@@ -1038,9 +1047,21 @@ int Solver::newton_cg_group(const std::vector<int> &cg_rows, bool subsample) {
             const int ks = (int)std::min<int64_t>(sk.second, p->K / (16 * maxW));
             if (ks > 1) relax.push_back({sk.first, ks});
         }
+    // The GEMM pass costs the same for a tile of 32 rows whatever the number of live ones in it; few rows go entry by entry
+    // instead (same integers, gml_hv_sparse.hip: their iterates do not depend on the path)
+    const bool sparse_ok = hv_sparse && p->i8ws != nullptr && formulation != GML_RPLE && hv_lf == 2 && hv_lb == 2 && d.ko <= 2 && maxW <= 65536 &&
+                           dT0m != nullptr;
+    if (sparse_ok) {
+        if (!dNw) HIPCHK(A.get(&dNw, (size_t)Rp));
+        HIPCHK(stg.h2d(dNw, nW.data(), sizeof(int) * R));
+    }
     // Hout = (sum_k h_k x_k x_k^T) theta for the listed rows: an hv pass over slots [0, n) of the u-plane workspace
     auto hv_pass = [&](const std::vector<int> &rows, const double *theta, double *Hout) -> int {
         const int64_t n = (int64_t)rows.size(), np = gml_round_up(n, 32);
+        int64_t sumW = 0;
+        for (int r : rows) sumW += nW[r];
+        const bool sparse = sparse_ok && (double)sumW < hv_sparse_ratio * (double)d.Qfp * (double)(np / 32) &&
+                            i8_hv_sparse_bytes(d, (int)n, maxW) <= ((size_t)2 << 30);
         std::vector<int> ctl((size_t)(3 * np + np / 32 + 4), -1);
         for (int64_t a = 0; a < np; ++a) {
             ctl[a] = a < n ? rows[a] : 0;
@@ -1049,6 +1070,26 @@ int Solver::newton_cg_group(const std::vector<int> &cg_rows, bool subsample) {
         }
         for (int64_t g = 0; g < np / 32; ++g) ctl[3 * np + g] = (int)g;
         HIPCHK(stg.h2d(dHv, ctl.data(), sizeof(int) * ctl.size()));
+        if (sparse) {
+            const size_t need = i8_hv_sparse_bytes(d, (int)n, maxW);
+            if (need > hvs_bytes) {
+                A.release(dHvsBuf);
+                dHvsBuf = nullptr;
+                hvs_bytes = need + need / 2;
+                char *b = nullptr;
+                HIPCHK(A.get(&b, hvs_bytes));
+                dHvsBuf = b;
+            }
+            std::string err;
+            const int rc = i8_hv_sparse(p->i8ws, d, (int)n, dHv, dHv + np, dHv + 2 * np, dT0m, dNw, dFV, kTile, maxW, theta, Hout, kchunk, kpart, dHvsBuf,
+                                        st, &err);
+            if (rc) return fail(rc, "%s", err.c_str());
+            ++stats.hessian_passes;
+            ++n_hv_sparse;
+            ++g_hv_sparse_calls;
+            stats.hv_evals += n;
+            return GML_OK;
+        }
         I8Pass a{};
         a.theta = theta;
         a.srow = dHv;

@@ -12,6 +12,11 @@ struct SelectOut {
     int nsupp, nviol;
     int pad;
 };
+// (test hook, gml_testhooks.cpp) the Hessian-vector products of few live rows go entry by entry when the sum of their working-set
+// sizes is below this multiple of (statistics columns x node tiles of the GEMM pass); < 0: never
+extern double g_hv_sparse_ratio;
+extern long long g_hv_sparse_calls; // products taken entry by entry so far (all solves of the process)
+
 struct CgState {
     double rs, rs0, pHp, rz;
 };

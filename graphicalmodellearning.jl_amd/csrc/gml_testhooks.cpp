@@ -17,6 +17,18 @@
 
 using namespace gml;
 
+namespace gml {
+double g_hv_sparse_ratio = 0.3; // (config 5 at the default regulariser: 25.6 s never, 23.6 s at 0.3 and at 0.6)
+long long g_hv_sparse_calls = 0;
+}
+// the solver's switch between the GEMM form and the entry-by-entry form of a Hessian-vector pass (gml_solver.h); returns the old value
+extern "C" long long gml_test_hv_sparse_calls(void) { return g_hv_sparse_calls; }
+extern "C" double gml_test_hv_sparse_ratio(double ratio) {
+    const double old = g_hv_sparse_ratio;
+    g_hv_sparse_ratio = ratio;
+    return old;
+}
+
 
 extern "C" int gml_test_tile_precond(int T, int ntiles, const int *m, const double *tiles /* ntiles x T x T */, double s1, double s2,
                                      const double *g /* ntiles x T */, const double *r /* ntiles x T */, double *z_out /* ntiles x T */,

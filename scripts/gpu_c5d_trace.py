@@ -10,6 +10,12 @@ for a in sys.argv[1:]:
     k, v = a.split('=')
     kw[k] = float(v) if '.' in v or 'e' in v else int(v)
 n, K = 512, 1000000
+if 'hvs' in kw:  # switch between the GEMM form and the entry-by-entry form of the Hessian-vector products (test hook)
+    import ctypes as C
+    L = gml._lib.lib()
+    L.gml_test_hv_sparse_ratio.restype = C.c_double
+    L.gml_test_hv_sparse_ratio.argtypes = [C.c_double]
+    L.gml_test_hv_sparse_ratio(float(kw.pop('hvs')))
 terms = syn.block_multibody_terms(n, block=16, seed=0)
 if kw.pop('perm', 0):  # the same model with its spins renumbered at random
     import numpy as np

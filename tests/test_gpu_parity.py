@@ -526,6 +526,43 @@ def test_multibody_dense_optimum_matrix_free_newton_cg():
         assert np.abs(pg).max() <= 5e-9
 
 
+@pytest.mark.parametrize("case", ["pairwise", "order3", "logRISE"])
+def test_hessian_vector_products_entry_by_entry_are_bit_identical(case):
+    # The last live rows of a matrix-free solve take their Hessian-vector products over their working sets on the vector ALUs
+    # (gml_hv_sparse.hip) instead of the GEMM pass over whole node tiles and every column.  Both forms compute the same integers,
+    # so forcing the one or the other for every product must not change one bit of the solution -- nor the iteration counts.
+    import ctypes as C
+    L = gml._lib.lib()
+    L.gml_test_hv_sparse_ratio.restype = C.c_double
+    L.gml_test_hv_sparse_ratio.argtypes = [C.c_double]
+    L.gml_test_hv_sparse_calls.restype = C.c_longlong
+    if case == "order3":
+        spins, _ = synthetic.block_multibody(36, 40000, block=12, seed=3)
+        kw, form, c = dict(order=3), "RISE", 0.4
+        opts = dict(tol=1e-9, precision="i8x", max_working=64, max_iter=100)
+    else:
+        spins, _ = synthetic.block_ising(192, 30000, block=16, seed=7)
+        kw, form, c = {}, ("logRISE" if case == "logRISE" else "RISE"), (0.1 if case == "logRISE" else 0.05)
+        opts = dict(tol=1e-9, precision="i8x", max_working=128, max_iter=200)
+    res = {}
+    old = L.gml_test_hv_sparse_ratio(1.0)
+    try:
+        with gml.Problem(spins=spins, **kw) as p:
+            for name, ratio in (("gemm", -1.0), ("entries", 1e30), ("mixed", 0.6 if case == "order3" else 3.0)):
+                L.gml_test_hv_sparse_ratio(ratio)
+                n0 = L.gml_test_hv_sparse_calls()
+                res[name] = p.learn(form, c, **opts) + (L.gml_test_hv_sparse_calls() - n0,)
+    finally:
+        L.gml_test_hv_sparse_ratio(old)
+    out_g, kkt_g, st_g, calls_g = res["gemm"]
+    assert st_g["not_converged"] == 0 and st_g["hv_evals"] > 0 and calls_g == 0  # the matrix-free path really ran, on the GEMM form
+    assert 0 < res["mixed"][3] < res["entries"][3]  # (mixed: only the products of the last few live rows)
+    for name in ("entries", "mixed"):
+        out, kkt, st, calls = res[name]
+        assert np.array_equal(out, out_g) and np.array_equal(kkt, kkt_g), name
+        assert (st["iterations"], st["passes"], st["hv_evals"]) == (st_g["iterations"], st_g["passes"], st_g["hv_evals"]), name
+
+
 def test_subsampled_hessian_does_not_change_the_optimum():
     n, K = 64, 40000
     spins, J = synthetic.block_ising(n, K, block=16, seed=8)
