@@ -144,20 +144,22 @@ __global__ __launch_bounds__(256) void k_hvs_fwd(const int *__restrict__ rows, c
     int acc[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) acc[j] = 0;
-    int prev = -1;
-    unsigned wi = 0;
-    for (int a = 0; a < cnt; ++a) {
-        const int2 s = ss[a];
-        const int q = sq[a];
-        if (s.x < 0) continue; // (uniform: the constant statistic)
-        if (s.x != prev) {
-            wi = Sb[(int64_t)s.x * wpr + w];
-            prev = s.x;
-        }
-        unsigned x = wi;
-        if (s.y >= 0) x ^= Sb[(int64_t)s.y * wpr + w];
+    // four entries at a time: their (L2-resident) sign words are requested together, ahead of the arithmetic
+    for (int a0 = 0; a0 < cnt; a0 += 4) {
+        unsigned x[4];
+        int q[4];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) acc[j] += __mul24((int)((x >> j) & 1u), q);
+        for (int u = 0; u < 4; ++u) {
+            const int a = a0 + u < cnt ? a0 + u : cnt - 1;
+            const int2 s = ss[a];
+            q[u] = a0 + u < cnt && s.x >= 0 ? sq[a] : 0; // (the constant statistic has no bits)
+            x[u] = s.x >= 0 ? Sb[(int64_t)s.x * wpr + w] : 0u;
+            if (s.y >= 0) x[u] ^= Sb[(int64_t)s.y * wpr + w];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc[j] = __mul24((int)__builtin_amdgcn_ubfe(x[u], j, 1), q[u]) + acc[j];
     }
     if (!wi_.valid) return;
     int *A = Abuf + (int64_t)i * 32 * ncdp + wi_.cd;
@@ -232,22 +234,33 @@ __global__ __launch_bounds__(256) void k_hvs_bwd(const int *__restrict__ rows, c
 #pragma unroll
     for (int j = 0; j < 32; ++j) vq[j] = wi_.valid ? U[(int64_t)j * ncdp] : 0;
     long long *Sr = S + (int64_t)i * wcap + base;
-    int prev = -1;
-    unsigned wi = 0;
-    for (int a = 0; a < cnt; ++a) {
-        const int2 s = ss[a];
-        if (s.x < 0) continue;
-        if (s.x != prev) {
-            wi = Sb[(int64_t)s.x * wpr + w];
-            prev = s.x;
-        }
-        unsigned x = wi;
-        if (s.y >= 0) x ^= Sb[(int64_t)s.y * wpr + w];
-        int part = 0;
+    for (int a0 = 0; a0 < cnt; a0 += 4) {
+        unsigned x[4];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) part += __mul24((int)((x >> j) & 1u), vq[j]);
-        part = wave_sum_i(part);
-        if ((tid & 63) == 0 && part != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&Sr[a]), (unsigned long long)(long long)part);
+        for (int u = 0; u < 4; ++u) {
+            const int a = a0 + u < cnt ? a0 + u : cnt - 1;
+            const int2 s = ss[a];
+            x[u] = a0 + u < cnt && s.x >= 0 ? Sb[(int64_t)s.x * wpr + w] : 0u;
+            if (a0 + u < cnt && s.y >= 0) x[u] ^= Sb[(int64_t)s.y * wpr + w];
+        }
+        int part[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            part[u] = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) part[u] = __mul24((int)__builtin_amdgcn_ubfe(x[u], j, 1), vq[j]) + part[u];
+        }
+        // four wave sums at once: the cross-lane steps of the four chains overlap
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) part[u] += __shfl_xor(part[u], o);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (a0 + u < cnt && part[u] != 0)
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&Sr[a0 + u]), (unsigned long long)(long long)part[u]);
+        }
     }
 }
 

@@ -1073,12 +1073,14 @@ int Solver::newton_cg_group(const std::vector<int> &cg_rows, bool subsample) {
         if (sparse) {
             const size_t need = i8_hv_sparse_bytes(d, (int)n, maxW);
             if (need > hvs_bytes) {
+                const double tr = gml_now_s();
                 A.release(dHvsBuf);
                 dHvsBuf = nullptr;
-                hvs_bytes = need + need / 2;
+                hvs_bytes = std::max(need + need / 2, (size_t)256 << 20);
                 char *b = nullptr;
                 HIPCHK(A.get(&b, hvs_bytes));
                 dHvsBuf = b;
+                if (o.verbose) fprintf(stderr, "[gml]   scratch of the entry-by-entry products: %.0f MB (%.1f ms)\n", hvs_bytes / 1048576.0, 1e3 * (gml_now_s() - tr));
             }
             std::string err;
             const int rc = i8_hv_sparse(p->i8ws, d, (int)n, dHv, dHv + np, dHv + 2 * np, dT0m, dNw, dFV, kTile, maxW, theta, Hout, kchunk, kpart, dHvsBuf,
