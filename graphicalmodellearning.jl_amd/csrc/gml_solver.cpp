@@ -1076,7 +1076,7 @@ int Solver::newton_cg_group(const std::vector<int> &cg_rows, bool subsample) {
                 const double tr = gml_now_s();
                 A.release(dHvsBuf);
                 dHvsBuf = nullptr;
-                hvs_bytes = std::max(need + need / 2, (size_t)256 << 20);
+                hvs_bytes = std::max(need + need / 2, (size_t)16 << 20);
                 char *b = nullptr;
                 HIPCHK(A.get(&b, hvs_bytes));
                 dHvsBuf = b;
