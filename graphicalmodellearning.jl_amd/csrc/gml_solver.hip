@@ -234,19 +234,22 @@ __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, co
     o.nviol = nviol;
     // ordered compaction: thread t owns the columns [t*chunk, (t+1)*chunk)
     const int64_t chunk = (Qp + 255) / 256, c0 = tid * chunk, c1 = c0 + chunk < Qp ? c0 + chunk : Qp;
-    int cnt = 0;
-    for (int64_t c = c0; c < c1; ++c) {
-        const uint8_t k = kr[c];
-        if (!k) continue;
-        cnt += (x[c] != 0.0 || k == 1) || (addv && pgr[c] != 0.0 && __float_as_uint((float)fabs(pgr[c])) >= thr);
+    int m = nsupp; // (a support above capW: matrix-free whatever the violators -- the ordered count below, a strided sweep, is not needed)
+    if (nsupp <= capW) {
+        int cnt = 0;
+        for (int64_t c = c0; c < c1; ++c) {
+            const uint8_t k = kr[c];
+            if (!k) continue;
+            cnt += (x[c] != 0.0 || k == 1) || (addv && pgr[c] != 0.0 && __float_as_uint((float)fabs(pgr[c])) >= thr);
+        }
+        scan[tid + 1] = cnt;
+        if (tid == 0) scan[0] = 0;
+        __syncthreads();
+        if (tid == 0)
+            for (int t = 1; t <= 256; ++t) scan[t] += scan[t - 1];
+        __syncthreads();
+        m = scan[256];
     }
-    scan[tid + 1] = cnt;
-    if (tid == 0) scan[0] = 0;
-    __syncthreads();
-    if (tid == 0)
-        for (int t = 1; t <= 256; ++t) scan[t] += scan[t - 1];
-    __syncthreads();
-    const int m = scan[256];
     if (m > capW) {
         // Matrix-free row: W = the support + the admitted violators (dense vectors, nothing gathered here: k_cg_tiles lists W
         // for the preconditioner once the host knows its size, m = -|W|).
