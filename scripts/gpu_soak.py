@@ -6,14 +6,22 @@ from importlib import import_module
 syn = import_module('gml_amd.synthetic')
 spins, J = syn.block_ising(256, 100000, block=16, seed=0)
 hist = np.column_stack([np.ones(len(spins), dtype=np.int64), spins.astype(np.int64)])
+spins3, _ = syn.block_multibody(36, 40000, block=12, seed=3)  # order 3, Newton blocks capped below the support: matrix-free rows
 free0 = torch.cuda.mem_get_info()[0]
 ref = None
+ref3 = None
 for it in range(40):
     kind = it % 4
     if kind == 0: p = gml.Problem(spins=spins)
     elif kind == 1: p = gml.Problem(np.asfortranarray(hist))
     elif kind == 2: p = gml.Problem(model=J, num_samples=100000, seed=1)
     else: p = gml.Problem(spins=spins, node_range=(64, 192))
+    if it % 5 == 4:
+        with gml.Problem(spins=spins3, order=3) as p3:
+            out3, _, st3 = p3.learn('RISE', 0.4, tol=1e-9, precision='i8x', max_working=64, max_iter=100)
+            assert st3['hv_evals'] > 0 and st3['not_converged'] == 0
+            if ref3 is None: ref3 = out3.copy()
+            assert np.array_equal(ref3, out3)
     with p:
         out, kkt, st = p.learn('RISE' if it % 3 else 'logRISE', 0.4, tol=1e-9, precision='i8x' if it % 2 else 'f64')
         if kind == 0 and it % 3 and it % 2:
