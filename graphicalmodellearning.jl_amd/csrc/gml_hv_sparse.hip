@@ -13,8 +13,9 @@
 // the XOR of the rows of its spins: no operand image is gathered), the same scales, the same dither sequence and the same
 // sub-sample of the configurations.  Every sum is an exact integer, so the result is BIT-IDENTICAL to the GEMM pass whatever the
 // order of the additions -- which path a row takes (it depends on how many rows are live on this GPU) cannot change its iterates.
-// Cost: 2 VALU operations per (configuration, entry) and direction, ~0.6 ms per row of 4 600 entries over 1e6 configurations,
-// against 14 ms for a tile.
+// Cost: ~3 VALU operations per (configuration, entry) and direction; measured 2.4 ms per row of 4 600 entries over 1e6
+// configurations against 14 ms for a tile of the GEMM pass, i.e. an entry costs about five columns of the tile: the solver takes
+// this path when the live rows' entries sum to less than 0.3 x (columns x node tiles)  (gml_solver.cpp, newton_cg_group).
 #include "gml_i8.h"
 #include <algorithm>
 #include <string>
