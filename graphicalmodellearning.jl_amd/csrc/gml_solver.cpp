@@ -1000,9 +1000,13 @@ int Solver::newton_cg_group(const std::vector<int> &cg_rows, bool subsample) {
     std::vector<int> liveflag((size_t)Rp, 0);
     for (int r : cg_rows) liveflag[r] = 1;
     HIPCHK(stg.h2d(dLive, liveflag.data(), sizeof(int) * Rp));
-    launch_pcg_init(dRows2, (int)cg_rows.size(), X, PG, kind, Qp, D, Rv, Zv, Wm, dCg, st);
+    // the rows' lists of W (k_cg_tiles, direction_blocks): the per-step vector kernels walk them instead of the 131 k columns
+    if (!dNw) HIPCHK(A.get(&dNw, (size_t)Rp));
+    HIPCHK(stg.h2d(dNw, nW.data(), sizeof(int) * R));
+    const WList wl{dFV, dT0m, dNw, kTile};
+    launch_pcg_init(dRows2, (int)cg_rows.size(), X, PG, kind, Qp, D, Rv, Zv, Pv, Wm, dCg, st);
     launch_tile_apply(kTile, dH + tile_base, dFV, dVm, dWrow, dLive, ntiles, Qp, Rv, Zv, st);
-    launch_pcg_dir(dRows2, (int)cg_rows.size(), Qp, Wm, Rv, Zv, Pv, 1, dCg, st);
+    launch_pcg_dir(dRows2, (int)cg_rows.size(), Qp, Wm, Rv, Zv, Pv, 1, dCg, wl, st);
     // Sub-sampled curvature: the Hessian-vector products run over ~1/ksub of the configurations -- as many as keep 32 of
     // them per working-set entry (the sample covariance of |W| statistics from 32 |W| configurations has its eigenvalues
     // within (1 +- 0.18)^2 of the true ones: a Newton step that is only solved to a 5 % residual loses nothing to that) --
@@ -1051,10 +1055,6 @@ int Solver::newton_cg_group(const std::vector<int> &cg_rows, bool subsample) {
     // instead (same integers, gml_hv_sparse.hip: their iterates do not depend on the path)
     const bool sparse_ok = hv_sparse && p->i8ws != nullptr && formulation != GML_RPLE && hv_lf == 2 && hv_lb == 2 && d.ko <= 2 && maxW <= 65536 &&
                            dT0m != nullptr;
-    if (sparse_ok) {
-        if (!dNw) HIPCHK(A.get(&dNw, (size_t)Rp));
-        HIPCHK(stg.h2d(dNw, nW.data(), sizeof(int) * R));
-    }
     // Hout = (sum_k h_k x_k x_k^T) theta for the listed rows: an hv pass over slots [0, n) of the u-plane workspace
     auto hv_pass = [&](const std::vector<int> &rows, const double *theta, double *Hout) -> int {
         const int64_t n = (int64_t)rows.size(), np = gml_round_up(n, 32);
@@ -1134,7 +1134,7 @@ int Solver::newton_cg_group(const std::vector<int> &cg_rows, bool subsample) {
                     if (ci == sk.first) RCCHK(set_plan(sk.second, live.size()));
             RCCHK(hv_pass(live, Pv, Hp));
             RCCHK(upload_rows(live, dRows2));
-            launch_pcg_step(dRows2, (int)live.size(), G, Wm, Qp, dS1cg, s2, Hp, D, Rv, Pv, dCg, st);
+            launch_pcg_step(dRows2, (int)live.size(), G, Wm, Qp, dS1cg, s2, Hp, D, Rv, Pv, dCg, wl, st);
             HIPCHK(stg.d2h(cgs.data(), dCg, sizeof(CgState) * Rp));
             HIPCHK(hipGetLastError());
             HIPCHK(stg.sync());
@@ -1155,7 +1155,7 @@ int Solver::newton_cg_group(const std::vector<int> &cg_rows, bool subsample) {
             if (live.empty() || ci + 1 == maxcg) break; // (at the cap the next direction would not be used)
             RCCHK(set_live(live));
             launch_tile_apply(kTile, dH + tile_base, dFV, dVm, dWrow, dLive, ntiles, Qp, Rv, Zv, st);
-            launch_pcg_dir(dRows2, (int)live.size(), Qp, Wm, Rv, Zv, Pv, 0, dCg, st);
+            launch_pcg_dir(dRows2, (int)live.size(), Qp, Wm, Rv, Zv, Pv, 0, dCg, wl, st);
         }
         if (round >= face_rounds) break;
         // orthant faces (gml_solver.hip, k_pcg_faces): the rows whose projected step would lose a noticeable part of its
@@ -1181,7 +1181,7 @@ int Solver::newton_cg_group(const std::vector<int> &cg_rows, bool subsample) {
         RCCHK(set_live(cur));
         launch_pcg_resid(dRows2, (int)cur.size(), PG, G, Qp, dS1cg, s2, Hp, D, Wm, Rv, dCg, st);
         launch_tile_apply(kTile, dH + tile_base, dFV, dVm, dWrow, dLive, ntiles, Qp, Rv, Zv, st);
-        launch_pcg_dir(dRows2, (int)cur.size(), Qp, Wm, Rv, Zv, Pv, 1, dCg, st);
+        launch_pcg_dir(dRows2, (int)cur.size(), Qp, Wm, Rv, Zv, Pv, 1, dCg, wl, st);
     }
     return GML_OK;
 }

@@ -17,6 +17,14 @@ struct SelectOut {
 extern double g_hv_sparse_ratio;
 extern long long g_hv_sparse_calls; // products taken entry by entry so far (all solves of the process)
 
+// the rows' lists of working-set columns (k_cg_tiles): row r's |W| = nw[r] columns, in column order, at FV + t0[r] * T
+struct WList {
+    const int *FV;
+    const long long *t0;
+    const int *nw;
+    int T;
+};
+
 struct CgState {
     double rs, rs0, pHp, rz;
 };
@@ -56,11 +64,11 @@ void launch_cg_tiles(const int *drows, int nrows, const double *X, const double 
 void launch_tile_apply(int T, const double *Minv, const int *FV, const int *vm, const int *wrow, const int *live, int64_t ntiles, int64_t Qp,
                        const double *Rv, double *Zv, hipStream_t st);
 void launch_pcg_init(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, double *D, double *Rv,
-                     double *Zv, uint8_t *Wm, CgState *cg, hipStream_t st);
+                     double *Zv, double *Pv, uint8_t *Wm, CgState *cg, hipStream_t st);
 void launch_pcg_dir(const int *drows, int nrows, int64_t Qp, const uint8_t *Wm, const double *Rv, const double *Zv, double *Pv, int first,
-                    CgState *cg, hipStream_t st);
+                    CgState *cg, const WList &wl, hipStream_t st);
 void launch_pcg_step(const int *drows, int nrows, const double *G, const uint8_t *Wm, int64_t Qp, const double *s1, double s2, double *Hp,
-                     double *D, double *Rv, const double *Pv, CgState *cg, hipStream_t st);
+                     double *D, double *Rv, const double *Pv, CgState *cg, const WList &wl, hipStream_t st);
 void launch_pcg_faces(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, double *D, uint8_t *Wm,
                       FaceOut *out, hipStream_t st);
 void launch_pcg_resid(const int *drows, int nrows, const double *PG, const double *G, int64_t Qp, const double *s1, double s2, const double *Hd,

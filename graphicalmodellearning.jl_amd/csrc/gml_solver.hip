@@ -621,10 +621,12 @@ void launch_tile_apply(int T, const double *Minv, const int *FV, const int *vm, 
     else hipLaunchKernelGGL(k_tile_apply<128>, dim3((unsigned)ntiles), dim3(256), 0, st, Minv, FV, vm, wrow, live, Qp, Rv, Zv);
 }
 
-// r = -pg on W, d = 0, z = 0;  Wm = the mask of W (k_pcg_faces shrinks it)
+// r = -pg on W, d = 0, z = 0, p = 0;  Wm = the mask of W (k_pcg_faces shrinks it).  The vectors are dense [Qp] arrays that are zero
+// outside W: the per-step kernels below walk the row's LIST of W (k_cg_tiles) and never touch the rest.
 __global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ PG,
                                                   const uint8_t *__restrict__ kind, int64_t Qp, double *__restrict__ D, double *__restrict__ Rv,
-                                                  double *__restrict__ Zv, uint8_t *__restrict__ Wm, CgState *__restrict__ cg) {
+                                                  double *__restrict__ Zv, double *__restrict__ Pv, uint8_t *__restrict__ Wm,
+                                                  CgState *__restrict__ cg) {
     const int r = rows[blockIdx.x];
     __shared__ double red[4];
     double rs = 0;
@@ -635,6 +637,7 @@ __global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ rows, 
         Rv[i] = v;
         D[i] = 0.0;
         Zv[i] = 0.0;
+        Pv[i] = 0.0;
         Wm[i] = inW;
         rs += v * v;
     }
@@ -647,30 +650,37 @@ __global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ rows, 
     }
 }
 void launch_pcg_init(const int *drows, int nrows, const double *X, const double *PG, const uint8_t *kind, int64_t Qp, double *D, double *Rv,
-                     double *Zv, uint8_t *Wm, CgState *cg, hipStream_t st) {
-    if (nrows > 0) hipLaunchKernelGGL(k_pcg_init, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, PG, kind, Qp, D, Rv, Zv, Wm, cg);
+                     double *Zv, double *Pv, uint8_t *Wm, CgState *cg, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_pcg_init, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, PG, kind, Qp, D, Rv, Zv, Pv, Wm, cg);
 }
 
 // With z = M^-1 r in Zv (k_tile_apply over the tiles of the original W; the preconditioner of the current, possibly smaller,
 // W is its restriction: z is masked):  beta = r.z / (r.z)_old (0 on the first call);  p = z + beta p.
 __global__ __launch_bounds__(256) void k_pcg_dir(const int *__restrict__ rows, int64_t Qp, const uint8_t *__restrict__ Wm,
                                                  const double *__restrict__ Rv, const double *__restrict__ Zv, double *__restrict__ Pv, int first,
-                                                 CgState *__restrict__ cg) {
+                                                 CgState *__restrict__ cg, const WList wl) {
     const int r = rows[blockIdx.x];
     const int64_t base = (int64_t)r * Qp;
+    const int *fv = wl.FV + wl.t0[r] * wl.T;
+    const int m = wl.nw[r];
     __shared__ double red[4];
     const double rzo = cg[r].rz;
     double rz = 0;
-    for (int64_t c = threadIdx.x; c < Qp; c += 256)
-        if (Wm[base + c]) rz += Rv[base + c] * Zv[base + c];
+    for (int a = threadIdx.x; a < m; a += 256) {
+        const int64_t i = base + fv[a];
+        if (Wm[i]) rz += Rv[i] * Zv[i];
+    }
     rz = block_sum(rz, red);
     const double be = (!first && rzo > 0) ? rz / rzo : 0.0;
-    for (int64_t c = threadIdx.x; c < Qp; c += 256) Pv[base + c] = Wm[base + c] ? Zv[base + c] + (first ? 0.0 : be * Pv[base + c]) : 0.0;
+    for (int a = threadIdx.x; a < m; a += 256) {
+        const int64_t i = base + fv[a];
+        Pv[i] = Wm[i] ? Zv[i] + (first ? 0.0 : be * Pv[i]) : 0.0;
+    }
     if (threadIdx.x == 0) cg[r].rz = rz;
 }
 void launch_pcg_dir(const int *drows, int nrows, int64_t Qp, const uint8_t *Wm, const double *Rv, const double *Zv, double *Pv, int first,
-                    CgState *cg, hipStream_t st) {
-    if (nrows > 0) hipLaunchKernelGGL(k_pcg_dir, dim3((unsigned)nrows), dim3(256), 0, st, drows, Qp, Wm, Rv, Zv, Pv, first, cg);
+                    CgState *cg, const WList &wl, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_pcg_dir, dim3((unsigned)nrows), dim3(256), 0, st, drows, Qp, Wm, Rv, Zv, Pv, first, cg, wl);
 }
 
 // Orthant faces.  The Newton system is solved on W without its sign constraints; the line search then projects the step onto
@@ -759,20 +769,25 @@ void launch_pcg_resid(const int *drows, int nrows, const double *PG, const doubl
 __global__ __launch_bounds__(256) void k_pcg_step(const int *__restrict__ rows, const double *__restrict__ G, const uint8_t *__restrict__ Wm,
                                                   int64_t Qp, const double *__restrict__ s1, double s2, double *__restrict__ Hp,
                                                   double *__restrict__ D, double *__restrict__ Rv, const double *__restrict__ Pv,
-                                                  CgState *__restrict__ cg) {
+                                                  CgState *__restrict__ cg, const WList wl) {
     const int r = rows[blockIdx.x];
     const int64_t base = (int64_t)r * Qp;
+    const int *fv = wl.FV + wl.t0[r] * wl.T;
+    const int m = wl.nw[r];
     __shared__ double red[4];
     const double rzo = cg[r].rz;
     double gp = 0;
     if (s2 != 0.0) {
-        for (int64_t c = threadIdx.x; c < Qp; c += 256) gp += G[base + c] * Pv[base + c];
+        for (int a = threadIdx.x; a < m; a += 256) {
+            const int64_t i = base + fv[a];
+            gp += G[i] * Pv[i];
+        }
         gp = block_sum(gp, red);
     }
     const double sc = s1[r];
     double pHp = 0;
-    for (int64_t c = threadIdx.x; c < Qp; c += 256) {
-        const int64_t i = base + c;
+    for (int a = threadIdx.x; a < m; a += 256) {
+        const int64_t i = base + fv[a];
         const double h = Wm[i] ? sc * Hp[i] - s2 * G[i] * gp : 0.0;
         Hp[i] = h;
         pHp += Pv[i] * h;
@@ -780,8 +795,8 @@ __global__ __launch_bounds__(256) void k_pcg_step(const int *__restrict__ rows, 
     pHp = block_sum(pHp, red);
     const double al = pHp > 0 ? rzo / pHp : 0.0;
     double rsn = 0;
-    for (int64_t c = threadIdx.x; c < Qp; c += 256) {
-        const int64_t i = base + c;
+    for (int a = threadIdx.x; a < m; a += 256) {
+        const int64_t i = base + fv[a];
         D[i] += al * Pv[i];
         const double rv = Rv[i] - al * Hp[i];
         Rv[i] = rv;
@@ -794,8 +809,8 @@ __global__ __launch_bounds__(256) void k_pcg_step(const int *__restrict__ rows, 
     }
 }
 void launch_pcg_step(const int *drows, int nrows, const double *G, const uint8_t *Wm, int64_t Qp, const double *s1, double s2, double *Hp,
-                     double *D, double *Rv, const double *Pv, CgState *cg, hipStream_t st) {
-    if (nrows > 0) hipLaunchKernelGGL(k_pcg_step, dim3((unsigned)nrows), dim3(256), 0, st, drows, G, Wm, Qp, s1, s2, Hp, D, Rv, Pv, cg);
+                     double *D, double *Rv, const double *Pv, CgState *cg, const WList &wl, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_pcg_step, dim3((unsigned)nrows), dim3(256), 0, st, drows, G, Wm, Qp, s1, s2, Hp, D, Rv, Pv, cg, wl);
 }
 
 } // namespace gml
