@@ -414,7 +414,7 @@ int Solver::init() {
     // sub-sampled Newton: the budget (rows x configurations) is kept roughly constant: as nodes converge, the remaining
     // ones get more configurations, up to all of them -- an inexact Hessian only costs iterations, and it costs the most on
     // the few ill-conditioned nodes that are still active at the end.
-    Kh_base = o.hess_samples == 0 ? 32768 : (o.hess_samples < 0 ? d.Kp : (int64_t)o.hess_samples);
+    Kh_base = o.hess_samples == 0 ? (g_tune[GML_TUNE_KH_BASE] > 0 ? (int64_t)g_tune[GML_TUNE_KH_BASE] : 32768) : (o.hess_samples < 0 ? d.Kp : (int64_t)o.hess_samples);
     nblk512 = d.Kp / 512;
     set_kh(R);
     return GML_OK;
@@ -955,6 +955,7 @@ int Solver::newton_blocks(const std::vector<int> &chol_rows) {
     // (a re-solve costs as much as the solve; what it saves is backtracking passes, whose cost grows with configurations x
     // statistics: config 2 -- 1e5 x 256 -- is 0.4 ms faster without, the headline problem 4 % faster with)
     nf.rounds = (double)p->K * (double)Qp >= 268435456.0 ? face_rounds : 0;
+    if (g_tune[GML_TUNE_FACE_ROUNDS] > 0) nf.rounds = (int)g_tune[GML_TUNE_FACE_ROUNDS] - 1;
     launch_newton_solve(dH, dHoff, dMt, dMt + 2 * R, dS1, s2, dgF, dpgF, (int)R, capP, dsol, dSdiag, st, maxm, &nf);
     launch_scatter_dir(dRows, (int)chol_rows.size(), dFidx, dsol, dMt + 2 * R, capP, Qp, D, st);
     HIPCHK(hipGetLastError());

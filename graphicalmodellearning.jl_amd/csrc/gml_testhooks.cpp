@@ -19,10 +19,18 @@ using namespace gml;
 
 namespace gml {
 double g_hv_sparse_ratio = 0.3; // (config 5 at the default regulariser: 25.6 s never, 23.6 s at 0.3 and at 0.6)
-long long g_hv_sparse_calls = 0;
+std::atomic<long long> g_hv_sparse_calls{0}; // (every part of a gml_multi_learn counts from its own host thread)
+double g_tune[GML_NTUNE] = {};               // experiment knobs of the solver, 0 = the built-in rule (gml_solver.h)
 }
 // the solver's switch between the GEMM form and the entry-by-entry form of a Hessian-vector pass (gml_solver.h); returns the old value
-extern "C" long long gml_test_hv_sparse_calls(void) { return g_hv_sparse_calls; }
+extern "C" long long gml_test_hv_sparse_calls(void) { return g_hv_sparse_calls.load(); }
+// experiment knob `id` of the solver (gml_solver.h: GML_TUNE_*); returns the old value.  Not part of include/gml.h; set between solves only
+extern "C" double gml_test_tune(int id, double value) {
+    if (id < 0 || id >= GML_NTUNE) return NAN;
+    const double old = g_tune[id];
+    g_tune[id] = value;
+    return old;
+}
 extern "C" double gml_test_hv_sparse_ratio(double ratio) {
     const double old = g_hv_sparse_ratio;
     g_hv_sparse_ratio = ratio;
