@@ -354,6 +354,14 @@ void launch_tile_inverse(int T, double *H, const long long *hoff, const int *vm,
     }
 }
 
+
+// value of lane l (wave-uniform index) of a double: two v_readlane_b32, the result in scalar registers.  (__shfl goes through
+// ds_bpermute: an LDS round trip per value -- the 496 of a 32 x 32 diagonal block were most of the batched Cholesky kernels' time.)
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 // ------------------------------------------------------------------------------------------
 // Batched Newton solve on the device: for every row r, A d = -pg with
 //   A = s1[r] * H_r  -  s2 * gF gF^T        (s2 = 1 for logRISE: Hess log Z = Hess Z / Z - g g^T)
@@ -387,11 +395,12 @@ __global__ __launch_bounds__(256) void k_newton_chol(double *__restrict__ H, con
                                                      const int *__restrict__ F, const double *__restrict__ X, const uint8_t *__restrict__ kind,
                                                      int64_t Qp, double share, int rounds,
                                                      // entries fixed from the start (tests): fix != 0 keeps the step dfix
-                                                     const uint8_t *__restrict__ fix, const double *__restrict__ dfix) {
+                                                     const uint8_t *__restrict__ fix, const double *__restrict__ dfix,
+                                                     int mlo /* blocks of up to mlo entries are another kernel's */) {
     constexpr int PW = 32, LP = PW + 1;
     const int r = blockIdx.x;
     const int m = msz[r];
-    if (m == 0) return;
+    if (m == 0 || m <= mlo) return;
     const int hp = 32 * mt[r];
     double *A = H + hoff[r];
     const double sc = s1[r];
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(256) void k_newton_chol(double *__restrict__ H, con
 #pragma unroll
                 for (int c = 0; c < PW; ++c) {
                     if (c < pw && !fail) {
-                        const double piv = __shfl(v[c], c);
+                        const double piv = readlane_f64(v[c], c);
                         if (!(piv > 1e-300 * dmax) || !isfinite(piv)) {
                             fail = true;
                         } else {
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(256) void k_newton_chol(double *__restrict__ H, con
                             v[c] = t == c ? dgc : v[c] * inv;
                             const double ltc = t > c ? v[c] : 0.0;
 #pragma unroll
-                            for (int k = c + 1; k < PW; ++k) v[k] = fma(-ltc, __shfl(v[c], k), v[k]);
+                            for (int k = c + 1; k < PW; ++k) v[k] = fma(-ltc, readlane_f64(v[c], k), v[k]);
                         }
                     }
                 }
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(256) void k_newton_chol(double *__restrict__ H, con
 #pragma unroll
                     for (int k = 0; k < PW; ++k) {
                         if (k < pw) {
-                            const double yk = __shfl(yc, k) * __shfl(invd, k);
+                            const double yk = readlane_f64(yc, k) * readlane_f64(invd, k);
                             if (t == k) yc = yk;
                             else if (t > k) yc = fma(-v[k], yk, yc);
                         }
@@ -625,7 +634,7 @@ __global__ __launch_bounds__(256) void k_newton_chol(double *__restrict__ H, con
             const int c = lane & 31;
             double yc = c < pw ? y[c0 + c] - tmp[c] : 0.0;
             for (int k = pw - 1; k >= 0; --k) { // d_k = y_k / L_kk; y_c -= L[c0 + k][c0 + c] d_k for c < k
-                const double dk = __shfl(yc, k) / dg[c0 + k];
+                const double dk = readlane_f64(yc, k) / dg[c0 + k];
                 if (c == k) yc = dk;
                 else if (c < k) yc = fma(-Ld[k * LP + c], dk, yc);
             }
@@ -681,17 +690,289 @@ __global__ __launch_bounds__(256) void k_newton_chol(double *__restrict__ H, con
     for (int i = tid; i < m; i += 256) dout[(int64_t)r * cap + i] = y[i];
 }
 
+// ------------------------------------------------------------------------------------------
+// The same solve for blocks of up to 128 entries -- the working sets of the pairwise configurations -- with the whole matrix
+// in LDS (round 5).  k_newton_chol above keeps the block in global memory and pays three dependent L2 round trips per panel:
+// 0.13 ms for 128 rows of 100 entries, one launch per Newton iteration of a solve whose other kernels had shrunk to less
+// (profiles/r5_shard128_kernel_stats.csv).  Here A = s1 H - s2 g g^T (lower triangle, masked) is loaded once into W [mcap][mcap + 1]
+// and factored in place: the diagonal block by one wave in registers (as above), the panel below it one thread per row, the
+// trailing matrix by v_mfma_f64_16x16x4_f64 tiles straight from W (lane (li, q) feeds A[row li][k q] and B[k q][col li], i.e. the
+// same access for both operands of L21 L21^T), the back substitution from W.  A ridge restart or an orthant-face re-solve reloads W
+// from the global block, which is never written.  Same arithmetic order inside a panel as above; results agree to rounding.
+// ------------------------------------------------------------------------------------------
+typedef double v4d_c __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restrict__ H, const long long *__restrict__ hoff, const int *__restrict__ mt,
+                                                         const int *__restrict__ msz, const double *__restrict__ s1, double s2,
+                                                         const double *__restrict__ gF, const double *__restrict__ pgF, int cap,
+                                                         double *__restrict__ dout, double *__restrict__ Sdiag, int mcap /* multiple of 32, <= 128, >= every msz handled here */,
+                                                         const int *__restrict__ F, const double *__restrict__ X, const uint8_t *__restrict__ kind,
+                                                         int64_t Qp, double share, int rounds, const uint8_t *__restrict__ fix,
+                                                         const double *__restrict__ dfix) {
+    constexpr int PW = 32;
+    const int r = blockIdx.x;
+    const int m = msz[r];
+    if (m == 0 || m > mcap) return;
+    const int hp = 32 * mt[r], LDW = mcap + 1, mp = (m + 15) & ~15;
+    const double *A = H + hoff[r];
+    const double sc = s1[r];
+    const double *g = gF + (int64_t)r * cap, *pg = pgF + (int64_t)r * cap;
+    extern __shared__ double sm[]; // W [mcap][mcap + 1] | idg | y | gg | fx | dfx [mcap each] | tmp [32]
+    double *W = sm, *idg = W + mcap * LDW, *y = idg + mcap, *gg = y + mcap, *fx = gg + mcap, *dfx = fx + mcap, *tmp = dfx + mcap;
+    __shared__ int bad;
+    __shared__ double red[4];
+    __shared__ int redi[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bool masked = fix != nullptr || F != nullptr; // some entries may be fixed
+    for (int i = tid; i < m; i += 256) {
+        gg[i] = s2 != 0.0 ? g[i] : 0.0;
+        fx[i] = fix && fix[(int64_t)r * cap + i] ? 1.0 : 0.0;
+        dfx[i] = fix ? dfix[(int64_t)r * cap + i] : 0.0;
+    }
+    __syncthreads();
+    auto a_orig = [&](int i, int j) { return sc * A[(int64_t)i * hp + j] - s2 * gg[i] * gg[j]; }; // i >= j: the matrix itself
+    auto a_low = [&](int i, int j) { // ... with the fixed entries decoupled (unit diagonal)
+        if (masked && (fx[i] != 0.0 || fx[j] != 0.0)) return i == j ? 1.0 : 0.0;
+        return a_orig(i, j);
+    };
+    double dmax = 0;
+    for (int i = tid; i < m; i += 256) dmax = fmax(dmax, fabs(a_low(i, i)));
+    for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
+    if (lane == 0) red[wave] = dmax;
+    __syncthreads();
+    dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (tid == 0) Sdiag[r] = a_orig(m - 1, m - 1);
+    for (int face = 0;; ++face) { // (re-solves on an orthant face, see the end of the loop)
+    double ridge = 0.0;
+    bool ok = false;
+    for (int attempt = 0; attempt < 10 && !ok; ++attempt) {
+        // W <- lower triangle of the (masked) matrix, ridge on the free diagonal; rows m .. mp - 1 (MFMA tile padding): zero
+        for (int idx = tid; idx < mp * mp; idx += 256) {
+            const int i = idx / mp, j = idx - i * mp;
+            if (j > i) continue;
+            double v = 0.0;
+            if (i < m) v = a_low(i, j) + (i == j && fx[i] == 0.0 ? ridge : 0.0);
+            W[i * LDW + j] = v;
+        }
+        for (int i = tid; i < m; i += 256) {
+            double v = -pg[i];
+            if (masked) {
+                if (fx[i] != 0.0) {
+                    v = dfx[i];
+                } else {
+                    for (int j = 0; j < m; ++j)
+                        if (fx[j] != 0.0 && dfx[j] != 0.0) v -= (i >= j ? a_orig(i, j) : a_orig(j, i)) * dfx[j];
+                }
+            }
+            y[i] = v;
+        }
+        if (tid == 0) bad = 0;
+        __syncthreads();
+        for (int c0 = 0; c0 < m; c0 += PW) {
+            const int pw = m - c0 < PW ? m - c0 : PW;
+            if (wave == 0) {
+                // (1) diagonal block: lane t holds row t in registers; right-looking: column c is scaled, then every lane updates the
+                // rest of its row with L[k][c] shuffled in from lane k (the dependent chain is the 32 pivots)
+                const int t = lane & 31;
+                double v[PW];
+#pragma unroll
+                for (int k = 0; k < PW; ++k) v[k] = (t < pw && k <= t) ? W[(c0 + t) * LDW + c0 + k] : 0.0;
+                bool fail = false;
+#pragma unroll
+                for (int c = 0; c < PW; ++c) {
+                    if (c < pw && !fail) {
+                        const double piv = readlane_f64(v[c], c);
+                        if (!(piv > 1e-300 * dmax) || !isfinite(piv)) {
+                            fail = true;
+                        } else {
+                            double inv = __builtin_amdgcn_rsq(piv);
+                            inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+                            inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+                            const double dgc = piv * inv;
+                            v[c] = t == c ? dgc : v[c] * inv;
+                            const double ltc = t > c ? v[c] : 0.0;
+#pragma unroll
+                            for (int k = c + 1; k < PW; ++k) v[k] = fma(-ltc, readlane_f64(v[c], k), v[k]);
+                        }
+                    }
+                }
+                if (fail) {
+                    if (lane == 0) bad = 1;
+                } else {
+                    if (lane < pw) {
+#pragma unroll
+                        for (int k = 0; k < PW; ++k)
+                            if (k <= t) W[(c0 + t) * LDW + c0 + k] = v[k];
+                    }
+                    double dgt = 1.0;
+#pragma unroll
+                    for (int k = 0; k < PW; ++k)
+                        if (k == t) dgt = v[k];
+                    const double invd = 1.0 / dgt;
+                    if (lane < pw) idg[c0 + t] = invd; // 1 / L_tt
+                    // forward substitution of the panel's right-hand side: lanes = rows of the block
+                    double yc = t < pw ? y[c0 + t] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < PW; ++k) {
+                        if (k < pw) {
+                            const double yk = readlane_f64(yc, k) * readlane_f64(invd, k);
+                            if (t == k) yc = yk;
+                            else if (t > k) yc = fma(-v[k], yk, yc);
+                        }
+                    }
+                    if (lane < pw) y[c0 + t] = yc;
+                }
+            }
+            __syncthreads();
+            if (bad) break;
+            const int r0 = c0 + pw, nt = m - r0; // trailing rows
+            if (nt <= 0) break;
+            // (2) panel solve: row i = r0 + a, one thread per row (pw = 32 here: only the last panel is narrower, and it has no rows below)
+            for (int a = tid; a < nt; a += 256) {
+                double *wr = W + (r0 + a) * LDW + c0;
+                double x[PW];
+#pragma unroll
+                for (int c = 0; c < PW; ++c) x[c] = wr[c];
+#pragma unroll
+                for (int c = 0; c < PW; ++c) {
+                    double v = x[c];
+                    const double *lc = W + (c0 + c) * LDW + c0;
+#pragma unroll
+                    for (int k = 0; k < c; ++k) v = fma(-x[k], lc[k], v);
+                    x[c] = v * idg[c0 + c];
+                }
+#pragma unroll
+                for (int c = 0; c < PW; ++c) wr[c] = x[c];
+            }
+            __syncthreads();
+            // (3) trailing update W22 -= L21 L21^T in 16 x 16 MFMA tiles (I >= J) over the waves, and the rest of the right-hand side
+            {
+                const int li = lane & 15, q = lane >> 4;
+                const int T = (nt + 15) >> 4, ntile = T * (T + 1) / 2;
+                for (int tile = wave; tile < ntile; tile += 4) {
+                    int I = 0, rem = tile;
+                    while (rem > I) {
+                        rem -= I + 1;
+                        ++I;
+                    }
+                    const int J = rem;
+                    const double *pa = W + (r0 + 16 * I + li) * LDW + c0 + q, *pb = W + (r0 + 16 * J + li) * LDW + c0 + q;
+                    v4d_c acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < PW / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * kk], pb[4 * kk], acc, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = r0 + 16 * I + q + 4 * j, col = r0 + 16 * J + li;
+                        if (row < mp && col <= row) W[row * LDW + col] -= acc[j];
+                    }
+                }
+                for (int a = tid; a < nt; a += 256) {
+                    const double *wr = W + (r0 + a) * LDW + c0;
+                    double v = 0.0;
+#pragma unroll
+                    for (int c = 0; c < PW; ++c) v = fma(wr[c], y[c0 + c], v);
+                    y[r0 + a] -= v;
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        ok = !bad;
+        __syncthreads();
+        if (!ok) ridge = ridge == 0.0 ? 1e-12 * fmax(dmax, 1e-300) : ridge * 100.0;
+    }
+    if (!ok) {
+        for (int i = tid; i < m; i += 256) dout[(int64_t)r * cap + i] = 0.0;
+        return;
+    }
+    // back substitution L^T d = y, panels in reverse
+    for (int c0 = (m - 1) / PW * PW; c0 >= 0; c0 -= PW) {
+        const int pw = m - c0 < PW ? m - c0 : PW, r0 = c0 + pw;
+        // tmp[c] = sum_{i >= r0} L[i][c0 + c] d_i
+        for (int c = wave; c < pw; c += 4) {
+            double v = 0.0;
+            for (int i = r0 + lane; i < m; i += 64) v = fma(W[i * LDW + c0 + c], y[i], v);
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) tmp[c] = v;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int c = lane & 31;
+            double yc = c < pw ? y[c0 + c] - tmp[c] : 0.0;
+            for (int k = pw - 1; k >= 0; --k) { // d_k = y_k / L_kk; y_c -= L[c0 + k][c0 + c] d_k for c < k
+                const double dk = readlane_f64(yc, k) * idg[c0 + k];
+                if (c == k) yc = dk;
+                else if (c < k) yc = fma(-W[(c0 + k) * LDW + c0 + c], dk, yc);
+            }
+            if (lane < pw) y[c0 + c] = yc;
+        }
+        __syncthreads();
+    }
+    // Orthant faces (as in k_newton_chol): entries whose step leaves the face of the iterate are fixed where the projection of the
+    // line search would put them and, when they carry more than `share` of the predicted decrease, the others are solved again
+    if (!F || face >= rounds) break;
+    int nf = 0;
+    double mass = 0, total = 0;
+    for (int a = tid; a < m; a += 256) {
+        if (fx[a] != 0.0) continue;
+        const int c = F[(int64_t)r * cap + a];
+        const double x = X[(int64_t)r * Qp + c], dc = y[a], pv = pg[a];
+        total += fabs(pv * dc);
+        if (kind[(int64_t)r * Qp + c] != 2) continue;
+        if (x == 0.0 ? dc * pv > 0.0 : (x + dc) * x < 0.0) {
+            const double fixed = x == 0.0 ? 0.0 : -x;
+            mass += fabs(pv * (dc - fixed));
+            fx[a] = 2.0; // candidate
+            dfx[a] = fixed;
+            ++nf;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        nf += __shfl_xor(nf, o);
+        mass += __shfl_xor(mass, o);
+        total += __shfl_xor(total, o);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        redi[wave] = nf;
+        red[wave] = mass;
+    }
+    __syncthreads();
+    nf = redi[0] + redi[1] + redi[2] + redi[3];
+    mass = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    if (lane == 0) red[wave] = total;
+    __syncthreads();
+    total = red[0] + red[1] + red[2] + red[3];
+    const bool again = nf > 0 && mass > share * total;
+    for (int a = tid; a < m; a += 256)
+        if (fx[a] == 2.0) fx[a] = again ? 1.0 : 0.0;
+    __syncthreads();
+    if (!again) break;
+    } // face
+    for (int i = tid; i < m; i += 256) dout[(int64_t)r * cap + i] = y[i];
+}
+
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
                          const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st, int maxm,
                          const NewtonFaces *faces, const uint8_t *fix, const double *dfix) {
     // maxm: largest block of this call, as far as the host knows it (0 = unknown): sizes the LDS of a workgroup
     int mcap = maxm <= 0 || maxm > cap ? cap : maxm;
     mcap = (mcap + 31) / 32 * 32;
-    const size_t lds = sizeof(double) * ((size_t)6 * mcap + 32 * 33 + 32 + (size_t)std::max(mcap - 32, 32) * 33);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_newton_chol), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const NewtonFaces nf = faces ? *faces : NewtonFaces{};
-    hipLaunchKernelGGL(k_newton_chol, dim3((unsigned)R), dim3(256), lds, st, H, hoff, mt, msz, s1, s2, gF, pgF, cap, dout, Sdiag, mcap, nf.F, nf.X,
-                       nf.kind, nf.Qp, nf.share, nf.rounds, fix, dfix);
+    // blocks of up to 128 entries: the matrix in LDS (k_newton_chol_lds); larger ones: the blocked kernel on the global block
+    const int msmall = mcap < 128 ? mcap : 128;
+    {
+        const size_t lds = sizeof(double) * ((size_t)msmall * (msmall + 1) + 5 * (size_t)msmall + 32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_newton_chol_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_newton_chol_lds, dim3((unsigned)R), dim3(256), lds, st, H, hoff, mt, msz, s1, s2, gF, pgF, cap, dout, Sdiag, msmall, nf.F,
+                           nf.X, nf.kind, nf.Qp, nf.share, nf.rounds, fix, dfix);
+    }
+    if (mcap > 128) {
+        const size_t lds = sizeof(double) * ((size_t)6 * mcap + 32 * 33 + 32 + (size_t)std::max(mcap - 32, 32) * 33);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_newton_chol), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_newton_chol, dim3((unsigned)R), dim3(256), lds, st, H, hoff, mt, msz, s1, s2, gF, pgF, cap, dout, Sdiag, mcap, nf.F, nf.X,
+                           nf.kind, nf.Qp, nf.share, nf.rounds, fix, dfix, 128);
+    }
 }
 
 } // namespace gml

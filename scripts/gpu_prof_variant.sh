@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 tag=$1; shift
 o=gpurun_out/prof_$tag
 rm -rf $o; mkdir -p $o
-export GML_LIB_OVERRIDE=gpurun_ab/libgml_$tag.so
+[ "$tag" = tree ] || export GML_LIB_OVERRIDE=gpurun_ab/libgml_$tag.so
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/p -- python3 scripts/gpu_shard_trace.py ${@:-128 i8w 0 5} > $o/log.txt 2>&1
 f=$(find $o/p -name "*kernel_stats.csv" | head -1); cp "$f" $o/kernel_stats.csv
 rm -rf $o/p
