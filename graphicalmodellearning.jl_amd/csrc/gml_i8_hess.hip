@@ -26,11 +26,12 @@ namespace gml {
 // ------------------------------------------------------------------------------------------
 constexpr int HL = 2;
 
-// bits by which a row's weights are shifted down so that its largest fits 15 bits (mm = the row's largest |V| in the unit of the
-// planes, as its last pass recorded it; RPLE: h <= 2 |V|)
+// bits by which a row's weights are shifted down so that its largest fits 15 bits.  exp forms: mm = the row's largest |V| in the unit
+// of the planes, as its last pass recorded it.  RPLE: the passes do not record it, and need not: tau comes from the bound 2 w_max,
+// which the weights of a well-classified configuration reach, and h = 4 w sig (1 - sig) <= w_max = half the planes' range (2^30).
 __device__ __forceinline__ int hw_shift(unsigned mm, int form) {
-    const unsigned long long top = ((unsigned long long)mm + 1ull) << (form == 2 ? 1 : 0);
-    const int bits = 64 - __clzll(top);
+    if (form == 2) return 16;
+    const int bits = 64 - __clzll((unsigned long long)mm + 1ull);
     return bits > 15 ? bits - 15 : 0;
 }
 
@@ -503,11 +504,8 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
     if (Kh > pitch) Kh = pitch;
     if (w->hKh != pitch || w->hrows < Rp) {
         if (w->Hq) (void)dev_free(w->Hq);
-        if (w->hS) (void)dev_free(w->hS);
         w->Hq = nullptr;
-        w->hS = nullptr;
         I8CHK(dev_malloc(&w->Hq, (size_t)Rp * HL * pitch));
-        I8CHK(dev_malloc(&w->hS, sizeof(long long) * Rp));
         w->hKh = pitch;
         w->hrows = Rp;
     }
@@ -516,7 +514,7 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
         I8CHK(hipMemsetAsync(w->Mb, 0, (size_t)d.Qp * (d.Kp / 8), st));
         hipLaunchKernelGGL(k_build_mb, dim3((unsigned)d.Qfp, (unsigned)((d.Kp / 64 + 255) / 256)), dim3(256), 0, st, d.Xtb, d.Kp / 64, w->Mb);
     }
-    const int64_t need = htotal;
+    const int64_t need = htotal + Rp; // the integer blocks, then the rows' weight sums: cleared by one fill
     if (need > w->hcap_elems) {
         if (w->H64) (void)dev_free(w->H64);
         w->H64 = nullptr;
@@ -524,19 +522,19 @@ int i8_hessian(void *wsp, const DevProblem &d, const int *dRowcol /* row -> node
         w->hcap_elems = need;
     }
     I8CHK(hipMemsetAsync(w->H64, 0, sizeof(long long) * need, st));
-    I8CHK(hipMemsetAsync(w->hS, 0, sizeof(long long) * Rp, st));
+    long long *hS = w->H64 + htotal;
     hipLaunchKernelGGL(k_make_hw, dim3((unsigned)((Kh / 4 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->Vq, d.Sb, d.w, w->sc[0].tau, w->sc[0].mmax,
-                       dRowcol, dVslot, dFlag, d.Kp, pitch, kstride, Kh, form, w->Hq, w->hS, w->LBT, w->vpl0(), w->vscale());
+                       dRowcol, dVslot, dFlag, d.Kp, pitch, kstride, Kh, form, w->Hq, hS, w->LBT, w->vpl0(), w->vscale());
     HessTiles rows_only = tl; // (the tiles are all of one size class: the other launch covers the rows' own blocks only)
     rows_only.n = 0;
     if (maxsmall > 0) launch_hess_small(w, d, dF, dMt, dHoff, R, cap, Kh, kstride, nsmall, st, tiles_small ? tl : rows_only);
     if (maxm > kHessSmall) launch_hess_blk<4>(w, d, dF, dMt, dHoff, R, cap, maxm, Kh, kstride, nlarge, st, tiles_small ? rows_only : tl);
-    hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64, w->hS,
+    hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((maxm * 32 * maxm * 32 + 255) / 256), (unsigned)R), dim3(256), 0, st, w->H64, hS,
                        w->sc[0].tau, w->sc[0].mmax, form, dVslot, dMt, dHoff, dH, 0, R, tl.wrow, w->vscale());
     const int tm = tl.T / 32;
     for (int64_t y0 = 0; y0 < tl.n; y0 += 8192)
         hipLaunchKernelGGL(k_hess_i8_fin, dim3((unsigned)((tm * 32 * tm * 32 + 255) / 256), (unsigned)std::min<int64_t>(8192, tl.n - y0)), dim3(256),
-                           0, st, w->H64, w->hS, w->sc[0].tau, w->sc[0].mmax, form, dVslot, dMt, dHoff, dH, (int)(R + y0), R, tl.wrow, w->vscale());
+                           0, st, w->H64, hS, w->sc[0].tau, w->sc[0].mmax, form, dVslot, dMt, dHoff, dH, (int)(R + y0), R, tl.wrow, w->vscale());
     I8CHK(hipGetLastError());
     return GML_OK;
 }

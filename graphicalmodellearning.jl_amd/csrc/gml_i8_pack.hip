@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
                                                      int8_t *__restrict__ Tq, double *__restrict__ sigma,
                                                      double *__restrict__ tau, double *__restrict__ invtau,
                                                      long long *__restrict__ qconst, long long *__restrict__ qconst2, const double *__restrict__ tauovr,
+                                                     const double *__restrict__ tauovr_lnrow,
                                                      double vdiv /* largest |V| / tau the planes of this pass hold */,
                                                      double vsrc_scale /* hv: unit of the V planes read, in multiples of tauV */) {
     const int r = slot0 + blockIdx.x; // slot
@@ -257,7 +258,10 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
             // theta); the caller then re-runs the row with tau taken from the largest |V| the first pass saw, and
             // the solver passes max|V| of its previous pass times exp(||step||_1), which bounds the new weights.
             t = B * (1.0 + 1e-12) / vdiv;
-            if (tauovr && tauovr[r] > 0.0 && tauovr[r] < t) t = tauovr[r]; // a tighter rigorous scale from the caller
+            if (tauovr && tauovr[r] > 0.0) { // a tighter rigorous scale from the caller
+                const double to = tauovr_lnrow ? tauovr[r] * exp(tauovr_lnrow[srow[r]]) : tauovr[r];
+                if (to < t) t = to;
+            }
             it = 1.0 / t;
         }
         sigma[r] = sg;
@@ -273,7 +277,7 @@ void launch_quant_theta(int LF, int ns, const I8Pass &a, const DevProblem &d, in
                         double vdiv, double vsrc_scale, hipStream_t st) {
 #define QUANT(LFV)                                                                                                                    \
     hipLaunchKernelGGL((k_quant_theta<LFV>), dim3(ns), dim3(256), 0, st, a.theta, a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.cconst,   \
-                       d.wmax, a.form, hv, a.vmap, tauV, Tq, sc.sigma, sc.tau, sc.invtau, sc.qconst, sc.qconst2, a.tauovr, vdiv, vsrc_scale)
+                       d.wmax, a.form, hv, a.vmap, tauV, Tq, sc.sigma, sc.tau, sc.invtau, sc.qconst, sc.qconst2, a.tauovr, a.tauovr_lnrow, vdiv, vsrc_scale)
     switch (LF) {
     case 2: QUANT(2); break;
     case 3: QUANT(3); break;

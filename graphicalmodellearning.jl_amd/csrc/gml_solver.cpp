@@ -72,7 +72,7 @@ struct Arena {
 // stream is waited for.  A transfer too large for the arena goes the plain way and is waited for at once.
 struct Stage {
     char *base = nullptr;
-    size_t cap = 0, off = 0;
+    size_t cap = 0, off = 0, floor = 0; // [0, floor): arrays that live as long as the solve (persist); the rest is recycled at every sync()
     hipStream_t st = nullptr;
     struct Pend {
         void *host;
@@ -85,6 +85,23 @@ struct Stage {
         if (a + n > cap) return nullptr;
         off = a + n;
         return base + a;
+    }
+    // Zero-copy: the arena is pinned, mapped host memory, so a kernel can read its control data from it and write its per-row results
+    // into it directly.  On small node shards an iteration is a chain of short launches, and every hipMemcpyAsync in it was a 4-us blit
+    // kernel plus 5 us of host time (profiles/r5_shard128_trace_before.txt: 15 per iteration).
+    // persist: an array the kernels write and the host reads after sync(), for the whole solve (before the first take only)
+    template <typename T> T *persist(size_t count) {
+        const size_t a = (floor + 63) & ~(size_t)63;
+        if (a + sizeof(T) * count > cap / 2) return nullptr;
+        floor = a + sizeof(T) * count;
+        if (off < floor) off = floor;
+        return reinterpret_cast<T *>(base + a);
+    }
+    // put: control data for kernels queued before the next sync(); NULL when it does not fit (the caller copies to a device buffer)
+    template <typename T> const T *put(const T *host, size_t count) {
+        void *q = sizeof(T) * count <= cap / 4 ? take(sizeof(T) * std::max<size_t>(count, 1)) : nullptr;
+        if (q && count) std::memcpy(q, host, sizeof(T) * count);
+        return reinterpret_cast<const T *>(q);
     }
     hipError_t h2d(void *dev, const void *host, size_t n) {
         if (n == 0) return hipSuccess;
@@ -107,7 +124,7 @@ struct Stage {
         const hipError_t e = hipStreamSynchronize(st);
         for (const Pend &x : pend) std::memcpy(x.host, x.pin, x.n);
         pend.clear();
-        off = 0;
+        off = floor;
         return e;
     }
 };
@@ -154,6 +171,7 @@ struct Solver {
     Stage stg;
     Arena A;
     PhaseTimer dir_time;
+    double t_dir_host = 0; // host time between the two marks of the direction phases (launches, and the waits of the CG steps)
     const int64_t R, Rp, Qp, P;
     const size_t nd;
     int capW = 0, capP = 0;
@@ -217,8 +235,17 @@ struct Solver {
     std::vector<double> f, ft, Fobj, kkt, best, Z, Zt, alpha, dd, fn, fnt, l1t, Fbest;
     std::vector<uint8_t> done, vstale, atfloor, nreg, accepted_fwd, need, iscg;
     std::vector<int> stall, msz, nW, vslot, vprev, owner, pslot;
-    std::vector<SelectOut> sel;
-    std::vector<TrialOut> trial;
+    // per-row results of k_select / k_trial + k_back / the passes' last kernels: written by the kernels straight into pinned host
+    // memory (Stage::persist) and read here after the stream has been waited for; device arrays + one download each when the
+    // pinned arena is too small for them (tens of thousands of local rows)
+    SelectOut *sel = nullptr, *kSel = nullptr;
+    TrialOut *trial = nullptr, *kTrial = nullptr;
+    SlotResult *res = nullptr, *kRes = nullptr;
+    std::vector<SelectOut> sel_v;
+    std::vector<TrialOut> trial_v;
+    std::vector<SlotResult> res_v;
+    bool zc = false;
+    double *dStepn = nullptr; // |trial - x|_1 by row, left on the device by k_trial: scales the weights' unit of the trial pass (k_quant_theta)
     int64_t slot_next = 0;
     // Scale of the fixed-point V (int8 path): instead of the worst-case bound w_max exp(sum|theta|) every pass after a row's
     // first uses vref = max_k |V_rk| measured by its previous pass, times exp(||theta - theta_ref||_1), which bounds the new
@@ -247,6 +274,22 @@ struct Solver {
         if (!rows.empty()) HIPCHK(stg.h2d(dst, rows.data(), sizeof(int) * rows.size()));
         return GML_OK;
     }
+    // a row list (or any small control array) for kernels queued before the next wait: read from the pinned arena where it fits,
+    // else uploaded to `fallback`
+    template <typename T> int ctl(const std::vector<T> &v, T *fallback, const T **out) {
+        *out = fallback;
+        if (v.empty()) return GML_OK;
+        if (const T *q = stg.put(v.data(), v.size())) {
+            *out = q;
+            return GML_OK;
+        }
+        HIPCHK(stg.h2d(fallback, v.data(), sizeof(T) * v.size()));
+        return GML_OK;
+    }
+    int fetch(void *host, const void *dev, size_t bytes) { // results the kernels left in device arrays (not zero-copy)
+        if (!zc) HIPCHK(stg.d2h(host, dev, bytes));
+        return GML_OK;
+    }
 
     int init();
     void set_kh(int64_t nactive, int maxm = 512);
@@ -256,7 +299,7 @@ struct Solver {
     // the pass and before the host waits for it (the acceptance scalars of a trial ride along with the pass results).
     int run_pass(const std::vector<int> &rows, const double *src, double *dst, bool want_grad, bool at_trial, std::vector<double> &fo,
                  std::vector<double> &zo, std::vector<double> &no, const std::vector<double> *ovr_in, int depth, int pp,
-                 const std::function<int()> *after = nullptr);
+                 const std::function<int()> *after = nullptr, bool step_on_device = false);
     int select(int it, int64_t *nactive);
     int start_polish(bool *started);
     int refresh_stale();
@@ -305,6 +348,7 @@ int Solver::init() {
     stg.base = p->stage;
     stg.cap = p->stage_bytes;
     stg.st = st;
+    stg.off = stg.floor = 0;
     dir_time.st = st;
     stats.lambda = lambda;
     prec = o.precision;
@@ -361,6 +405,31 @@ int Solver::init() {
     HIPCHK(A.get(&dSdiag, (size_t)Rp));
     HIPCHK(A.get(&dSel, (size_t)Rp));
     HIPCHK(A.get(&dTrial, (size_t)Rp));
+    HIPCHK(A.get(&dStepn, (size_t)Rp));
+    HIPCHK(hipMemsetAsync(dStepn, 0, sizeof(double) * Rp, st));
+    sel = stg.persist<SelectOut>((size_t)Rp);
+    trial = stg.persist<TrialOut>((size_t)Rp);
+    res = stg.persist<SlotResult>((size_t)Scap);
+    zc = sel && trial && res;
+    if (zc) {
+        kSel = sel;
+        kTrial = trial;
+        kRes = res;
+        std::memset(sel, 0, sizeof(SelectOut) * Rp);
+        std::memset(trial, 0, sizeof(TrialOut) * Rp);
+        std::memset(res, 0, sizeof(SlotResult) * Scap);
+    } else {
+        stg.off = stg.floor = 0;
+        sel_v.resize((size_t)Rp);
+        trial_v.resize((size_t)Rp);
+        res_v.resize((size_t)Scap);
+        sel = sel_v.data();
+        trial = trial_v.data();
+        res = res_v.data();
+        kSel = dSel;
+        kTrial = dTrial;
+        kRes = dRes;
+    }
     HIPCHK(hipMemsetAsync(X, 0, sizeof(double) * nd, st));
     HIPCHK(hipMemsetAsync(Xb, 0, sizeof(double) * nd, st));
     HIPCHK(hipMemsetAsync(G, 0, sizeof(double) * nd, st));
@@ -395,8 +464,6 @@ int Solver::init() {
     vprev.assign((size_t)R, -1);
     pslot.assign((size_t)R, -1);
     owner.assign((size_t)Scap, -1);
-    sel.resize((size_t)Rp);
-    trial.resize((size_t)Rp);
     vref.assign((size_t)R, 0.0);
     dref.assign((size_t)R, 0.0);
     stepn.assign((size_t)R, 0.0);
@@ -443,7 +510,7 @@ void Solver::set_kh(int64_t nactive, int maxm) {
 
 int Solver::run_pass(const std::vector<int> &rows, const double *src, double *dst, bool want_grad, bool at_trial, std::vector<double> &fo,
                      std::vector<double> &zo, std::vector<double> &no, const std::vector<double> *ovr_in, int depth, int pp,
-                     const std::function<int()> *after) {
+                     const std::function<int()> *after, bool step_on_device) {
     const int64_t n = (int64_t)rows.size();
     if (n == 0) return GML_OK;
     const double t0 = gml_now_s();
@@ -514,8 +581,8 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
             srow[q] = r;
             rowcol[q] = (int)(p->node0 + r);
             if (ovr_in) ovr[q] = (*ovr_in)[r];
-            else if (track && vref[r] > 0.0)
-                ovr[q] = vref[r] * std::exp(dref[r] + (at_trial ? stepn[r] : 0.0)) * (1.0 + 1e-6) / i8_vdiv(wide);
+            else if (track && vref[r] > 0.0) // (step_on_device: times exp(|trial - x|_1), which k_trial left in dStepn)
+                ovr[q] = vref[r] * std::exp(dref[r] + (at_trial && !step_on_device ? stepn[r] : 0.0)) * (1.0 + 1e-6) / i8_vdiv(wide);
         }
         {
             int k = 0;
@@ -538,7 +605,8 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         a.F = dFs;
         a.G = dst;
         a.tauovr = rebase(reinterpret_cast<const double *>(dPass + ioff), lo);
-        a.res = dRes;
+        a.tauovr_lnrow = !ovr_in && track && step_on_device ? dStepn : nullptr;
+        a.res = kRes;
         a.lf = o.limbs_fwd;
         a.wide = wide;
         a.coarse = coarse_on;
@@ -546,17 +614,18 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         int rc = i8_pass(&p->i8ws, d, Scap, a, st, nullptr, &err);
         if (rc) return fail(rc, "%s", err.c_str());
         if (formulation == GML_LOGRISE && want_grad) // grad log Z = grad Z / Z (:279), Z from the pass results on the device
-            launch_scale_slots_inv(a.srow, a.rowcol, (int)lo, (int)ns, dRes, Qp, dst, st);
-        std::vector<SlotResult> rr((size_t)ns);
-        HIPCHK(stg.d2h(rr.data(), dRes + lo, sizeof(SlotResult) * ns));
+            launch_scale_slots_inv(a.srow, a.rowcol, (int)lo, (int)ns, kRes, Qp, dst, st);
+        RCCHK(fetch(res + lo, dRes + lo, sizeof(SlotResult) * ns));
         if (after) RCCHK((*after)());
         HIPCHK(hipGetLastError());
         HIPCHK(stg.sync());
+        if (step_on_device) // (the trial's scalars came down with the pass)
+            for (int64_t a2 = 0; a2 < n; ++a2) stepn[rows[a2]] = trial[rows[a2]].stepn;
         fh.resize((size_t)n);
         tauh.resize((size_t)n);
         mmh.resize((size_t)n);
         for (int64_t a2 = 0; a2 < n; ++a2) {
-            const SlotResult &q = rr[(size_t)(slot[a2] - lo)];
+            const SlotResult &q = res[(size_t)slot[a2]];
             fh[a2] = q.f;
             tauh[a2] = q.tau;
             mmh[a2] = q.mmax;
@@ -597,6 +666,8 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         if (after) RCCHK((*after)());
         HIPCHK(hipGetLastError());
         HIPCHK(stg.sync());
+        if (step_on_device)
+            for (int64_t a2 = 0; a2 < n; ++a2) stepn[rows[a2]] = trial[rows[a2]].stepn;
     }
     std::vector<int> again;
     std::vector<double> ovr2;
@@ -656,10 +727,11 @@ int Solver::select(int it, int64_t *nactive_out) {
     std::vector<int> act;
     for (int64_t r = 0; r < R; ++r)
         if (!done[r]) act.push_back((int)r);
-    RCCHK(upload_rows(act, dRows));
+    const int *rows_k = nullptr;
+    RCCHK(ctl(act, dRows, &rows_k));
     trace("select");
-    launch_select(dRows, (int)act.size(), X, G, kind, Qp, lambda, o.max_add, capW, capP, viol_frac, PG, dFidx, dgF, dpgF, dSel, dBest, Xb, st);
-    HIPCHK(stg.d2h(sel.data(), dSel, sizeof(SelectOut) * Rp));
+    launch_select(rows_k, (int)act.size(), X, G, kind, Qp, lambda, o.max_add, capW, capP, viol_frac, PG, dFidx, dgF, dpgF, kSel, dBest, Xb, st);
+    RCCHK(fetch(sel, dSel, sizeof(SelectOut) * Rp));
     HIPCHK(hipGetLastError());
     HIPCHK(stg.sync());
     int64_t nactive = 0, ncg = 0;
@@ -905,7 +977,9 @@ int Solver::direction_blocks(const std::vector<int> &cg_rows) {
         tl.wrow = dWrow;
         tl.hflag = dWrow + ntiles;
     }
-    HIPCHK(hipMemsetAsync(dH, 0, sizeof(double) * htotal, st));
+    // (the int8 kernel's finalisation writes every lower tile of the rows' blocks and the solve reads nothing else of them; the FP64
+    // kernel accumulates in place, and the tiles' inverses read whole tiles)
+    if (!gml_is_i8(prec) || ntiles > 0) HIPCHK(hipMemsetAsync(dH, 0, sizeof(double) * htotal, st));
     trace("hessian");
     if (gml_is_i8(prec) || ntiles > 0) {
         std::string err;
@@ -930,11 +1004,12 @@ int Solver::newton_blocks(const std::vector<int> &chol_rows) {
     trace("cholesky");
     int maxm = 1;
     for (int r : chol_rows) maxm = std::max(maxm, msz[r]);
-    RCCHK(upload_rows(chol_rows, dRows));
+    const int *rows_k = nullptr;
+    RCCHK(ctl(chol_rows, dRows, &rows_k));
     // (a block over every configuration is the Hessian itself: nothing to correct -- and a secant over a finite step would spoil it)
     const bool secant = use_secant && Kh < d.Kp;
     if (secant)
-        launch_secant(dRows, (int)chol_rows.size(), dFidx, dMt + 2 * R, capP, X, Qp, dgF, dH, dHoff, dMt, dS1, s2, dYnoise, dFprev, dMprev, dXprev, dGprev,
+        launch_secant(rows_k, (int)chol_rows.size(), dFidx, dMt + 2 * R, capP, X, Qp, dgF, dH, dHoff, dMt, dS1, s2, dYnoise, dFprev, dMprev, dXprev, dGprev,
                       dSec, dSec + 2 * Rp * capP, dNpairs, Rp * (int64_t)capP, st);
     if (secant && o.verbose >= 2) {
         std::vector<int> npv((size_t)Rp);
@@ -957,7 +1032,7 @@ int Solver::newton_blocks(const std::vector<int> &chol_rows) {
     nf.rounds = (double)p->K * (double)Qp >= 268435456.0 ? face_rounds : 0;
     if (g_tune[GML_TUNE_FACE_ROUNDS] > 0) nf.rounds = (int)g_tune[GML_TUNE_FACE_ROUNDS] - 1;
     launch_newton_solve(dH, dHoff, dMt, dMt + 2 * R, dS1, s2, dgF, dpgF, (int)R, capP, dsol, dSdiag, st, maxm, &nf);
-    launch_scatter_dir(dRows, (int)chol_rows.size(), dFidx, dsol, dMt + 2 * R, capP, Qp, D, st);
+    launch_scatter_dir(rows_k, (int)chol_rows.size(), dFidx, dsol, dMt + 2 * R, capP, Qp, D, st);
     HIPCHK(hipGetLastError());
     return GML_OK;
 }
@@ -1205,29 +1280,43 @@ int Solver::line_search() {
         for (int64_t r = 0; r < R; ++r)
             if (need[r]) rows.push_back((int)r);
         if (rows.empty()) break;
-        RCCHK(upload_rows(rows, dRows));
-        HIPCHK(stg.h2d(dAlpha, alpha.data(), sizeof(double) * R));
+        const int *rows_k = nullptr;
+        const double *alpha_k = nullptr;
+        RCCHK(ctl(rows, dRows, &rows_k));
+        RCCHK(ctl(alpha, dAlpha, &alpha_k));
         trace("trial");
-        launch_trial(dRows, (int)rows.size(), X, D, PG, kind, Qp, lambda, dAlpha, Xt, dTrial, st);
-        HIPCHK(stg.d2h(trial.data(), dTrial, sizeof(TrialOut) * Rp));
-        HIPCHK(hipGetLastError());
-        HIPCHK(stg.sync());
+        launch_trial(rows_k, (int)rows.size(), X, D, PG, kind, Qp, lambda, alpha_k, Xt, kTrial, dStepn, st);
+        // The first trial of an iteration is a full pass whatever the trial's scalars say, and the one thing the pass needs of them --
+        // |trial - x|_1, which scales the unit of its weights -- is applied on the device (k_quant_theta): the host does not wait here,
+        // the scalars come down with the results of the pass.  Later trials choose their kind of pass from the scalars.
+        const bool early = ls > 0;
+        auto read_trial = [&]() {
+            for (int r : rows) {
+                dd[r] = trial[r].dd;
+                stepn[r] = trial[r].stepn; // ||trial - x||_1: bounds the change of every energy
+                l1t[r] = trial[r].l1t;
+                nreg[r] = !(-0.1 * dd[r] > 8.0 * fn[r]); // the step's expected decrease (~|dd|/2) vs the uncertainty of f
+            }
+        };
         bool anynoise = false;
-        for (int r : rows) {
-            dd[r] = trial[r].dd;
-            stepn[r] = trial[r].stepn; // ||trial - x||_1: bounds the change of every energy
-            l1t[r] = trial[r].l1t;
-            nreg[r] = !(-0.1 * dd[r] > 8.0 * fn[r]); // the step's expected decrease (~|dd|/2) vs the uncertainty of f
-            anynoise |= nreg[r] != 0;
+        if (early) {
+            RCCHK(fetch(trial, dTrial, sizeof(TrialOut) * Rp));
+            HIPCHK(hipGetLastError());
+            HIPCHK(stg.sync());
+            read_trial();
+            for (int r : rows) anynoise |= nreg[r] != 0;
         }
         const bool full = (ls == 0) || anynoise;
         // a full pass is followed on the stream by the directional derivatives back towards x: both come down in one wait
         const std::function<int()> back = [&]() -> int {
-            launch_back(dRows, (int)rows.size(), X, Xt, Gt, kind, Qp, lambda, dTrial, st);
-            HIPCHK(stg.d2h(trial.data(), dTrial, sizeof(TrialOut) * Rp));
+            const int *rk = nullptr; // (listed again: a re-run of some rows repeats this after a wait, which recycles the arena)
+            RCCHK(ctl(rows, dRows, &rk));
+            launch_back(rk, (int)rows.size(), X, Xt, Gt, kind, Qp, lambda, kTrial, st);
+            RCCHK(fetch(trial, dTrial, sizeof(TrialOut) * Rp));
             return GML_OK;
         };
-        RCCHK(run_pass(rows, Xt, Gt, full, true, ft, Zt, fnt, nullptr, 0, prec, full ? &back : nullptr));
+        RCCHK(run_pass(rows, Xt, Gt, full, true, ft, Zt, fnt, nullptr, 0, prec, full ? &back : nullptr, !early));
+        if (!early) read_trial();
         std::vector<int> acc;
         for (int r : rows) {
             bool ok;
@@ -1269,8 +1358,9 @@ int Solver::line_search() {
             for (int r : rows) nn += nreg[r] != 0;
             fprintf(stderr, "[gml]   ls %2d: %zu rows (%d in the noise regime), %zu accepted, %s pass\n", ls, rows.size(), nn, acc.size(), full ? "full" : "forward");
         }
-        RCCHK(upload_rows(acc, dRows2));
-        launch_copy_rows(dRows2, (int)acc.size(), Qp, Xt, X, full ? Gt : nullptr, G, st);
+        const int *acc_k = nullptr;
+        RCCHK(ctl(acc, dRows2, &acc_k));
+        launch_copy_rows(acc_k, (int)acc.size(), Qp, Xt, X, full ? Gt : nullptr, G, st);
         HIPCHK(hipGetLastError());
     }
     // rows accepted on an objective-only trial still need their gradient (and V)
@@ -1326,6 +1416,9 @@ int Solver::finish(double *out, double *kkt_out, int iterations) {
     stats.max_kkt = maxk;
     stats.not_converged = notconv;
     stats.t_hess = dir_time.seconds();
+    // (the host does not wait at the end of the direction phase: what of it was still running when the first trial pass was queued
+    // shows up in that pass's host-side wait)
+    stats.t_pass = std::max(0.0, stats.t_pass - std::max(0.0, stats.t_hess - t_dir_host));
     if (notconv)
         return fail(GML_ENOTCONV, "%d of %lld nodes did not reach the KKT tolerance %.1e (worst %.3e)", notconv, (long long)R, o.tol, maxk);
     return GML_OK;
@@ -1388,11 +1481,13 @@ int Solver::iterate(double *out, double *kkt_out) {
         for (int64_t r = 0; r < R; ++r)
             if (!done[r]) (iscg[r] ? cg_rows : chol_rows).push_back((int)r);
         dir_time.mark();
+        const double t_dir0 = gml_now_s();
         RCCHK(direction_blocks(cg_rows));
         RCCHK(newton_blocks(chol_rows));
         RCCHK(newton_cg(cg_rows));
         trace("directions done");
         dir_time.mark();
+        t_dir_host += gml_now_s() - t_dir0;
         RCCHK(line_search());
     }
     return finish(out, kkt_out, it);

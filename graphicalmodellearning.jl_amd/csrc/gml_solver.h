@@ -61,7 +61,7 @@ void launch_secant(const int *drows, int nrows, const int *F, const int *msz, in
                    const long long *hoff, const int *mt, const double *s1, double s2, const double *ynoise, int *Fprev, int *mprev, double *xprev,
                    double *gprev, double *S, double *Y, int *npairs, int64_t pair_stride, hipStream_t st);
 void launch_trial(const int *drows, int nrows, const double *X, const double *D, const double *PG, const uint8_t *kind, int64_t Qp,
-                  double lambda, const double *alpha, double *Xt, TrialOut *out, hipStream_t st);
+                  double lambda, const double *alpha, double *Xt, TrialOut *out, double *stepn, hipStream_t st);
 void launch_back(const int *drows, int nrows, const double *X, const double *Xt, const double *Gt, const uint8_t *kind, int64_t Qp,
                  double lambda, TrialOut *out, hipStream_t st);
 void launch_cg_tiles(const int *drows, int nrows, const double *X, const double *PG, const double *G, const uint8_t *kind, int64_t Qp, int T,

@@ -443,7 +443,8 @@ void launch_secant(const int *drows, int nrows, const int *F, const int *msz, in
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_trial(const int *__restrict__ rows, const double *__restrict__ X, const double *__restrict__ D,
                                                const double *__restrict__ PG, const uint8_t *__restrict__ kind, int64_t Qp, double lambda,
-                                               const double *__restrict__ alpha, double *__restrict__ Xt, TrialOut *__restrict__ out) {
+                                               const double *__restrict__ alpha, double *__restrict__ Xt, TrialOut *__restrict__ out,
+                                               double *__restrict__ stepn /* [rows] or NULL: |xt - x|_1 again, for the trial pass on the device */) {
     const int r = rows[blockIdx.x];
     const int tid = threadIdx.x;
     const double *x = X + (int64_t)r * Qp, *d = D + (int64_t)r * Qp, *pg = PG + (int64_t)r * Qp;
@@ -496,11 +497,12 @@ __global__ __launch_bounds__(256) void k_trial(const int *__restrict__ rows, con
         o.l1t = l1;
         o.back = 0.0;
         out[r] = o;
+        if (stepn) stepn[r] = sn;
     }
 }
 void launch_trial(const int *drows, int nrows, const double *X, const double *D, const double *PG, const uint8_t *kind, int64_t Qp,
-                  double lambda, const double *alpha, double *Xt, TrialOut *out, hipStream_t st) {
-    if (nrows > 0) hipLaunchKernelGGL(k_trial, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, D, PG, kind, Qp, lambda, alpha, Xt, out);
+                  double lambda, const double *alpha, double *Xt, TrialOut *out, double *stepn, hipStream_t st) {
+    if (nrows > 0) hipLaunchKernelGGL(k_trial, dim3((unsigned)nrows), dim3(256), 0, st, drows, X, D, PG, kind, Qp, lambda, alpha, Xt, out, stepn);
 }
 
 // back[r] = F'(xt; x - xt): directional derivative of F at the trial point back towards x (gradient Gt at xt).  F is
