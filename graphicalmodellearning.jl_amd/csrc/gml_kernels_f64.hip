@@ -716,46 +716,80 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
     const double *A = H + hoff[r];
     const double sc = s1[r];
     const double *g = gF + (int64_t)r * cap, *pg = pgF + (int64_t)r * cap;
-    extern __shared__ double sm[]; // W [mcap][mcap + 1] | idg | y | gg | fx | dfx [mcap each] | tmp [32]
-    double *W = sm, *idg = W + mcap * LDW, *y = idg + mcap, *gg = y + mcap, *fx = gg + mcap, *dfx = fx + mcap, *tmp = dfx + mcap;
+    extern __shared__ double sm[]; // W [mcap][mcap + 1] | idg | y | gg | fx | dfx [mcap each]
+    double *W = sm, *idg = W + mcap * LDW, *y = idg + mcap, *gg = y + mcap, *fx = gg + mcap, *dfx = fx + mcap;
+    __shared__ double part8[8 * 32];
     __shared__ int bad;
     __shared__ double red[4];
     __shared__ int redi[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool masked = fix != nullptr || F != nullptr; // some entries may be fixed
+#ifdef CHOL_TIMING
+    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = __builtin_amdgcn_s_memrealtime(), tn;
+#define TMARK(i) do { tn = __builtin_amdgcn_s_memrealtime(); tm[i] += tn - tq; tq = tn; } while (0)
+#else
+#define TMARK(i)
+#endif
+    // one global round trip: the lower triangle of s1 H straight into W, eight independent loads per thread and turn (one element
+    // per turn, each waiting for its own load, took 28 of the 99 us of a 100-entry solve); the rank-one term, the masks and the ridge
+    // are applied in LDS
     for (int i = tid; i < m; i += 256) {
         gg[i] = s2 != 0.0 ? g[i] : 0.0;
         fx[i] = fix && fix[(int64_t)r * cap + i] ? 1.0 : 0.0;
         dfx[i] = fix ? dfix[(int64_t)r * cap + i] : 0.0;
     }
-    __syncthreads();
-    auto a_orig = [&](int i, int j) { return sc * A[(int64_t)i * hp + j] - s2 * gg[i] * gg[j]; }; // i >= j: the matrix itself
-    auto a_low = [&](int i, int j) { // ... with the fixed entries decoupled (unit diagonal)
-        if (masked && (fx[i] != 0.0 || fx[j] != 0.0)) return i == j ? 1.0 : 0.0;
-        return a_orig(i, j);
+    auto a_orig = [&](int i, int j) { return sc * A[(int64_t)i * hp + j] - s2 * gg[i] * gg[j]; }; // i >= j: the matrix itself (global)
+    auto load_raw = [&]() { // W <- sc * H on the lower triangle of the first mp rows (rows m .. mp - 1, the MFMA tile padding: zero)
+        const int total = mp * mp;
+        for (int base = 0; base < total; base += 256 * 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + tid + 256 * u, i = idx / mp, j = idx - i * mp;
+                v[u] = (idx < total && j <= i && i < m) ? A[(int64_t)i * hp + j] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + tid + 256 * u, i = idx / mp, j = idx - i * mp;
+                if (idx < total && j <= i) W[i * LDW + j] = sc * v[u];
+            }
+        }
     };
+    load_raw();
+    __syncthreads();
     double dmax = 0;
-    for (int i = tid; i < m; i += 256) dmax = fmax(dmax, fabs(a_low(i, i)));
+    for (int i = tid; i < m; i += 256) dmax = fmax(dmax, masked && fx[i] != 0.0 ? 1.0 : fabs(W[i * LDW + i] - s2 * gg[i] * gg[i]));
     for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
     if (lane == 0) red[wave] = dmax;
     __syncthreads();
     dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-    if (tid == 0) Sdiag[r] = a_orig(m - 1, m - 1);
+    if (tid == 0) Sdiag[r] = W[(m - 1) * LDW + m - 1] - s2 * gg[m - 1] * gg[m - 1];
+    bool fresh = true;              // W holds the raw block
+    bool anyfixed = fix != nullptr; // some entries are decoupled (test hook, or a face re-solve below)
     for (int face = 0;; ++face) { // (re-solves on an orthant face, see the end of the loop)
     double ridge = 0.0;
     bool ok = false;
     for (int attempt = 0; attempt < 10 && !ok; ++attempt) {
-        // W <- lower triangle of the (masked) matrix, ridge on the free diagonal; rows m .. mp - 1 (MFMA tile padding): zero
-        for (int idx = tid; idx < mp * mp; idx += 256) {
-            const int i = idx / mp, j = idx - i * mp;
-            if (j > i) continue;
-            double v = 0.0;
-            if (i < m) v = a_low(i, j) + (i == j && fx[i] == 0.0 ? ridge : 0.0);
-            W[i * LDW + j] = v;
+        if (!fresh) {
+            __syncthreads();
+            load_raw();
+            __syncthreads();
+        }
+        fresh = false;
+        // the (masked) matrix: rank-one term, fixed entries decoupled (unit diagonal), ridge on the free diagonal
+        if (s2 != 0.0 || anyfixed || ridge != 0.0) {
+            for (int idx = tid; idx < m * m; idx += 256) {
+                const int i = idx / m, j = idx - i * m;
+                if (j > i) continue;
+                double v = W[i * LDW + j] - s2 * gg[i] * gg[j];
+                if (anyfixed && (fx[i] != 0.0 || fx[j] != 0.0)) v = i == j ? 1.0 : 0.0;
+                else if (i == j) v += ridge;
+                W[i * LDW + j] = v;
+            }
         }
         for (int i = tid; i < m; i += 256) {
             double v = -pg[i];
-            if (masked) {
+            if (anyfixed) {
                 if (fx[i] != 0.0) {
                     v = dfx[i];
                 } else {
@@ -767,6 +801,7 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
         }
         if (tid == 0) bad = 0;
         __syncthreads();
+        TMARK(0);
         for (int c0 = 0; c0 < m; c0 += PW) {
             const int pw = m - c0 < PW ? m - c0 : PW;
             if (wave == 0) {
@@ -776,24 +811,24 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
                 double v[PW];
 #pragma unroll
                 for (int k = 0; k < PW; ++k) v[k] = (t < pw && k <= t) ? W[(c0 + t) * LDW + c0 + k] : 0.0;
+                // (straight-line code: a pivot that fails -- or lies beyond the block -- is replaced by 1 and remembered, so that no
+                // control flow separates the columns and the scheduler can start a pivot's chain under the previous column's updates)
                 bool fail = false;
 #pragma unroll
                 for (int c = 0; c < PW; ++c) {
-                    if (c < pw && !fail) {
-                        const double piv = readlane_f64(v[c], c);
-                        if (!(piv > 1e-300 * dmax) || !isfinite(piv)) {
-                            fail = true;
-                        } else {
-                            double inv = __builtin_amdgcn_rsq(piv);
-                            inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
-                            inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
-                            const double dgc = piv * inv;
-                            v[c] = t == c ? dgc : v[c] * inv;
-                            const double ltc = t > c ? v[c] : 0.0;
+                    double piv = readlane_f64(v[c], c);
+                    const bool live = c < pw, good = piv > 1e-300 * dmax && isfinite(piv);
+                    fail |= live && !good;
+                    piv = live && good ? piv : 1.0;
+                    // 1 / sqrt(piv): the hardware estimate + two Newton steps
+                    double inv = __builtin_amdgcn_rsq(piv);
+                    inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+                    inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+                    const double dgc = piv * inv;
+                    v[c] = t == c ? dgc : v[c] * inv;
+                    const double ltc = t > c ? v[c] : 0.0;
 #pragma unroll
-                            for (int k = c + 1; k < PW; ++k) v[k] = fma(-ltc, readlane_f64(v[c], k), v[k]);
-                        }
-                    }
+                    for (int k = c + 1; k < PW; ++k) v[k] = fma(-ltc, readlane_f64(v[c], k), v[k]);
                 }
                 if (fail) {
                     if (lane == 0) bad = 1;
@@ -823,6 +858,7 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
                 }
             }
             __syncthreads();
+            TMARK(1);
             if (bad) break;
             const int r0 = c0 + pw, nt = m - r0; // trailing rows
             if (nt <= 0) break;
@@ -844,6 +880,7 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
                 for (int c = 0; c < PW; ++c) wr[c] = x[c];
             }
             __syncthreads();
+            TMARK(2);
             // (3) trailing update W22 -= L21 L21^T in 16 x 16 MFMA tiles (I >= J) over the waves, and the rest of the right-hand side
             {
                 const int li = lane & 15, q = lane >> 4;
@@ -874,6 +911,7 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
                 }
             }
             __syncthreads();
+            TMARK(3);
         }
         __syncthreads();
         ok = !bad;
@@ -887,26 +925,41 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
     // back substitution L^T d = y, panels in reverse
     for (int c0 = (m - 1) / PW * PW; c0 >= 0; c0 -= PW) {
         const int pw = m - c0 < PW ? m - c0 : PW, r0 = c0 + pw;
-        // tmp[c] = sum_{i >= r0} L[i][c0 + c] d_i
-        for (int c = wave; c < pw; c += 4) {
+        // tmp[c] = sum_{i >= r0} L[i][c0 + c] d_i: lanes over the columns, the rows split over the eight half-waves, partial sums
+        // through LDS (no shuffles: a xor-reduction is six ds_bpermute round trips per column)
+        {
+            const int c = lane & 31, part = tid >> 5;
             double v = 0.0;
-            for (int i = r0 + lane; i < m; i += 64) v = fma(W[i * LDW + c0 + c], y[i], v);
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (lane == 0) tmp[c] = v;
+            if (c < pw)
+                for (int i = r0 + part; i < m; i += 8) v = fma(W[i * LDW + c0 + c], y[i], v);
+            part8[part * 32 + c] = v;
         }
         __syncthreads();
         if (wave == 0) {
             const int c = lane & 31;
-            double yc = c < pw ? y[c0 + c] - tmp[c] : 0.0;
-            for (int k = pw - 1; k >= 0; --k) { // d_k = y_k / L_kk; y_c -= L[c0 + k][c0 + c] d_k for c < k
-                const double dk = readlane_f64(yc, k) * idg[c0 + k];
-                if (c == k) yc = dk;
-                else if (c < k) yc = fma(-W[(c0 + k) * LDW + c0 + c], dk, yc);
+            double yc = 0.0;
+            if (c < pw) {
+                double ts = 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ts += part8[q * 32 + c];
+                yc = y[c0 + c] - ts;
+            }
+            double lc[PW], iv = c < pw ? idg[c0 + c] : 0.0; // column c of the block, below the diagonal: L[c0 + k][c0 + c], k > c
+#pragma unroll
+            for (int k = 0; k < PW; ++k) lc[k] = (k < pw && c < k) ? W[(c0 + k) * LDW + c0 + c] : 0.0;
+#pragma unroll
+            for (int k = PW - 1; k >= 0; --k) { // d_k = y_k / L_kk; y_c -= L[c0 + k][c0 + c] d_k for c < k
+                if (k < pw) {
+                    const double dk = readlane_f64(yc, k) * readlane_f64(iv, k);
+                    if (c == k) yc = dk;
+                    else yc = fma(-lc[k], dk, yc);
+                }
             }
             if (lane < pw) y[c0 + c] = yc;
         }
         __syncthreads();
     }
+    TMARK(4);
     // Orthant faces (as in k_newton_chol): entries whose step leaves the face of the iterate are fixed where the projection of the
     // line search would put them and, when they carry more than `share` of the predicted decrease, the others are solved again
     if (!F || face >= rounds) break;
@@ -948,8 +1001,15 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
         if (fx[a] == 2.0) fx[a] = again ? 1.0 : 0.0;
     __syncthreads();
     if (!again) break;
+    anyfixed = true;
     } // face
     for (int i = tid; i < m; i += 256) dout[(int64_t)r * cap + i] = y[i];
+#ifdef CHOL_TIMING
+    TMARK(5);
+    if (tid == 0 && cap >= 508)
+        for (int i = 0; i < 6; ++i) dout[(int64_t)r * cap + 500 + i] = (double)tm[i] * 0.01; // us
+#endif
+#undef TMARK
 }
 
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,

@@ -481,7 +481,13 @@ int Solver::init() {
     // sub-sampled Newton: the budget (rows x configurations) is kept roughly constant: as nodes converge, the remaining
     // ones get more configurations, up to all of them -- an inexact Hessian only costs iterations, and it costs the most on
     // the few ill-conditioned nodes that are still active at the end.
-    Kh_base = o.hess_samples == 0 ? (g_tune[GML_TUNE_KH_BASE] > 0 ? (int64_t)g_tune[GML_TUNE_KH_BASE] : 32768) : (o.hess_samples < 0 ? d.Kp : (int64_t)o.hess_samples);
+    // The base: 32 768 configurations per row, more on small node shards -- below ~2^23 row-configurations a Hessian launch costs its
+    // latency, not its work, so a shard of 128 rows takes 65 536 per row for the price of 32 768 and saves two of fourteen iterations
+    // (profiles/r5_hess_budget_sweep.txt; 1 024 rows: 32 768 -> 109 ms, 49 152 -> 113 ms, 24 576 -> 112 ms).  Like the rule above this
+    // makes a row's Newton trajectory -- not its optimum -- depend on how many rows share its GPU.
+    Kh_base = std::min<int64_t>(131072, std::max<int64_t>(32768, ((int64_t)1 << 23) / std::max<int64_t>(R, 1)));
+    if (g_tune[GML_TUNE_KH_BASE] > 0) Kh_base = (int64_t)g_tune[GML_TUNE_KH_BASE];
+    if (o.hess_samples != 0) Kh_base = o.hess_samples < 0 ? d.Kp : (int64_t)o.hess_samples;
     nblk512 = d.Kp / 512;
     set_kh(R);
     return GML_OK;

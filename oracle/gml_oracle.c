@@ -189,6 +189,57 @@ static void node_eval(const node_t *nd, int form, const double *theta, double *f
             for (int64_t j = 0; j < i; ++j) H[j * P + i] = H[i * P + j];
 }
 
+/* The Hessian of the same smooth part on the free coordinates fr[0..m) only (m x m, row-major, full): what node_eval's H holds
+ * at (fr[a], fr[b]).  The Newton step of node_solve uses nothing else of H, and K m^2 instead of K P^2 is what lets the
+ * restatement solve order-3 problems of a few hundred parameters per node in seconds (tests: n = 36, P = 631).  g: the gradient
+ * node_eval returned at theta (logRISE: Hess log Z = Hess Z / Z - g g^T). */
+static void node_hess_free(const node_t *nd, int form, const double *theta, const double *g, const int64_t *fr, int64_t m,
+                           double *HF, double *row /* scratch P */) {
+    const int64_t K = nd->K, P = nd->P;
+    memset(HF, 0, sizeof(double) * m * m);
+    double shift = 0.0;
+    if (form == GML_LOGRISE) {
+        double mx = -INFINITY;
+        for (int64_t k = 0; k < K; ++k) {
+            if (nd->counts[k] <= 0) continue;
+            stat_row(nd, k, row);
+            double E = 0;
+            for (int64_t j = 0; j < P; ++j) E += theta[j] * row[j];
+            if (-E > mx) mx = -E;
+        }
+        shift = mx;
+    }
+    double acc = 0.0;
+    double *rf = malloc(sizeof(double) * (m > 0 ? m : 1));
+    for (int64_t k = 0; k < K; ++k) {
+        double w = nd->counts[k] / nd->M;
+        if (w == 0) continue;
+        stat_row(nd, k, row);
+        double E = 0;
+        for (int64_t j = 0; j < P; ++j) E += theta[j] * row[j];
+        double h;
+        if (form == GML_RPLE) {
+            double sg = 1.0 / (1.0 + exp(2.0 * E));
+            h = 4.0 * w * sg * (1.0 - sg);
+        } else {
+            h = w * exp(-E - shift);
+            acc += h;
+        }
+        for (int64_t a = 0; a < m; ++a) rf[a] = row[fr[a]];
+        for (int64_t a = 0; a < m; ++a) {
+            double ha = h * rf[a];
+            double *Ha = HF + a * m;
+            for (int64_t b = 0; b <= a; ++b) Ha[b] += ha * rf[b];
+        }
+    }
+    free(rf);
+    if (form == GML_LOGRISE)
+        for (int64_t a = 0; a < m; ++a)
+            for (int64_t b = 0; b <= a; ++b) HF[a * m + b] = HF[a * m + b] / acc - g[fr[a]] * g[fr[b]];
+    for (int64_t a = 0; a < m; ++a)
+        for (int64_t b = 0; b < a; ++b) HF[b * m + a] = HF[a * m + b];
+}
+
 /* pseudo-gradient of f + lambda * sum_{j penalised} |x_j|  (minimum-norm subgradient) */
 static inline double pseudo_grad(double x, double g, double lam) {
     if (lam == 0.0) return g;
@@ -244,11 +295,11 @@ static double node_solve(const node_t *nd, int form, double lam, const uint8_t *
     double *xn = malloc(sizeof(double) * P), *gn = malloc(sizeof(double) * P);
     int64_t *fr = malloc(sizeof(int64_t) * P);
     double *xbest = malloc(sizeof(double) * P);
-    double f, kkt = INFINITY, best = INFINITY;
+    double f, kkt = INFINITY, best = INFINITY, Fbest = INFINITY;
     int it, stall = 0;
     memcpy(xbest, x, sizeof(double) * P);
     for (it = 0; it < maxit; ++it) {
-        node_eval(nd, form, x, &f, g, H, row);
+        node_eval(nd, form, x, &f, g, NULL, row);
         double F = f;
         kkt = 0;
         int64_t m = 0;
@@ -259,18 +310,28 @@ static double node_solve(const node_t *nd, int form, double lam, const uint8_t *
             if (fabs(pg[j]) > kkt) kkt = fabs(pg[j]);
             if (x[j] != 0.0 || pg[j] != 0.0) fr[m++] = j;
         }
+        /* progress = a smaller KKT residual (beyond its last digits) or a smaller objective (beyond its summation noise): while
+         * many coordinates still enter and leave the support -- order-3 problems with hundreds of violators -- the residual is
+         * not monotone along a converging sequence, the objective is */
+        const int fdown = F < Fbest - 1e-12 * fmax(1.0, fabs(F));
+        if (F < Fbest) Fbest = F;
         if (kkt < best) {
+            if (kkt < 0.99 * best || fdown) stall = 0;
+            else ++stall;
             best = kkt;
             memcpy(xbest, x, sizeof(double) * P);
+        } else if (fdown) {
             stall = 0;
-        } else if (++stall >= 3) {
-            break; /* at the FP64 noise floor: keep the best iterate */
+        } else {
+            ++stall;
         }
+        if (stall >= 3) break; /* at the FP64 noise floor: keep the best iterate */
         if (kkt <= tol) break;
+        node_hess_free(nd, form, x, g, fr, m, H, row); /* H: the m x m block on the free coordinates */
         double ridge = 0.0;
         for (;;) {
             for (int64_t a = 0; a < m; ++a) {
-                for (int64_t b = 0; b < m; ++b) HF[a * m + b] = H[fr[a] * P + fr[b]];
+                for (int64_t b = 0; b < m; ++b) HF[a * m + b] = H[a * m + b];
                 HF[a * m + a] += ridge;
                 d[a] = -pg[fr[a]];
             }
@@ -302,6 +363,20 @@ static double node_solve(const node_t *nd, int form, double lam, const uint8_t *
             if (Fn <= F + 1e-4 * dd + 4e-16 * fmax(1.0, fabs(F))) {
                 ok = 1;
                 break;
+            }
+            /* Below the summation noise of f (K terms: ~1e-13 relative at K = 4e4, where the expected decrease of a step at KKT
+             * 1e-7 is 1e-14) function values cannot rank the trial: it is accepted iff its KKT residual, from the gradient
+             * just evaluated, is smaller than the iterate's.  The reference's own fixtures (K <= 512) never get here. */
+            if (-dd < 1e-11 * fmax(1.0, fabs(F)) && Fn <= F + 1e-11 * fmax(1.0, fabs(F))) {
+                double kn = 0.0;
+                for (int64_t j = 0; j < P; ++j) {
+                    double pj = fabs(pseudo_grad(xn[j], gn[j], pen[j] ? lam : 0.0));
+                    if (pj > kn) kn = pj;
+                }
+                if (kn < kkt) {
+                    ok = 1;
+                    break;
+                }
             }
         }
         if (!ok) break; /* cannot improve within FP64 resolution */

@@ -20,3 +20,5 @@ for m in [int(v) for v in sys.argv[2:]]:
         _lib.check(L.gml_test_newton_solve(R, _lib._ptr(ms), cap, _lib._ptr(blocks), _lib._ptr(pg), 0.0, None, _lib._ptr(out), 0))
     want = np.linalg.solve(A, -pg[0, :m])
     print(m, "max rel err", np.abs(out[0, :m] - want).max() / np.abs(want).max())
+    if np.abs(out[0, 500:506]).max() > 0:  # a -DCHOL_TIMING build: phase times of row 0's workgroup, us
+        print("   phases us: load %.1f  diag %.1f  panel %.1f  trailing %.1f  back %.1f  out %.1f" % tuple(out[0, 500:506]))
