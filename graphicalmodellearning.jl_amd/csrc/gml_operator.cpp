@@ -104,7 +104,7 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
                        int form, int precision, bool want_grad, double *f, double *g, gml_stats *stats,
                        float *ms /* [2]: fwd, bwd or NULL */ = nullptr,
                        const std::vector<double> *tau_ovr = nullptr /* Rp per-row tau of the rescaled re-run below */,
-                       int depth = 0) {
+                       int depth = 0, bool f64_fallback = false /* rows the fixed point cannot hold go to the FP64 path (precision auto) */) {
     const int64_t R = rs.R, Qp = p->d.Qp;
     const int64_t Rp = round_up(R, 32);
     int rc = ensure_ws(p, R);
@@ -236,8 +236,15 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
                 ++nagain;
             }
         if (nagain > 0) {
-            if (depth >= 6) return fail(GML_EUNSUPPORTED, "precision i8x / i8w: the weights exp(-E) of a row underflow its fixed-point range; use precision f64");
-            return device_pass(p, rs, again, theta, form, precision, want_grad, f, g, stats, nullptr, &ovr, depth + 1);
+            if (depth >= 6) {
+                // Six rescalings did not bring the row's largest weight into the planes: energies spread over hundreds of units
+                // (|theta|_1 in the hundreds -- a far trial point of an external solver).  The reference's Float64 operator
+                // (GraphicalModelLearning.jl:191-197) returns a number there, so `auto` -- its stand-in -- evaluates these rows on
+                // the FP64 path; a caller who named an int8-limb precision gets the error.
+                if (f64_fallback) return device_pass(p, rs, again, theta, form, GML_PREC_F64, want_grad, f, g, stats);
+                return fail(GML_EUNSUPPORTED, "precision i8x / i8w: the weights exp(-E) of a row underflow its fixed-point range; use precision f64 (or auto)");
+            }
+            return device_pass(p, rs, again, theta, form, precision, want_grad, f, g, stats, nullptr, &ovr, depth + 1, f64_fallback);
         }
     }
     return GML_OK;
@@ -252,6 +259,7 @@ extern "C" int gml_objgrad_batch(gml_problem *p, int formulation, int precision,
     if (formulation < 0 || formulation > 2) return fail(GML_EINVAL, "unknown formulation %d", formulation);
     if (nrows <= 0) return fail(GML_EINVAL, "nrows must be positive");
     if (ld < p->P) return fail(GML_EINVAL, "ld %lld smaller than the %lld parameters per node", (long long)ld, (long long)p->P);
+    const bool asked_auto = precision == GML_PREC_AUTO;
     {
         const int asked = precision;
         precision = gml_resolve_precision(p, asked);
@@ -279,7 +287,7 @@ extern "C" int gml_objgrad_batch(gml_problem *p, int formulation, int precision,
         if (badrow[r]) return fail(GML_EINVAL, "theta of row %lld contains a non-finite value", (long long)r);
     std::vector<uint8_t> act((size_t)nrows, 1);
     std::vector<double> fv((size_t)nrows);
-    int rc = device_pass(p, rs, act, Th.data(), formulation, precision, g != nullptr, fv.data(), Gi.data(), nullptr);
+    int rc = device_pass(p, rs, act, Th.data(), formulation, precision, g != nullptr, fv.data(), Gi.data(), nullptr, nullptr, nullptr, 0, asked_auto);
     if (rc) return rc;
     parallel_for(nrows, [&](int64_t r) {
         double z = fv[r];

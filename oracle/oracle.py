@@ -234,6 +234,18 @@ def objgrad_multi(samples, order, u, theta):
     return f.value, g
 
 
+def learn_multi_rows(samples, c=0.4, order=2, tol=1e-12):
+    """The per-node solutions of learn(samples, multiRISE(c, ., order)) before the reconstruction (:94-127): (n x P array in the
+    key order of multi_keys, per-node KKT residual)."""
+    counts, spins = split_histogram(samples)
+    K, n = spins.shape
+    P = lib().gml_oracle_multi_nparams(n, order)
+    out = np.zeros((n, P))
+    kkt = np.zeros(n)
+    lib().gml_oracle_learn_multi(K, n, int(order), _ptr(counts), _ptr(spins), float(c), float(tol), _ptr(out), _ptr(kkt))
+    return out, kkt
+
+
 def learn_multi(samples, c=0.4, symmetrize=True, order=2, tol=1e-12):
     """learn(samples, multiRISE(c, symmetrize, order)) restated (:83-152).
     Returns (dict {1-based key tuple: value}, per-node KKT).  Keys are 1-based like the reference's."""

@@ -141,7 +141,8 @@ def _multi3_kkt(spins, out, nodes, lam):
     return worst
 
 
-def test_c5_multibody_order3_full_size():
+@pytest.mark.parametrize("prec", ["i8x", "i8w"])
+def test_c5_multibody_order3_full_size(prec):
     # config 5: n=512 spins with 3-spin interactions, 1e6 samples, multiRISE/ISODUS order 3 (130 817 parameters
     # per node, 131 k statistics columns).  Objective/gradient against the oracle's order-3 restatement on 2 nodes;
     # learn() at the regulariser of the timing runs (c = 1.2: lambda from n^2 as in :86, sparse optimum).
@@ -151,11 +152,11 @@ def test_c5_multibody_order3_full_size():
     with gml.Problem(terms=terms, n=n, num_samples=K, seed=5, order=3) as p:
         P = p.P
         assert P == 1 + 511 + 511 * 510 // 2
-        (out, kkt, st), t_learn = _timed_learn(p, "RISE", 1.2, tol=1e-8, precision="i8x", max_iter=60)
+        (out, kkt, st), t_learn = _timed_learn(p, "RISE", 1.2, tol=1e-8, precision=prec, max_iter=60)
         lam = st["lambda_"]
         keys0 = p.multi_keys(0)
         th = out[some].copy()
-        f8, g8 = p.objgrad("RISE", some, th, precision="i8x")
+        f8, g8 = p.objgrad("RISE", some, th, precision=prec)
         spins = p.spins()
     assert st["not_converged"] == 0 and kkt.max() <= 1e-8
     assert keys0[:3] == [(0,), (0, 1), (0, 2)] and keys0[512] == (0, 1, 2) and len(keys0) == P

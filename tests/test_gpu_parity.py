@@ -13,6 +13,7 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 synthetic = __import__("importlib").import_module("gml_amd.synthetic")
+_lib = __import__("importlib").import_module("gml_amd._lib")
 FORMS = ["RISE", "logRISE", "RPLE"]
 PRECS = ["f64", "i8x", "i8w"]
 EXACT = ("f64", "i8w")  # held to the tolerances of Float64 arithmetic: the FP64-MFMA path and the FP64-grade int8-limb path
@@ -23,6 +24,9 @@ EXACT = ("f64", "i8w")  # held to the tolerances of Float64 arithmetic: the FP64
 FTOL = {"f64": 1e-12, "i8x": 1e-7, "i8w": 1e-12}
 GTOL = {"f64": 1e-12, "i8x": 1e-7, "i8w": 1e-12}
 SOLTOL = {"f64": 1e-9, "i8x": 1e-7, "i8w": 1e-9}
+# i8w on dense theta (sum|theta| 40 .. 100, the weights of a row spread over tens of e-folds), against the FP64-MFMA path: 10x the
+# largest deviation measured (K = 3e4: rel f 3.7e-12, grad / f 1.0e-11; K = 1e6: 1.0e-11, 2.7e-11 -- the tests print them)
+I8W_DYN_TOL = 3e-10
 
 
 def hist_from_spins(spins):
@@ -158,6 +162,39 @@ def test_multirise_higher_order_matches_oracle(order):
         rec, kkt = O.learn_multi(s, c=c, symmetrize=sym, order=order)
         assert set(fg.keys()) == set(rec.keys())
         assert max(abs(fg[k] - v) for k, v in rec.items()) <= 1e-8
+
+
+_ORDER3_ORACLE = {}
+
+
+def _order3_midsize(c):
+    """n = 36 spins in blocks of 12 with triples, 40 000 samples, order 3: P = 631 parameters per node, a size at which the plain
+    restatement (oracle/gml_oracle.c: Newton on all free coordinates) SOLVES every node in well under a minute."""
+    if c not in _ORDER3_ORACLE:
+        spins, _ = synthetic.block_multibody(36, 40000, block=12, seed=3)
+        rows, kkt = O.learn_multi_rows(hist_from_spins(spins), c=c, order=3, tol=1e-11)
+        assert kkt.max() <= 1e-10
+        _ORDER3_ORACLE[c] = (spins, rows)
+    return _ORDER3_ORACLE[c]
+
+
+@pytest.mark.parametrize("prec", ["i8x", "i8w", "f64"])
+@pytest.mark.parametrize("c", [0.4, 1.2])
+def test_multirise_order3_solutions_match_oracle_midsize(c, prec):
+    # The north-star metric -- learned parameters within 1e-6 relative of the CPU reference's -- asserted for ORDER 3 on every
+    # node, solution against solution (runtests.jl:132-172 compares learned models the same way; the reference holds no order-3
+    # golden, so the other side is the oracle's own solve).  c = 0.4 is the reference's default regulariser (dense optimum: ~86
+    # non-zeros per node), c = 1.2 the sparse one of the timing runs.
+    spins, ref = _order3_midsize(c)
+    with gml.Problem(spins=spins, order=3) as p:
+        assert p.P == ref.shape[1] == 1 + 35 + 35 * 34 // 2
+        out, kkt, st = p.learn("RISE", c, tol=1e-10 if prec in EXACT else 1e-9, precision=prec, max_iter=200)
+    assert st["not_converged"] == 0
+    assert np.linalg.norm(out - ref) / np.linalg.norm(ref) <= 1e-6
+    assert np.abs(out - ref).max() / np.abs(ref).max() <= 1e-6
+    assert ((out == 0) == (ref == 0)).all()  # same exact-zero pattern
+    print(f"order 3, n = 36, c = {c}, {prec}: rel-Frobenius {np.linalg.norm(out - ref) / np.linalg.norm(ref):.2e}, "
+          f"max-abs {np.abs(out - ref).max():.2e}, non-zeros per node {int((ref != 0).sum(1).mean())}")
 
 
 def test_multirise_recovers_true_terms():
@@ -841,24 +878,76 @@ def test_i8w_deterministic_shard_independent_and_linear_in_counts():
     assert np.array_equal(fc, f1) and np.array_equal(gc, g1)
 
 
+def _i8w_vs_f64(p, n, theta, label):
+    """largest deviation of the i8w operator from the FP64-MFMA one on dense theta: (relative f, gradient relative to f, log Z)"""
+    nodes = np.arange(n)
+    fw, gw = p.objgrad("RISE", nodes, theta, precision="i8w")
+    f64, g64 = p.objgrad("RISE", nodes, theta, precision="f64")
+    lw, _ = p.objgrad("logRISE", nodes, theta, precision="i8w")
+    l64, _ = p.objgrad("logRISE", nodes, theta, precision="f64")
+    e = (float(np.abs(fw / f64 - 1).max()), float((np.abs(gw - g64) / np.abs(f64)[:, None]).max()), float(np.abs(lw - l64).max()))
+    print(f"i8w vs f64, {label}: sum|theta| {np.abs(theta).sum(1).mean():.0f}: rel f {e[0]:.2e}, grad / f {e[1]:.2e}, log Z {e[2]:.2e}")
+    return e
+
+
 def test_i8w_dense_theta_dynamic_range():
-    # sum|theta| ~ 40, 80: the weights exp(-E) of a row spread over tens of e-folds.  47 bits relative to the largest weight
-    # keep what the 31 bits of i8x lose: K / 2^48 relative to f at worst (coherent rounding), against K / 2^32
+    # sum|theta| ~ 40, 80: the weights exp(-E) of a row spread over tens of e-folds.  The 47 bits of V are relative to the row's
+    # LARGEST weight (rows that leave four of them unused are re-run with the scale taken from the largest weight seen), and the
+    # rounding is dithered, so the error of f and of the gradient is ~0.4 sqrt(K) 2^-43 of the largest weight at worst -- not
+    # K 2^-48, the coherent worst case the round-4 test allowed (1e-10 at this K, 3.6e-9 at K = 1e6).  When a few configurations
+    # carry the sum, "of the largest weight" is "of f": MEASURED (printed below) 4e-12 / 1e-11 here and 1e-11 / 3e-11 at K = 1e6
+    # (the next test) -- outside the 1e-12 the well-scaled inputs are held to, inside 3e-10 everywhere tried.
     n, K = 100, 30000
     spins, J = synthetic.block_ising(n, K, block=10, seed=4)
     rng = np.random.default_rng(0)
-    nodes = np.arange(n)
     with gml.Problem(spins=spins) as p:
         for scale in (0.5, 1.0):
             theta = rng.normal(scale=scale, size=(n, n))
-            fw, gw = p.objgrad("RISE", nodes, theta, precision="i8w")
-            f64, g64 = p.objgrad("RISE", nodes, theta, precision="f64")
-            tol = max(K / 2.0**48, 1e-12)
-            assert np.abs(fw / f64 - 1).max() <= tol
-            assert (np.abs(gw - g64) / np.abs(f64)[:, None]).max() <= tol
-            lw, _ = p.objgrad("logRISE", nodes, theta, precision="i8w")
-            l64, _ = p.objgrad("logRISE", nodes, theta, precision="f64")
-            assert np.abs(lw - l64).max() <= tol
+            e = _i8w_vs_f64(p, n, theta, f"n={n} K={K}")
+            assert max(e) <= I8W_DYN_TOL
+
+
+def test_i8w_dense_theta_dynamic_range_one_million_samples():
+    # the same at K = 1e6 (device-drawn samples, n = 128): sum|theta| ~ 50 and ~ 100
+    n, K = 128, 1000000
+    J = synthetic.block_ising_model(n, block=16, seed=2)
+    rng = np.random.default_rng(1)
+    with gml.Problem(model=J, num_samples=K, seed=3) as p:
+        for scale in (0.5, 1.0):
+            theta = rng.normal(scale=scale, size=(n, n))
+            e = _i8w_vs_f64(p, n, theta, f"n={n} K={K}")
+            assert max(e) <= I8W_DYN_TOL
+
+
+def test_operator_auto_is_a_float64_stand_in_where_the_fixed_point_gives_up():
+    # sum|theta| ~ 300 with energies of a few tens: the largest weight lies a hundred decades below the bound w_max exp(sum|theta|)
+    # the fixed-point scale starts from, and six rescalings do not reach it.  The reference's operator (:191-197) is plain Float64
+    # and returns a number; `auto` -- what an external solver binds (operator export) -- must too: those rows go to the FP64 path.
+    # A caller who names an int8-limb precision gets a clean GML_EUNSUPPORTED.
+    n, K = 256, 8192
+    spins, _ = synthetic.block_ising(n, K, block=16, seed=6)
+    hist = hist_from_spins(spins)
+    rng = np.random.default_rng(5)
+    theta = rng.choice([-1.0, 1.0], size=(4, n)) * rng.uniform(1.0, 1.4, size=(4, n))
+    theta[3] = rng.normal(scale=0.05, size=n)  # an ordinary row in the same call: stays on the int8 path
+    nodes = np.array([0, 100, 255, 7])
+    assert np.abs(theta[:3]).sum(1).min() > 290
+    with gml.Problem(spins=spins) as p:
+        f, g = p.objgrad("RISE", nodes, theta, precision="auto")
+        lf, lg = p.objgrad("logRISE", nodes, theta, precision="auto")
+        for prec in ("i8w", "i8x"):
+            with pytest.raises(gml.GMLError) as e:
+                p.objgrad("RISE", nodes, theta, precision=prec)
+            assert e.value.code == _lib.GML_EUNSUPPORTED and "underflow" in str(e.value)
+        f2, g2 = p.objgrad("RISE", nodes[3:], theta[3:], precision="i8w")  # (the handle is still good after the refusal)
+    for r, u in enumerate(nodes):
+        f0, g0 = O.objgrad_pair(hist, "RISE", int(u), theta[r])
+        assert np.isfinite(f0) and f[r] == pytest.approx(f0, rel=1e-12)
+        np.testing.assert_allclose(g[r], g0, rtol=1e-10, atol=1e-12 * abs(f0))
+        l0, lg0 = O.objgrad_pair(hist, "logRISE", int(u), theta[r])
+        assert lf[r] == pytest.approx(l0, rel=1e-12, abs=1e-12)
+        np.testing.assert_allclose(lg[r], lg0, rtol=1e-9, atol=1e-12)
+    assert f2[0] == f[3] and np.array_equal(g2[0], g[3])
 
 
 def test_i8w_multibody_narrow_and_wide_column_counts():
