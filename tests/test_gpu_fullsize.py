@@ -127,6 +127,48 @@ def test_c4_sparse_ising_shard_full_size(node_range):
     assert np.abs(off).max() <= 0.02                               # nothing outside the diagonal blocks
 
 
+def test_c4_whole_problem_dress_rehearsal_on_one_gpu():
+    # config 4 end to end, everything but distinct devices: the K x (1 + n) histogram a caller holds (int8 here: 4.1 GB; the
+    # reference's Matrix{Int64} is 32.8 GB) -> gml_multi_create with EIGHT parts (packed once on the host, the bits copied per part;
+    # all parts on device 0) -> gml_multi_learn with dev_out (every part's rows written device to device into its block, the gather
+    # in place) -> 0.5 (R + R^T) as learn() does (:184-188).  What the first 8-GPU run adds is eight different device ids.
+    import torch
+    n, K, parts = 4096, 1000000, 8
+    J = synthetic.block_ising_model(n, block=8, seed=1)
+    shards = {}
+    with gml.Problem(model=J, num_samples=K, seed=4, node_range=(0, 512)) as p:
+        shards[0] = p.learn("RISE", 0.4, tol=1e-9, precision="i8x")[0]
+        hist = np.empty((K, n + 1), dtype=np.int8)
+        hist[:, 0] = 1
+        hist[:, 1:] = p.spins()
+    with gml.Problem(hist, node_range=(3584, 4096)) as p:  # (the other end of the node range, from the caller's matrix)
+        shards[7] = p.learn("RISE", 0.4, tol=1e-9, precision="i8x")[0]
+    bufs = [torch.full((n, n), float("nan"), dtype=torch.float64, device="cuda:0") for _ in range(parts)]
+    t0 = time.perf_counter()
+    with gml.MultiProblem(hist, [0] * parts) as m:
+        t_create = time.perf_counter() - t0
+        assert (m.n, m.K, m.P, m.ndev) == (n, K, n, parts)
+        t0 = time.perf_counter()
+        out, kkt, st = m.learn("RISE", 0.4, tol=1e-9, precision="i8x", dev_out=[b.data_ptr() for b in bufs])
+        t_learn = time.perf_counter() - t0
+        stats = m.part_stats()
+        kind = m.gather_kind()
+    torch.cuda.synchronize()
+    print(f"C4 dress rehearsal: create {t_create:.2f} s, learn + gather {t_learn:.2f} s ({kind}), per-part solves "
+          f"{[round(q['t_total'], 2) for q in stats]} s, iterations {[q['iterations'] for q in stats]}")
+    assert st["not_converged"] == 0 and kkt.max() <= 1e-9 and out.shape == (n, n)
+    assert len(stats) == parts and all(q["iterations"] > 0 and q["not_converged"] == 0 for q in stats)
+    assert sum(q["node_evals"] for q in stats) == st["node_evals"]
+    # the rows of a part do not depend on the other parts, nor on how the handle came about: bit for bit the single-shard solves
+    assert np.array_equal(out[0:512], shards[0]) and np.array_equal(out[3584:4096], shards[7])
+    assert kind == "peer-copy"  # (a device list that repeats a GPU; distinct devices: rccl-allgather)
+    for b in (bufs[0], bufs[parts - 1]):  # the gathered matrix is on every part's device
+        assert np.array_equal(b.cpu().numpy(), out)
+    sym = 0.5 * (out + out.T)
+    assert np.abs(sym - J).max() <= 0.06
+    assert t_create < 1.0 and t_learn < 5.0  # measured 0.13 s and 1.67 s (eight parts' solves sharing one GPU: 1.2 - 1.65 s each)
+
+
 def _multi3_kkt(spins, out, nodes, lam):
     """KKT residual of order-3 rows by the ORACLE's order-3 gradient; slot 0 (the field, key (u,)) is not penalised (:118)"""
     worst = 0.0
