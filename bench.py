@@ -42,7 +42,17 @@ KERNELS = {"f64": {"fwd": "k_fwd_f64", "bwd": "k_bwd_f64"}, "i8x": {"fwd": "k_fw
 # int8 digit-plane products issued per algorithmic product (forward: planes of Theta, backward: planes of V)
 LIMBS = {"i8x": {"fwd": 5, "bwd": 4}, "i8w": {"fwd": 7, "bwd": 6}}
 PMC_FILES = {"i8w": ("r4_i8w_pmc_traffic.json",), "i8x": ("r3_i8x_pmc_traffic.json", "r2_i8x_pmc_traffic.json")}
-KERNEL_SOURCES = {"i8w": "gml_kernels_i8w.hip", "i8x": "gml_i8_fwd.hip"}
+# sources of the kernels of an int8-limb pass (forward, backward, quantisation, finalisation -- whichever of them dominates): the PMC
+# summaries carry their hash (scripts/pmc_summarize.py), and a line whose traffic comes from counters of other kernels says so
+PASS_KERNEL_SOURCES = ("gml_kernels_i8w.hip", "gml_i8_fwd.hip", "gml_i8_bwd.hip", "gml_i8_pack.hip", "gml_i8_pass.hip", "gml_i8.h", "gml_bits.h")
+
+
+def pass_kernels_sha256():
+    import hashlib
+    h = hashlib.sha256()
+    for fn in PASS_KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "graphicalmodellearning.jl_amd", "csrc", fn), "rb").read())
+    return h.hexdigest()
 
 
 def parse_args():
@@ -242,11 +252,8 @@ def main():
                 roofline["traffic_note"] = ("HBM bytes per launch of %s from profiles/%s (2*FETCH_SIZE + WRITE_SIZE, KB; a separate "
                                             "rocprofv3 --pmc run of this command, not this run)" % (kn, fn))
                 # were the counters taken on the kernels that ran just now?
-                import hashlib
-                ksrc = os.path.join(ROOT, "graphicalmodellearning.jl_amd", "csrc", KERNEL_SOURCES[args.precision])
-                sha = pm.get("_kernel_source_sha256")
-                roofline["traffic_kernels_match"] = (None if sha is None else
-                                                     sha == hashlib.sha256(open(ksrc, "rb").read()).hexdigest())
+                sha = pm.get("_pass_kernels_sha256")  # (summaries of rounds 2-4 hashed one file: reported as not matching)
+                roofline["traffic_kernels_match"] = sha == pass_kernels_sha256()
                 break
             except Exception:
                 continue
@@ -262,6 +269,24 @@ def main():
     extra["collective_backend"] = (dist.get_backend() + (" (RCCL)" if backend == "nccl" else " (ranks share a GPU: host tensors)")) if world > 1 else "none (1 rank)"
     extra["collective_ranks"] = world
     extra["devices_visible"] = ndev
+    # which physical GPU every rank drives: a wrong binding (two ranks on one device, a rank off its local GPU) shows in the line itself
+    prop = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "local_rank": local_rank, "device": device, "name": prop.name,
+          "pci": "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", -1) & 0xff, getattr(prop, "pci_device_id", 0) & 0xff),
+          "uuid": str(getattr(prop, "uuid", "")), "hbm_gb": round(prop.total_memory / 2**30, 1), "nodes": [node0, node1],
+          "visible_env": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", ""))}
+    ranks_info = [None] * world
+    if world > 1:
+        dist.all_gather_object(ranks_info, me)
+    else:
+        ranks_info = [me]
+    extra["ranks"] = ranks_info
+    extra["distinct_devices"] = len({(q["pci"], q["uuid"]) for q in ranks_info})
+    try:
+        extra["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:  # (not fatal: the line must come out)
+        extra["rccl_version"] = "unknown (%s)" % type(e).__name__
+    extra["torch_version"], extra["hip_version"] = torch.__version__, str(torch.version.hip)
 
     # ---- the other arithmetics on the same workload ------------------------------------------------------------------
     # f64: the FP64-MFMA path (fewer steps: ~85 ms each); i8x: the 38/31-bit int8-limb pass (learn()'s default)

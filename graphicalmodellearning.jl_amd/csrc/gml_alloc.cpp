@@ -83,13 +83,18 @@ hipError_t dev_malloc_bytes(void **out, size_t bytes) {
 static hipError_t free_impl(void *p, bool synced) {
     if (!p) return hipSuccess;
     Cache &c = cache();
-    std::lock_guard<std::mutex> lock(c.mu);
-    auto it = c.live.find(p);
-    if (it == c.live.end()) return hipFree(p); // not ours (never happens for library memory)
-    const Block b = it->second;
-    c.live.erase(it);
+    Block b;
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        auto it = c.live.find(p);
+        if (it == c.live.end()) return hipFree(p); // not ours (never happens for library memory)
+        b = it->second;
+        c.live.erase(it);
+    }
     if (b.bytes < kMinCached) return hipFree(p);
     if (!synced) {
+        // waited for OUTSIDE the lock: with one host thread per GPU (gml_multi) a drain of this block's device must not stall
+        // the other devices' allocations.  Between the two critical sections the block is in neither table: nobody can hand it out.
         int cur = 0;
         (void)hipGetDevice(&cur);
         if (cur != b.device) (void)hipSetDevice(b.device);
@@ -97,6 +102,7 @@ static hipError_t free_impl(void *p, bool synced) {
         if (cur != b.device) (void)hipSetDevice(cur);
         if (es != hipSuccess) return hipFree(p); // a failed device: do not recycle anything it may still own
     }
+    std::lock_guard<std::mutex> lock(c.mu);
     if (!c.limit.count(b.device)) {
         size_t freeb = 0, total = 0;
         int cur = 0;

@@ -354,7 +354,10 @@ int Solver::init() {
     prec = o.precision;
     // (launch-bound problems gain nothing from cheaper passes and pay for the re-evaluation at the switch: config 2 takes 16 + 3
     // passes instead of 13 + 2)
-    coarse_on = gml_is_i8(o.precision) && o.coarse >= 0 && formulation != GML_RPLE && (double)p->K * (double)Qp * (double)R >= 17179869184.0;
+    // (decided on the whole problem -- n, not the local rows -- so that a node shard runs the form its problem would run on one GPU;
+    // WHEN the phase ends still depends on the rows of this handle: it ends for all of them with the first that gets close, a per-row
+    // switch having been measured slower, DESIGN.md 4.2 -- trajectories differ between shardings, optima do not)
+    coarse_on = gml_is_i8(o.precision) && o.coarse >= 0 && formulation != GML_RPLE && (double)p->K * (double)Qp * (double)p->n >= 17179869184.0;
     if (o.coarse > 0) coarse_thr = std::pow(10.0, -(double)o.coarse); // (tuning: the KKT residual at which the coarse phase ends)
 
     // slots of the int8-limb workspace: every active row of a pass in its own slot, the passes of one iteration in
@@ -1449,8 +1452,9 @@ int Solver::iterate(double *out, double *kkt_out) {
             bool dense = false; // a row has gone matrix-free: a dense optimum, whose many more iterations gain nothing from cheaper early
                                 // passes (config 5 at the default regulariser: 52 iterations instead of 39 for the same wall-clock)
             for (int64_t r = 0; r < R; ++r) dense |= !done[r] && iscg[r];
+            // (also the rows this selection ended at their stall count, above the threshold: declared done on coarse gradients)
             for (int64_t r = 0; r < R; ++r)
-                if (!done_before[r] && (dense ? !done[r] || !(kkt[r] > thr) : !(kkt[r] > thr))) low.push_back((int)r);
+                if (!done_before[r] && (done[r] || !(kkt[r] > thr) || dense)) low.push_back((int)r);
             if (!low.empty()) {
                 coarse_on = false;
                 if (o.verbose)
@@ -1460,6 +1464,7 @@ int Solver::iterate(double *out, double *kkt_out) {
                 for (int r : low) {
                     done[r] = 0;
                     atfloor[r] = 0;
+                    stall[r] = 0;
                     best[r] = INFINITY;
                     Fbest[r] = INFINITY;
                     HIPCHK(stg.h2d(dBest + r, &inf, sizeof(double)));

@@ -14,10 +14,10 @@ for d in dirs:
             name = k.split("(")[0].replace("void ", "")
             res[name][c + "_KB"] = max(res[name].get(c + "_KB", 0.0), v)
 # the kernels the counters belong to: bench.py compares this with the source it runs and says so when they differ
-import hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "graphicalmodellearning.jl_amd", "csrc", os.environ.get("PMC_KERNEL_SOURCE", "gml_kernels_i8w.hip"))
+sys.path.insert(0, root)
+import bench  # (the hash of every source file a pass's kernels come from: bench.pass_kernels_sha256)
 summary = {k: v for k, v in res.items() if k.startswith("gml::")}
-summary["_kernel_source_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
+summary["_pass_kernels_sha256"] = bench.pass_kernels_sha256()
 json.dump(summary, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if "fwd_i8" in k or "bwd_i8" in k or "_f64" in k}, indent=1))
