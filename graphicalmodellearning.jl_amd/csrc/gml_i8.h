@@ -146,7 +146,7 @@ struct FwdLaunch {
 };
 void launch_fwd_i8(const FwdLaunch &a, int LF, int form, bool wantf, int hv);
 // gml_i8_bwd.hip
-void launch_zero_pass(const SlotScalars &sc, double *F, int slot0, int ns, int32_t *gacc0, int64_t ngacc4, int nplanes, int64_t plane_stride4,
+void launch_zero_pass(const SlotScalars &sc, double *F, const int *rowcol, int slot0, int ns, int32_t *gacc0, int64_t ngacc4, int nplanes, int64_t plane_stride4,
                       hipStream_t st);
 void launch_bwd_i8(int NL, const int8_t *Vin, const DevProblem &d, const int *groups, int ngt, int nNt, int64_t kchunk, int nsplit, int32_t *Gacc,
                    int cpp, int64_t plane_stride, int64_t kpart, int lbt, int pl0, hipStream_t st);

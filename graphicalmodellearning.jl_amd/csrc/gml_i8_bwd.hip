@@ -193,10 +193,13 @@ __global__ __launch_bounds__(256) void k_finalize_i8(const int32_t *__restrict__
 // gradient planes of those slots' tiles
 __global__ __launch_bounds__(256) void k_zero_pass(long long *__restrict__ csum, long long *__restrict__ asum,
                                                    long long *__restrict__ csum2, long long *__restrict__ asum2,
-                                                   unsigned *__restrict__ mmax, double *__restrict__ f, int slot0, int ns,
-                                                   v4i *__restrict__ gacc, int64_t ngacc, int nplanes, int64_t plane_stride4) {
+                                                   unsigned *__restrict__ mmax, double *__restrict__ f, const int *__restrict__ rowcol,
+                                                   int slot0, int ns, v4i *__restrict__ gacc, int64_t ngacc, int nplanes,
+                                                   int64_t plane_stride4) {
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
-    if (i0 < ns) {
+    // (only the slots this pass evaluates: a re-run of some rows of a tile leaves the others' planes in place, and with them the
+    // scalars that describe those planes -- the working-set Hessians read tau and the largest |V| of a row's LAST pass)
+    if (i0 < ns && rowcol[slot0 + i0] >= 0) {
         csum[slot0 + i0] = 0;
         asum[slot0 + i0] = 0;
         csum2[slot0 + i0] = 0;
@@ -210,9 +213,9 @@ __global__ __launch_bounds__(256) void k_zero_pass(long long *__restrict__ csum,
 }
 
 
-void launch_zero_pass(const SlotScalars &sc, double *F, int slot0, int ns, int32_t *gacc0, int64_t ngacc4, int nplanes, int64_t plane_stride4,
-                      hipStream_t st) {
-    hipLaunchKernelGGL(k_zero_pass, dim3(1024), dim3(256), 0, st, sc.csum, sc.asum, sc.csum2, sc.asum2, sc.mmax, F, slot0, ns,
+void launch_zero_pass(const SlotScalars &sc, double *F, const int *rowcol, int slot0, int ns, int32_t *gacc0, int64_t ngacc4, int nplanes,
+                      int64_t plane_stride4, hipStream_t st) {
+    hipLaunchKernelGGL(k_zero_pass, dim3(1024), dim3(256), 0, st, sc.csum, sc.asum, sc.csum2, sc.asum2, sc.mmax, F, rowcol, slot0, ns,
                        reinterpret_cast<v4i *>(gacc0), ngacc4, nplanes, plane_stride4);
 }
 

@@ -26,13 +26,14 @@ namespace gml {
 // ------------------------------------------------------------------------------------------
 constexpr int HL = 2;
 
-// bits by which a row's weights are shifted down so that its largest fits 15 bits.  exp forms: mm = the row's largest |V| in the unit
+// bits by which a row's weights are shifted down so that its largest fits the 15 bits of two balanced digits.  exp forms: mm = the row's largest |V| in the unit
 // of the planes, as its last pass recorded it.  RPLE: the passes do not record it, and need not: tau comes from the bound 2 w_max,
 // which the weights of a well-classified configuration reach, and h = 4 w sig (1 - sig) <= w_max = half the planes' range (2^30).
 __device__ __forceinline__ int hw_shift(unsigned mm, int form) {
     if (form == 2) return 16;
-    const int bits = 64 - __clzll((unsigned long long)mm + 1ull);
-    return bits > 15 ? bits - 15 : 0;
+    int sh = 0;
+    while ((mm >> sh) + 1u > 32639u) ++sh; // (the dither adds less than one unit after the shift; 32 639 = two balanced digits' largest)
+    return sh;
 }
 
 // Hessian weights of the active rows as limb planes over the compact index, in the sample order of the bit images

@@ -131,7 +131,7 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     const int lbg = wide ? LBW : LB; // limb planes of this pass's V and of its gradient accumulators
     int32_t *gacc0 = w->Gacc + (int64_t)a.slot0 * lbg * d.Qfp;
     const int64_t gplane_stride = (int64_t)w->slots * lbg * d.Qfp;
-    launch_zero_pass(sc, a.F, a.slot0, ns, gacc0, grad ? (int64_t)ns * lbg * d.Qfp / 4 : 0, w->gplanes, gplane_stride / 4, st);
+    launch_zero_pass(sc, a.F, a.rowcol, a.slot0, ns, gacc0, grad ? (int64_t)ns * lbg * d.Qfp / 4 : 0, w->gplanes, gplane_stride / 4, st);
     if (LF < 3 && !hv) LF = 3; // 2 limbs exist for the directions of Hessian-vector passes only
     launch_quant_theta(LF, ns, a, d, hv, w->sc[0].tau, w->Tq, sc, wide ? kVdiv6 : kVdiv4, w->vscale(), st);
     // split-K plan of the backward GEMM (made here: a sub-sampled pass runs its forward kernel over the same parts)

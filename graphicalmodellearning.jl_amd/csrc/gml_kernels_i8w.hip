@@ -348,6 +348,9 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
         // sched_barriers, as in k_fwd_i8 -- a wave in its epilogue then issues back to back instead of waiting out the latency
         // of each dependent FP64 instruction.
 #define SB __builtin_amdgcn_sched_barrier(0)
+#ifdef I8W_LINE_STORES
+        v4i plk[WM][LBW]; // the digits of both sample tiles, until the wave's image leaves in whole lines (below)
+#endif
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             const unsigned nsg = ~sgn[i]; // bit 8g + j set <=> s = +1
@@ -450,17 +453,64 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifndef I8W_LINE_STORES
 #ifdef ABL_NOSTORE
             if (active && pl[0][0] == 0x12345678 && pl[5][3] == 0x1234567) {
 #else
             if (active) {
 #endif
-                // (holding tile 0's dwords back until tile 1 is packed, so that a lane's neighbouring 16-byte pieces go out
-                // together, and double-buffered B fragments in the GEMM loops, were measured: no change -- DESIGN.md)
+                // (every lane stores its 16 bytes per plane and tile straight from registers: an instruction covers 32 rows x 16 B, a
+                // quarter of each 64-byte row, and the write-combining of L2 puts the lines together -- WRITE_SIZE reads 8.8 GB per
+                // launch for 6.1 GB of planes.  The line-wide form below (-DI8W_LINE_STORES) removes that inflation and is 0.8 %
+                // SLOWER: profiles/r5_ab_i8w_line_stores.txt -- the partial writes cost no time, the LDS round trip does.)
 #pragma unroll
                 for (int lb = COARSE ? 2 : 0; lb < LBW; ++lb) *reinterpret_cast<v4i *>(vimg + lb * 32 * 64 + i * 16) = pl[lb];
             }
+#else
+#pragma unroll
+            for (int lb = COARSE ? 2 : 0; lb < LBW; ++lb) plk[i][lb] = pl[lb];
+#endif
         }
+#ifdef I8W_LINE_STORES
+        // (A/B variant, not the default -- see above.)  The wave's 64 samples x 32 rows x 6 planes are ONE contiguous 12-KB image of
+        // Vq.  It leaves through LDS -- the two ring
+        // stages the last GEMM step no longer reads are free: every wave has passed that step's barrier -- so that each store
+        // instruction writes 1 KB = eight whole 128-byte lines: the lanes put their 16-byte pieces where the image has them
+        // (16-byte slots XOR-swizzled by (row >> 2) & 3: conflict-free on both sides), then read the image back linearly.  Three
+        // planes at a time (6 KB per wave).  Rows that are not part of this pass keep what they hold (a re-run of some rows of a
+        // tile must not touch the planes of the others): their lines are stored partially.
+        {
+            const int lastslot = (ntot - 1) % NSW;
+            int8_t *stg = lds + ((lastslot + 1 + (wave >> 1)) % NSW) * STAGEW + (wave & 1) * 6144;
+            const unsigned amask = (unsigned)__ballot(active); // bit lr (lanes 0..31)
+            int8_t *img = Vq + vq_off(mytile * 32, 0, kw, Kp, LBW);
+            constexpr int G0 = COARSE ? 2 : 0, NG = COARSE ? 2 : 3; // plane groups [G0, G0 + NG), [G0 + NG, LBW)
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp) {
+                const int p0 = G0 + grp * NG;
+#pragma unroll
+                for (int lbl = 0; lbl < NG; ++lbl)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) {
+                        const int row = lbl * 32 + lr, sl = 2 * h + i;
+                        *reinterpret_cast<v4i *>(stg + row * 64 + ((sl ^ ((row >> 2) & 3)) << 4)) = plk[i][p0 + lbl];
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (one wave: its LDS accesses execute in order)
+#pragma unroll
+                for (int j = 0; j < 2 * NG; ++j) {
+                    const int o = j * 1024 + lane * 16, row = o >> 6, sl = (o >> 4) & 3;
+                    const v4i dv = *reinterpret_cast<const v4i *>(stg + row * 64 + ((sl ^ ((row >> 2) & 3)) << 4));
+#ifdef ABL_NOSTORE
+                    if (dv[0] == 0x12345678 && dv[3] == 0x1234567 && ((amask >> (row & 31)) & 1u))
+#else
+                    if ((amask >> (row & 31)) & 1u)
+#endif
+                        *reinterpret_cast<v4i *>(img + p0 * 2048 + o) = dv;
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+#endif
     } else { // RPLE (:317): f = w log(1 + exp(-2E)), V = -2 w s / (1 + exp(2E)), E = s Ea
 #pragma unroll
         for (int i = 0; i < WM; ++i) {

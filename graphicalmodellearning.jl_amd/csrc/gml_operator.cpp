@@ -388,6 +388,82 @@ extern "C" int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows,
     return GML_OK;
 }
 
+// Test hook (not part of include/gml.h): the working-set Hessian blocks the solver builds its Newton steps from (gml_i8_hess.hip), for
+// a few rows at theta -- an int8-limb objective pass leaves the curvature weights in the rows' slots, then i8_hessian runs over the
+// configurations of every kstride-th block of 512 (Kh of them).  cols [nrows][m]: the working set of each row as parameter indices
+// in the reference's order.  H [nrows][mp][mp] (mp = m rounded up to 32): the lower 32 x 32 tiles of sum_k h_k stat_i stat_j over
+// the sub-sample, in the unit of f, not rescaled by the sub-sample's weight.
+extern "C" int gml_test_hessian_blocks(gml_problem *p, int formulation, int precision, int64_t nrows, const int64_t *nodes, const double *theta,
+                                       int64_t ld, const int32_t *cols, int m, int64_t Kh, int64_t kstride, double *H) {
+    if (!p || !nodes || !theta || !cols || !H || nrows <= 0 || m <= 0 || m > 512) return fail(GML_EINVAL, "bad argument");
+    if (!gml_is_i8(precision)) return fail(GML_EINVAL, "an int8-limb precision (the planes of V are what the kernel reads)");
+    HIPCHK(hipSetDevice(p->device));
+    const int64_t Qp = p->d.Qp, P = p->P, Rp = round_up(nrows, 32);
+    const int mt = (m + 31) / 32, mp = mt * 32;
+    RowSet rs;
+    rs.R = nrows;
+    rs.node.assign(nodes, nodes + nrows);
+    std::vector<NodeLayout> lay((size_t)nrows);
+    std::vector<double> Th((size_t)nrows * Qp, 0.0), Gi((size_t)nrows * Qp);
+    std::vector<int> F((size_t)nrows * mp, 0);
+    for (int64_t r = 0; r < nrows; ++r) {
+        build_layout(p, nodes[r], lay[r]);
+        for (int64_t j = 0; j < P; ++j) Th[(size_t)r * Qp + lay[r].cols[j]] = theta[r * ld + j];
+        for (int a = 0; a < mp; ++a) {
+            const int32_t j = cols[r * m + (a < m ? a : 0)]; // (the padding repeats the first entry, as the solver's lists do not care)
+            if (j < 0 || j >= P) return fail(GML_EINVAL, "working-set entry out of range");
+            F[(size_t)r * mp + a] = lay[r].cols[j];
+        }
+    }
+    std::vector<uint8_t> act((size_t)nrows, 1);
+    std::vector<double> fv((size_t)nrows);
+    int rc = device_pass(p, rs, act, Th.data(), formulation, precision, true, fv.data(), Gi.data(), nullptr);
+    if (rc) return rc;
+    hipStream_t st = p->st;
+    std::vector<int> ctl((size_t)(3 * nrows), 0); // rowcol | vslot | mt
+    std::vector<long long> hoff((size_t)nrows + 1, 0);
+    std::vector<int> hmt((size_t)nrows, mt);
+    for (int64_t r = 0; r < nrows; ++r) {
+        ctl[r] = (int)nodes[r];
+        ctl[nrows + r] = (int)r;
+        ctl[2 * nrows + r] = mt;
+        hoff[r + 1] = hoff[r] + (long long)mp * mp;
+    }
+    int *dCtl = nullptr, *dF = nullptr;
+    long long *dHoff = nullptr;
+    double *dH = nullptr;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(st);
+        for (void *q : {(void *)dCtl, (void *)dF, (void *)dHoff, (void *)dH})
+            if (q) (void)dev_free_synced(q);
+    };
+    const size_t htotal = (size_t)nrows * mp * mp;
+    hipError_t e = dev_malloc(&dCtl, sizeof(int) * ctl.size());
+    if (e == hipSuccess) e = dev_malloc(&dF, sizeof(int) * F.size());
+    if (e == hipSuccess) e = dev_malloc(&dHoff, sizeof(long long) * hoff.size());
+    if (e == hipSuccess) e = dev_malloc(&dH, sizeof(double) * htotal);
+    if (e == hipSuccess) e = hipMemcpyAsync(dCtl, ctl.data(), sizeof(int) * ctl.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dF, F.data(), sizeof(int) * F.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dHoff, hoff.data(), sizeof(long long) * hoff.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(dH, 0, sizeof(double) * htotal, st);
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(GML_EHIP, "gml_test_hessian_blocks: %s", hipGetErrorString(e));
+    }
+    std::string err;
+    rc = gml::i8_hessian(p->i8ws, p->d, dCtl, dCtl + nrows, dF, dCtl + 2 * nrows, hmt.data(), dHoff, (int64_t)htotal, (int)nrows, mp, formulation, Kh, kstride,
+                         dH, st, &err, nullptr);
+    if (rc == GML_OK) {
+        e = hipMemcpyAsync(H, dH, sizeof(double) * htotal, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = GML_EHIP;
+    }
+    cleanup();
+    (void)Rp;
+    if (rc) return fail(rc, "%s", err.empty() ? "gml_test_hessian_blocks failed" : err.c_str());
+    return GML_OK;
+}
+
 // Timing hook with the parameters RESIDENT in HBM: Theta is uploaded once, then `warmup + steps` passes run back
 // to back on the handle's stream with no host round trip (a device-side optimiser would call the operator this
 // way); f and the gradient of the last pass are downloaded once at the end.  kernel_ms[3] = device time per pass.
