@@ -187,9 +187,18 @@ struct NewtonFaces {
     double share = 0.05;
     int rounds = 0;
 };
+// the rows' last secant pairs (k_secant keeps them): pair l of row r at S / Y + l * stride + r * cap, npairs[r] of them.  Blocks of up
+// to 128 entries take the BFGS correction inside the solve kernel, on the matrix it holds in LDS
+struct SecantPairs {
+    const double *S = nullptr, *Y = nullptr;
+    const int *npairs = nullptr;
+    int64_t stride = 0;
+};
+constexpr int kCholLds = 128; // blocks of up to this many entries are solved with the matrix in LDS
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
                          const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st, int maxm = 0,
-                         const NewtonFaces *faces = nullptr, const uint8_t *fix = nullptr, const double *dfix = nullptr);
+                         const NewtonFaces *faces = nullptr, const uint8_t *fix = nullptr, const double *dfix = nullptr,
+                         const SecantPairs *pairs = nullptr);
 // Preconditioner tiles (T = 64 or 128): tile t holds the lower triangle of its T x T Hessian block at H + hoff[t] (pitch T);
 // A = s1[wrow[t]] * H_t - s2 * g g^T on its first vm[t] entries is replaced, in place, by its inverse (full symmetric matrix);
 // a block that is not positive definite even with a ridge becomes its inverse diagonal.

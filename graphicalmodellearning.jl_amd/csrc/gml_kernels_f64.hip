@@ -701,13 +701,32 @@ __global__ __launch_bounds__(256) void k_newton_chol(double *__restrict__ H, con
 // from the global block, which is never written.  Same arithmetic order inside a panel as above; results agree to rounding.
 // ------------------------------------------------------------------------------------------
 typedef double v4d_c __attribute__((ext_vector_type(4)));
+// sum over the 256 threads of a workgroup through 8 x 32 doubles of LDS (no shuffles); every thread gets the result
+__device__ __forceinline__ double wg_sum(double v, double *buf /* [256] */) {
+    __syncthreads();
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x < 64) {
+        s = buf[threadIdx.x] + buf[threadIdx.x + 64] + buf[threadIdx.x + 128] + buf[threadIdx.x + 192];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) buf[0] = s;
+    __syncthreads();
+    return buf[0];
+}
 __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restrict__ H, const long long *__restrict__ hoff, const int *__restrict__ mt,
                                                          const int *__restrict__ msz, const double *__restrict__ s1, double s2,
                                                          const double *__restrict__ gF, const double *__restrict__ pgF, int cap,
                                                          double *__restrict__ dout, double *__restrict__ Sdiag, int mcap /* multiple of 32, <= 128, >= every msz handled here */,
                                                          const int *__restrict__ F, const double *__restrict__ X, const uint8_t *__restrict__ kind,
                                                          int64_t Qp, double share, int rounds, const uint8_t *__restrict__ fix,
-                                                         const double *__restrict__ dfix) {
+                                                         const double *__restrict__ dfix,
+                                                         // BFGS correction of the (sub-sampled) block by the row's last secant pairs,
+                                                         // applied to the matrix in LDS (npairs = NULL: none)
+                                                         const double *__restrict__ secS, const double *__restrict__ secY,
+                                                         const int *__restrict__ npairs, int64_t pair_stride) {
     constexpr int PW = 32;
     const int r = blockIdx.x;
     const int m = msz[r];
@@ -733,11 +752,7 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
     // one global round trip: the lower triangle of s1 H straight into W, eight independent loads per thread and turn (one element
     // per turn, each waiting for its own load, took 28 of the 99 us of a 100-entry solve); the rank-one term, the masks and the ridge
     // are applied in LDS
-    for (int i = tid; i < m; i += 256) {
-        gg[i] = s2 != 0.0 ? g[i] : 0.0;
-        fx[i] = fix && fix[(int64_t)r * cap + i] ? 1.0 : 0.0;
-        dfx[i] = fix ? dfix[(int64_t)r * cap + i] : 0.0;
-    }
+    for (int i = tid; i < m; i += 256) gg[i] = s2 != 0.0 ? g[i] : 0.0;
     auto a_orig = [&](int i, int j) { return sc * A[(int64_t)i * hp + j] - s2 * gg[i] * gg[j]; }; // i >= j: the matrix itself (global)
     auto load_raw = [&]() { // W <- sc * H on the lower triangle of the first mp rows (rows m .. mp - 1, the MFMA tile padding: zero)
         const int total = mp * mp;
@@ -755,7 +770,53 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
             }
         }
     };
+    // B <- B + y y^T / (y.s) - (B s)(B s)^T / (s.B s) for the row's pairs, oldest first, on B = s1 H - s2 g g^T (the pairs come from
+    // exact gradients, so they describe the true Hessian along the last steps: gml_solver.hip, k_secant, which keeps them and
+    // applies them itself to the larger blocks).  W holds s1 H; the rank-one term rides along in B s only.
+    const int np = npairs ? npairs[r] : 0;
+    auto secant = [&]() {
+        double *vs = fx, *vy = dfx; // (free here: the masks are set up after the correction) -- s and y of the pair; y doubles as B s below
+        for (int l = 0; l < np; ++l) {
+            __syncthreads();
+            for (int i = tid; i < m; i += 256) {
+                vs[i] = secS[l * pair_stride + (int64_t)r * cap + i];
+                vy[i] = secY[l * pair_stride + (int64_t)r * cap + i];
+            }
+            __syncthreads();
+            double gs = 0.0;
+            if (s2 != 0.0) {
+                for (int i = tid; i < m; i += 256) gs += gg[i] * vs[i];
+                gs = wg_sum(gs, part8);
+            }
+            double bs = 0.0, sAs = 0.0, ysl = 0.0;
+            if (tid < m) {
+                const int i = tid;
+                for (int j = 0; j <= i; ++j) bs = fma(W[i * LDW + j], vs[j], bs);
+                for (int j = i + 1; j < m; ++j) bs = fma(W[j * LDW + i], vs[j], bs);
+                bs -= s2 * gg[i] * gs;
+                sAs = vs[i] * bs;
+                ysl = vs[i] * vy[i];
+            }
+            sAs = wg_sum(sAs, part8);
+            ysl = wg_sum(ysl, part8);
+            if (!(sAs > 0.0 && ysl > 0.0)) continue; // (uniform)
+            if (tid < m) y[tid] = bs; // (y: the right-hand side's place, not set yet)
+            __syncthreads();
+            const double ia = 1.0 / sAs, iy = 1.0 / ysl;
+            for (int idx = tid; idx < m * m; idx += 256) {
+                const int i = idx / m, j = idx - i * m;
+                if (j <= i) W[i * LDW + j] += vy[i] * vy[j] * iy - y[i] * y[j] * ia;
+            }
+        }
+        __syncthreads();
+    };
     load_raw();
+    __syncthreads();
+    if (np > 0) secant();
+    for (int i = tid; i < m; i += 256) { // (the masks, after the correction borrowed their place)
+        fx[i] = fix && fix[(int64_t)r * cap + i] ? 1.0 : 0.0;
+        dfx[i] = fix ? dfix[(int64_t)r * cap + i] : 0.0;
+    }
     __syncthreads();
     double dmax = 0;
     for (int i = tid; i < m; i += 256) dmax = fmax(dmax, masked && fx[i] != 0.0 ? 1.0 : fabs(W[i * LDW + i] - s2 * gg[i] * gg[i]));
@@ -774,6 +835,19 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
             __syncthreads();
             load_raw();
             __syncthreads();
+            if (np > 0) { // (the correction borrows the masks' place: saved around it)
+                double f0 = 0.0, d0 = 0.0;
+                if (tid < m) {
+                    f0 = fx[tid];
+                    d0 = dfx[tid];
+                }
+                secant();
+                if (tid < m) {
+                    fx[tid] = f0;
+                    dfx[tid] = d0;
+                }
+                __syncthreads();
+            }
         }
         fresh = false;
         // the (masked) matrix: rank-one term, fixed entries decoupled (unit diagonal), ridge on the free diagonal
@@ -1014,24 +1088,25 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
 
 void launch_newton_solve(double *H, const long long *hoff, const int *mt, const int *msz, const double *s1, double s2,
                          const double *gF, const double *pgF, int R, int cap, double *dout, double *Sdiag, hipStream_t st, int maxm,
-                         const NewtonFaces *faces, const uint8_t *fix, const double *dfix) {
+                         const NewtonFaces *faces, const uint8_t *fix, const double *dfix, const SecantPairs *pairs) {
     // maxm: largest block of this call, as far as the host knows it (0 = unknown): sizes the LDS of a workgroup
     int mcap = maxm <= 0 || maxm > cap ? cap : maxm;
     mcap = (mcap + 31) / 32 * 32;
     const NewtonFaces nf = faces ? *faces : NewtonFaces{};
     // blocks of up to 128 entries: the matrix in LDS (k_newton_chol_lds); larger ones: the blocked kernel on the global block
-    const int msmall = mcap < 128 ? mcap : 128;
+    const int msmall = mcap < kCholLds ? mcap : kCholLds;
+    const SecantPairs sp = pairs ? *pairs : SecantPairs{};
     {
         const size_t lds = sizeof(double) * ((size_t)msmall * (msmall + 1) + 5 * (size_t)msmall + 32);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_newton_chol_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_newton_chol_lds, dim3((unsigned)R), dim3(256), lds, st, H, hoff, mt, msz, s1, s2, gF, pgF, cap, dout, Sdiag, msmall, nf.F,
-                           nf.X, nf.kind, nf.Qp, nf.share, nf.rounds, fix, dfix);
+                           nf.X, nf.kind, nf.Qp, nf.share, nf.rounds, fix, dfix, sp.S, sp.Y, sp.npairs, sp.stride);
     }
-    if (mcap > 128) {
+    if (mcap > kCholLds) {
         const size_t lds = sizeof(double) * ((size_t)6 * mcap + 32 * 33 + 32 + (size_t)std::max(mcap - 32, 32) * 33);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_newton_chol), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_newton_chol, dim3((unsigned)R), dim3(256), lds, st, H, hoff, mt, msz, s1, s2, gF, pgF, cap, dout, Sdiag, mcap, nf.F, nf.X,
-                           nf.kind, nf.Qp, nf.share, nf.rounds, fix, dfix, 128);
+                           nf.kind, nf.Qp, nf.share, nf.rounds, fix, dfix, kCholLds);
     }
 }
 

@@ -1019,7 +1019,7 @@ int Solver::newton_blocks(const std::vector<int> &chol_rows) {
     const bool secant = use_secant && Kh < d.Kp;
     if (secant)
         launch_secant(rows_k, (int)chol_rows.size(), dFidx, dMt + 2 * R, capP, X, Qp, dgF, dH, dHoff, dMt, dS1, s2, dYnoise, dFprev, dMprev, dXprev, dGprev,
-                      dSec, dSec + 2 * Rp * capP, dNpairs, Rp * (int64_t)capP, st);
+                      dSec, dSec + 2 * Rp * capP, dNpairs, Rp * (int64_t)capP, kCholLds, st);
     if (secant && o.verbose >= 2) {
         std::vector<int> npv((size_t)Rp);
         HIPCHK(hipMemcpyAsync(npv.data(), dNpairs, sizeof(int) * Rp, hipMemcpyDeviceToHost, st));
@@ -1040,7 +1040,11 @@ int Solver::newton_blocks(const std::vector<int> &chol_rows) {
     // statistics: config 2 -- 1e5 x 256 -- is 0.4 ms faster without, the headline problem 4 % faster with)
     nf.rounds = (double)p->K * (double)Qp >= 268435456.0 ? face_rounds : 0;
     if (g_tune[GML_TUNE_FACE_ROUNDS] > 0) nf.rounds = (int)g_tune[GML_TUNE_FACE_ROUNDS] - 1;
-    launch_newton_solve(dH, dHoff, dMt, dMt + 2 * R, dS1, s2, dgF, dpgF, (int)R, capP, dsol, dSdiag, st, maxm, &nf);
+    // (blocks of up to kCholLds entries take the secant correction inside the solve, on the matrix in LDS; k_secant above kept the
+    // pairs and corrected the larger blocks itself)
+    SecantPairs sp;
+    if (secant) sp = SecantPairs{dSec, dSec + 2 * Rp * capP, dNpairs, Rp * (int64_t)capP};
+    launch_newton_solve(dH, dHoff, dMt, dMt + 2 * R, dS1, s2, dgF, dpgF, (int)R, capP, dsol, dSdiag, st, maxm, &nf, nullptr, nullptr, secant ? &sp : nullptr);
     launch_scatter_dir(rows_k, (int)chol_rows.size(), dFidx, dsol, dMt + 2 * R, capP, Qp, D, st);
     HIPCHK(hipGetLastError());
     return GML_OK;

@@ -59,7 +59,7 @@ void launch_scatter_dir(const int *drows, int nrows, const int *F, const double 
                         hipStream_t st);
 void launch_secant(const int *drows, int nrows, const int *F, const int *msz, int cap, const double *X, int64_t Qp, const double *gF, double *H,
                    const long long *hoff, const int *mt, const double *s1, double s2, const double *ynoise, int *Fprev, int *mprev, double *xprev,
-                   double *gprev, double *S, double *Y, int *npairs, int64_t pair_stride, hipStream_t st);
+                   double *gprev, double *S, double *Y, int *npairs, int64_t pair_stride, int apply_above, hipStream_t st);
 void launch_trial(const int *drows, int nrows, const double *X, const double *D, const double *PG, const uint8_t *kind, int64_t Qp,
                   double lambda, const double *alpha, double *Xt, TrialOut *out, double *stepn, hipStream_t st);
 void launch_back(const int *drows, int nrows, const double *X, const double *Xt, const double *Gt, const uint8_t *kind, int64_t Qp,

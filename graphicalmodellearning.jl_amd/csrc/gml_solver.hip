@@ -211,20 +211,48 @@ __global__ __launch_bounds__(256) void k_select(const int *__restrict__ rows, co
     unsigned thr = 0;
     if (addv && nviol > max_add && nsupp <= capW) {
         unsigned lo = 0, hi = 0x7f800000u; // invariant: count(v >= lo) > max_add >= count(v >= hi)
-        while (hi - lo > 1) {
-            const unsigned mid = lo + (hi - lo) / 2;
+        constexpr int NREG = 8;
+        if (Qp <= 256 * NREG) {
+            // rows of up to 2048 columns (the pairwise configurations): the candidates' float patterns in registers, counted by
+            // ballots -- the 31 steps touch no memory but the four per-wave counts (31 strided sweeps of the row with a block
+            // reduction each were 45 of this kernel's 60 us on a 128-node shard)
+            unsigned v[NREG];
+#pragma unroll
+            for (int q = 0; q < NREG; ++q) {
+                const int64_t c = tid + 256 * q;
+                v[q] = (c < Qp && kr[c] == 2 && x[c] == 0.0 && pgr[c] != 0.0) ? __float_as_uint((float)fabs(pgr[c])) : 0u;
+            }
+            auto count_ge = [&](unsigned t) {
+                int cnt = 0;
+#pragma unroll
+                for (int q = 0; q < NREG; ++q) cnt += __popcll(__ballot(v[q] >= t && v[q] != 0u));
+                __syncthreads();
+                if ((tid & 63) == 0) redi[tid >> 6] = cnt;
+                __syncthreads();
+                return redi[0] + redi[1] + redi[2] + redi[3];
+            };
+            while (hi - lo > 1) {
+                const unsigned mid = lo + (hi - lo) / 2;
+                if (count_ge(mid) > max_add) lo = mid;
+                else hi = mid;
+            }
+            thr = count_ge(hi) > 0 ? hi : lo;
+        } else {
+            while (hi - lo > 1) {
+                const unsigned mid = lo + (hi - lo) / 2;
+                int cnt = 0;
+                for (int64_t c = tid; c < Qp; c += 256)
+                    if (kr[c] == 2 && x[c] == 0.0 && pgr[c] != 0.0 && __float_as_uint((float)fabs(pgr[c])) >= mid) ++cnt;
+                cnt = block_sum_i(cnt, redi);
+                if (cnt > max_add) lo = mid;
+                else hi = mid;
+            }
             int cnt = 0;
             for (int64_t c = tid; c < Qp; c += 256)
-                if (kr[c] == 2 && x[c] == 0.0 && pgr[c] != 0.0 && __float_as_uint((float)fabs(pgr[c])) >= mid) ++cnt;
+                if (kr[c] == 2 && x[c] == 0.0 && pgr[c] != 0.0 && __float_as_uint((float)fabs(pgr[c])) >= hi) ++cnt;
             cnt = block_sum_i(cnt, redi);
-            if (cnt > max_add) lo = mid;
-            else hi = mid;
+            thr = cnt > 0 ? hi : lo; // nothing above the tie class at `lo`: take that class (a large one sends the row to CG)
         }
-        int cnt = 0;
-        for (int64_t c = tid; c < Qp; c += 256)
-            if (kr[c] == 2 && x[c] == 0.0 && pgr[c] != 0.0 && __float_as_uint((float)fabs(pgr[c])) >= hi) ++cnt;
-        cnt = block_sum_i(cnt, redi);
-        thr = cnt > 0 ? hi : lo; // nothing above the tie class at `lo`: take that class (a large one sends the row to CG)
     }
     SelectOut o;
     o.l1 = l1;
@@ -338,7 +366,8 @@ __global__ __launch_bounds__(256) void k_secant(const int *__restrict__ rows, co
                                                 const long long *__restrict__ hoff, const int *__restrict__ mt, const double *__restrict__ s1,
                                                 double s2, const double *__restrict__ ynoise, int *__restrict__ Fprev, int *__restrict__ mprev,
                                                 double *__restrict__ xprev, double *__restrict__ gprev, double *__restrict__ S,
-                                                double *__restrict__ Y, int *__restrict__ npairs, int64_t pair_stride) {
+                                                double *__restrict__ Y, int *__restrict__ npairs, int64_t pair_stride,
+                                                int apply_above /* blocks of up to this many entries are corrected by their solve kernel, in LDS */) {
     constexpr int L = 2;
     const int r = rows[blockIdx.x], tid = threadIdx.x;
     const int m = msz[r];
@@ -390,7 +419,7 @@ __global__ __launch_bounds__(256) void k_secant(const int *__restrict__ rows, co
         npairs[r] = np;
         mprev[r] = m;
     }
-    if (np == 0) return;
+    if (np == 0 || m <= apply_above) return;
     const int hp = 32 * mt[r];
     double *A = H + hoff[r];
     const double sc = s1[r];
@@ -428,10 +457,10 @@ __global__ __launch_bounds__(256) void k_secant(const int *__restrict__ rows, co
 }
 void launch_secant(const int *drows, int nrows, const int *F, const int *msz, int cap, const double *X, int64_t Qp, const double *gF, double *H,
                    const long long *hoff, const int *mt, const double *s1, double s2, const double *ynoise, int *Fprev, int *mprev, double *xprev,
-                   double *gprev, double *S, double *Y, int *npairs, int64_t pair_stride, hipStream_t st) {
+                   double *gprev, double *S, double *Y, int *npairs, int64_t pair_stride, int apply_above, hipStream_t st) {
     if (nrows > 0)
         hipLaunchKernelGGL(k_secant, dim3((unsigned)nrows), dim3(256), 0, st, drows, F, msz, cap, X, Qp, gF, H, hoff, mt, s1, s2, ynoise, Fprev, mprev,
-                           xprev, gprev, S, Y, npairs, pair_stride);
+                           xprev, gprev, S, Y, npairs, pair_stride, apply_above);
 }
 
 // ------------------------------------------------------------------------------------------
