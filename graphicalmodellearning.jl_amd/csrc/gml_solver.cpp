@@ -488,7 +488,10 @@ int Solver::init() {
     // latency, not its work, so a shard of 128 rows takes 65 536 per row for the price of 32 768 and saves two of fourteen iterations
     // (profiles/r5_hess_budget_sweep.txt; 1 024 rows: 32 768 -> 109 ms, 49 152 -> 113 ms, 24 576 -> 112 ms).  Like the rule above this
     // makes a row's Newton trajectory -- not its optimum -- depend on how many rows share its GPU.
-    Kh_base = std::min<int64_t>(131072, std::max<int64_t>(32768, ((int64_t)1 << 23) / std::max<int64_t>(R, 1)));
+    // (int8 kernels only: the FP64 path's Hessian kernel is bound by its FP64 work at any size -- n = 200, K = 1e5 on that path took
+    // 17 % longer with the larger budget, profiles/r5_robust_sweep.txt)
+    Kh_base = 32768;
+    if (gml_is_i8(o.precision)) Kh_base = std::min<int64_t>(131072, std::max<int64_t>(32768, ((int64_t)1 << 23) / std::max<int64_t>(R, 1)));
     if (g_tune[GML_TUNE_KH_BASE] > 0) Kh_base = (int64_t)g_tune[GML_TUNE_KH_BASE];
     if (o.hess_samples != 0) Kh_base = o.hess_samples < 0 ? d.Kp : (int64_t)o.hess_samples;
     nblk512 = d.Kp / 512;
