@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GML_LIB_OVERRIDE") or os.path.join(_HERE, "libgml_hip
 GML_OK, GML_EINVAL, GML_ENOTCONV, GML_EHIP, GML_ENOMEM, GML_EUNSUPPORTED = range(6)
 FORMULATION_IDS = {"RISE": 0, "RISEA": 0, "multiRISE": 0, "logRISE": 1, "RPLE": 2}
 DTYPES = {np.dtype(np.int8): 0, np.dtype(np.int32): 1, np.dtype(np.int64): 2, np.dtype(np.float64): 3}
-PRECISIONS = {"f64": 0, "i8x": 1, "auto": 2, "i8w": 3}  # auto (learn only): i8x, FP64 for launch-bound sizes; i8w: FP64-grade int8 limbs
+PRECISIONS = {"f64": 0, "i8x": 1, "auto": 2, "i8w": 3}  # auto: i8x, i8w for tight tolerances / small problems / operator calls; i8w: FP64-grade int8 limbs
 
 
 class GMLError(RuntimeError):

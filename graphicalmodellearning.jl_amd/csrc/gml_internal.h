@@ -60,15 +60,21 @@ struct NodeLayout {
 };
 void gml_build_layout(const gml_problem *p, int64_t u, NodeLayout &L);
 
-// GML_PREC_AUTO -> the int8-limb path, or FP64 where samples x parameters x nodes is launch-bound either way (decided on
-// the whole problem, not on the rows of one call or one shard: the arithmetic does not depend on the GPU count); -1: unknown value
-// (tol: the KKT tolerance of a solve, 0 for operator calls.  Operator calls -- gml_objgrad_batch is what an external solver registers
-// in place of the reference's Float64 obj / grad pair -- take the FP64-grade limbs.  Solves below 2e-10 too: the 38/31-bit pass would
-// stall at the noise floor of its gradient and finish on the FP64-MFMA path, the 54/47-bit pass gets there directly)
+// GML_PREC_AUTO -> an int8-limb precision, decided on the whole problem, not on the rows of one call or one shard (the arithmetic does
+// not depend on the GPU count); -1: unknown value.  tol: the KKT tolerance of a solve, 0 for operator calls.
+//  * operator calls -- gml_objgrad_batch is what an external solver registers in place of the reference's Float64 obj / grad pair --
+//    and solves below 2e-10 take the FP64-grade limbs (the 38/31-bit pass would stall at the noise floor of its gradient and finish on
+//    the FP64-MFMA path; the 54/47-bit pass gets there directly);
+//  * small problems (samples x parameters x spins <= 2^28: the reference's own fixtures, the README example) take them too, at any
+//    tolerance: every kernel is launch-bound there, the wide pass costs the same, and it converges in as few iterations as Float64.
+//    (Rounds 1-4 sent these to the FP64-MFMA path, which round 5's int8 direction phase left 2-10x behind: README example 1.19 ms
+//    against 0.63, n = 64 / K = 2e4 13.1 ms against 1.3 -- profiles/r5_auto_probe.txt.  GML_PREC_F64 stays available by name.)
+//  * everything else: the 38/31-bit pass.
 inline int gml_resolve_precision(const gml_problem *p, int precision, double tol = 0.0) {
     if (precision == GML_PREC_AUTO) {
-        if ((double)p->K * (double)p->P * (double)p->n <= 268435456.0) return GML_PREC_F64;
-        return (tol <= 0.0 || tol < 2e-10) && p->d.Qfp <= ((int64_t)1 << 21) ? GML_PREC_I8W : GML_PREC_I8X; // (i8w: up to 2^21 columns)
+        if (p->d.Qfp > ((int64_t)1 << 21)) return GML_PREC_I8X; // (i8w: up to 2^21 statistics columns)
+        const bool small = (double)p->K * (double)p->P * (double)p->n <= 268435456.0;
+        return (tol <= 0.0 || tol < 2e-10 || small) ? GML_PREC_I8W : GML_PREC_I8X;
     }
     return precision == GML_PREC_F64 || precision == GML_PREC_I8X || precision == GML_PREC_I8W ? precision : -1;
 }

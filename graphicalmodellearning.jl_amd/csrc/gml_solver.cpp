@@ -1524,7 +1524,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     if (opts_in) o = *opts_in;
     else gml_default_opts(&o);
     {
-        // (auto: launch-bound sizes gain nothing from the int8 path and converge in fewer FP64 iterations)
+        // (auto: gml_internal.h -- the 38/31-bit limbs, the FP64-grade ones for tight tolerances and for small problems)
         const int asked = o.precision;
         o.precision = gml_resolve_precision(p, asked, o.tol > 0 ? o.tol : 1e-9);
         if (o.precision < 0) return fail(GML_EINVAL, "unknown precision %d", asked);

@@ -56,7 +56,7 @@ class HIP(GMLMethod):
                on the FP64 path unless polish=False), "i8w" (the same int8 matrix cores at the width of the reference's
                Float64 arithmetic: theta in 54-bit, the weights in 47-bit limbs, exp in FP64 -- objective and gradient to the
                1e-12 the FP64 path is held to, ~1.4x the time of "i8x"), "f64" (FP64 MFMA throughout) or "auto" (the
-               default: "i8x", except for problems so small that every kernel is launch-bound, which run in FP64)
+               default: "i8x"; "i8w" for tolerances below 2e-10 and for small problems -- the reference's fixtures, the README example)
     device     HIP device ordinal; with distributed=True the local rank's device
     devices    several GPUs of this node from this one process: the library shards the nodes over them (one host thread
                per GPU, gml_multi_*); what the Julia wrapper's HIP(devices = 0:7) binds

@@ -50,7 +50,7 @@ end
 
 GMLMethod that solves every node-wise problem on MI355X through libgml_hip (same fields and defaults as the Python
 twin, graphicalmodellearning.jl_amd/formulations.py).
-`precision = :auto` (default) is `:i8x` except for launch-bound sizes, which run in FP64; `:i8x` is the int8-limb fixed-point pass; rows it cannot bring below `tol` are finished on the
+`precision = :auto` (default) is `:i8x`, and `:i8w` for tolerances below 2e-10 and for small problems (the reference's fixtures); `:i8x` is the int8-limb fixed-point pass; rows it cannot bring below `tol` are finished on the
 FP64 path unless `polish = false`; `:i8w` is the same int8 matrix-core pass at the width of Float64 (theta in 54-bit, the weights in
 47-bit limbs, exp in FP64: objective and gradient to the 1e-12 the FP64 path is held to, about 1.5x the time of `:i8x`); `:f64` runs
 FP64 MFMA throughout.  `devices = 0:7` shards the nodes over several

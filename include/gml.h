@@ -50,11 +50,10 @@ extern "C" {
                             1e-12 the GML_PREC_F64 path is held to, at ~6x its speed.  gml_learn builds its Hessians and
                             Hessian-vector products from the top 31 bits of the same V planes                              */
 #define GML_PREC_AUTO 2  /* gml_objgrad_batch (the pair an external solver registers in place of the reference's Float64 obj / grad):
-                            GML_PREC_I8W.  gml_learn: GML_PREC_I8X, except for problems so small (samples x parameters x spins <= 2^28: a
-                            property of the problem, not of the call or of the node shard) that every kernel is
-                            launch-bound either way: those run in FP64, which needs fewer iterations near tight
-                            tolerances (README example: 1.2 ms against 5.5), and except for solves with tol < 2e-10, which
-                            take GML_PREC_I8W (the 31-bit weights would stall at their noise floor).  Never GML_EUNSUPPORTED for a
+                            GML_PREC_I8W.  gml_learn: GML_PREC_I8X, except for solves with tol < 2e-10 and for small problems
+                            (samples x parameters x spins <= 2^28: a property of the problem, not of the call or of the node
+                            shard -- the reference's own fixtures, the README example; every kernel is launch-bound there), which
+                            take GML_PREC_I8W (as few iterations as Float64; the 31-bit weights would stall at their noise floor).  Never GML_EUNSUPPORTED for a
                             valid histogram: beyond 2^24 configurations the int8 path keeps one set of i32
                             gradient accumulators per 2^23 configurations and adds them in int64             */
 
