@@ -73,6 +73,7 @@ struct Arena {
 struct Stage {
     char *base = nullptr;
     size_t cap = 0, off = 0, floor = 0; // [0, floor): arrays that live as long as the solve (persist); the rest is recycled at every sync()
+    bool mapped = false;                // the device reads and writes the arena under its host address (checked by the solver's init)
     hipStream_t st = nullptr;
     struct Pend {
         void *host;
@@ -92,14 +93,14 @@ struct Stage {
     // persist: an array the kernels write and the host reads after sync(), for the whole solve (before the first take only)
     template <typename T> T *persist(size_t count) {
         const size_t a = (floor + 63) & ~(size_t)63;
-        if (a + sizeof(T) * count > cap / 2) return nullptr;
+        if (!mapped || a + sizeof(T) * count > cap / 2) return nullptr;
         floor = a + sizeof(T) * count;
         if (off < floor) off = floor;
         return reinterpret_cast<T *>(base + a);
     }
     // put: control data for kernels queued before the next sync(); NULL when it does not fit (the caller copies to a device buffer)
     template <typename T> const T *put(const T *host, size_t count) {
-        void *q = sizeof(T) * count <= cap / 4 ? take(sizeof(T) * std::max<size_t>(count, 1)) : nullptr;
+        void *q = mapped && sizeof(T) * count <= cap / 4 ? take(sizeof(T) * std::max<size_t>(count, 1)) : nullptr;
         if (q && count) std::memcpy(q, host, sizeof(T) * count);
         return reinterpret_cast<const T *>(q);
     }
@@ -343,7 +344,14 @@ int Solver::init() {
 
     if (!p->stage) {
         p->stage_bytes = (size_t)8 << 20;
-        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p->stage), p->stage_bytes, hipHostMallocDefault));
+        // (portable + mapped: one process may drive several devices -- gml_multi -- and the kernels of this handle's device read and
+        // write the arena directly)
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p->stage), p->stage_bytes, hipHostMallocPortable | hipHostMallocMapped));
+    }
+    {
+        void *dp = nullptr; // zero-copy only where the device sees the arena under the same address (unified addressing); else copies
+        stg.mapped = hipHostGetDevicePointer(&dp, p->stage, 0) == hipSuccess && dp == static_cast<void *>(p->stage);
+        if (!stg.mapped) (void)hipGetLastError();
     }
     stg.base = p->stage;
     stg.cap = p->stage_bytes;
