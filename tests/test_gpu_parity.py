@@ -224,6 +224,30 @@ def test_learn_synthetic_block_ising_vs_oracle(prec):
     assert ((out == 0) == (R0 == 0)).mean() > 0.999
 
 
+def test_learn_sharded_above_the_coarse_gate_same_optimum():
+    # Above the gate of the coarse early passes (samples x columns x SPINS >= 2^34: decided on the whole problem, so a shard runs the
+    # form its problem runs on one GPU) a row's Newton trajectory depends on its shard -- the Hessian budget grows on small shards, the
+    # coarse phase ends with the first row of the HANDLE that gets close -- but its optimum does not: shards and the whole problem
+    # agree to the KKT tolerance, and every row is certified at full width either way.  (ADVICE r4 #2.)
+    n, K = 256, 270000
+    spins, _ = synthetic.block_ising(n, K, block=16, seed=9)
+    assert K * 320 * n >= 2**34
+    with gml.Problem(spins=spins) as p:
+        full, kf, sf = p.learn("RISE", 0.4, tol=1e-10, precision="i8w")
+        f_all, g_all = p.objgrad("RISE", np.arange(n), full, precision="i8w")
+    parts = []
+    for rng_ in ((0, 64), (64, 256)):
+        with gml.Problem(spins=spins, node_range=rng_) as p:
+            o, k, st = p.learn("RISE", 0.4, tol=1e-10, precision="i8w")
+            assert st["not_converged"] == 0 and k.max() <= 1e-10
+            fs, gs = p.objgrad("RISE", np.arange(*rng_), full[rng_[0]:rng_[1]], precision="i8w")
+            assert np.array_equal(fs, f_all[rng_[0]:rng_[1]]) and np.array_equal(gs, g_all[rng_[0]:rng_[1]])  # the passes: bit for bit
+            parts.append(o)
+    got = np.concatenate(parts, axis=0)
+    assert sf["not_converged"] == 0 and kf.max() <= 1e-10
+    assert np.abs(got - full).max() <= 2e-9 and ((got == 0) == (full == 0)).all()
+
+
 def test_learn_sharded_node_ranges_concatenate_bitwise():
     # node-wise sharding: the rows a rank computes do not depend on which other rows it owns
     spins, _ = synthetic.block_ising(64, 4096, block=16, seed=1)
