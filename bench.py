@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 # guide lists no FP64 figure.
 PEAKS = {"f64": 78.6e12, "i8x": 5.0e15, "i8w": 5.0e15}
 KERNELS = {"f64": {"fwd": "k_fwd_f64", "bwd": "k_bwd_f64"}, "i8x": {"fwd": "k_fwd_i8", "bwd": "k_bwd_i8"},
-           "i8w": {"fwd": "k_fwd_i8w", "bwd": "k_bwd_i8<1, 3>"}}
+           "i8w": {"fwd": "k_fwd_i8w", "bwd": "k_bwd_i8<1, 6>"}}
 # int8 digit-plane products issued per algorithmic product (forward: planes of Theta, backward: planes of V)
 LIMBS = {"i8x": {"fwd": 5, "bwd": 4}, "i8w": {"fwd": 7, "bwd": 6}}
 PMC_FILES = {"i8w": ("r5_i8w_pmc_traffic.json", "r4_i8w_pmc_traffic.json"), "i8x": ("r3_i8x_pmc_traffic.json", "r2_i8x_pmc_traffic.json")}
@@ -127,7 +127,7 @@ def pass_roofline(km, K, P, nloc, precision):
         rf["note"] = ("achieved counts algorithmic flops once; the kernel issues limb_products int8 MFMA products per "
                       "algorithmic product (fixed point), so frac <= 1/limb_products")
         if precision == "i8w":
-            rf["note"] += ("; the backward GEMM of i8w runs as two launches of the 3-plane kernel (bwd_ms = both), the forward "
+            rf["note"] += ("; the backward GEMM of i8w is one launch over all six planes of V (k_bwd_i8<1, 6>), the forward "
                            "kernel as one launch sweeping the columns twice (4 + 3 planes)")
     return rf, dom
 

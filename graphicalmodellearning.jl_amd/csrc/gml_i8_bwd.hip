@@ -17,7 +17,7 @@ namespace gml {
 // ------------------------------------------------------------------------------------------
 template <int TM /* node tiles per workgroup: 1 (4 waves, two workgroups per CU) or 2 (8 waves) */,
           int NL /* limb planes of Vq multiplied: 4; 2 for the products of a 2-limb Hessian-vector pass; 3 for one half of the
-                    6 planes of the i8w pass (TM = 1) */>
+                    6 planes of the i8w pass (TM = 1); 6 for all of them in one launch (TM = 1: wave tile 192 x 64) */>
 __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
     const int8_t *__restrict__ Vq, const unsigned *__restrict__ Xtb, const int *__restrict__ groups, int ngroups_t,
     int nNt, int64_t Qfp, int64_t Kp, int64_t kchunk, int nsplit, int32_t *__restrict__ Gacc,
@@ -26,9 +26,10 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
     int64_t kpart /* configurations of every chunk that take part (== kchunk: all; less: sub-sampled Hessian-vector products) */,
     int lbt /* limb planes of a Vq image (and of the accumulator rows of a node tile) */, int pl0 /* first plane multiplied */) {
     constexpr int NW = 4 * TM;
-    constexpr int AR = 128 * TM, NPIECE = 8 * TM + 2, STAGE = NPIECE * 1024, NS = 4;
-    constexpr int WMT = NL, WNT = 2; // wave tile 128 (96, 64) x 64: MFMA tile i <-> limb plane pl0 + i of the node tile
-    static_assert(NL == 4 || ((NL == 2 || NL == 3) && TM == 1), "the 2- and 3-limb forms exist for 4-wave workgroups");
+    constexpr int AP = NL == 6 ? 12 : 8 * TM; // 1-KB pieces (16 rows x 64 B) of limb rows in a stage
+    constexpr int AR = AP * 16, NPIECE = AP + 2, STAGE = NPIECE * 1024, NS = 4;
+    constexpr int WMT = NL, WNT = 2; // wave tile 128 (192, 96, 64) x 64: MFMA tile i <-> limb plane pl0 + i of the node tile
+    static_assert(NL == 4 || ((NL == 2 || NL == 3 || NL == 6) && TM == 1), "the 2-, 3- and 6-limb forms exist for 4-wave workgroups");
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lr = lane & 31, h = lane >> 5;
@@ -49,25 +50,27 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
     // 8*TM + 2 pieces over 4*TM waves: waves 0 and 1 load three (the third is a piece of bits), the others two.
     // NL = 2: only the four pieces of limb planes 0 and 1 (rows 0..63 of the image) + the bits: two per wave.
     // NL = 3: the six pieces of three planes + the bits: two per wave.
-    const bool three = NL == 4 && wave < 2;
-    const int8_t *src[3];
-    int adv[3], dst[3];
+    // NL = 6: the twelve pieces of six planes + the bits: waves 0 and 1 load four, the others three.
+    constexpr int NJ = NL == 6 ? 4 : 3;               // loads of the waves that carry one more
+    const bool three = (NL == 4 || NL == 6) && wave < 2; // ... which are these
+    const int8_t *src[NJ];
+    int adv[NJ], dst[NJ];
     const int img = lbt * 2048; // bytes of a Vq image
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        int pc = wave + NW * j; // piece of the full stage image: 0 .. 8 TM - 1 rows of Vq, then the bits
+    for (int j = 0; j < NJ; ++j) {
+        int pc = wave + NW * j; // piece of the full stage image: 0 .. AP - 1 rows of Vq, then the bits
         if (NL == 2) pc = j == 0 ? wave : 8 * TM + (wave & 1);
         if (NL == 3) pc = wave + 4 * j < 6 ? wave + 4 * j : 8 * TM + ((wave + 4 * j - 6) & 1);
         dst[j] = pc * 1024;
-        if (pc < 8 * TM) {
-            int tl = tiles[pc >> 3];
+        if (pc < AP) {
+            int tl = tiles[NL == 6 ? 0 : pc >> 3];
             if (tl < 0) tl = tiles[0];
-            const int row = (pc & 7) * 16 + (lane >> 2);
+            const int row = (NL == 6 ? pc : (pc & 7)) * 16 + (lane >> 2);
             const int slot = (lane & 3) ^ ((row >> 2) & 3);
             src[j] = Vq + ((int64_t)tl * nkk + kt0) * img + (pl0 * 32 + row) * 64 + slot * 16;
             adv[j] = img;
         } else {
-            const int pb = pc < NPIECE ? pc - 8 * TM : 0;
+            const int pb = pc < NPIECE ? pc - AP : 0;
             src[j] = reinterpret_cast<const int8_t *>(Xtb) + ((int64_t)(2 * nt + pb) * nkk + kt0) * 1024 + lane * 16;
             adv[j] = 1024;
         }
@@ -75,9 +78,9 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
     auto issue = [&](int kt) {
         int8_t *stage_base = lds + (kt & (NS - 1)) * STAGE;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ - 1; ++j)
             __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (int64_t)kt * adv[j]), (lptr_t)(stage_base + dst[j]), 16, 0, 0);
-        if (three) __builtin_amdgcn_global_load_lds((gptr_t)(src[2] + (int64_t)kt * adv[2]), (lptr_t)(stage_base + dst[2]), 16, 0, 0);
+        if (three) __builtin_amdgcn_global_load_lds((gptr_t)(src[NJ - 1] + (int64_t)kt * adv[NJ - 1]), (lptr_t)(stage_base + dst[NJ - 1]), 16, 0, 0);
     };
     v16i acc[WMT][WNT];
 #pragma unroll
@@ -92,8 +95,8 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s);
     for (int kt = 0; kt < nk; ++kt) {
-        if (three) ring_wait_ahead<3>(nk - 1 - kt);
-        else ring_wait_ahead<2>(nk - 1 - kt);
+        if (three) ring_wait_ahead<NJ>(nk - 1 - kt);
+        else ring_wait_ahead<NJ - 1>(nk - 1 - kt);
         if (kt + NS - 1 < nk) issue(kt + NS - 1);
         const int8_t *cur = lds + (kt & (NS - 1)) * STAGE;
         unsigned vb[WNT];
@@ -125,11 +128,11 @@ __global__ __launch_bounds__(256 * TM, 2) void k_bwd_i8(
         for (int jn = 0; jn < WNT; ++jn) {
             const int64_t c = n0 + wn * 64 + jn * 32 + lr;
             const int grow = wm * 128 + i * 32; // first row of this MFMA tile within the workgroup tile
-            const int tl = tiles[grow >> 7];
+            const int tl = tiles[NL == 6 ? 0 : grow >> 7];
             if (c < Qfp && tl >= 0) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int mrow = (grow & 127) + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int mrow = (NL == 6 ? grow : (grow & 127)) + (e & 3) + 8 * (e >> 2) + 4 * h;
                     atomicAdd(&Gacc[((int64_t)tl * lbt * 32 + pl0 * 32 + mrow) * Qfp + c], acc[i][jn][e]);
                 }
             }
@@ -224,7 +227,7 @@ void launch_bwd_i8(int NL, const int8_t *Vin, const DevProblem &d, const int *gr
     constexpr int TM = 1; // node tiles per backward workgroup (the 8-wave form with two, TM = 2, measured slower)
     const int T = ngt * nNt;
     const int grid = ((nsplit + 7) / 8) * 8 * T;
-    const int shmem = 4 * (8 * TM + 2) * 1024;
+    const int shmem = 4 * ((NL == 6 ? 12 : 8 * TM) + 2) * 1024;
 #define BWD(NLV)                                                                                                                            \
     do {                                                                                                                                    \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd_i8<1, NLV>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem);     \
@@ -233,6 +236,7 @@ void launch_bwd_i8(int NL, const int8_t *Vin, const DevProblem &d, const int *gr
     } while (0)
     if (NL == 2) BWD(2);
     else if (NL == 3) BWD(3);
+    else if (NL == 6) BWD(6);
     else BWD(4);
 #undef BWD
 }

@@ -170,9 +170,18 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
         // cpp chunks each: cpp * kchunk < (Kp + kchunk) / gplanes + kchunk <= 2^23 + 1.5 * 2^22 < 2^24, so |sum| < 2^31
         const int cpp = (nsplit + w->gplanes - 1) / w->gplanes;
         const int8_t *Vin = hv ? w->Uq : w->Vq;
-        if (wide) { // the two halves of the 6 planes: two launches of the 3-plane form (coarse passes: the high half only)
+        if (wide) {
+#ifndef I8W_BWD33
+            // all six planes in ONE launch (wave tile 192 x 64, 230 registers): the bit operand is loaded and expanded once for six
+            // planes.  Rounds 4 ran it as two launches of the 3-plane form (-DI8W_BWD33): 4.52 against 4.43 ms per headline pass, the
+            // pass 10.89 against 10.74 ms, interleaved on one box (profiles/r5_ab_i8w_bwd6.txt); the sums are integers either way --
+            // the same bits.  Coarse passes: the high half only, the 3-plane form.
+            if (!coarse) launch_bwd_i8(6, Vin, d, a.groups, ngt, nNt, kchunk, nsplit, w->Gacc, cpp, gplane_stride, kpart, LBW, 0, st);
+            else launch_bwd_i8(3, Vin, d, a.groups, ngt, nNt, kchunk, nsplit, w->Gacc, cpp, gplane_stride, kpart, LBW, 3, st);
+#else
             for (int half = coarse ? 1 : 0; half < 2; ++half)
                 launch_bwd_i8(3, Vin, d, a.groups, ngt, nNt, kchunk, nsplit, w->Gacc, cpp, gplane_stride, kpart, LBW, 3 * half, st);
+#endif
         } else if (coarse) { // the planes 1..3 carry the 23-bit value (plane 0 is zero, its accumulators stay zero)
             launch_bwd_i8(3, Vin, d, a.groups, ngt, nNt, kchunk, nsplit, w->Gacc, cpp, gplane_stride, kpart, LB, 1, st);
         } else {
