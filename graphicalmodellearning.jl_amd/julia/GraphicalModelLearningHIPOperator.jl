@@ -26,7 +26,9 @@ export HIPOperator
 
 const libgml = get(ENV, "LIBGML_HIP", "libgml_hip.so")
 const GML_RISE, GML_I64, GML_F64 = Cint(0), Cint(2), Cint(3)
-const GML_PREC_I8W = Cint(3)   # the int8 matrix cores at the width of Float64 (objective and gradient to 1e-12; include/gml.h)
+const GML_PREC_AUTO = Cint(2)  # operator calls: the int8 matrix cores at the width of Float64 (objective and gradient to 1e-12), and the
+                               # FP64-MFMA path for a trial point whose weights the fixed point cannot hold -- like the reference's
+                               # Float64 `risea_obj` (:191-197) it never refuses a finite x (include/gml.h)
 
 "`HIPOperator(NLP(solver); device = 0)`: keep the reference's NLP method, evaluate objective and gradient on the GPU."
 struct HIPOperator <: GMLMethod
@@ -56,7 +58,7 @@ function learn(samples::Array{T,2}, formulation::Union{RISE,RISEA}, method::HIPO
                 xbuf .= x
                 rc = ccall((:gml_objgrad_batch, libgml), Cint,
                            (Ptr{Cvoid}, Cint, Cint, Int64, Ref{Int64}, Ptr{Cdouble}, Int64, Ref{Cdouble}, Ptr{Cdouble}),
-                           handle[], GML_RISE, GML_PREC_I8W, 1, node, xbuf, num_spins, fbuf, gbuf)
+                           handle[], GML_RISE, GML_PREC_AUTO, 1, node, xbuf, num_spins, fbuf, gbuf)
                 rc == 0 || error("gml_objgrad_batch: $(lasterr())")
             end
             obj(x...) = (evaluate!(collect(x)); fbuf[])                          # risea_obj       (:191-197)

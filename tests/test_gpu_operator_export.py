@@ -14,7 +14,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("prec", ["f64", "i8w"])  # (the Julia operator file binds i8w: FP64-grade, several times the FP64-MFMA rate)
+@pytest.mark.parametrize("prec", ["f64", "i8w", "auto"])  # (the Julia operator file binds auto: the FP64-grade limbs i8w, FP64 for rows they cannot hold)
 @pytest.mark.parametrize("name", ["a", "c"])
 def test_external_first_order_solver_reproduces_the_goldens(name, prec):
     s = load_csv(f"{name}_samples.csv")
