@@ -169,6 +169,21 @@ struct Solver {
     gml_opts o;
     gml_stats stats{};
     hipStream_t st;
+    // (experiment, gml_test_tune GML_TUNE_DUAL_STREAMS: the passes on a stream of the lowest priority, everything else on one of the highest,
+    // so that another handle's pass running on the same GPU lets this handle's short direction-phase kernels in as workgroups retire)
+    hipStream_t st_pass = nullptr, st_own_hi = nullptr, st_own_lo = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    bool dual = false;
+    ~Solver() {
+        if (dual) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamSynchronize(st_pass);
+            (void)hipEventDestroy(ev_a);
+            (void)hipEventDestroy(ev_b);
+            (void)hipStreamDestroy(st_own_hi);
+            (void)hipStreamDestroy(st_own_lo);
+        }
+    }
     Stage stg;
     Arena A;
     PhaseTimer dir_time;
@@ -352,6 +367,19 @@ int Solver::init() {
         void *dp = nullptr; // zero-copy only where the device sees the arena under the same address (unified addressing); else copies
         stg.mapped = hipHostGetDevicePointer(&dp, p->stage, 0) == hipSuccess && dp == static_cast<void *>(p->stage);
         if (!stg.mapped) (void)hipGetLastError();
+    }
+    st_pass = st;
+    if (g_tune[GML_TUNE_DUAL_STREAMS] > 0 && gml_is_i8(o.precision)) {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamSynchronize(st)); // (what the handle's own stream still holds: the samples' images)
+        HIPCHK(hipStreamCreateWithPriority(&st_own_hi, hipStreamNonBlocking, greatest));
+        HIPCHK(hipStreamCreateWithPriority(&st_own_lo, hipStreamNonBlocking, g_tune[GML_TUNE_DUAL_STREAMS] > 1 ? greatest : least));
+        HIPCHK(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
+        st = st_own_hi;
+        st_pass = st_own_lo;
+        dual = true;
     }
     stg.base = p->stage;
     stg.cap = p->stage_bytes;
@@ -631,8 +659,16 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         a.wide = wide;
         a.coarse = coarse_on;
         std::string err;
-        int rc = i8_pass(&p->i8ws, d, Scap, a, st, nullptr, &err);
+        if (dual) { // the pass behind what this handle has queued so far, on the low-priority stream
+            HIPCHK(hipEventRecord(ev_a, st));
+            HIPCHK(hipStreamWaitEvent(st_pass, ev_a, 0));
+        }
+        int rc = i8_pass(&p->i8ws, d, Scap, a, st_pass, nullptr, &err);
         if (rc) return fail(rc, "%s", err.c_str());
+        if (dual) { // ... and everything that follows behind the pass
+            HIPCHK(hipEventRecord(ev_b, st_pass));
+            HIPCHK(hipStreamWaitEvent(st, ev_b, 0));
+        }
         if (formulation == GML_LOGRISE && want_grad) // grad log Z = grad Z / Z (:279), Z from the pass results on the device
             launch_scale_slots_inv(a.srow, a.rowcol, (int)lo, (int)ns, kRes, Qp, dst, st);
         RCCHK(fetch(res + lo, dRes + lo, sizeof(SlotResult) * ns));
