@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--no-f64", action="store_true", help="skip the FP64-path leg")
     ap.add_argument("--no-i8x", action="store_true", help="skip the i8x (accelerated mode) leg")
     ap.add_argument("--no-weighted", action="store_true", help="skip the weighted-histogram pass")
+    ap.add_argument("--no-shards", action="store_true", help="skip the one-GPU measurement of every rank's workload of an 8-GPU run")
     ap.add_argument("--cpu-learn-max-s", type=float, default=100.0, help="run the CPU learn() of THIS config in full when the "
                                                                            "measured CPU rate predicts at most this many seconds")
     ap.add_argument("--no-host-learn", action="store_true", help="skip learn() from an 8.2 GB host Matrix{Int64}")
@@ -398,6 +399,33 @@ def main():
             del hist
         else:
             extra["learn_from_host"] = {"skipped": "needs %.0f GB of host memory, %.0f available" % (1.5 * need_gb + 8, avail_gb)}
+
+    # ---- what every rank of an 8-GPU run of THIS problem would solve, measured one shard after the other on this GPU (rank 0 of a 1-GPU
+    # run only).  A PROJECTION of the N = 8 line, clearly not a measurement of it: no second device, no RCCL, no contention for the host.
+    # It exists because the one thing that does not scale with the node count -- the latency-bound direction phase of a small shard -- can
+    # be measured on one GPU, and because an 8-GPU node is not always available to the driver (SCALE_r01..r04 are skip records).
+    if rank == 0 and world == 1 and not args.no_learn and not args.no_shards and n % 8 == 0 and "learn_wall_s" in extra:
+        parts, shard = 8, []
+        for r8 in range(parts):
+            a0, a1 = r8 * n // parts, (r8 + 1) * n // parts
+            with gml.Problem(model=J, num_samples=K, seed=0, node_range=(a0, a1), device=device) as ps:
+                ps.learn("RISE", 0.4, tol=1e-9, precision=args.precision, raise_on_fail=False)
+                ts = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    _, _, st8 = ps.learn("RISE", 0.4, tol=1e-9, precision=args.precision, raise_on_fail=False)
+                    ts.append(time.perf_counter() - t0)
+                km8 = ps.bench_pass_resident("RISE", np.ascontiguousarray(J[a0:a1]), steps=10, warmup=2, precision=args.precision)
+            shard.append({"nodes": [a0, a1], "learn_s": sorted(ts)[1], "iterations": st8["iterations"], "passes": st8["passes"],
+                          "t_pass_s": st8["t_pass"], "t_hess_s": st8["t_hess"], "not_converged": st8["not_converged"],
+                          "pass_ms": float(km8["device_ms_per_pass"])})
+        worst_learn, worst_pass = max(q["learn_s"] for q in shard), max(q["pass_ms"] for q in shard)
+        extra["projection_8gpu"] = {
+            "kind": "projection from one-GPU runs of every rank's workload (NOT a multi-GPU measurement)",
+            "precision": args.precision, "shards": shard, "slowest_shard_learn_s": worst_learn, "slowest_shard_pass_ms": worst_pass,
+            "learn_scaling": extra["learn_wall_s"] / worst_learn, "pass_scaling": km["device_ms_per_pass"] / worst_pass,
+            "not_included": "the final all-gather of the n x n result (1 MiB per rank over xGMI), the ranks' barrier"}
 
     # ---- one pass over a WEIGHTED histogram (rank 0 of a 1-GPU run only): non-uniform counts take the weight-loading template
     # of the forward kernel (UNIW = false); the timed region above runs the uniform-weight one (every count equal) -----------
