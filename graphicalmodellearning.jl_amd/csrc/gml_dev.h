@@ -86,6 +86,8 @@ struct I8Pass {
     double *F;            // device [slots]: f per slot (RISE f, logRISE Z, RPLE f)
     double *G;            // device, [rows][Qp]: gradient rows (row srow[slot]); may be NULL when !want_grad
     const double *tauovr; // device [slots] or NULL: per-slot scale of V imposed by the caller (0 = from the bound)
+    bool zero_theta;      // the caller guarantees that every listed row of theta is zero (a solve's first pass at x = 0): all energies are 0
+                          // and the forward kernel skips its sweeps over the columns -- the same bits, without the GEMM
     const double *tauovr_lnrow; // device [rows of theta] or NULL: tauovr[slot] is multiplied by exp(tauovr_lnrow[srow[slot]]) (a trial
                           //    point's distance from the iterate the scale was measured at, left on the device by the kernel that formed it)
     int hv;               // 1: Hessian-vector product -- theta rows are directions p, G receives sum_k h_k (x_k.p) x_k with the

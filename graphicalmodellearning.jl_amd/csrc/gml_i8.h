@@ -143,6 +143,7 @@ struct FwdLaunch {
     int8_t *Vout;
     hipStream_t st;
     bool coarse = false; // exp forms, LF = 4: V to multiples of 2^8 tau (planes 1..3)
+    bool zero_theta = false; // every row of Theta is zero (the first pass of a solve): all energies are 0, the column sweep is skipped
 };
 void launch_fwd_i8(const FwdLaunch &a, int LF, int form, bool wantf, int hv);
 // gml_i8_bwd.hip
@@ -165,6 +166,7 @@ struct FwdWArgs {
     double *F;   // RPLE: the FP64 sum of the objective terms per slot
     int8_t *Vq;
     hipStream_t st;
+    bool zero_theta = false; // every row of Theta is zero: no column sweeps (the energies are 0)
 };
 void launch_fwd_i8w(const FwdWArgs &a);
 void launch_finalize_i8w(const int32_t *Gacc, const SlotScalars &sc, const int *srow, const int *rowcol, int slot0, int ns, int64_t Qp,

@@ -220,8 +220,17 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
             }
         }
     };
-    gemm_stage(0, std::true_type{}); // nk >= 1: Qfp >= 64
-    for (int ks = 1; ks < nst; ++ks) gemm_stage(ks, std::false_type{});
+    if (nk > 0) { // Qfp >= 64; nk = 0: every row of Theta is zero (the caller says so), the sums are
+        gemm_stage(0, std::true_type{});
+        for (int ks = 1; ks < nst; ++ks) gemm_stage(ks, std::false_type{});
+    } else {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int l = 0; l < LF; ++l)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][l][e] = 0;
+    }
     __builtin_amdgcn_s_setprio(0);
     // ---- epilogue ----------------------------------------------------------------------------
     // lane <-> node row (lr), register e <-> sample (e&3) + 8*(e>>2) + 4*h within the 32-sample tile.  The
@@ -574,7 +583,7 @@ static void launch_fwd5(const FwdLaunch &a) {
     const int ntk = a.ntk;
     const int grid = ((ntk + 7) / 8) * 8 * a.ngroups; // one workgroup per (sample tile, node tile); see the kernel's block mapping
     hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE, COARSE, UNIW>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.w->Tq, a.rowcol, a.groups,
-                       a.ngroups, d.w, a.sc->sigma, a.sc->qconst, a.sc->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, a.Vout,
+                       a.ngroups, d.w, a.sc->sigma, a.sc->qconst, a.sc->invtau, d.Kp, ntk, a.zero_theta ? 0 : (int)(d.Qfp / 64), d.wuni, d.K, a.Vout,
                        a.sc->csum, a.sc->asum, a.F, a.sc->mmax, a.w->Vq, a.vmap, a.w->sc[0].tau, a.w->LBT, a.w->vpl0(), a.w->vscale(),
                        a.chunk_tiles, a.part_tiles);
 }

@@ -151,10 +151,12 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     if (ev) I8CHK(hipEventRecord(ev[0], st));
     if (wide) {
         FwdWArgs fw{&d, w->Tq, &sc, a.rowcol, a.groups, a.ngroups, a.form, !a.want_grad, coarse, a.F, w->Vq, st};
+        fw.zero_theta = a.zero_theta && !hv;
         launch_fwd_i8w(fw);
     } else {
         FwdLaunch fl{(int)(kchunk / 256), (int)(kpart / 256), 0, w, &d, &sc, a.rowcol, a.groups, a.vmap, a.ngroups, a.F, hv ? w->Uq : w->Vq, st};
         fl.coarse = coarse;
+        fl.zero_theta = a.zero_theta && !hv && kpart == kchunk;
         fl.ntk = ksub > 1 ? nsplit * fl.part_tiles : (int)(d.Kp / 256);
         if (ksub == 1) fl.chunk_tiles = fl.part_tiles = 1; // (every tile: no remapping)
         if (!hv && w->LBT != LB) {

@@ -234,8 +234,17 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
     double us[WM][16];
     {
         v16i acc[WM][LFA];
-        gemm_stage(0, 0, std::true_type{}, acc); // nk >= 1: Qfp >= 64
-        for (int ks = 1; ks < nst; ++ks) gemm_stage(ks, ks, std::false_type{}, acc);
+        if (nk > 0) { // Qfp >= 64; nk = 0: every row of Theta is zero (the caller says so): all sums are 0, nothing is loaded
+            gemm_stage(0, 0, std::true_type{}, acc);
+            for (int ks = 1; ks < nst; ++ks) gemm_stage(ks, ks, std::false_type{}, acc);
+        } else {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int l = 0; l < LFA; ++l)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][l][e] = 0;
+        }
 #ifdef ABL_TIMING
         tst[1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -266,12 +275,21 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
         // Done for all 32 elements of the lane at once: the 96 accumulators and the 64 registers of `us` become 64 registers of
         // energies before the pointwise arithmetic starts.
         v16i acc[WM][LFB];
-        gemm_stage(nst, 0, std::true_type{}, acc);
+        if (nk > 0) {
+            gemm_stage(nst, 0, std::true_type{}, acc);
 #ifndef ABL_ONESWEEP
-        for (int ks = 1; ks < nst; ++ks) gemm_stage(nst + ks, ks, std::false_type{}, acc);
+            for (int ks = 1; ks < nst; ++ks) gemm_stage(nst + ks, ks, std::false_type{}, acc);
 #else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+        } else {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int l = 0; l < LFB; ++l)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][l][e] = 0;
+        }
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -480,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
         // planes at a time (6 KB per wave).  Rows that are not part of this pass keep what they hold (a re-run of some rows of a
         // tile must not touch the planes of the others): their lines are stored partially.
         {
-            const int lastslot = (ntot - 1) % NSW;
+            const int lastslot = (ntot > 0 ? ntot - 1 : 0) % NSW;
             int8_t *stg = lds + ((lastslot + 1 + (wave >> 1)) % NSW) * STAGEW + (wave & 1) * 6144;
             const unsigned amask = (unsigned)__ballot(active); // bit lr (lanes 0..31)
             int8_t *img = Vq + vq_off(mytile * 32, 0, kw, Kp, LBW);
@@ -659,7 +677,7 @@ static void launch_fwd_w5(const FwdWArgs &a) {
     const int ntk = (int)(d.Kp / 256);
     const int grid = ((ntk + 7) / 8) * 8 * a.ngroups; // one workgroup per (sample tile, node tile)
     hipLaunchKernelGGL((k_fwd_i8w<FORM, WANTF, WIDE, UNIW, COARSE>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.Tq, a.rowcol, a.groups,
-                       a.ngroups, d.w, a.sc->sigma, a.sc->qconst, a.sc->qconst2, a.sc->invtau, d.Kp, ntk, (int)(d.Qfp / 64), d.wuni, d.K, a.Vq,
+                       a.ngroups, d.w, a.sc->sigma, a.sc->qconst, a.sc->qconst2, a.sc->invtau, d.Kp, ntk, a.zero_theta ? 0 : (int)(d.Qfp / 64), d.wuni, d.K, a.Vq,
                        a.sc->csum, a.sc->csum2, a.sc->asum, a.sc->asum2, a.F, a.sc->mmax);
 }
 

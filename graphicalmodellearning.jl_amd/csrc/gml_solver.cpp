@@ -174,6 +174,7 @@ struct Solver {
     hipStream_t st_pass = nullptr, st_own_hi = nullptr, st_own_lo = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bool dual = false;
+    bool at_zero = false; // the pass being queued evaluates X = 0 (the first pass of a solve; also its rescaled re-runs)
     ~Solver() {
         if (dual) {
             (void)hipStreamSynchronize(st);
@@ -658,6 +659,7 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         a.lf = o.limbs_fwd;
         a.wide = wide;
         a.coarse = coarse_on;
+        a.zero_theta = at_zero && g_tune[GML_TUNE_NO_ZERO_SHORTCUT] == 0; // the first pass of a solve: X = 0 for every row
         std::string err;
         if (dual) { // the pass behind what this handle has queued so far, on the low-priority stream
             HIPCHK(hipEventRecord(ev_a, st));
@@ -1485,10 +1487,14 @@ int Solver::finish(double *out, double *kkt_out, int iterations) {
 }
 
 int Solver::iterate(double *out, double *kkt_out) {
-    // first pass at X = 0
+    // first pass at X = 0: every energy is 0, the forward kernel skips its sweeps over the columns (the same bits without the GEMM:
+    // 3.4 -> 1 ms of the headline solve's first pass)
     std::vector<int> rows_all((size_t)R);
     for (int64_t r = 0; r < R; ++r) rows_all[r] = (int)r;
-    RCCHK(run_pass(rows_all, X, G, true, false, f, Z, fn, nullptr, 0, prec));
+    at_zero = true;
+    const int rc0 = run_pass(rows_all, X, G, true, false, f, Z, fn, nullptr, 0, prec);
+    at_zero = false;
+    RCCHK(rc0);
     int it = 0;
     for (it = 0; it < o.max_iter; ++it) {
         int64_t nactive = 0;

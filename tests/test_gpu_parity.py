@@ -1031,6 +1031,32 @@ def test_auto_precision_takes_the_wide_limbs_for_tight_tolerances():
     assert np.array_equal(b, c) and sb["passes"] == sc["passes"]
 
 
+@pytest.mark.parametrize("prec", ["i8x", "i8w"])
+@pytest.mark.parametrize("form", FORMS)
+def test_first_pass_without_its_gemm_gives_the_same_bits(form, prec):
+    # The first pass of a solve evaluates X = 0: every energy is 0 and the forward kernels skip their sweeps over the columns (the
+    # caller says so: I8Pass.zero_theta).  The epilogue sees the same zeros either way, so the solve must not change by a bit --
+    # checked against the same solve with the shortcut switched off (experiment knob 4), with and without the coarse early passes.
+    import ctypes as C
+    L = _lib.lib()
+    L.gml_test_tune.restype = C.c_double
+    L.gml_test_tune.argtypes = [C.c_int, C.c_double]
+    for n, K in ((48, 20000), (256, 270000)):  # (below / above the gate of the coarse passes)
+        spins, _ = synthetic.block_ising(n, K, block=16, seed=12)
+        with gml.Problem(spins=spins) as p:
+            res = {}
+            for off in (0.0, 1.0):
+                L.gml_test_tune(4, off)
+                try:
+                    res[off] = p.learn(form, 0.4, tol=1e-9, precision=prec)
+                finally:
+                    L.gml_test_tune(4, 0.0)
+        (a, ka, sa), (b, kb, sb) = res[0.0], res[1.0]
+        assert np.array_equal(a, b) and np.array_equal(ka, kb)
+        assert (sa["iterations"], sa["passes"], sa["forward_passes"], sa["node_evals"]) == (sb["iterations"], sb["passes"], sb["forward_passes"], sb["node_evals"])
+        assert sa["not_converged"] == 0
+
+
 def test_coarse_early_passes_do_not_change_the_answer():
     # gml_opts.coarse: the int8-limb precisions run their passes in the 30 / 23-bit form (one forward sweep, one backward launch) while every
     # active node is far from its optimum and at full width afterwards: same optimum, same iteration count +- 1, and the rows are
