@@ -61,8 +61,8 @@ def pairwise(name, desc, J, K, form, c, seed, node_range=None, sample_nodes=4, c
     n = J.shape[0] if J is not None else hist.shape[1] - 1
     n0, n1 = node_range or (0, n)
     rec = {"config": desc, "n": n, "K": K, "formulation": f"{form}({c})", "seed": seed,
-           # learn() at the library default: "auto" = the int8-limb path, FP64 for launch-bound sizes (config 1)
-           "precision": ("auto -> f64" if K * n * n <= 2 ** 28 else ("auto -> i8x" if PREC == "i8x" else PREC)), "tol": tol,
+           # learn() at the library default: "auto" = the 38/31-bit int8 limbs, the FP64-grade ones for small problems (config 1)
+           "precision": ("auto -> i8w" if K * n * n <= 2 ** 28 else ("auto -> i8x" if PREC == "i8x" else PREC)), "tol": tol,
            "node_range": [n0, n1], "n_gpus": 1, **cpu_info()}
     t0 = time.time()
     prob = gml.Problem(hist, node_range=node_range) if hist is not None else \
@@ -74,10 +74,10 @@ def pairwise(name, desc, J, K, form, c, seed, node_range=None, sample_nodes=4, c
         small = K * n * n <= 2 ** 28
         out, kkt, st = p.learn(form, c, tol=tol, raise_on_fail=False, precision="auto" if (small or PREC == "i8x") else PREC)
         rec["learn_s"] = time.time() - t0
-        if not small:  # a second solve on the warm handle (the first one of a process also pays for the workspace allocation)
-            t0 = time.time()
-            p.learn(form, c, tol=tol, raise_on_fail=False, precision="auto" if PREC == "i8x" else PREC)
-            rec["learn_warm_s"] = time.time() - t0
+        # a second solve on the warm handle (the first one of a handle also pays for the workspace allocation)
+        t0 = time.time()
+        p.learn(form, c, tol=tol, raise_on_fail=False, precision="auto" if (small or PREC == "i8x") else PREC)
+        rec["learn_warm_s"] = time.time() - t0
         rec.update({"lambda": st["lambda_"], "iterations": st["iterations"], "passes": st["passes"],
                     "forward_passes": st["forward_passes"], "hessian_passes": st["hessian_passes"], "node_evals": st["node_evals"],
                     "max_kkt": st["max_kkt"], "not_converged": st["not_converged"], "polished": st["polished"],
