@@ -368,6 +368,7 @@ int Solver::init() {
         void *dp = nullptr; // zero-copy only where the device sees the arena under the same address (unified addressing); else copies
         stg.mapped = hipHostGetDevicePointer(&dp, p->stage, 0) == hipSuccess && dp == static_cast<void *>(p->stage);
         if (!stg.mapped) (void)hipGetLastError();
+        if (g_tune[GML_TUNE_NO_ZEROCOPY] > 0) stg.mapped = false; // (tests: the copy path that very large handles take)
     }
     st_pass = st;
     if (g_tune[GML_TUNE_DUAL_STREAMS] > 0 && gml_is_i8(o.precision)) {

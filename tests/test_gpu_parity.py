@@ -1057,6 +1057,29 @@ def test_first_pass_without_its_gemm_gives_the_same_bits(form, prec):
         assert sa["not_converged"] == 0
 
 
+@pytest.mark.parametrize("form,prec", [("RISE", "i8w"), ("logRISE", "i8x"), ("RPLE", "i8x"), ("RISE", "f64")])
+def test_solver_staging_zero_copy_and_copies_agree(form, prec):
+    # The solver's kernels write their per-row results straight into pinned host memory and read their row lists from it; a handle
+    # whose rows do not fit the pinned arena (tens of thousands of local rows) goes through device arrays and copies instead.  Both
+    # routes must give the same solve, bit for bit (experiment knob 5 forces the copy route).
+    import ctypes as C
+    L = _lib.lib()
+    L.gml_test_tune.restype = C.c_double
+    L.gml_test_tune.argtypes = [C.c_int, C.c_double]
+    spins, _ = synthetic.block_ising(96, 30000, block=16, seed=14)
+    with gml.Problem(spins=spins) as p:
+        res = {}
+        for off in (0.0, 1.0):
+            L.gml_test_tune(5, off)
+            try:
+                res[off] = p.learn(form, 0.4, tol=1e-9, precision=prec)
+            finally:
+                L.gml_test_tune(5, 0.0)
+    (a, ka, sa), (b, kb, sb) = res[0.0], res[1.0]
+    assert np.array_equal(a, b) and np.array_equal(ka, kb) and sa["not_converged"] == 0
+    assert (sa["iterations"], sa["passes"], sa["forward_passes"], sa["node_evals"]) == (sb["iterations"], sb["passes"], sb["forward_passes"], sb["node_evals"])
+
+
 def test_coarse_early_passes_do_not_change_the_answer():
     # gml_opts.coarse: the int8-limb precisions run their passes in the 30 / 23-bit form (one forward sweep, one backward launch) while every
     # active node is far from its optimum and at full width afterwards: same optimum, same iteration count +- 1, and the rows are
