@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GML_LIB_OVERRIDE") or os.path.join(_HERE, "libgml_hip.so")  # override: A/B builds
 
 GML_OK, GML_EINVAL, GML_ENOTCONV, GML_EHIP, GML_ENOMEM, GML_EUNSUPPORTED = range(6)
+GML_ABI_VERSION = 6  # include/gml.h: the revision of the C ABI the mirrors below (Opts, Stats, argument lists) were written against
 FORMULATION_IDS = {"RISE": 0, "RISEA": 0, "multiRISE": 0, "logRISE": 1, "RPLE": 2}
 DTYPES = {np.dtype(np.int8): 0, np.dtype(np.int32): 1, np.dtype(np.int64): 2, np.dtype(np.float64): 3}
 PRECISIONS = {"f64": 0, "i8x": 1, "auto": 2, "i8w": 3}  # auto: i8x, i8w for tight tolerances / small problems / operator calls; i8w: FP64-grade int8 limbs
@@ -41,7 +42,7 @@ class Stats(C.Structure):
                 ("hessian_passes", C.c_int32), ("node_evals", C.c_int64), ("max_kkt", C.c_double),
                 ("lambda_", C.c_double), ("t_pack", C.c_double), ("t_pass", C.c_double),
                 ("t_hess", C.c_double), ("t_host", C.c_double), ("t_total", C.c_double),
-                ("not_converged", C.c_int32), ("polished", C.c_int32), ("hv_evals", C.c_int64)]
+                ("not_converged", C.c_int32), ("polished", C.c_int32), ("hv_evals", C.c_int64), ("t_assemble", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -65,6 +66,7 @@ def lib():
         pass
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     i64, dbl, p, i32 = C.c_int64, C.c_double, C.c_void_p, C.c_int
+    _check_abi(L)
     L.gml_last_error.restype = C.c_char_p
     L.gml_default_opts.argtypes = [C.POINTER(Opts)]
     L.gml_default_opts.restype = None
@@ -98,10 +100,31 @@ def lib():
     L.gml_multi_destroy.argtypes = [p]
     L.gml_multi_destroy.restype = None
     L.gml_learn.argtypes = [p, i32, dbl, C.POINTER(Opts), p, p, C.POINTER(Stats)]
+    L.gml_terms_count.restype = i64
+    L.gml_terms_count.argtypes = [i64, i32, i32]
+    L.gml_terms_assemble.argtypes = [p, i64, i64, i32, i32, i32, p]
+    L.gml_terms_keys.argtypes = [i64, i32, i32, i64, i64, p]
+    L.gml_terms_rank.restype = i64
+    L.gml_terms_rank.argtypes = [i64, i32, i32, p, i32]
+    L.gml_learn_terms.argtypes = [p, i32, dbl, i32, C.POINTER(Opts), p, p, C.POINTER(Stats)]
     L.gml_bench_pass.argtypes = [p, i32, i32, p, i32, i32, p]
     L.gml_bench_pass_resident.argtypes = [p, i32, i32, p, i32, i32, p, p, p, p]
     _lib = L
     return L
+
+
+def _check_abi(L):
+    """A library of another ABI revision would read / write Opts and Stats at the wrong offsets without any error: refuse it
+    (include/gml.h, "ABI identity").  Libraries older than the check itself lack the symbols."""
+    try:
+        L.gml_sizeof_opts.restype = L.gml_sizeof_stats.restype = C.c_int64
+        got = (int(L.gml_abi_version()), int(L.gml_sizeof_opts()), int(L.gml_sizeof_stats()))
+    except AttributeError:
+        raise GMLError(GML_EUNSUPPORTED, f"{LIB_PATH} predates gml_abi_version(): rebuild it (this binding is ABI {GML_ABI_VERSION})")
+    want = (GML_ABI_VERSION, C.sizeof(Opts), C.sizeof(Stats))
+    if got != want:
+        raise GMLError(GML_EUNSUPPORTED, f"{LIB_PATH} has ABI version / sizeof(gml_opts) / sizeof(gml_stats) = {got}, this binding "
+                                         f"was written against {want}: library and binding come from different revisions")
 
 
 def check(rc, allow=()):
@@ -153,6 +176,44 @@ def pack_histogram(samples):
     M = C.c_double()
     check(L.gml_pack_histogram(_ptr(s), dt, K, n, ld, cm, _ptr(bits), wpr, _ptr(counts), C.byref(M)))
     return bits, counts, M.value
+
+
+def terms_count(n, order, symmetrize):
+    """number of terms of a learned model of `n` spins (gml_terms_count): symmetrised C(n,1)+...+C(n,order), else n P"""
+    T = int(lib().gml_terms_count(int(n), int(order), int(bool(symmetrize))))
+    if T < 0:
+        raise GMLError(GML_EUNSUPPORTED, lib().gml_last_error().decode())
+    return T
+
+
+def terms_assemble(rows, n, order, symmetrize, device=0, ld=None):
+    """gml_terms_assemble: the n solved rows -> the model's weights in (length, key) order, on the device.  rows: an (n, P)
+    float64 ndarray, or an int device pointer (then ld = its row pitch in doubles)."""
+    out = np.empty(terms_count(n, order, symmetrize))
+    if isinstance(rows, (int, np.integer)):
+        ptr, ld = C.c_void_p(int(rows)), int(ld)
+    else:
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        if rows.ndim != 2 or rows.shape[0] != n:
+            raise GMLError(GML_EINVAL, f"terms_assemble needs the rows of all {n} nodes, got {rows.shape}")
+        ptr, ld = _ptr(rows), rows.shape[1]
+    check(lib().gml_terms_assemble(ptr, ld, int(n), int(order), int(bool(symmetrize)), int(device), _ptr(out)))
+    return out
+
+
+def terms_keys(n, order, symmetrize, first=0, count=None):
+    """keys of the terms [first, first + count) (gml_terms_keys; host only): int32 [count, order], 0-based spins, -1 = unused"""
+    if count is None:
+        count = terms_count(n, order, symmetrize) - first
+    keys = np.empty((int(count), int(order)), dtype=np.int32)
+    check(lib().gml_terms_keys(int(n), int(order), int(bool(symmetrize)), int(first), int(count), _ptr(keys)))
+    return keys
+
+
+def terms_rank(n, order, symmetrize, key0):
+    """position of the 0-based key among the terms (gml_terms_rank), -1 if the model has no such key"""
+    k = np.ascontiguousarray(key0, dtype=np.int32)
+    return int(lib().gml_terms_rank(int(n), int(order), int(bool(symmetrize)), _ptr(k), len(k)))
 
 
 class Problem:
@@ -304,7 +365,10 @@ class Problem:
 
     def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="auto", max_working=512, max_add=64,
               verbose=0, hess_samples=0, polish=True, max_cg=0, limbs_fwd=0, hv_limbs_fwd=0, hv_limbs_bwd=0, debug_row=0,
-              hv_subsample=0, cg_viol_frac=0.0, cg_eta=0.0, coarse=True, out_ptr=None, raise_on_fail=True):
+              hv_subsample=0, cg_viol_frac=0.0, cg_eta=0.0, coarse=True, out_ptr=None, raise_on_fail=True, terms=None):
+        """gml_learn: (rows, kkt, stats).  terms = True / False (handles over all nodes): gml_learn_terms instead -- the solved
+        rows stay on the device and the first result is the model's weight array in (length, key) order, symmetrised (True) or
+        not (False): the input of a FactorGraph (TermArray)."""
         L = lib()
         o = Opts()
         L.gml_default_opts(C.byref(o))
@@ -319,12 +383,17 @@ class Problem:
         o.coarse = (0 if coarse else -1) if isinstance(coarse, bool) else int(coarse)
         R = self.node1 - self.node0
         out = None
-        if out_ptr is None:
-            out = np.zeros((R, self.P))
-            out_ptr = _ptr(out)
         kkt = np.zeros(R)
         st = Stats()
-        rc = L.gml_learn(self._h, FORMULATION_IDS[formulation], float(c), C.byref(o), out_ptr, _ptr(kkt), C.byref(st))
+        if terms is not None:
+            out = np.empty(terms_count(self.n, self.order, terms))
+            rc = L.gml_learn_terms(self._h, FORMULATION_IDS[formulation], float(c), int(bool(terms)), C.byref(o), _ptr(out), _ptr(kkt),
+                                   C.byref(st))
+        else:
+            if out_ptr is None:
+                out = np.zeros((R, self.P))
+                out_ptr = _ptr(out)
+            rc = L.gml_learn(self._h, FORMULATION_IDS[formulation], float(c), C.byref(o), out_ptr, _ptr(kkt), C.byref(st))
         if rc == GML_ENOTCONV:
             if raise_on_fail:
                 err = GMLConvergenceError(L.gml_last_error().decode())
@@ -333,6 +402,12 @@ class Problem:
         else:
             check(rc)
         return out, kkt, st.asdict()
+
+    def multi_keys_array(self, u):
+        """gml_multi_keys as it comes: int32 [P, order], 0-based, -1 = unused slot"""
+        keys = np.zeros((self.P, self.order), dtype=np.int32)
+        check(lib().gml_multi_keys(self._h, int(u), _ptr(keys)))
+        return keys
 
     def bench_pass(self, formulation, theta=None, steps=5, warmup=1, precision="f64"):
         ms = np.zeros(3)

@@ -142,6 +142,11 @@ extern "C" double gml_lambda(double c, int64_t n, double M) {
     return c * std::sqrt(std::log(((double)n * (double)n) / 0.05) / M);
 }
 
+// ABI identity (include/gml.h): the bindings compare these with their own mirrors when they load the library
+extern "C" int gml_abi_version(void) { return GML_ABI_VERSION; }
+extern "C" int64_t gml_sizeof_opts(void) { return (int64_t)sizeof(gml_opts); }
+extern "C" int64_t gml_sizeof_stats(void) { return (int64_t)sizeof(gml_stats); }
+
 extern "C" void gml_default_opts(gml_opts *o) {
     std::memset(o, 0, sizeof *o);
     o->tol = 1e-9;

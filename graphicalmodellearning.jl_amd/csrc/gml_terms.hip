@@ -1,0 +1,327 @@
+// Result assembly of the multi-body learn() on the device: what the reference does after its node loop
+// (GraphicalModelLearning.jl:129-132 `reconstruction[inter] = ...` per node, :135-149 group by sorted key + `mean`, :151
+// FactorGraph(order, n, :spin, reconstruction)) without a key table and without a host loop.
+//
+// The n solved rows (n x P doubles, row u in the key order of :94-104 = gml_multi_keys(u)) become ONE array of weights in the
+// order the reference itself lists a model's terms in (models.jl:61,72: sort by (length(key), key)):
+//   symmetrised     every ascending key S, |S| <= order: sizes 1..order, lexicographic within a size; C(n,1) + ... + C(n,order)
+//                   values, value = mean over u in S of row u's entry for the key (u, S \ {u})      (:135-149)
+//   unsymmetrised   every key (u, S'), S' an ascending subset of the other spins: by size, then u, then S'; n P values   (:129-132)
+// A key <-> its position is closed-form (combinatorial number system, lexicographic): the kernel unranks its output index,
+// ranks S \ {u} among the (|S|-1)-subsets of the n-1 other spins to find row u's slot, and adds the |S| entries in ascending
+// u.  C5 (n = 512, order 3): 67.0 M row entries (536 MB) -> 22.5 M terms (179 MB), one launch.
+#include "gml_internal.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace {
+
+constexpr int MAXORD = 8; // (an order-9 model with n >= 32 has > 2^24 parameters per node; the statistics side stops far earlier)
+
+struct TermPlan {
+    int64_t n;
+    int order;
+    int pairwise; // order 2: the rows keep the pairwise slot layout of the C ABI (slot i <-> spin i, slot u = field, :162)
+    int64_t off[MAXORD + 2];  // symmetrised: first position of the size-s keys, off[order + 1] = total
+    int64_t uoff[MAXORD + 2]; // unsymmetrised: the same
+    int64_t roff[MAXORD + 2]; // first slot of the size-s keys within a node's row (multi-body layout): roff[1] = 0
+    int64_t rcnt[MAXORD + 2]; // C(n-1, s-1): size-s keys of one node
+};
+
+__host__ __device__ inline int64_t binom(int64_t m, int q) {
+    if (q < 0 || q > m) return 0;
+    int64_t r = 1;
+    for (int i = 1; i <= q; ++i) r = r * (m - q + i) / i; // exact at every step: r = C(m - q + i, i)
+    return r;
+}
+
+// the q-subset of {0..m-1} of lexicographic rank r -> c[0..q)
+__host__ __device__ inline void unrank_lex(int64_t r, int64_t m, int q, int32_t *c) {
+    int64_t base = 0; // the items below base are spent
+    for (int i = 0; i < q; ++i) {
+        const int rem = q - i;
+        const int64_t mm = m - base;
+        const int64_t tot = binom(mm, rem);
+        // subsets of the remaining items whose first element lies below base + a: tot - C(mm - a, rem); the largest a with that <= r
+        int64_t lo = 0, hi = mm - rem;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (tot - binom(mm - mid, rem) <= r) lo = mid;
+            else hi = mid - 1;
+        }
+        r -= tot - binom(mm - lo, rem);
+        c[i] = (int32_t)(base + lo);
+        base += lo + 1;
+    }
+}
+
+// lexicographic rank of the ascending q-subset c of {0..m-1}
+__host__ __device__ inline int64_t rank_lex(const int32_t *c, int q, int64_t m) {
+    int64_t r = 0, base = 0;
+    for (int i = 0; i < q; ++i) {
+        r += binom(m - base, q - i) - binom(m - c[i], q - i);
+        base = (int64_t)c[i] + 1;
+    }
+    return r;
+}
+
+// slot of the key (u, S \ {u}) in row u; S = c[0..s) ascending, u = c[a]
+__host__ __device__ inline int64_t row_slot(const TermPlan &pl, const int32_t *c, int s, int a) {
+    const int32_t u = c[a];
+    if (pl.pairwise) return s == 1 ? u : c[1 - a];
+    if (s == 1) return 0;
+    int32_t o[MAXORD];
+    for (int t = 0, j = 0; t < s; ++t)
+        if (t != a) o[j++] = c[t] - (c[t] > u); // the other spins renumbered 0..n-2 (`neighbours`, :96)
+    return pl.roff[s] + rank_lex(o, s - 1, pl.n - 1);
+}
+
+__global__ __launch_bounds__(256) void k_terms_sym(TermPlan pl, const double *__restrict__ rows, int64_t ld, double *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= pl.off[pl.order + 1]) return;
+    int s = 1;
+    while (t >= pl.off[s + 1]) ++s;
+    int32_t c[MAXORD];
+    unrank_lex(t - pl.off[s], pl.n, s, c);
+    double sum = 0.0;
+    for (int a = 0; a < s; ++a) sum += rows[(int64_t)c[a] * ld + row_slot(pl, c, s, a)]; // ascending u
+    out[t] = sum / (double)s; // `mean` (:147)
+}
+
+__global__ __launch_bounds__(256) void k_terms_unsym(TermPlan pl, const double *__restrict__ rows, int64_t ld, double *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= pl.uoff[pl.order + 1]) return;
+    int s = 1;
+    while (t >= pl.uoff[s + 1]) ++s;
+    const int64_t r = t - pl.uoff[s], u = r / pl.rcnt[s], j = r % pl.rcnt[s];
+    int64_t slot;
+    if (pl.pairwise) slot = s == 1 ? u : j + (j >= u);
+    else slot = pl.roff[s] + j;
+    out[t] = rows[u * ld + slot];
+}
+
+int make_plan(int64_t n, int order, TermPlan &pl) {
+    if (n < 1 || order < 1) return fail(GML_EINVAL, "terms: n = %lld, order = %d", (long long)n, order);
+    if (order > MAXORD) return fail(GML_EUNSUPPORTED, "terms: interaction orders above %d are not assembled on the device", MAXORD);
+    std::memset(&pl, 0, sizeof pl);
+    pl.n = n;
+    pl.order = order;
+    pl.pairwise = order == 2;
+    const double lim = 1.0e12; // (8 TB of doubles; keeps the exact binomials and their intermediate products inside int64)
+    double chk = 0;
+    for (int s = 1; s <= order; ++s) {
+        double b = 1; // C(n, s) in floating point, against overflow of the exact one
+        for (int i = 1; i <= s; ++i) b = b * (double)(n - s + i) / i;
+        chk += b * s;
+        if (chk > lim) return fail(GML_EUNSUPPORTED, "terms: the model has more than 1e12 terms");
+        pl.rcnt[s] = binom(n - 1, s - 1);
+        pl.off[s + 1] = pl.off[s] + binom(n, s);
+        pl.uoff[s + 1] = pl.uoff[s] + n * pl.rcnt[s];
+        pl.roff[s + 1] = pl.roff[s] + pl.rcnt[s];
+    }
+    return GML_OK;
+}
+
+bool is_device_ptr(const void *q, int *dev) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, q) == hipSuccess) {
+        if (attr.type == hipMemoryTypeDevice) {
+            if (dev) *dev = attr.device;
+            return true;
+        }
+        return false;
+    }
+    (void)hipGetLastError();
+    return false;
+}
+
+} // namespace
+
+extern "C" int64_t gml_terms_count(int64_t n, int order, int symmetrize) {
+    TermPlan pl;
+    if (make_plan(n, order, pl) != GML_OK) return -1;
+    return symmetrize ? pl.off[order + 1] : pl.uoff[order + 1];
+}
+
+// device-side core: rows and out on `device`, launched on st
+int gml_terms_assemble_dev(const double *drows, int64_t ld, int64_t n, int order, int symmetrize, double *dout, hipStream_t st) {
+    TermPlan pl;
+    const int rc = make_plan(n, order, pl);
+    if (rc != GML_OK) return rc;
+    const int64_t T = symmetrize ? pl.off[order + 1] : pl.uoff[order + 1];
+    const unsigned nb = (unsigned)((T + 255) / 256);
+    if (symmetrize) hipLaunchKernelGGL(k_terms_sym, dim3(nb), dim3(256), 0, st, pl, drows, ld, dout);
+    else hipLaunchKernelGGL(k_terms_unsym, dim3(nb), dim3(256), 0, st, pl, drows, ld, dout);
+    HIPCHK(hipGetLastError());
+    return GML_OK;
+}
+
+extern "C" int gml_terms_assemble(const double *rows, int64_t ld, int64_t n, int order, int symmetrize, int device, double *out) {
+    if (!rows || !out) return fail(GML_EINVAL, "NULL argument");
+    TermPlan pl;
+    int rc = make_plan(n, order, pl);
+    if (rc != GML_OK) return rc;
+    const int64_t P = pl.pairwise ? n : pl.roff[order + 1];
+    if (ld < P) return fail(GML_EINVAL, "terms: leading dimension %lld < %lld parameters per node", (long long)ld, (long long)P);
+    const int64_t T = symmetrize ? pl.off[order + 1] : pl.uoff[order + 1];
+    int rdev = device, odev = device;
+    const bool rows_dev = is_device_ptr(rows, &rdev), out_dev = is_device_ptr(out, &odev);
+    if (rows_dev) device = rdev;
+    else if (out_dev) device = odev;
+    HIPCHK(hipSetDevice(device));
+    hipStream_t st = nullptr; // the device's null stream: ordered after whatever the caller queued there
+    double *drows = nullptr, *dout = nullptr;
+    auto cleanup = [&]() {
+        if (drows) (void)gml::dev_free(drows);
+        if (dout) (void)gml::dev_free(dout);
+    };
+    const double *src = rows;
+    if (!rows_dev) {
+        const size_t bytes = sizeof(double) * (size_t)((n - 1) * ld + P);
+        hipError_t e = gml::dev_malloc(&drows, bytes);
+        if (e == hipSuccess) e = hipMemcpyAsync(drows, rows, bytes, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            cleanup();
+            return fail(e == hipErrorOutOfMemory ? GML_ENOMEM : GML_EHIP, "terms: staging the rows failed: %s", hipGetErrorString(e));
+        }
+        src = drows;
+    }
+    double *dst = out;
+    if (!out_dev) {
+        const hipError_t e = gml::dev_malloc(&dout, sizeof(double) * (size_t)T);
+        if (e != hipSuccess) {
+            cleanup();
+            return fail(e == hipErrorOutOfMemory ? GML_ENOMEM : GML_EHIP, "terms: allocating the result failed: %s", hipGetErrorString(e));
+        }
+        dst = dout;
+    }
+    rc = gml_terms_assemble_dev(src, ld, n, order, symmetrize, dst, st);
+    hipError_t e = hipSuccess;
+    if (rc == GML_OK && !out_dev) e = hipMemcpyAsync(out, dout, sizeof(double) * (size_t)T, hipMemcpyDeviceToHost, st);
+    if (rc == GML_OK && e == hipSuccess) e = hipStreamSynchronize(st);
+    cleanup();
+    if (rc != GML_OK) return rc;
+    if (e != hipSuccess) return fail(GML_EHIP, "terms: %s", hipGetErrorString(e));
+    return GML_OK;
+}
+
+// keys of the terms [first, first + count): `order` int32 each, 0-based spins, -1 in the unused slots.  Host only.
+extern "C" int gml_terms_keys(int64_t n, int order, int symmetrize, int64_t first, int64_t count, int32_t *keys) {
+    TermPlan pl;
+    const int rc = make_plan(n, order, pl);
+    if (rc != GML_OK) return rc;
+    const int64_t T = symmetrize ? pl.off[order + 1] : pl.uoff[order + 1];
+    if (first < 0 || count < 0 || first + count > T) return fail(GML_EINVAL, "terms: [%lld, %lld) is outside the %lld terms", (long long)first, (long long)(first + count), (long long)T);
+    if (count == 0) return GML_OK;
+    if (!keys) return fail(GML_EINVAL, "NULL argument");
+    const int64_t chunk = 1 << 16, nchunk = (count + chunk - 1) / chunk;
+    gml_parallel_for(nchunk, [&](int64_t ci) {
+        const int64_t t0 = first + ci * chunk, t1 = std::min(first + count, t0 + chunk);
+        int s = 0;
+        int64_t u = -1, left = 0; // positions left in the current (size[, node]) run
+        int32_t c[MAXORD];
+        const int64_t m = symmetrize ? n : n - 1;
+        for (int64_t t = t0; t < t1; ++t) {
+            int32_t *k = keys + (t - first) * order;
+            if (left == 0) { // (re)start: unrank
+                const int64_t *off = symmetrize ? pl.off : pl.uoff;
+                s = 1;
+                while (t >= off[s + 1]) ++s;
+                int64_t r = t - off[s];
+                int q = s;
+                if (!symmetrize) {
+                    u = r / pl.rcnt[s];
+                    r = r % pl.rcnt[s];
+                    q = s - 1;
+                    left = pl.rcnt[s] - r;
+                } else {
+                    left = off[s + 1] - t;
+                }
+                unrank_lex(r, m, q, c);
+            } else { // next subset in lexicographic order
+                const int q = symmetrize ? s : s - 1;
+                int i = q - 1;
+                while (i >= 0 && c[i] == (int32_t)(m - q + i)) --i;
+                ++c[i];
+                for (int j = i + 1; j < q; ++j) c[j] = c[j - 1] + 1;
+            }
+            --left;
+            for (int j = 0; j < order; ++j) k[j] = -1;
+            if (symmetrize) {
+                for (int j = 0; j < s; ++j) k[j] = c[j];
+            } else {
+                k[0] = (int32_t)u;
+                for (int j = 0; j + 1 < s; ++j) k[1 + j] = c[j] + (c[j] >= u); // `neighbours` back to spin ids (:96)
+            }
+        }
+    });
+    return GML_OK;
+}
+
+// position of a key (len spins, 0-based) among the terms; -1 if it is not a key of the model
+extern "C" int64_t gml_terms_rank(int64_t n, int order, int symmetrize, const int32_t *key, int len) {
+    TermPlan pl;
+    if (make_plan(n, order, pl) != GML_OK) return -1;
+    if (!key || len < 1 || len > order) return -1;
+    for (int j = 0; j < len; ++j)
+        if (key[j] < 0 || key[j] >= n) return -1;
+    if (symmetrize) {
+        for (int j = 1; j < len; ++j)
+            if (key[j] <= key[j - 1]) return -1;
+        return pl.off[len] + rank_lex(key, len, n);
+    }
+    int32_t o[MAXORD];
+    const int32_t u = key[0];
+    for (int j = 1; j < len; ++j) {
+        if (key[j] == u || (j > 1 && key[j] <= key[j - 1])) return -1;
+        o[j - 1] = key[j] - (key[j] > u);
+    }
+    return pl.uoff[len] + (int64_t)u * pl.rcnt[len] + rank_lex(o, len - 1, n - 1);
+}
+
+// gml_learn for every node of the handle + the assembly above, the rows never leaving the device (include/gml.h)
+extern "C" int gml_learn_terms(gml_problem *p, int formulation, double regularizer_c, int symmetrize, const gml_opts *opts, double *terms,
+                               double *kkt, gml_stats *stats) {
+    if (!p || !terms) return fail(GML_EINVAL, "NULL argument");
+    if (p->node0 != 0 || p->node1 != p->n)
+        return fail(GML_EINVAL, "gml_learn_terms needs a handle over all nodes (this one holds [%lld, %lld) of %lld): gather the rows of "
+                                "gml_learn and call gml_terms_assemble", (long long)p->node0, (long long)p->node1, (long long)p->n);
+    TermPlan pl;
+    int rc = make_plan(p->n, p->order, pl);
+    if (rc != GML_OK) return rc;
+    HIPCHK(hipSetDevice(p->device));
+    const int64_t T = symmetrize ? pl.off[p->order + 1] : pl.uoff[p->order + 1];
+    double *drows = nullptr, *dout = nullptr;
+    HIPCHK(gml::dev_malloc(&drows, sizeof(double) * (size_t)p->n * (size_t)p->P));
+    gml_stats st_local;
+    std::memset(&st_local, 0, sizeof st_local);
+    rc = gml_learn(p, formulation, regularizer_c, opts, drows, kkt, &st_local);
+    std::string learn_msg = gml_last_error();
+    int rc2 = GML_OK;
+    if (rc == GML_OK || rc == GML_ENOTCONV) {
+        const double t0 = gml_now_s();
+        int odev = 0;
+        const bool out_dev = is_device_ptr(terms, &odev);
+        hipError_t e = hipSuccess;
+        double *dst = terms;
+        if (!out_dev) {
+            e = gml::dev_malloc(&dout, sizeof(double) * (size_t)T);
+            dst = dout;
+        }
+        if (e == hipSuccess) {
+            rc2 = gml_terms_assemble_dev(drows, p->P, p->n, p->order, symmetrize, dst, p->st);
+            if (rc2 == GML_OK && !out_dev) e = hipMemcpyAsync(terms, dout, sizeof(double) * (size_t)T, hipMemcpyDeviceToHost, p->st);
+            if (rc2 == GML_OK && e == hipSuccess) e = hipStreamSynchronize(p->st);
+        }
+        if (e != hipSuccess) rc2 = fail(e == hipErrorOutOfMemory ? GML_ENOMEM : GML_EHIP, "terms: %s", hipGetErrorString(e));
+        st_local.t_assemble = gml_now_s() - t0;
+        st_local.t_total += st_local.t_assemble;
+    }
+    if (dout) (void)gml::dev_free(dout);
+    (void)gml::dev_free(drows);
+    if (stats && (rc == GML_OK || rc == GML_ENOTCONV)) *stats = st_local;
+    if (rc2 != GML_OK) return rc2;
+    if (rc == GML_ENOTCONV) return fail(GML_ENOTCONV, "%s", learn_msg.c_str());
+    return rc;
+}

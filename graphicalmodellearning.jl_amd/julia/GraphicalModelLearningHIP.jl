@@ -16,13 +16,13 @@ module GraphicalModelLearningHIP
 using GraphicalModelLearning
 import GraphicalModelLearning: learn, GMLMethod, GMLFormulation, RISE, RISEA, logRISE, RPLE, multiRISE, FactorGraph
 import LinearAlgebra
-import Statistics: mean
 
 export HIP, trim_cache
 
 const libgml = get(ENV, "LIBGML_HIP", "libgml_hip.so")
 
 # gml.h constants
+const GML_ABI_VERSION = Cint(6)     # the revision of include/gml.h this file mirrors; checked against the library in __init__
 const GML_OK, GML_ENOTCONV = Cint(0), Cint(2)
 const GML_RISE, GML_LOGRISE, GML_RPLE = Cint(0), Cint(1), Cint(2)
 const GML_I64, GML_F64 = Cint(2), Cint(3)
@@ -42,6 +42,21 @@ struct GmlStats                     # struct gml_stats
     t_pack::Cdouble; t_pass::Cdouble; t_hess::Cdouble; t_host::Cdouble; t_total::Cdouble
     not_converged::Int32; polished::Int32
     hv_evals::Int64
+    t_assemble::Cdouble
+end
+
+# A library built from another revision of gml.h would read GmlOpts / write GmlStats at the wrong offsets without any error:
+# refuse it when the module loads (gml.h, "ABI identity").
+function __init__()
+    v = try
+        ccall((:gml_abi_version, libgml), Cint, ())
+    catch
+        error("$libgml predates gml_abi_version(): rebuild it (this binding is ABI $GML_ABI_VERSION)")
+    end
+    so, ss = ccall((:gml_sizeof_opts, libgml), Int64, ()), ccall((:gml_sizeof_stats, libgml), Int64, ())
+    (v, so, ss) == (GML_ABI_VERSION, sizeof(GmlOpts), sizeof(GmlStats)) ||
+        error("$libgml has ABI version / sizeof(gml_opts) / sizeof(gml_stats) = $((v, so, ss)), this binding was written against " *
+              "$((GML_ABI_VERSION, sizeof(GmlOpts), sizeof(GmlStats))): library and binding come from different revisions")
 end
 
 """
@@ -121,16 +136,7 @@ function solve_rows(samples::Array{T,2}, formulation, method::HIP, order::Int) w
         # the reference: @assert JuMP.termination_status(model) == JuMP.MOI.LOCALLY_SOLVED  (:180)
         rc == GML_ENOTCONV && throw(AssertionError(lasterr()))
         rc == GML_OK || error("gml_learn: $(lasterr())")
-        keys = nothing
-        if order != 2
-            keys = Vector{Matrix{Int32}}()
-            for u in n0:(n1 - 1)
-                k = Array{Int32}(undef, order, P[])
-                ccall((:gml_multi_keys, libgml), Cint, (Ptr{Cvoid}, Int64, Ptr{Int32}), handle[], u, k)
-                push!(keys, k)
-            end
-        end
-        return permutedims(out), keys, n0                # R x P
+        return permutedims(out), nothing, n0             # R x P
     finally
         ccall((:gml_problem_destroy, libgml), Cvoid, (Ptr{Cvoid},), handle[])
     end
@@ -161,21 +167,7 @@ function solve_rows_multi(s, dtype, formulation, method::HIP, order::Int)
                    handle[], formulation_id(formulation), Float64(formulation.regularizer), gmlopts(method), out, C_NULL, stats, C_NULL)
         rc == GML_ENOTCONV && throw(AssertionError(lasterr()))   # @assert ... LOCALLY_SOLVED (:180)
         rc == GML_OK || error("gml_multi_learn: $(lasterr())")
-        keys = nothing
-        if order != 2   # keys of node u in the reference's order (:94-104): (u), (u,i) ascending, (u,i,j) lexicographic, ...
-            keys = Vector{Matrix{Int32}}()
-            for u in 0:(n - 1)
-                others = [i for i in 0:(n - 1) if i != u]
-                cols = Vector{Vector{Int32}}()
-                for p in 1:order
-                    for c in GraphicalModelLearning.permutations(others, p - 1, asymmetric=false)
-                        k = fill(Int32(-1), order); k[1] = u; k[2:p] .= collect(c); push!(cols, k)
-                    end
-                end
-                push!(keys, reduce(hcat, cols))
-            end
-        end
-        return permutedims(out), keys, 0
+        return permutedims(out), nothing, 0
     finally
         ccall((:gml_multi_destroy, libgml), Cvoid, (Ptr{Cvoid},), handle[])
     end
@@ -190,27 +182,50 @@ function learn(samples::Array{T,2}, formulation::Union{RISE,RISEA,logRISE,RPLE},
     return reconstruction
 end
 
-# multiRISE: FactorGraph keyed by (u, ascending others), optionally symmetrised  (:83-152)
+# multiRISE: FactorGraph keyed by (u, ascending others), optionally symmetrised  (:83-152).
+# The per-key storage (:129-132), the grouping by sorted key and the `mean` (:135-149) run on the device (gml_learn_terms /
+# gml_terms_assemble: one kernel, keys <-> positions in closed form); what comes back is ONE weight vector in the order the
+# reference lists a model's terms in (models.jl:61,72: by (length, key)) and the matching key table from gml_terms_keys, and the
+# Dict the FactorGraph constructor wants is built from the two in a single comprehension.
 function learn(samples::Array{T,2}, formulation::multiRISE, method::HIP) where T <: Real
     order = formulation.interaction_order
-    rows, keys, n0 = solve_rows(samples, formulation, method, order)
     n = size(samples, 2) - 1
-    reconstruction = Dict{Tuple,Real}()
-    for r in 1:size(rows, 1)
-        u = n0 + r
-        for j in 1:size(rows, 2)
-            key = order == 2 ? (j == u ? (u,) : (u, j)) :                      # order 2 keeps the pairwise slots
-                               tuple((Int(k) + 1 for k in keys[r][:, j] if k >= 0)...)
-            reconstruction[key] = rows[r, j]                                      # :129-132
+    sym = formulation.symmetrization ? Cint(1) : Cint(0)
+    nterms = ccall((:gml_terms_count, libgml), Int64, (Int64, Cint, Cint), n, order, sym)
+    nterms >= 0 || error("gml_terms_count: $(lasterr())")
+    weights = Vector{Float64}(undef, nterms)
+    if method.devices === nothing && method.node_range === nothing
+        # one GPU, all nodes: solve + assembly in one call, the n x P rows never leave the device
+        s = T <: AbstractFloat ? convert(Array{Float64,2}, samples) : convert(Array{Int64,2}, samples)
+        K = size(s, 1)
+        handle = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:gml_problem_create, libgml), Cint,
+                   (Ptr{Cvoid}, Cint, Int64, Int64, Int64, Cint, Cint, Int64, Int64, Cint, Ref{Ptr{Cvoid}}),
+                   s, eltype(s) == Float64 ? GML_F64 : GML_I64, K, n, K, 1, order, 0, n, method.device, handle)
+        rc == GML_OK || error("gml_problem_create: $(lasterr())")
+        try
+            stats = Ref{GmlStats}()
+            rc = ccall((:gml_learn_terms, libgml), Cint,
+                       (Ptr{Cvoid}, Cint, Cdouble, Cint, Ref{GmlOpts}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{GmlStats}),
+                       handle[], GML_RISE, Float64(formulation.regularizer), sym, gmlopts(method), weights, C_NULL, stats)
+            rc == GML_ENOTCONV && throw(AssertionError(lasterr()))                # @assert ... LOCALLY_SOLVED (:127)
+            rc == GML_OK || error("gml_learn_terms: $(lasterr())")
+        finally
+            ccall((:gml_problem_destroy, libgml), Cvoid, (Ptr{Cvoid},), handle[])
         end
+    else
+        method.node_range === nothing ||
+            throw(ArgumentError("HIP: multiRISE assembles a FactorGraph from the rows of all nodes; node_range solves a shard"))
+        rows, _, _ = solve_rows(samples, formulation, method, order)              # n x P (gml_multi_learn over method.devices)
+        rt = permutedims(rows)                                                    # back to C row-major n x P
+        rc = ccall((:gml_terms_assemble, libgml), Cint, (Ptr{Cdouble}, Int64, Int64, Cint, Cint, Cint, Ptr{Cdouble}),
+                   rt, size(rt, 1), n, order, sym, method.devices[1], weights)
+        rc == GML_OK || error("gml_terms_assemble: $(lasterr())")
     end
-    if formulation.symmetrization                                                 # :135-149
-        groups = Dict{Tuple,Vector{Real}}()
-        for (k, v) in reconstruction
-            push!(get!(groups, tuple(sort(collect(k))...), Vector{Real}()), v)
-        end
-        reconstruction = Dict{Tuple,Real}(k => mean(v) for (k, v) in groups)
-    end
+    keys = Array{Int32}(undef, order, nterms)                                     # C [nterms][order], 0-based, -1 = unused slot
+    rc = ccall((:gml_terms_keys, libgml), Cint, (Int64, Cint, Cint, Int64, Int64, Ptr{Int32}), n, order, sym, 0, nterms, keys)
+    rc == GML_OK || error("gml_terms_keys: $(lasterr())")
+    reconstruction = Dict{Tuple,Real}(tuple((Int(k) + 1 for k in view(keys, :, t) if k >= 0)...) => weights[t] for t in 1:nterms)
     return FactorGraph(order, n, :spin, reconstruction)                           # :151
 end
 

@@ -7,7 +7,7 @@ result assembly (:181-188, :129-151)."""
 import numpy as np
 
 from . import _lib
-from .factor_graph import FactorGraph
+from .factor_graph import FactorGraph, TermArray
 from .formulations import HIP, NLP, RISE, RISEA, RPLE, GMLFormulation, GMLMethod, logRISE, multiRISE
 
 
@@ -20,24 +20,29 @@ def _node_partition(n, world, rank):
     return (rank * n) // world, ((rank + 1) * n) // world
 
 
-def _local_solve_hip(samples, formulation, method, order, node_range, device):
-    """rows of the local node range through libgml_hip: (out, kkt, stats, keys)"""
+# A learned multi-body model of at most this many terms is handed back with the reference's own container, a dict
+# (models.jl:12); above it the FactorGraph keeps the weight array the device assembled (factor_graph.TermArray): config 5's
+# 22.5 M terms are 179 MB that way, and ~25 GB / minutes of interpreter time as a dict.
+DICT_TERMS_MAX = 1 << 17
+
+
+def _local_solve_hip(samples, formulation, method, order, node_range, device, terms=None):
+    """rows of the local node range through libgml_hip: (out, kkt, stats).  terms = True / False (all nodes, multiRISE): the
+    model's weight array instead of the rows -- solve and assembly in one library call, the rows never leave the device."""
     with _lib.Problem(samples, order=order, node_range=node_range, device=device) as prob:
         out, kkt, st = prob.learn(_form_name(formulation), formulation.regularizer, tol=method.tol,
                                   max_iter=method.max_iter, precision=method.precision,
                                   max_working=method.max_working, max_add=method.max_add, verbose=method.verbose,
-                                  hess_samples=method.hess_samples, polish=method.polish)
-        keys = None
-        if isinstance(formulation, multiRISE):
-            if order == 2:  # the C ABI keeps the pairwise slot layout for order 2 (slot u = field)
-                n = prob.n
-                keys = [[(u,) if i == u else (u, i) for i in range(n)] for u in range(node_range[0], node_range[1])]
-            else:
-                keys = [prob.multi_keys(u) for u in range(node_range[0], node_range[1])]
-    return out, kkt, st, keys
+                                  hess_samples=method.hess_samples, polish=method.polish, terms=terms)
+    return out, kkt, st
 
 
-_local_solve_hip.pairwise_slots = True  # the C ABI keeps the pairwise slot layout for order 2 (slot u = field)
+_PRODUCT_SOLVE = _local_solve_hip  # (what `solve` is unless a test substituted the module attribute)
+
+
+def _assemble_terms_hip(rows, n, order, symmetrize, device):
+    """the gathered rows of all n nodes -> the model's weights in (length, key) order (gml_terms_assemble: one kernel; :129-149)"""
+    return _lib.terms_assemble(rows, n, order, symmetrize, device=device)
 
 
 def _local_solve_multi(samples, formulation, method, order):
@@ -47,7 +52,7 @@ def _local_solve_multi(samples, formulation, method, order):
                                   precision=method.precision, max_working=method.max_working, max_add=method.max_add,
                                   verbose=method.verbose, hess_samples=method.hess_samples, polish=method.polish)
         st["n_gpus"] = prob.ndev
-    return out, kkt, st, None
+    return out, kkt, st
 
 
 def _gather_rows(local, n, P, method):
@@ -108,13 +113,22 @@ def learn(samples, formulation=None, method=None):
         if method.distributed:
             import torch
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
-    solve = _local_solve_hip  # (module attribute, looked up per call: the CPU-only tests of this layer substitute the oracle)
+    # (module attributes, looked up per call: the CPU-only tests of this layer substitute the oracle for both steps)
+    solve, assemble = _local_solve_hip, _assemble_terms_hip
+    multi = isinstance(formulation, multiRISE)
+    if multi and not (method.distributed and world > 1) and method.devices is None and tuple(node_range) != (0, n):
+        raise ValueError("multiRISE assembles a FactorGraph from the rows of ALL nodes (:129-151): solve node shards with "
+                         "Problem.learn and hand the gathered rows to _lib.terms_assemble")
+    # one process, one GPU, all nodes: solve + assembly in one library call (gml_learn_terms)
+    fused = multi and solve is _PRODUCT_SOLVE and method.devices is None and not (method.distributed and world > 1)
     try:
         if method.devices is not None:
-            out, kkt, st, keys = _local_solve_multi(samples, formulation, method, order)
+            out, kkt, st = _local_solve_multi(samples, formulation, method, order)
             node_range = (0, n)
+        elif fused:
+            out, kkt, st = solve(samples, formulation, method, order, node_range, device, terms=bool(formulation.symmetrization))
         else:
-            out, kkt, st, keys = solve(samples, formulation, method, order, node_range, device)
+            out, kkt, st = solve(samples, formulation, method, order, node_range, device)[:3]
     except _lib.GMLConvergenceError as e:  # the reference's @assert (:180): keep what the solver reached
         method.stats.clear()
         method.stats.update(getattr(e, "stats", {}) or {})
@@ -127,43 +141,20 @@ def learn(samples, formulation=None, method=None):
     if method.distributed and world > 1:
         # the ranks may share a GPU with each other and share it with torch's allocator (the gather below): hand the blocks the
         # library keeps for the next handle back to the driver before anybody else needs the memory
-        if solve is _local_solve_hip:
+        if solve is _PRODUCT_SOLVE:
             _lib.trim_cache()
         P = out.shape[1]
         out = _gather_rows(out, n, P, method)
         node_range = (0, n)
 
-    if isinstance(formulation, multiRISE):
-        if keys is None or method.distributed and world > 1:
-            keys = _all_multi_keys(n, order, node_range, pairwise_slots=(order == 2 and getattr(solve, "pairwise_slots", False)))
-        rec = {}
-        for r, u in enumerate(range(node_range[0], node_range[1])):
-            for key, v in zip(keys[r], out[r]):
-                rec[tuple(i + 1 for i in key)] = float(v)  # (u, ascending others), 1-based (:129-132)
-        if formulation.symmetrization:  # :135-149 group by sorted key, mean
-            groups = {}
-            for k, v in rec.items():
-                groups.setdefault(tuple(sorted(k)), []).append(v)
-            rec = {k: float(np.mean(v)) for k, v in groups.items()}
-        return FactorGraph(order, n, "spin", rec)  # :151
+    if multi:
+        # :129-151 -- per-key storage, grouping by sorted key and `mean` happen on the device; what comes back is the weight array
+        # in the reference's (length, key) listing order, and the keys are never built (factor_graph.TermArray ranks them)
+        weights = out if fused else assemble(out, n, order, bool(formulation.symmetrization), device)
+        terms = TermArray(n, order, bool(formulation.symmetrization), weights)
+        return FactorGraph(order, n, "spin", terms.to_dict() if len(terms) <= DICT_TERMS_MAX else terms)  # :151
 
     R = np.array(out)  # rows node_range; out[u, :] = reconstruction[u, 1:n] (:181)
     if formulation.symmetrization and R.shape[0] == R.shape[1]:
         R = 0.5 * (R + R.T)  # :184-186
     return R
-
-
-def _all_multi_keys(n, order, node_range, pairwise_slots=False):
-    """(u), (u,i)..., (u,i,j)... in the reference's order (:94-104, models.jl:228-246); 0-based.
-    pairwise_slots: the order-2 slot layout of the C ABI (slot i <-> spin i, slot u = field)."""
-    from itertools import combinations
-    keys = []
-    if pairwise_slots:
-        return [[(u,) if i == u else (u, i) for i in range(n)] for u in range(node_range[0], node_range[1])]
-    for u in range(node_range[0], node_range[1]):
-        others = [i for i in range(n) if i != u]
-        ku = []
-        for p in range(1, order + 1):
-            ku.extend((u,) + c for c in combinations(others, p - 1))
-        keys.append(ku)
-    return keys

@@ -113,7 +113,20 @@ typedef struct gml_stats {
     int32_t not_converged;   /* number of local nodes above tol                             */
     int32_t polished;        /* 1 if rows were finished on the FP64 path (precision i8x, see gml_opts.polish) */
     int64_t hv_evals;        /* node evaluations of the Hessian-vector passes of the matrix-free rows (their time: t_hess) */
+    double t_assemble;       /* gml_learn_terms: the device-side assembly of the term array + its copy to the caller (part of t_total) */
 } gml_stats;
+
+/*
+ * ABI identity.  gml_opts and gml_stats are plain structs mirrored field by field in the bindings (the Julia file, the ctypes
+ * twin): a binding built against another revision of this header would read and write the wrong bytes without any error.  Every
+ * binding therefore checks, when it loads the library, that gml_abi_version() is the GML_ABI_VERSION it was written against and that
+ * gml_sizeof_opts() / gml_sizeof_stats() equal the sizes of its own mirrors -- and refuses to run otherwise.  GML_ABI_VERSION is
+ * bumped by every change of a struct layout, of an argument list or of the meaning of a constant.
+ */
+#define GML_ABI_VERSION 6
+int gml_abi_version(void);
+int64_t gml_sizeof_opts(void);
+int64_t gml_sizeof_stats(void);
 
 const char *gml_last_error(void);
 void gml_default_opts(gml_opts *o);
@@ -291,6 +304,34 @@ int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows, const int6
  */
 int gml_learn(gml_problem *p, int formulation, double regularizer_c, const gml_opts *opts,
               double *out, double *kkt, gml_stats *stats);
+
+/*
+ * Result assembly of multiRISE on the device -- replaces the tail of learn(samples, ::multiRISE, ...): the per-node
+ * `reconstruction[inter] = ...` (:129-132), the symmetrisation (group by sorted key, `mean`: :135-149) and the Dict that
+ * FactorGraph(order, n, :spin, reconstruction) (:151, models.jl:8-17) is built from.  The terms of the learned model are returned
+ * as ONE array of weights in the order the reference itself lists a model's terms in (models.jl:61,72: `sort(..., by = x ->
+ * (length(x), x))`), so no key table exists anywhere; a key <-> its position is closed-form (combinatorial number system):
+ *   symmetrize != 0   every ascending key S with |S| <= order: by size, lexicographic within a size; C(n,1) + ... + C(n,order)
+ *                     weights, each the mean over u in S of row u's entry for (u, S \ {u}), added in ascending u
+ *   symmetrize == 0   every key (u, S'), S' an ascending subset of the other spins: by size, then u, then S'; n P weights
+ *
+ *   gml_terms_count     number of terms (-1: unsupported order / overflow)
+ *   gml_terms_assemble  rows: the n x P solved rows (row u in the layout of gml_learn's `out`, leading dimension ld), host OR device
+ *                       pointer; out: gml_terms_count doubles, host OR device pointer.  One kernel launch on `device` (on the
+ *                       device that holds rows / out when one of them is a device pointer); host rows are staged through it
+ *   gml_terms_keys      host only: the keys of the terms [first, first + count), `order` int32 per term, 0-based spins, -1 = unused
+ *   gml_terms_rank      host only: position of a key of `len` spins (0-based), -1 if the model has no such key
+ *   gml_learn_terms     gml_learn over ALL nodes of the handle + the assembly, the rows never leaving the device: `terms` (host or
+ *                       device pointer) receives the term array; kkt, stats as gml_learn (stats->t_assemble = the assembly).
+ *                       GML_EINVAL for a handle over a node sub-range (gather the rows, then gml_terms_assemble).
+ *                       C5 (n = 512, order 3): 67.0 M row entries -> 22.5 M terms (179 MB) in one launch.
+ */
+int64_t gml_terms_count(int64_t n, int order, int symmetrize);
+int gml_terms_assemble(const double *rows, int64_t ld, int64_t n, int order, int symmetrize, int device, double *out);
+int gml_terms_keys(int64_t n, int order, int symmetrize, int64_t first, int64_t count, int32_t *keys);
+int64_t gml_terms_rank(int64_t n, int order, int symmetrize, const int32_t *key, int len);
+int gml_learn_terms(gml_problem *p, int formulation, double regularizer_c, int symmetrize, const gml_opts *opts, double *terms,
+                    double *kkt, gml_stats *stats);
 
 /*
  * gml_multi_* -- the node loop of `learn` (:161: `for current_spin = 1:num_spins`, rows stored at :181) over several

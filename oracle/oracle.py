@@ -246,6 +246,27 @@ def learn_multi_rows(samples, c=0.4, order=2, tol=1e-12):
     return out, kkt
 
 
+def assemble_multi_dict(rows, keys, symmetrize):
+    """The tail of learn(samples, ::multiRISE, ...) restated (:129-151): rows[r] holds the solved parameters of one node in the
+    order of keys[r] (0-based tuples (u, ascending others)); returns the reference's Dict {1-based key tuple: value}, symmetrised
+    (group by sorted key, `mean`; the members in ascending u) or not."""
+    rec = {}
+    for kr, xr in zip(keys, rows):
+        for key, v in zip(kr, xr):
+            rec[tuple(int(i) + 1 for i in key)] = float(v)  # :129-132
+    if symmetrize:  # :135-149
+        groups = {}
+        for k, v in rec.items():
+            groups.setdefault(tuple(sorted(k)), []).append(v)
+        rec = {k: float(np.mean(v)) for k, v in groups.items()}
+    return rec
+
+
+def listing_order(rec):
+    """keys of a model in the order the reference lists them in (models.jl:61,72: sort by (length, key))"""
+    return sorted(rec, key=lambda k: (len(k), k))
+
+
 def learn_multi(samples, c=0.4, symmetrize=True, order=2, tol=1e-12):
     """learn(samples, multiRISE(c, symmetrize, order)) restated (:83-152).
     Returns (dict {1-based key tuple: value}, per-node KKT).  Keys are 1-based like the reference's."""

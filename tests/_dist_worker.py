@@ -19,8 +19,8 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     out_dir, mode = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "oracle")
     if mode == "oracle":  # the CPU oracle stands in for the device solver of every rank
-        from test_host_api import learn_module, oracle_local_solve
-        learn_module._local_solve_hip = oracle_local_solve
+        from test_host_api import inject_oracle
+        inject_oracle()
         method = lambda: gml.HIP(distributed=True)  # noqa: E731
     else:
         import torch

@@ -55,7 +55,11 @@ static int layout(void) {
     OFF(gml_stats, iterations); OFF(gml_stats, passes); OFF(gml_stats, forward_passes); OFF(gml_stats, hessian_passes);
     OFF(gml_stats, node_evals); OFF(gml_stats, max_kkt); OFF(gml_stats, lambda); OFF(gml_stats, t_pack); OFF(gml_stats, t_pass);
     OFF(gml_stats, t_hess); OFF(gml_stats, t_host); OFF(gml_stats, t_total); OFF(gml_stats, not_converged); OFF(gml_stats, polished);
-    OFF(gml_stats, hv_evals);
+    OFF(gml_stats, hv_evals); OFF(gml_stats, t_assemble);
+    /* what the .jl file checks in __init__ (no device needed) */
+    printf("const GML_ABI_VERSION %d\n", GML_ABI_VERSION);
+    printf("call gml_abi_version %d\ncall gml_sizeof_opts %lld\ncall gml_sizeof_stats %lld\n", gml_abi_version(), (long long)gml_sizeof_opts(),
+           (long long)gml_sizeof_stats());
     /* the constants of the .jl file */
     printf("const GML_OK %d\nconst GML_ENOTCONV %d\nconst GML_RISE %d\nconst GML_LOGRISE %d\nconst GML_RPLE %d\n", GML_OK, GML_ENOTCONV, GML_RISE,
            GML_LOGRISE, GML_RPLE);

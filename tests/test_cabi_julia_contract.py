@@ -55,8 +55,16 @@ def test_struct_layouts_and_constants_match_the_julia_file(exe):
         for f, o in offs.items():
             assert int(got[f"{c_name}.{f}"]) == o, (c_name, f)
         assert len(offs) == sum(1 for k in got if k.startswith(c_name + "."))  # no field of the C struct is missing in Julia
-    # the integer constants the .jl file hard-codes
+    # the ABI identity the .jl file checks in __init__: its constant = the header's = what the library answers, and the library's
+    # struct sizes = the sizes of the Julia mirrors
     text = open(JL).read()
+    calls = dict(re.findall(r"^call (\S+) (\d+)$", txt, re.M))
+    assert int(re.search(r"const GML_ABI_VERSION = Cint\((\d+)\)", text).group(1)) == int(got["GML_ABI_VERSION"]) == int(calls["gml_abi_version"])
+    assert int(calls["gml_sizeof_opts"]) == c_layout(julia_struct("GmlOpts"))[1]
+    assert int(calls["gml_sizeof_stats"]) == c_layout(julia_struct("GmlStats"))[1]
+    import gml_amd as gml
+    assert gml._lib.GML_ABI_VERSION == int(got["GML_ABI_VERSION"])
+    # the integer constants the .jl file hard-codes
     for names, vals in re.findall(r"const ((?:GML_\w+(?:, )?)+) = ((?:Cint\(\d+\)(?:, )?)+)", text):
         for nm, v in zip(names.split(", "), re.findall(r"Cint\((\d+)\)", vals)):
             assert int(got[nm]) == int(v), nm

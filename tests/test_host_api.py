@@ -22,21 +22,33 @@ def oracle_local_solve(samples, formulation, method, order, node_range, device):
         kkt = np.zeros(n)
         O.lib().gml_oracle_learn_multi(spins.shape[0], n, order, O._ptr(counts), O._ptr(spins),
                                        float(formulation.regularizer), 1e-12, O._ptr(out), O._ptr(kkt))
-        keys = [O.multi_keys(n, order, u) for u in range(node_range[0], node_range[1])]
-        return out[node_range[0]:node_range[1]], kkt, {}, keys
+        return out[node_range[0]:node_range[1]], kkt, {}
     form = {"RISEA": "RISE"}.get(name, name)
     R, kkt, _ = O.learn_pair(samples, form, c=formulation.regularizer, symmetrize=False)
-    return R[node_range[0]:node_range[1]], kkt[node_range[0]:node_range[1]], {}, None
+    return R[node_range[0]:node_range[1]], kkt[node_range[0]:node_range[1]], {}
+
+
+def oracle_assemble_terms(rows, n, order, symmetrize, device):
+    """the reference's dict assembly (:129-151, restated in the oracle) in place of the device kernel: the model's weights in
+    (length, key) listing order -- checks the closed-form key order of the product's TermArray on the way"""
+    rec = O.assemble_multi_dict(rows, [O.multi_keys(n, order, u) for u in range(n)], symmetrize)
+    return np.array([rec[k] for k in O.listing_order(rec)])
+
+
+def inject_oracle():
+    learn_module._local_solve_hip = oracle_local_solve
+    learn_module._assemble_terms_hip = oracle_assemble_terms
 
 
 def oracle_learn(*args):
-    """gml.learn with the CPU oracle standing in for the per-rank device solver (host-layer tests without a GPU)"""
-    old = learn_module._local_solve_hip
-    learn_module._local_solve_hip = oracle_local_solve
+    """gml.learn with the CPU oracle standing in for the per-rank device solver and the device assembly (host-layer tests
+    without a GPU)"""
+    old = learn_module._local_solve_hip, learn_module._assemble_terms_hip
+    inject_oracle()
     try:
         return gml.learn(*args)
     finally:
-        learn_module._local_solve_hip = old
+        learn_module._local_solve_hip, learn_module._assemble_terms_hip = old
 
 
 def test_type_defaults_match_reference():
