@@ -37,11 +37,12 @@ sys.path.insert(0, ROOT)
 # ~2.5 PF dense, i8 = 2x bf16 per clock).  FP64: AMD datasheet (78.6 TF matrix = vector); the local
 # guide lists no FP64 figure.
 PEAKS = {"f64": 78.6e12, "i8x": 5.0e15, "i8w": 5.0e15}
+HBM_PEAK = 8.0e12  # B/s (MI355X_MICROARCH.md: HBM3E ~8 TB/s)
 KERNELS = {"f64": {"fwd": "k_fwd_f64", "bwd": "k_bwd_f64"}, "i8x": {"fwd": "k_fwd_i8", "bwd": "k_bwd_i8"},
            "i8w": {"fwd": "k_fwd_i8w", "bwd": "k_bwd_i8<1, 6>"}}
 # int8 digit-plane products issued per algorithmic product (forward: planes of Theta, backward: planes of V)
 LIMBS = {"i8x": {"fwd": 5, "bwd": 4}, "i8w": {"fwd": 7, "bwd": 6}}
-PMC_FILES = {"i8w": ("r5_i8w_pmc_traffic.json", "r4_i8w_pmc_traffic.json"), "i8x": ("r3_i8x_pmc_traffic.json", "r2_i8x_pmc_traffic.json")}
+PMC_FILES = {"i8w": ("r6_i8w_pmc_traffic.json", "r5_i8w_pmc_traffic.json", "r4_i8w_pmc_traffic.json"), "i8x": ("r3_i8x_pmc_traffic.json", "r2_i8x_pmc_traffic.json")}
 # sources of the kernels of an int8-limb pass (forward, backward, quantisation, finalisation -- whichever of them dominates): the PMC
 # summaries carry their hash (scripts/pmc_summarize.py), and a line whose traffic comes from counters of other kernels says so
 PASS_KERNEL_SOURCES = ("gml_kernels_i8w.hip", "gml_i8_fwd.hip", "gml_i8_bwd.hip", "gml_i8_pack.hip", "gml_i8_pass.hip", "gml_i8.h", "gml_bits.h")
@@ -239,6 +240,11 @@ def main():
     # (Theta in, G out); what this implementation moves on top (both operand images, the limb planes of V out and back) is
     # reported apart as traffic_impl.
     roofline["bytes_alg_per_pass"] = K * n / 8.0 + 8.0 * K + 16.0 * nloc * n
+    # achieved HBM rate on the ALGORITHMIC bytes and its fraction of the 8 TB/s peak: ~0.2 % is the signature of a compute-bound
+    # contraction (arithmetic intensity 4 n_loc ops per spin byte), not a defect -- the binding roofline is the MFMA one above
+    roofline["hbm_gbps_alg"] = roofline["bytes_alg_per_pass"] / (km["device_ms_per_pass"] * 1e-3) / 1e9
+    roofline["hbm_frac_alg"] = roofline["hbm_gbps_alg"] / (HBM_PEAK / 1e9)
+    roofline["hbm_peak_gbps"] = HBM_PEAK / 1e9
     if args.precision in LIMBS:
         roofline["traffic_impl_per_pass"] = 2.0 * K * n / 8.0 + 2.0 * LIMBS[args.precision]["bwd"] * K * nloc
         roofline["traffic_impl_note"] = ("bytes this implementation must move per pass: the two operand bit images (K n / 8 each) and the "
@@ -255,6 +261,18 @@ def main():
                 # were the counters taken on the kernels that ran just now?
                 sha = pm.get("_pass_kernels_sha256")  # (summaries of rounds 2-4 hashed one file: reported as not matching)
                 roofline["traffic_kernels_match"] = sha == pass_kernels_sha256()
+                # SURVEY.md 8(d) / north_star: achieved HBM GB/s next to the 8 TB/s peak -- from the counters, per kernel and for
+                # the pass (both GEMM kernels; the quantise / finalise kernels move < 0.2 % of it), over THIS run's kernel times
+                per = {}
+                for leg in ("fwd", "bwd"):
+                    kk = [k for k in pm if KERNELS[args.precision][leg].split("<")[0] in k and not k.startswith("_")][0]
+                    per[leg] = (2.0 * pm[kk]["FETCH_SIZE_KB"] + pm[kk]["WRITE_SIZE_KB"]) * 1024.0
+                roofline["traffic_per_kernel"] = {"fwd": per["fwd"], "bwd": per["bwd"], "pass": per["fwd"] + per["bwd"]}
+                roofline["hbm_gbps_counter"] = {leg: per[leg] / (km[leg + "_ms"] * 1e-3) / 1e9 for leg in ("fwd", "bwd")}
+                roofline["hbm_gbps_counter"]["pass"] = (per["fwd"] + per["bwd"]) / ((km["fwd_ms"] + km["bwd_ms"]) * 1e-3) / 1e9
+                roofline["hbm_frac_counter"] = {leg: v / (HBM_PEAK / 1e9) for leg, v in roofline["hbm_gbps_counter"].items()}
+                roofline["traffic_ratio_vs_alg"] = {"fwd": per["fwd"] / roofline["bytes_alg_per_pass"],
+                                                    "pass": (per["fwd"] + per["bwd"]) / roofline["bytes_alg_per_pass"]}
                 break
             except Exception:
                 continue
@@ -360,6 +378,30 @@ def main():
             extra["learn_wall_s_" + prec] = t_o
             extra["learn_" + prec] = dict({k: st_o[k] for k in STKEYS}, runs_s=runs_o,
                                           max_abs_diff_vs_headline_solution=float(np.abs(out_o - out).max()))
+
+    # ---- N > 1: the front door of the process-per-GPU route, learn(samples, RISE(), HIP(distributed=True)) from a HOST matrix that
+    # only rank 0 holds: rank 0 packs it once (1 bit per spin), the bits go out by one broadcast (RCCL over xGMI), every rank builds
+    # its handle from them, solves its node range, and the rows are all-gathered (start / end collectives)
+    if world > 1 and not args.no_learn and not args.no_host_learn:
+        hist = None
+        if rank == 0:
+            sp = prob.spins()
+            hist = np.empty((K, n + 1), dtype=np.int8)
+            hist[:, 0] = 1
+            hist[:, 1:] = sp
+            del sp
+        md = gml.HIP(distributed=True, device=device, tol=1e-9, precision=args.precision)
+        sync()
+        t0 = time.perf_counter()
+        Rd = gml.learn(hist, gml.RISE(0.4, False), md)
+        sync()
+        t_fd, _ = max_over_ranks(time.perf_counter() - t0)
+        extra["learn_distributed_front_door"] = {
+            "wall_s": t_fd, "input": "K x (1+n) int8 histogram on rank 0 only; the other ranks pass None",
+            "pack_s": gather_list(md.stats["pack_s"]), "bcast_s": gather_list(md.stats["bcast_s"]), "bcast_bytes": md.stats["bcast_bytes"],
+            "solve_s": gather_list(md.stats["t_total"]), "handle_from_bits_s": gather_list(md.stats["t_pack"]),
+            "same_rows_as_device_sampled_handles": bool(out is not None and np.array_equal(Rd, full))}
+        del hist
 
     # ---- learn() from a HOST histogram: what a `learn(samples, RISE(), HIP())` caller pays (pack + upload +
     # solve + gather + symmetrise).  The samples as the reference holds them: a column-major Matrix{Int64}, K x (1+n)

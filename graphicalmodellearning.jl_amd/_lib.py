@@ -353,6 +353,21 @@ class Problem:
                                       _ptr(nodes), _ptr(theta), theta.shape[1], _ptr(f), _ptr(g)))
         return f, g
 
+    def objgrad_device(self, formulation, nodes, theta_ptr, ld, f_ptr, g_ptr=None, precision="auto"):
+        """gml_objgrad_batch on rows resident in HBM: theta_ptr / f_ptr / g_ptr are device addresses (ints: tensor.data_ptr()) of
+        [len(nodes), ld], [len(nodes)] and [len(nodes), ld] float64 arrays on the handle's GPU; nothing is staged through the host.
+        Ordered after the caller's work on the device's null stream; returns when f and g are written."""
+        nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+        check(lib().gml_objgrad_batch(self._h, FORMULATION_IDS[formulation], PRECISIONS[precision], len(nodes), _ptr(nodes),
+                                      C.c_void_p(int(theta_ptr)), int(ld), C.c_void_p(int(f_ptr)),
+                                      C.c_void_p(int(g_ptr)) if g_ptr else None))
+
+    def hessvec_device(self, formulation, nodes, theta_ptr, vec_ptr, ld, hv_ptr):
+        """gml_hessvec_batch on rows resident in HBM (device addresses, as objgrad_device)"""
+        nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+        check(lib().gml_hessvec_batch(self._h, FORMULATION_IDS[formulation], len(nodes), _ptr(nodes), C.c_void_p(int(theta_ptr)),
+                                      C.c_void_p(int(vec_ptr)), int(ld), C.c_void_p(int(hv_ptr))))
+
     def hessvec(self, formulation, nodes, theta, vec):
         """Hess f_u(theta) @ vec for the listed nodes (gml_hessvec_batch; int8-limb passes)."""
         nodes = np.ascontiguousarray(nodes, dtype=np.int64)

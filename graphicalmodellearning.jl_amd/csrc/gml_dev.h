@@ -56,6 +56,13 @@ void launch_convert_hist(const void *H, int dtype, int64_t K, int64_t n, int64_t
                          long long *bad, hipStream_t st);
 void launch_check_pm1(const int8_t *S, int64_t K, int64_t n, long long *bad, hipStream_t st);
 int64_t xtb_bytes(const DevProblem &d);
+// device-pointer operator calls (gml_oplayout.hip): the caller's rows in the reference's parameter order <-> the internal columns
+void launch_ref_to_internal(const double *theta, int64_t ld, int64_t R, int64_t P, int64_t Qp, const int *rowcol, int64_t cconst,
+                            const int32_t *cols, double *X, int *bad, hipStream_t st);
+void launch_internal_to_ref(const double *G, const double *F, int64_t R, int64_t Qp, int64_t P, int64_t ld, const int *rowcol, const uint8_t *sel,
+                            int64_t cconst, const int32_t *cols, int logz, double *f, double *g, hipStream_t st);
+void launch_hv_to_ref(const double *Hv, const double *Gz, const double *F, int64_t R, int64_t Qp, int64_t P, int64_t ld, const int *rowcol,
+                      int64_t cconst, const int32_t *cols, int logz, const double *vec, double *hv, hipStream_t st);
 
 // Byte offset of limb l of V[r][k] in the int8 limb image Vq of the fixed-point pass: images [node tile r/32][k/64]
 // of [lbt limbs x 32 rows][64 B], contiguous (lbt = 4: 8 KB each, the i8x pass; 6: 12 KB, the i8w pass); within a row the

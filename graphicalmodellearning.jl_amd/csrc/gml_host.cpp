@@ -198,7 +198,7 @@ extern "C" void gml_problem_destroy(gml_problem *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->st) (void)hipStreamSynchronize(p->st);
-    void *ptrs[] = {p->d.Xt, p->d.Sb, p->d.keys, p->d.Xb, p->d.Xtb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dSrow};
+    void *ptrs[] = {p->d.Xt, p->d.Sb, p->d.keys, p->d.Xb, p->d.Xtb, p->d.w, p->dTheta, p->dV, p->dG, p->dF, p->dSrow, p->opCols, p->opFlag, p->opSel, p->opG2};
     for (void *q : ptrs)
         if (q) (void)dev_free(q);
     void *hptrs[] = {p->hTh, p->hG, p->hF, p->hCtl, p->stage};

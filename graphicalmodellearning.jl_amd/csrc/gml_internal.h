@@ -50,6 +50,16 @@ struct gml_problem {
     // pinned staging arena of the solver's small control / scalar transfers (gml_solver.cpp), allocated on first use
     char *stage = nullptr;
     size_t stage_bytes = 0;
+    // device-pointer operator calls (gml_operator.cpp: objgrad_dev / hessvec_dev): parameter-slot -> column table of the node list
+    // of the last multi-body call (kept: an external solver calls with the same nodes every iteration), flag + row mask, and the
+    // gradient rows a logRISE Hessian-vector call keeps across its second pass
+    std::vector<int64_t> opNodes;
+    int32_t *opCols = nullptr;
+    int *opFlag = nullptr;
+    uint8_t *opSel = nullptr;
+    int64_t opSelCap = 0;
+    double *opG2 = nullptr;
+    int64_t opG2rows = 0;
     // how long building the handle took (gml_problem_ingest_times): host packing, uploads not hidden by it, bit images, total
     double t_ingest[6] = {0, 0, 0, 0, 0, 0};
 };

@@ -242,10 +242,188 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
                 // (GraphicalModelLearning.jl:191-197) returns a number there, so `auto` -- its stand-in -- evaluates these rows on
                 // the FP64 path; a caller who named an int8-limb precision gets the error.
                 if (f64_fallback) return device_pass(p, rs, again, theta, form, GML_PREC_F64, want_grad, f, g, stats);
-                return fail(GML_EUNSUPPORTED, "precision i8x / i8w: the weights exp(-E) of a row underflow its fixed-point range; use precision f64 (or auto)");
+                return fail(GML_EUNSUPPORTED, "precision %s: the weights exp(-E) of a row underflow its fixed-point range; use precision f64 (or auto)",
+                            wide ? "i8w" : "i8x");
             }
             return device_pass(p, rs, again, theta, form, precision, want_grad, f, g, stats, nullptr, &ovr, depth + 1, f64_fallback);
         }
+    }
+    return GML_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// The same pass for callers whose rows live in HBM (device pointers for theta / f / g): the reference-order rows are
+// scattered into the internal layout by a kernel, the pass runs, a kernel gathers the results back -- no staging, no PCIe.
+// The only host round trip is the one the dynamic-range check needs (two small per-row arrays).
+// ------------------------------------------------------------------------------------------
+static bool is_device_ptr(const void *q) {
+    if (!q) return false;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, q) == hipSuccess) return attr.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    return false;
+}
+
+// slot -> column table of a multi-body node list on the device (NULL for pairwise: closed form in the kernels)
+static int dev_cols(gml_problem *p, int64_t nrows, const int64_t *nodes, const int32_t **out) {
+    *out = nullptr;
+    if (p->order == 2) return GML_OK;
+    if (p->opCols && (int64_t)p->opNodes.size() == nrows && std::equal(nodes, nodes + nrows, p->opNodes.begin())) {
+        *out = p->opCols;
+        return GML_OK;
+    }
+    if (p->opCols) (void)dev_free(p->opCols);
+    p->opCols = nullptr;
+    p->opNodes.clear();
+    const int64_t P = p->P;
+    std::vector<int32_t> cols((size_t)nrows * P);
+    parallel_for(nrows, [&](int64_t r) {
+        NodeLayout L;
+        build_layout(p, nodes[r], L);
+        std::memcpy(cols.data() + (size_t)r * P, L.cols.data(), sizeof(int32_t) * P);
+    });
+    HIPCHK(dev_malloc(&p->opCols, sizeof(int32_t) * (size_t)nrows * P));
+    HIPCHK(hipMemcpyAsync(p->opCols, cols.data(), sizeof(int32_t) * (size_t)nrows * P, hipMemcpyHostToDevice, p->st));
+    HIPCHK(hipStreamSynchronize(p->st)); // cols is a local
+    p->opNodes.assign(nodes, nodes + nrows);
+    *out = p->opCols;
+    return GML_OK;
+}
+
+static int dev_scratch(gml_problem *p, int64_t Rp) {
+    if (!p->opFlag) HIPCHK(dev_malloc(&p->opFlag, sizeof(int) * 4));
+    if (p->opSelCap < Rp) {
+        if (p->opSel) (void)dev_free(p->opSel);
+        p->opSel = nullptr;
+        p->opSelCap = 0;
+        HIPCHK(dev_malloc(&p->opSel, (size_t)Rp));
+        p->opSelCap = Rp;
+    }
+    return GML_OK;
+}
+
+// control block of a pass over the rows flagged in act (slot = row): srow | rowcol | active tiles; returns the tiles
+static int upload_ctl(gml_problem *p, int64_t R, const int64_t *nodes, const std::vector<uint8_t> &act, std::vector<int> &groups, int *npad_out) {
+    const int64_t Rp = round_up(R, 32), W = p->ws_rows;
+    groups.clear();
+    for (int64_t r = 0; r < Rp; ++r) {
+        p->hCtl[r] = (int)r;
+        p->hCtl[W + r] = (r < R && act[r]) ? (int)nodes[r] : -1;
+    }
+    for (int64_t gidx = 0; gidx < Rp / 32; ++gidx) {
+        bool any = false;
+        for (int64_t r = gidx * 32; r < std::min(R, (gidx + 1) * 32); ++r) any |= (act[r] != 0);
+        if (any) groups.push_back((int)gidx);
+    }
+    int npad = 0;
+    for (size_t g = 0; g < groups.size() || (npad % 4); ++g, ++npad) p->hCtl[2 * W + g] = g < groups.size() ? groups[g] : -1;
+    *npad_out = npad;
+    HIPCHK(hipMemcpyAsync(p->dSrow, p->hCtl, sizeof(int) * (2 * W + npad), hipMemcpyHostToDevice, p->st));
+    return GML_OK;
+}
+
+// dtheta [R][ld] in, df [R] / dg [R][ldg] out (either may be NULL); raw: f and g as the pass leaves them (logRISE: Z and grad Z, no
+// log / division)
+static int pass_dev(gml_problem *p, int64_t R, const int64_t *nodes, const std::vector<uint8_t> &act, const double *dtheta, int64_t ld,
+                    int form, int precision, bool want_grad, double *df, double *dg, int64_t ldg, const int32_t *dcols,
+                    const std::vector<double> *tau_ovr, int depth, bool f64_fallback, bool raw = false) {
+    const int64_t Qp = p->d.Qp, P = p->P, Rp = round_up(R, 32);
+    int rc = ensure_ws(p, R);
+    if (rc) return rc;
+    rc = dev_scratch(p, Rp);
+    if (rc) return rc;
+    hipStream_t st = p->st;
+    std::vector<int> groups;
+    int npad = 0;
+    rc = upload_ctl(p, R, nodes, act, groups, &npad);
+    if (rc) return rc;
+    if (groups.empty()) return GML_OK;
+    const int64_t W = p->ws_rows;
+    if (depth == 0) { // (a re-run finds the rows where the first pass put them)
+        HIPCHK(hipMemsetAsync(p->opFlag, 0, sizeof(int) * 4, st));
+        HIPCHK(hipMemsetAsync(p->dTheta, 0, sizeof(double) * Rp * Qp, st));
+        launch_ref_to_internal(dtheta, ld, R, P, Qp, p->dRowcol, p->d.cconst, dcols, p->dTheta, p->opFlag, st);
+    }
+    double *dOvr = nullptr;
+    const bool wide = precision == GML_PREC_I8W;
+    if (gml_is_i8(precision)) {
+        if (tau_ovr) {
+            HIPCHK(dev_malloc(&dOvr, sizeof(double) * Rp));
+            HIPCHK(hipMemcpyAsync(dOvr, tau_ovr->data(), sizeof(double) * Rp, hipMemcpyHostToDevice, st));
+        }
+        std::string err;
+        gml::I8Pass a{};
+        a.theta = p->dTheta;
+        a.srow = p->dSrow;
+        a.rowcol = p->dRowcol;
+        a.groups = p->dGroups;
+        a.ngroups = (int)groups.size();
+        a.slot0 = 0;
+        a.slot1 = (int)Rp;
+        a.form = form;
+        a.want_grad = want_grad;
+        a.F = p->dF;
+        a.G = p->dG;
+        a.tauovr = dOvr;
+        a.wide = wide;
+        rc = gml::i8_pass(&p->i8ws, p->d, W, a, st, nullptr, &err);
+        if (rc) {
+            if (dOvr) (void)dev_free(dOvr);
+            return fail(rc, "%s", err.c_str());
+        }
+    } else {
+        rc = gml_ensure_f64(p, p->ws_rows);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(p->dF, 0, sizeof(double) * Rp, st));
+        if (want_grad) HIPCHK(hipMemsetAsync(p->dG, 0, sizeof(double) * Rp * Qp, st));
+        launch_fwd_f64(p->d, p->dTheta, p->dRowcol, p->dGroups, npad, form, p->dV, p->dF, st);
+        if (want_grad) launch_bwd_f64(p->d, p->dV, p->dGroups, (int)groups.size(), p->dG, st);
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<double> tauh;
+    std::vector<unsigned> mmaxh;
+    int bad[4] = {0, 0, 0, 0};
+    const bool i8exp = gml_is_i8(precision) && form != GML_RPLE;
+    if (i8exp) {
+        const double *tau = nullptr;
+        const unsigned *mm = nullptr;
+        gml::i8_slot_results(p->i8ws, 0, &tau, &mm);
+        tauh.resize((size_t)Rp);
+        mmaxh.resize((size_t)Rp);
+        HIPCHK(hipMemcpyAsync(tauh.data(), tau, sizeof(double) * Rp, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(mmaxh.data(), mm, sizeof(unsigned) * Rp, hipMemcpyDeviceToHost, st));
+    }
+    if (depth == 0) HIPCHK(hipMemcpyAsync(bad, p->opFlag, sizeof bad, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (dOvr) (void)dev_free(dOvr);
+    if (bad[0]) return fail(GML_EINVAL, "theta contains a non-finite value");
+    // dynamic range of the fixed-point V: as device_pass
+    std::vector<uint8_t> again((size_t)R, 0), sel((size_t)Rp, 0);
+    std::vector<double> ovr((size_t)Rp, 0.0);
+    int64_t nagain = 0;
+    if (i8exp) {
+        const unsigned mm_min = wide ? (1u << 27) : (1u << 23);
+        for (int64_t r = 0; r < R; ++r)
+            if (act[r] && mmaxh[r] < mm_min) {
+                again[r] = 1;
+                ovr[r] = ((double)mmaxh[r] + 1.0) * gml::i8_mmax_unit(wide) * tauh[r] * (1.0 + 1e-12) / gml::i8_vdiv(wide);
+                ++nagain;
+            }
+    }
+    for (int64_t r = 0; r < R; ++r) sel[r] = act[r] && !again[r];
+    // the rows this pass settled go back to the caller's arrays (a re-run of the others overwrites the workspace rows of its tiles)
+    HIPCHK(hipMemcpyAsync(p->opSel, sel.data(), (size_t)Rp, hipMemcpyHostToDevice, st));
+    launch_internal_to_ref(p->dG, p->dF, R, Qp, P, ldg, p->dRowcol, p->opSel, p->d.cconst, dcols, (form == GML_LOGRISE && !raw) ? 1 : 0, df,
+                           want_grad ? dg : nullptr, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st)); // (sel is a local; and the call returns with its outputs written)
+    if (nagain > 0) {
+        if (depth >= 6) {
+            if (f64_fallback) return pass_dev(p, R, nodes, again, dtheta, ld, form, GML_PREC_F64, want_grad, df, dg, ldg, dcols, nullptr, 0, false, raw);
+            return fail(GML_EUNSUPPORTED, "precision %s: the weights exp(-E) of a row underflow its fixed-point range; use precision f64 (or auto)",
+                        wide ? "i8w" : "i8x");
+        }
+        return pass_dev(p, R, nodes, again, dtheta, ld, form, precision, want_grad, df, dg, ldg, dcols, &ovr, depth + 1, f64_fallback, raw);
     }
     return GML_OK;
 }
@@ -269,6 +447,18 @@ extern "C" int gml_objgrad_batch(gml_problem *p, int formulation, int precision,
         if (nodes[r] < 0 || nodes[r] >= p->n) return fail(GML_EINVAL, "node id %lld out of range", (long long)nodes[r]);
     HIPCHK(hipSetDevice(p->device));
     const int64_t Qp = p->d.Qp, P = p->P;
+    {
+        // rows resident in HBM: theta, f and g (if given) are device pointers -- all of them or none
+        const bool td = is_device_ptr(theta), fd = is_device_ptr(f), gd = g ? is_device_ptr(g) : td;
+        if (td != fd || td != gd) return fail(GML_EINVAL, "theta, f and g must be all host or all device pointers");
+        if (td) {
+            const int32_t *dcols = nullptr;
+            int rcd = dev_cols(p, nrows, nodes, &dcols);
+            if (rcd) return rcd;
+            std::vector<uint8_t> act((size_t)nrows, 1);
+            return pass_dev(p, nrows, nodes, act, theta, ld, formulation, precision, g != nullptr, f, g, ld, dcols, nullptr, 0, asked_auto);
+        }
+    }
     RowSet rs;
     rs.R = nrows;
     rs.node.assign(nodes, nodes + nrows);
@@ -303,6 +493,64 @@ extern "C" int gml_objgrad_batch(gml_problem *p, int formulation, int precision,
     return GML_OK;
 }
 
+// gml_hessvec_batch for rows resident in HBM: the objective pass at theta leaves the curvature weights in the slots, the directions are
+// scattered into the internal layout, the Hessian-vector pass runs, a kernel writes hv (logRISE: with the rank-one correction)
+static int hessvec_dev(gml_problem *p, int form, int64_t nrows, const int64_t *nodes, const double *dtheta, const double *dvec, int64_t ld,
+                       double *dhv) {
+    const int64_t Qp = p->d.Qp, P = p->P, Rp = round_up(nrows, 32);
+    const int32_t *dcols = nullptr;
+    int rc = dev_cols(p, nrows, nodes, &dcols);
+    if (rc) return rc;
+    double *G2 = nullptr, *F2 = nullptr;
+    if (form == GML_LOGRISE) { // Z and grad Z of every row, in the reference order, kept across the second pass
+        if (p->opG2rows < nrows) {
+            if (p->opG2) (void)dev_free(p->opG2);
+            p->opG2 = nullptr;
+            p->opG2rows = 0;
+            HIPCHK(dev_malloc(&p->opG2, sizeof(double) * ((size_t)nrows * P + (size_t)Rp)));
+            p->opG2rows = nrows;
+        }
+        G2 = p->opG2;
+        F2 = p->opG2 + (size_t)p->opG2rows * P;
+    }
+    std::vector<uint8_t> act((size_t)nrows, 1);
+    rc = pass_dev(p, nrows, nodes, act, dtheta, ld, form, GML_PREC_I8X, true, F2, G2, P, dcols, nullptr, 0, false, true);
+    if (rc) return rc;
+    hipStream_t st = p->st;
+    std::vector<int> groups;
+    int npad = 0;
+    rc = upload_ctl(p, nrows, nodes, act, groups, &npad);
+    if (rc) return rc;
+    const int64_t W = p->ws_rows;
+    HIPCHK(hipMemsetAsync(p->opFlag, 0, sizeof(int) * 4, st));
+    HIPCHK(hipMemsetAsync(p->dTheta, 0, sizeof(double) * Rp * Qp, st));
+    launch_ref_to_internal(dvec, ld, nrows, P, Qp, p->dRowcol, p->d.cconst, dcols, p->dTheta, p->opFlag, st);
+    gml::I8Pass a{};
+    a.theta = p->dTheta;
+    a.srow = p->dSrow;
+    a.rowcol = p->dRowcol;
+    a.groups = p->dGroups;
+    a.ngroups = (int)groups.size();
+    a.slot0 = 0;
+    a.slot1 = (int)Rp;
+    a.form = form;
+    a.want_grad = true;
+    a.F = nullptr;
+    a.G = p->dG;
+    a.hv = 1;
+    a.vmap = p->dSrow;
+    std::string err;
+    rc = gml::i8_pass(&p->i8ws, p->d, W, a, st, nullptr, &err);
+    if (rc) return fail(rc, "%s", err.c_str());
+    launch_hv_to_ref(p->dG, G2, F2, nrows, Qp, P, ld, p->dRowcol, p->d.cconst, dcols, form == GML_LOGRISE ? 1 : 0, dvec, dhv, st);
+    HIPCHK(hipGetLastError());
+    int bad[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(bad, p->opFlag, sizeof bad, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (bad[0]) return fail(GML_EINVAL, "vec contains a non-finite value");
+    return GML_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // gml_hessvec_batch: curvature operator, H_u(theta) v for many nodes at once
 // ------------------------------------------------------------------------------------------
@@ -316,6 +564,11 @@ extern "C" int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows,
         if (nodes[r] < 0 || nodes[r] >= p->n) return fail(GML_EINVAL, "node id %lld out of range", (long long)nodes[r]);
     HIPCHK(hipSetDevice(p->device));
     const int64_t Qp = p->d.Qp, P = p->P, Rp = round_up(nrows, 32);
+    {
+        const bool td = is_device_ptr(theta), vd = is_device_ptr(vec), hd = is_device_ptr(hv);
+        if (td != vd || td != hd) return fail(GML_EINVAL, "theta, vec and hv must be all host or all device pointers");
+        if (td) return hessvec_dev(p, formulation, nrows, nodes, theta, vec, ld, hv);
+    }
     // 1. objective + gradient pass at theta: leaves the curvature weights (limb planes of V) in the slots 0..nrows-1
     RowSet rs;
     rs.R = nrows;

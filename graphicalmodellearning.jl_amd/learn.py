@@ -26,10 +26,13 @@ def _node_partition(n, world, rank):
 DICT_TERMS_MAX = 1 << 17
 
 
-def _local_solve_hip(samples, formulation, method, order, node_range, device, terms=None):
+def _local_solve_hip(samples, formulation, method, order, node_range, device, terms=None, packed=None):
     """rows of the local node range through libgml_hip: (out, kkt, stats).  terms = True / False (all nodes, multiRISE): the
-    model's weight array instead of the rows -- solve and assembly in one library call, the rows never leave the device."""
-    with _lib.Problem(samples, order=order, node_range=node_range, device=device) as prob:
+    model's weight array instead of the rows -- solve and assembly in one library call, the rows never leave the device.
+    packed = (sign_bits, counts or None, K): the handle is built from the packed form (gml_problem_create_packed) and `samples`
+    is not looked at -- the ranks of a distributed run, which receive the bits from rank 0."""
+    src = {"packed": packed} if packed is not None else {"samples": samples}
+    with _lib.Problem(order=order, node_range=node_range, device=device, **src) as prob:
         out, kkt, st = prob.learn(_form_name(formulation), formulation.regularizer, tol=method.tol,
                                   max_iter=method.max_iter, precision=method.precision,
                                   max_working=method.max_working, max_add=method.max_add, verbose=method.verbose,
@@ -72,6 +75,54 @@ def _gather_rows(local, n, P, method):
     return np.concatenate([allb[r, : sizes[r]] for r in range(world)], axis=0)
 
 
+def _packed_from_rank0(samples, n_hint=None):
+    """The start of a distributed learn ("broadcast of packed spins + weights"): rank 0 reads its sample matrix
+    ONCE (gml_pack_histogram: 1 bit per spin, validation in the same sweep), and the sign bits + counts go to the other ranks by
+    one broadcast each (RCCL over xGMI under the nccl backend, gloo on CPU).  The other ranks never look at a sample matrix --
+    theirs may be None.  At config 4 that is one 32.8 GB read and 0.5 GB per rank on the wire instead of eight concurrent
+    packers reading 32.8 GB each.  Returns ((sign_bits, counts or None, K), n, {"pack_s", "bcast_s"})."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    use_cuda = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+    t0 = time.perf_counter()
+    hdr = torch.zeros(4, dtype=torch.int64)  # ok, K, n, counts all one
+    bits = counts = None
+    err = None
+    if rank == 0:
+        try:
+            bits, counts, _ = _lib.pack_histogram(samples)
+            uniform = bool((counts == 1.0).all())
+            hdr = torch.tensor([1, len(counts), bits.shape[0], int(uniform)], dtype=torch.int64)
+        except Exception as e:  # a bad matrix must fail on EVERY rank, not leave the others waiting in a broadcast
+            err = e
+    t_pack = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    hdr = hdr.to(dev)
+    dist.broadcast(hdr, 0)
+    ok, K, n, uniform = (int(v) for v in hdr.cpu().tolist())
+    if not ok:
+        raise err if err is not None else _lib.GMLError(_lib.GML_EINVAL, "rank 0 could not pack the sample histogram")
+    wpr = int(_lib.lib().gml_packed_words(K))
+    tb = torch.from_numpy(bits.view(np.int32)) if rank == 0 else torch.empty((n, wpr), dtype=torch.int32)
+    tb = tb.to(dev)
+    dist.broadcast(tb, 0)
+    if rank != 0:
+        bits = tb.cpu().numpy().view(np.uint32)
+    if uniform:
+        counts = None
+    else:
+        tc = (torch.from_numpy(counts) if rank == 0 else torch.empty(K, dtype=torch.float64)).to(dev)
+        dist.broadcast(tc, 0)
+        if rank != 0:
+            counts = tc.cpu().numpy()
+    t_bcast = time.perf_counter() - t0
+    return (bits, counts, K), n, {"pack_s": t_pack, "bcast_s": t_bcast, "bcast_bytes": int(n * wpr * 4 + (0 if uniform else 8 * K))}
+
+
 def learn(samples, formulation=None, method=None):
     """learn(samples) / learn(samples, formulation) / learn(samples, formulation, method)
     (:69-70: defaults RISE(), NLP()).
@@ -90,11 +141,24 @@ def learn(samples, formulation=None, method=None):
         raise TypeError(f"no method matching learn(..., ::{type(method).__name__})")
     if isinstance(method, NLP):
         method = HIP()
-    samples = np.asarray(samples)
-    if samples.ndim != 2 or samples.shape[1] < 2:
-        raise ValueError("samples must be a K x (1+n) histogram matrix")
-    n = samples.shape[1] - 1
     order = int(formulation.interaction_order) if isinstance(formulation, multiRISE) else 2
+    world, rank = 1, 0
+    if method.distributed:
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(), dist.get_rank()
+    packed, start = None, None
+    if method.distributed and world > 1:
+        # rank 0 packs its matrix once and broadcasts the bits; the other ranks' `samples` is not looked at (and may be None)
+        if rank == 0:
+            samples = np.asarray(samples)
+            if samples.ndim != 2 or samples.shape[1] < 2:
+                samples = None  # (packing reports it, on every rank)
+        packed, n, start = _packed_from_rank0(samples if rank == 0 else None)
+    else:
+        samples = np.asarray(samples)
+        if samples.ndim != 2 or samples.shape[1] < 2:
+            raise ValueError("samples must be a K x (1+n) histogram matrix")
+        n = samples.shape[1] - 1
 
     if method.devices is not None and (method.distributed or method.node_range is not None or method.device is not None):
         raise ValueError("HIP: devices (all nodes over several GPUs from this process) excludes distributed, node_range and device")
@@ -102,10 +166,6 @@ def learn(samples, formulation=None, method=None):
         raise ValueError("HIP: distributed=True derives the node range from the rank; node_range must not be given")
     if method.precision not in _lib.PRECISIONS:
         raise ValueError(f"HIP: unknown precision {method.precision!r} (use 'auto', 'i8x', 'i8w' or 'f64')")
-    world, rank = 1, 0
-    if method.distributed:
-        import torch.distributed as dist
-        world, rank = dist.get_world_size(), dist.get_rank()
     node_range = method.node_range or _node_partition(n, world, rank)
     device = method.device
     if device is None:
@@ -127,6 +187,8 @@ def learn(samples, formulation=None, method=None):
             node_range = (0, n)
         elif fused:
             out, kkt, st = solve(samples, formulation, method, order, node_range, device, terms=bool(formulation.symmetrization))
+        elif packed is not None:
+            out, kkt, st = solve(None, formulation, method, order, node_range, device, packed=packed)[:3]
         else:
             out, kkt, st = solve(samples, formulation, method, order, node_range, device)[:3]
     except _lib.GMLConvergenceError as e:  # the reference's @assert (:180): keep what the solver reached
@@ -137,6 +199,8 @@ def learn(samples, formulation=None, method=None):
     method.stats.clear()
     method.stats.update(st or {})
     method.stats["kkt"] = kkt
+    if start is not None:
+        method.stats.update(start)  # pack_s (rank 0's one read of the matrix), bcast_s, bcast_bytes
 
     if method.distributed and world > 1:
         # the ranks may share a GPU with each other and share it with torch's allocator (the gather below): hand the blocks the

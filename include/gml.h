@@ -272,6 +272,14 @@ int gml_multi_keys(const gml_problem *p, int64_t u, int32_t *keys);
  *   f[r]            smooth objective (no l1 term)
  *   g[r*ld + j]     its gradient, same layout as theta
  * One "node evaluation" = one row.
+ *
+ * theta, f and g are host pointers, or -- all three -- DEVICE pointers on the handle's GPU (detected): rows that live in HBM (a
+ * device-side optimiser, torch / CuPy / Julia GPU arrays) are scattered into the internal layout, evaluated and gathered back by
+ * kernels, with no staging copy and nothing crossing PCIe but the control block and two small per-row arrays (headline pass
+ * n = 1024, K = 1e6: 10.4 ms instead of 13.4 through host pointers; the same bits either way).  `nodes` is a host array in both
+ * forms.  Ordering: the kernels run on the handle's own stream, a blocking stream -- ordered after everything the caller enqueued on
+ * the device's null stream (torch's default stream) before the call; work on other streams must have completed.  The call returns
+ * when f and g are written.
  */
 int gml_objgrad_batch(gml_problem *p, int formulation, int precision, int64_t nrows,
                       const int64_t *nodes, const double *theta, int64_t ld, double *f,
@@ -283,6 +291,7 @@ int gml_objgrad_batch(gml_problem *p, int formulation, int precision, int64_t nr
  * second-order / Newton-CG external solvers, same layouts as gml_objgrad_batch.  Two GEMM passes on the int8 matrix
  * cores with the curvature weights of an objective pass at theta (precision i8x; ~1e-8 relative).  This is the
  * operator gml_learn's matrix-free Newton-CG uses for working sets above max_working.
+ * theta, vec and hv: host pointers, or all three device pointers (as gml_objgrad_batch).
  */
 int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows, const int64_t *nodes, const double *theta,
                       const double *vec, int64_t ld, double *hv);

@@ -152,6 +152,36 @@ def c5(name, K=1000000, n=512, c=1.2, seed=5, tol=1e-8, max_iter=100):
         f8, g8 = p.objgrad("RISE", some, out[some], precision=PREC)
         keys0 = p.multi_keys(0)
         spins = p.spins()
+    if "--front-door" in sys.argv:
+        # learn(samples, ISODUS(c, true, 3), HIP()) as a user calls it: the K x (1+n) matrix in, a FactorGraph out (round 6: the
+        # assembly of the 67 M solved parameters runs on the device, gml_learn_terms; the terms stay an array, factor_graph.TermArray)
+        import threading
+
+        import psutil
+        hist = np.empty((K, n + 1), dtype=np.int8)
+        hist[:, 0] = 1
+        hist[:, 1:] = spins
+        proc, stop = psutil.Process(), threading.Event()
+        peak = [proc.memory_info().rss]
+        base = peak[0]
+
+        def watch():
+            while not stop.wait(0.01):
+                peak[0] = max(peak[0], proc.memory_info().rss)
+        th = threading.Thread(target=watch, daemon=True)
+        th.start()
+        m = gml.HIP(precision=PREC, tol=tol, max_iter=max_iter)
+        t0 = time.time()
+        fg = gml.learn(hist, gml.ISODUS(c, True, 3), m)
+        rec["learn_front_door_s"] = time.time() - t0
+        stop.set()
+        th.join()
+        rec["front_door"] = {"solve_s": m.stats["t_total"] - m.stats["t_assemble"], "handle_from_matrix_s": m.stats["t_pack"],
+                             "assemble_s": m.stats["t_assemble"], "terms": len(fg), "container": type(fg.terms).__name__,
+                             "overhead_over_solve_s": rec["learn_front_door_s"] - (m.stats["t_total"] - m.stats["t_assemble"]),
+                             "peak_host_rss_over_entry_GB": (peak[0] - base) / 1e9,
+                             "max_err_vs_generating_terms": max(abs(fg[k] - v) for k, v in terms.items())}
+        del hist, fg
     t0 = time.time()
     fo, go = O.objgrad_multi3_nodes(None, spins, some, out[some])
     t_cpu = time.time() - t0
@@ -201,7 +231,8 @@ def main():
                                      cpu_learn="measure" if "--cpu-full" in sys.argv else "extrapolate"))
     if "c4" in which:
         jobs.append(lambda: pairwise("C4_rank0of8", "n=4096 sparse (8-spin block) Ising, 1e6 samples, RISE(0.4): the shard of rank 0 of 8",
-                                     syn.block_ising_model(4096, 8, 1), 1000000, "RISE", 0.4, 4, node_range=(0, 512), cpu_learn="extrapolate"))
+                                     syn.block_ising_model(4096, 8, 1), 1000000, "RISE", 0.4, 4, node_range=(0, 512),
+                                     cpu_learn="measure" if "--cpu-full" in sys.argv else "extrapolate"))
     if "c4full" in which:  # the whole of config 4 on ONE GPU (what an 8-GPU run shards): all 4096 nodes, 1e6 samples
         jobs.append(lambda: pairwise("C4_full_1gpu", "n=4096 sparse (8-spin block) Ising, 1e6 samples, RISE(0.4): all nodes on one GPU",
                                      syn.block_ising_model(4096, 8, 1), 1000000, "RISE", 0.4, 4, cpu_learn="extrapolate"))

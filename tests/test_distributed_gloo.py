@@ -43,6 +43,12 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     assert np.allclose(r0["multi_vals"], [fg[k] for k in keys], atol=1e-15)
     assert np.array_equal(r0["multi_vals"], r1["multi_vals"])
     assert np.abs(r0["rise"] - load_csv("mvt_RISE_learned.csv")).max() <= 3e-4
+    # the start of the run: rank 0 packed the matrix (rank 1 was handed None), both took part in one broadcast of the bits --
+    # 9 spins x 32 words of 32 configurations + the 512 counts -- and a matrix that cannot be packed raised on both
+    wpr = 1024 // 32
+    for rr in (r0, r1):
+        assert rr["start"][2] == 9 * wpr * 4 + 8 * 512 and rr["start"][1] > 0 and int(rr["bad_raised"]) == 1
+    assert r1["start"][0] < r0["start"][0]  # (rank 1's "packing" is the empty branch)
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
@@ -101,6 +107,10 @@ def test_bench_two_ranks_on_the_gpu_box():
     assert line["n_gpus"] == 2 and line["config"]["nodes_per_gpu"] == 128 and len(line["per_rank_ms_per_step"]) == 2
     assert line["value"] > 0 and line["learn_not_converged"] == 0 and line["max_err_vs_true_model"] < 0.1
     assert line["collective_ranks"] == 2 and "gather_s" in line
+    # the front door of the process-per-GPU route from a host matrix only rank 0 holds: packed once, the bits broadcast
+    fd = line["learn_distributed_front_door"]
+    assert fd["same_rows_as_device_sampled_handles"] and len(fd["pack_s"]) == 2 and fd["pack_s"][1] < fd["pack_s"][0]
+    assert fd["bcast_bytes"] == 256 * (50176 // 32) * 4 and all(v > 0 for v in fd["bcast_s"])
     # the headline is measured in arithmetic as wide as the reference's Float64 (the int8 limbs at 54 / 47 bits), the other two
     # arithmetics ride along, and a first multi-GPU run is diagnosable from the line alone
     assert line["dtype"] == "i8w" and line["learn_precision"] == "i8w"

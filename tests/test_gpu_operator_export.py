@@ -12,6 +12,7 @@ from conftest import load_csv
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
+synthetic = __import__("importlib").import_module("gml_amd.synthetic")
 
 
 @pytest.mark.parametrize("prec", ["f64", "i8w", "auto"])  # (the Julia operator file binds auto: the FP64-grade limbs i8w, FP64 for rows they cannot hold)
@@ -61,3 +62,110 @@ def test_operator_one_row_calls_equal_the_batched_call():
                     assert f1[0] == fb[u] and np.array_equal(g1[0], gb[u])
                 else:
                     assert abs(f1[0] - fb[u]) <= 1e-14 and np.abs(g1[0] - gb[u]).max() <= 1e-14
+
+
+# ---- the operator on rows resident in HBM (device pointers for theta / f / g / vec / hv: include/gml.h) -------------------------------
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("form", ["RISE", "logRISE", "RPLE"])
+@pytest.mark.parametrize("prec", ["f64", "i8w", "i8x", "auto"])
+def test_device_pointer_operator_equals_host_pointer_operator(form, prec):
+    import torch
+    n, K = 96, 30000
+    J = synthetic.block_ising_model(n, block=16, seed=2)
+    rng = np.random.default_rng(5)
+    nodes = rng.permutation(n)[:70].astype(np.int64)  # (a partial last tile, rows not in node order, a padded leading dimension)
+    ld = n + 3
+    theta = np.zeros((len(nodes), ld))
+    theta[:, :n] = J[nodes] + rng.normal(scale=0.05, size=(len(nodes), n)) * (rng.random((len(nodes), n)) < 0.2)
+    with gml.Problem(model=J, num_samples=K, seed=3) as p:
+        f_h, g_h = p.objgrad(form, nodes, theta, precision=prec)
+        d_th, d_f, d_g = _dev(theta), torch.full((len(nodes),), np.nan, dtype=torch.float64, device="cuda"), \
+            torch.full((len(nodes), ld), np.nan, dtype=torch.float64, device="cuda")
+        p.objgrad_device(form, nodes, d_th.data_ptr(), ld, d_f.data_ptr(), d_g.data_ptr(), precision=prec)
+        f_d, g_d = d_f.cpu().numpy(), d_g.cpu().numpy()
+        if prec == "f64":  # (floating-point atomics: two runs agree to rounding)
+            assert np.abs(f_d / f_h - 1).max() <= 1e-13 and np.abs(g_d[:, :n] - g_h[:, :n]).max() <= 1e-13
+        else:
+            assert np.array_equal(f_d, f_h) and np.array_equal(g_d[:, :n], g_h[:, :n])
+        assert np.isnan(g_d[:, n:]).all()  # the padding of the caller's rows is not touched
+        # objective only
+        d_f2 = torch.zeros_like(d_f)
+        p.objgrad_device(form, nodes, d_th.data_ptr(), ld, d_f2.data_ptr(), None, precision=prec)
+        f_only, _ = p.objgrad(form, nodes, theta, precision=prec, want_grad=False)
+        assert np.allclose(d_f2.cpu().numpy(), f_only, rtol=1e-13, atol=0) if prec == "f64" else np.array_equal(d_f2.cpu().numpy(), f_only)
+        # Hessian-vector products
+        vec = np.zeros_like(theta)
+        vec[:, :n] = rng.normal(size=(len(nodes), n))
+        hv_h = p.hessvec(form, nodes, theta, vec)
+        d_hv = torch.full((len(nodes), ld), np.nan, dtype=torch.float64, device="cuda")
+        p.hessvec_device(form, nodes, d_th.data_ptr(), _dev(vec).data_ptr(), ld, d_hv.data_ptr())
+        hv_d = d_hv.cpu().numpy()
+        if form == "logRISE":  # (the rank-one correction is a device reduction there, a host loop here)
+            assert np.abs(hv_d[:, :n] - hv_h[:, :n]).max() <= 1e-12 * max(1.0, np.abs(hv_h).max())
+        else:
+            assert np.array_equal(hv_d[:, :n], hv_h[:, :n])
+        # mixed pointers and non-finite rows are refused
+        with pytest.raises(gml.GMLError, match="all host or all device"):
+            gml._lib.check(gml._lib.lib().gml_objgrad_batch(p._h, 0, 2, len(nodes), nodes.ctypes.data, d_th.data_ptr(), ld,
+                                                            f_h.ctypes.data, None))
+        bad = theta.copy()
+        bad[3, 5] = np.inf
+        with pytest.raises(gml.GMLError, match="non-finite"):
+            p.objgrad_device(form, nodes, _dev(bad).data_ptr(), ld, d_f.data_ptr(), d_g.data_ptr(), precision=prec)
+
+
+def test_device_pointer_operator_multibody_and_dynamic_range():
+    import torch
+    # order 3 (the slot -> column table goes to the device once per node list), and a dense theta that forces the rescaled re-run
+    n, K = 24, 20000
+    terms = synthetic.block_multibody_terms(n, block=12, seed=1)
+    rng = np.random.default_rng(1)
+    with gml.Problem(terms=terms, n=n, num_samples=K, seed=2, order=3) as p:
+        nodes = np.arange(n, dtype=np.int64)
+        for scale in (0.02, 0.4):
+            theta = rng.normal(scale=scale, size=(n, p.P))
+            for prec in ("i8w", "i8x"):
+                f_h, g_h = p.objgrad("RISE", nodes, theta, precision=prec)
+                d_f, d_g = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros((n, p.P), dtype=torch.float64, device="cuda")
+                p.objgrad_device("RISE", nodes, _dev(theta).data_ptr(), p.P, d_f.data_ptr(), d_g.data_ptr(), precision=prec)
+                assert np.array_equal(d_f.cpu().numpy(), f_h) and np.array_equal(d_g.cpu().numpy(), g_h)
+        sub = np.array([5, 2, 17], dtype=np.int64)  # another node list: the cached table is replaced
+        th = rng.normal(scale=0.05, size=(3, p.P))
+        f_h, g_h = p.objgrad("RISE", sub, th, precision="i8w")
+        d_f, d_g = torch.zeros(3, dtype=torch.float64, device="cuda"), torch.zeros((3, p.P), dtype=torch.float64, device="cuda")
+        p.objgrad_device("RISE", sub, _dev(th).data_ptr(), p.P, d_f.data_ptr(), d_g.data_ptr(), precision="i8w")
+        assert np.array_equal(d_f.cpu().numpy(), f_h) and np.array_equal(d_g.cpu().numpy(), g_h)
+
+
+def test_device_pointer_operator_headline_pass_time():
+    # the headline pass (n = 1024, K = 1e6, precision i8w) through the PUBLIC operator with the rows in HBM: within 3 % + 0.2 ms of
+    # the resident timing hook the benchmark uses, where the host-pointer form pays ~3 ms of staging and PCIe
+    import time
+
+    import torch
+    n, K = 1024, 1000000
+    J = synthetic.block_ising_model(n, block=16, seed=0)
+    nodes = np.arange(n, dtype=np.int64)
+    with gml.Problem(model=J, num_samples=K, seed=0) as p:
+        d_th = _dev(J)
+        d_f, d_g = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros((n, n), dtype=torch.float64, device="cuda")
+        for _ in range(3):
+            p.objgrad_device("RISE", nodes, d_th.data_ptr(), n, d_f.data_ptr(), d_g.data_ptr(), precision="i8w")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            p.objgrad_device("RISE", nodes, d_th.data_ptr(), n, d_f.data_ptr(), d_g.data_ptr(), precision="i8w")
+        t_dev = (time.perf_counter() - t0) / 20 * 1e3
+        t0 = time.perf_counter()
+        for _ in range(5):
+            f_h, g_h = p.objgrad("RISE", nodes, J, precision="i8w")
+        t_host = (time.perf_counter() - t0) / 5 * 1e3
+        res = p.bench_pass_resident("RISE", J, steps=20, warmup=2, precision="i8w")
+    print(f"headline pass through gml_objgrad_batch: device pointers {t_dev:.2f} ms, host pointers {t_host:.2f} ms, resident hook "
+          f"{res['device_ms_per_pass']:.2f} ms")
+    assert np.array_equal(d_g.cpu().numpy(), g_h) and np.array_equal(d_f.cpu().numpy(), f_h)
+    assert t_dev <= 1.03 * res["device_ms_per_pass"] + 0.2 and t_dev <= 10.8

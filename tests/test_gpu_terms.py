@@ -3,7 +3,6 @@ reference's dict assembly restated in the oracle (GraphicalModelLearning.jl:129-
 orders 1-5; the front door learn(samples, multiRISE / ISODUS, HIP()) on a whole mid-size problem against the dict path applied
 to the very same rows; and at config-5 size (n = 512, order 3, 1e6 samples), where the interpreted host loop used to take
 minutes and tens of GB."""
-import resource
 import time
 
 import numpy as np
@@ -79,12 +78,19 @@ def test_front_door_order3_whole_problem_equals_dict_path(sym, prec, monkeypatch
     m = gml.HIP(tol=1e-9, precision=prec)
     fg = gml.learn(hist, gml.multiRISE(0.6, sym, 3), m)
     assert isinstance(fg, gml.FactorGraph) and isinstance(fg.terms, dict) and (fg.order, fg.varible_count, fg.alphabet) == (3, n, "spin")
-    assert fg.terms == rec and m.stats["not_converged"] == 0 and m.stats["t_assemble"] > 0
+    # (the int8-limb passes are integer GEMMs: two solves of the same problem give the same bits; the FP64-MFMA pass accumulates
+    #  with floating-point atomics, so its two solves agree to rounding only)
+    same = (lambda a, b: a == b) if prec != "f64" else (lambda a, b: abs(a - b) <= 1e-13)
+    assert fg.terms.keys() == rec.keys() and all(same(fg.terms[k], v) for k, v in rec.items())
+    assert m.stats["not_converged"] == 0 and m.stats["t_assemble"] > 0
     monkeypatch.setattr(__import__("importlib").import_module("gml_amd.learn"), "DICT_TERMS_MAX", 0)
     fa = gml.learn(hist, gml.multiRISE(0.6, sym, 3), gml.HIP(tol=1e-9, precision=prec))
-    assert isinstance(fa.terms, TermArray) and np.array_equal(fa.terms.weights, want)
-    assert len(fa) == len(rec) and all(fa[k] == v for k, v in rec.items())
-    assert fa.jsondata() == fg.jsondata()
+    assert isinstance(fa.terms, TermArray) and len(fa) == len(rec) and list(fa.keys()) == O.listing_order(rec)
+    if prec != "f64":
+        assert np.array_equal(fa.terms.weights, want) and all(fa[k] == v for k, v in rec.items())
+        assert fa.jsondata() == fg.jsondata()
+    else:
+        assert np.abs(fa.terms.weights - want).max() <= 1e-13
     if sym:  # the generating triples come back (sampling noise + l1 shrinkage)
         assert max(abs(fa[k] - v) for k, v in terms.items() if len(k) == 3) <= 0.12
 
@@ -125,6 +131,31 @@ def test_front_door_refuses_a_node_shard():
             p.learn("RISE", 0.2, terms=True)
 
 
+class PeakRSS:
+    """peak resident set of this process while the block runs, over what it was at entry (sampled: psutil, 10 ms)"""
+
+    def __enter__(self):
+        import threading
+
+        import psutil
+        self._proc = psutil.Process()
+        self.base = self.peak = self._proc.memory_info().rss
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.wait(0.01):
+                self.peak = max(self.peak, self._proc.memory_info().rss)
+        self._t = threading.Thread(target=loop, daemon=True)
+        self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._t.join()
+        self.peak = max(self.peak, self._proc.memory_info().rss)
+        self.over = self.peak - self.base
+
+
 def test_c5_front_door_full_size():
     # config 5 THROUGH THE FRONT DOOR: learn(samples, ISODUS(), HIP(precision="i8x", tol=1e-8)), n = 512, 1e6 samples drawn on the
     # device, the reference's default regulariser.  What learn() adds to the solve -- the sample matrix -> handle, the assembly of
@@ -133,40 +164,37 @@ def test_c5_front_door_full_size():
     terms = synthetic.block_multibody_terms(n, block=16, seed=0)
     with gml.Problem(terms=terms, n=n, num_samples=K, seed=5, order=3) as p:
         spins = p.spins()
-        # the dict path's input: the same solve into host rows (one GPU, one handle shape: the same bits as the front door's)
+    hist = np.empty((K, n + 1), dtype=np.int8)
+    hist[:, 0] = 1
+    hist[:, 1:] = spins
+    del spins
+    m = gml.HIP(precision="i8x", tol=1e-8, max_iter=120)
+    with PeakRSS() as rss:
+        t0 = time.perf_counter()
+        fg = gml.learn(hist, gml.ISODUS(0.4, True, 3), m)
+        t_front = time.perf_counter() - t0
+    st = m.stats
+    t_solve = st["t_total"] - st["t_assemble"]
+    overhead = t_front - t_solve
+    assert isinstance(fg.terms, TermArray) and len(fg) == 512 + 512 * 511 // 2 + 512 * 511 * 510 // 6
+    assert st["not_converged"] == 0 and st["max_kkt"] <= 1e-8
+    # the dict path's input: the same solve into host rows (one GPU, one handle shape, integer GEMMs: the same bits as the front door's)
+    with gml.Problem(hist, order=3) as p:
         t0 = time.perf_counter()
         rows, kkt_rows, st_rows = p.learn("RISE", gml.ISODUS().regularizer, tol=1e-8, precision="i8x", max_iter=120)
         t_rows = time.perf_counter() - t0
         pick = np.sort(np.random.default_rng(9).choice(n, 30, replace=False))
         slot = {int(u): {tuple(int(v) for v in k if v >= 0): j for j, k in enumerate(p.multi_keys_array(u))} for u in pick}
-    hist = np.empty((K, n + 1), dtype=np.int8)
-    hist[:, 0] = 1
-    hist[:, 1:] = spins
-    del spins
-    sample_rows = {int(u): rows[u].copy() for u in pick}
-    supp = int((rows != 0).sum(1).max())
-    del rows
-    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
-    m = gml.HIP(precision="i8x", tol=1e-8, max_iter=120)
-    t0 = time.perf_counter()
-    fg = gml.learn(hist, gml.ISODUS(0.4, True, 3), m)
-    t_front = time.perf_counter() - t0
-    rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
-    st = m.stats
-    t_solve = st["t_total"] - st["t_assemble"]
-    overhead = t_front - t_solve
     print(f"C5 front door: learn() {t_front:.2f} s = solve {t_solve:.2f} s + {overhead:.2f} s (handle from the matrix {st['t_pack']:.2f} s, "
-          f"assembly {st['t_assemble'] * 1e3:.0f} ms); peak RSS +{(rss1 - rss0) / 1e6:.2f} GB; Problem.learn into host rows {t_rows:.2f} s; "
-          f"{len(fg)} terms, max support {supp}")
-    assert isinstance(fg.terms, TermArray) and len(fg) == 512 + 512 * 511 // 2 + 512 * 511 * 510 // 6
-    assert st["not_converged"] == 0 and st["max_kkt"] <= 1e-8
-    assert overhead <= 1.5 and rss1 - rss0 <= 2.0e6  # (ru_maxrss is in kB)
+          f"assembly {st['t_assemble'] * 1e3:.0f} ms); peak host RSS over entry +{rss.over / 1e9:.2f} GB; Problem.learn into host rows "
+          f"{t_rows:.2f} s; {len(fg)} terms, max support {int((rows != 0).sum(1).max())}")
+    assert overhead <= 1.5 and rss.over <= 2.0e9
     # the dict path (:135-149: group by sorted key, mean in ascending u) on every key among 30 spins: 4 525 keys, bit for bit
     from itertools import combinations
     checked = 0
     for s in (1, 2, 3):
         for key in combinations([int(u) for u in pick], s):
-            vals = [float(sample_rows[u][slot[u][(u,) + tuple(v for v in key if v != u)]]) for u in key]
+            vals = [float(rows[u][slot[u][(u,) + tuple(v for v in key if v != u)]]) for u in key]
             assert fg[tuple(i + 1 for i in key)] == float(np.mean(vals))
             checked += 1
     assert checked == 30 + 435 + 4060
@@ -174,4 +202,4 @@ def test_c5_front_door_full_size():
     assert max(abs(fg[k] - v) for k, v in terms.items()) <= 0.08
     nz = np.count_nonzero(fg.terms.weights)
     assert len(terms) <= nz < len(fg)
-    assert t_front < 75.0  # measured ~23 s
+    assert t_front < 75.0  # measured 21.9 s (solve 21.8 s)

@@ -12,8 +12,20 @@ synthetic = __import__("importlib").import_module("gml_amd.synthetic")
 learn_module = __import__("importlib").import_module("gml_amd.learn")
 
 
-def oracle_local_solve(samples, formulation, method, order, node_range, device):
+def unpack_histogram(packed):
+    """(sign_bits [n][words] uint32, counts or None, K) -> K x (1+n) float64 histogram (bit set <=> spin -1; include/gml.h)"""
+    bits, counts, K = packed
+    n = bits.shape[0]
+    sp = ((bits[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(n, -1)[:, :K].T
+    return np.concatenate([(np.ones(K) if counts is None else counts)[:, None], 1.0 - 2.0 * sp], axis=1)
+
+
+def oracle_local_solve(samples, formulation, method, order, node_range, device, terms=None, packed=None):
     name = type(formulation).__name__
+    assert terms is None  # (the fused solve + assembly call is the product solver's own)
+    if packed is not None:  # a rank of a distributed run: the bits rank 0 broadcast, no sample matrix
+        assert samples is None
+        samples = unpack_histogram(packed)
     n = samples.shape[1] - 1
     if name == "multiRISE":
         counts, spins = O.split_histogram(samples)
