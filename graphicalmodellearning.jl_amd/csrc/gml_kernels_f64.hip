@@ -753,7 +753,6 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
     // per turn, each waiting for its own load, took 28 of the 99 us of a 100-entry solve); the rank-one term, the masks and the ridge
     // are applied in LDS
     for (int i = tid; i < m; i += 256) gg[i] = s2 != 0.0 ? g[i] : 0.0;
-    auto a_orig = [&](int i, int j) { return sc * A[(int64_t)i * hp + j] - s2 * gg[i] * gg[j]; }; // i >= j: the matrix itself (global)
     auto load_raw = [&]() { // W <- sc * H on the lower triangle of the first mp rows (rows m .. mp - 1, the MFMA tile padding: zero)
         const int total = mp * mp;
         for (int base = 0; base < total; base += 256 * 8) {
@@ -850,6 +849,23 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
             }
         }
         fresh = false;
+        // the right-hand side first, from the matrix as it stands in W -- s1 H with the secant correction, the SAME matrix that is
+        // factored below -- before the masks decouple the fixed entries: a free row's share of the fixed steps is A_corr[i][j] dfx[j]
+        // (the global block, a_orig, lacks the correction: both sides of a face re-solve must see one matrix)
+        for (int i = tid; i < m; i += 256) {
+            double v = -pg[i];
+            if (anyfixed) {
+                if (fx[i] != 0.0) {
+                    v = dfx[i];
+                } else {
+                    for (int j = 0; j < m; ++j)
+                        if (fx[j] != 0.0 && dfx[j] != 0.0)
+                            v -= ((i >= j ? W[i * LDW + j] : W[j * LDW + i]) - s2 * gg[i] * gg[j]) * dfx[j];
+                }
+            }
+            y[i] = v;
+        }
+        __syncthreads();
         // the (masked) matrix: rank-one term, fixed entries decoupled (unit diagonal), ridge on the free diagonal
         if (s2 != 0.0 || anyfixed || ridge != 0.0) {
             for (int idx = tid; idx < m * m; idx += 256) {
@@ -860,18 +876,6 @@ __global__ __launch_bounds__(256) void k_newton_chol_lds(const double *__restric
                 else if (i == j) v += ridge;
                 W[i * LDW + j] = v;
             }
-        }
-        for (int i = tid; i < m; i += 256) {
-            double v = -pg[i];
-            if (anyfixed) {
-                if (fx[i] != 0.0) {
-                    v = dfx[i];
-                } else {
-                    for (int j = 0; j < m; ++j)
-                        if (fx[j] != 0.0 && dfx[j] != 0.0) v -= (i >= j ? a_orig(i, j) : a_orig(j, i)) * dfx[j];
-                }
-            }
-            y[i] = v;
         }
         if (tid == 0) bad = 0;
         __syncthreads();

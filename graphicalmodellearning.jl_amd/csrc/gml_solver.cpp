@@ -93,7 +93,8 @@ struct Stage {
     // persist: an array the kernels write and the host reads after sync(), for the whole solve (before the first take only)
     template <typename T> T *persist(size_t count) {
         const size_t a = (floor + 63) & ~(size_t)63;
-        if (!mapped || a + sizeof(T) * count > cap / 2) return nullptr;
+        // only while nothing has been taken from the recycled part: [floor, off) may hold bytes of a copy still in flight
+        if (!mapped || off != floor || !pend.empty() || a + sizeof(T) * count > cap / 2) return nullptr;
         floor = a + sizeof(T) * count;
         if (off < floor) off = floor;
         return reinterpret_cast<T *>(base + a);
@@ -174,17 +175,17 @@ struct Solver {
     hipStream_t st_pass = nullptr, st_own_hi = nullptr, st_own_lo = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bool dual = false;
+    bool underflow = false; // the solve ended because a row's weights left the fixed-point range at an iterate (gml_learn: auto -> FP64)
     bool at_zero = false; // the pass being queued evaluates X = 0 (the first pass of a solve; also its rescaled re-runs)
-    ~Solver() {
-        if (dual) {
-            (void)hipStreamSynchronize(st);
-            (void)hipStreamSynchronize(st_pass);
-            (void)hipEventDestroy(ev_a);
-            (void)hipEventDestroy(ev_b);
-            (void)hipStreamDestroy(st_own_hi);
-            (void)hipStreamDestroy(st_own_lo);
-        }
+    ~Solver() { // (each handle by itself: init may have returned between two of the four creations)
+        if (st_own_hi) (void)hipStreamSynchronize(st_own_hi);
+        if (st_own_lo) (void)hipStreamSynchronize(st_own_lo);
+        if (ev_a) (void)hipEventDestroy(ev_a);
+        if (ev_b) (void)hipEventDestroy(ev_b);
+        if (st_own_hi) (void)hipStreamDestroy(st_own_hi);
+        if (st_own_lo) (void)hipStreamDestroy(st_own_lo);
     }
+    double tune[GML_NTUNE] = {}; // the experiment knobs as they stood when the solve began (gml_test_tune may be called meanwhile)
     Stage stg;
     Arena A;
     PhaseTimer dir_time;
@@ -368,15 +369,16 @@ int Solver::init() {
         void *dp = nullptr; // zero-copy only where the device sees the arena under the same address (unified addressing); else copies
         stg.mapped = hipHostGetDevicePointer(&dp, p->stage, 0) == hipSuccess && dp == static_cast<void *>(p->stage);
         if (!stg.mapped) (void)hipGetLastError();
-        if (g_tune[GML_TUNE_NO_ZEROCOPY] > 0) stg.mapped = false; // (tests: the copy path that very large handles take)
+        for (int i = 0; i < GML_NTUNE; ++i) tune[i] = g_tune[i];
+        if (tune[GML_TUNE_NO_ZEROCOPY] > 0) stg.mapped = false; // (tests: the copy path that very large handles take)
     }
     st_pass = st;
-    if (g_tune[GML_TUNE_DUAL_STREAMS] > 0 && gml_is_i8(o.precision)) {
+    if (tune[GML_TUNE_DUAL_STREAMS] > 0 && gml_is_i8(o.precision)) {
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(hipStreamSynchronize(st)); // (what the handle's own stream still holds: the samples' images)
         HIPCHK(hipStreamCreateWithPriority(&st_own_hi, hipStreamNonBlocking, greatest));
-        HIPCHK(hipStreamCreateWithPriority(&st_own_lo, hipStreamNonBlocking, g_tune[GML_TUNE_DUAL_STREAMS] > 1 ? greatest : least));
+        HIPCHK(hipStreamCreateWithPriority(&st_own_lo, hipStreamNonBlocking, tune[GML_TUNE_DUAL_STREAMS] > 1 ? greatest : least));
         HIPCHK(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
         st = st_own_hi;
@@ -530,7 +532,7 @@ int Solver::init() {
     // 17 % longer with the larger budget, profiles/r5_robust_sweep.txt)
     Kh_base = 32768;
     if (gml_is_i8(o.precision)) Kh_base = std::min<int64_t>(131072, std::max<int64_t>(32768, ((int64_t)1 << 23) / std::max<int64_t>(R, 1)));
-    if (g_tune[GML_TUNE_KH_BASE] > 0) Kh_base = (int64_t)g_tune[GML_TUNE_KH_BASE];
+    if (tune[GML_TUNE_KH_BASE] > 0) Kh_base = (int64_t)tune[GML_TUNE_KH_BASE];
     if (o.hess_samples != 0) Kh_base = o.hess_samples < 0 ? d.Kp : (int64_t)o.hess_samples;
     nblk512 = d.Kp / 512;
     set_kh(R);
@@ -660,7 +662,7 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         a.lf = o.limbs_fwd;
         a.wide = wide;
         a.coarse = coarse_on;
-        a.zero_theta = at_zero && g_tune[GML_TUNE_NO_ZERO_SHORTCUT] == 0; // the first pass of a solve: X = 0 for every row
+        a.zero_theta = at_zero && tune[GML_TUNE_NO_ZERO_SHORTCUT] == 0; // the first pass of a solve: X = 0 for every row
         std::string err;
         if (dual) { // the pass behind what this handle has queued so far, on the low-priority stream
             HIPCHK(hipEventRecord(ev_a, st));
@@ -767,7 +769,11 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         if (depth >= 6) {
             // the weights exp(-E) of these rows underflow the fixed-point range even after six rescalings (|theta|_1 in the
             // hundreds): a trial point that far out is simply rejected; at the iterate itself it is an error
-            if (!at_trial) return fail(GML_EUNSUPPORTED, "precision i8x: the weights exp(-E) of a row underflow its fixed-point range; use precision f64");
+            if (!at_trial) {
+                underflow = true;
+                return fail(GML_EUNSUPPORTED, "precision %s: the weights exp(-E) of a row underflow its fixed-point range at an iterate; use precision f64 "
+                                              "(or auto, which does so by itself)", wide ? "i8w" : "i8x");
+            }
             for (int r : again) {
                 fo[r] = INFINITY;
                 no[r] = 0.0;
@@ -1089,7 +1095,7 @@ int Solver::newton_blocks(const std::vector<int> &chol_rows) {
     // (a re-solve costs as much as the solve; what it saves is backtracking passes, whose cost grows with configurations x
     // statistics: config 2 -- 1e5 x 256 -- is 0.4 ms faster without, the headline problem 4 % faster with)
     nf.rounds = (double)p->K * (double)Qp >= 268435456.0 ? face_rounds : 0;
-    if (g_tune[GML_TUNE_FACE_ROUNDS] > 0) nf.rounds = (int)g_tune[GML_TUNE_FACE_ROUNDS] - 1;
+    if (tune[GML_TUNE_FACE_ROUNDS] > 0) nf.rounds = (int)tune[GML_TUNE_FACE_ROUNDS] - 1;
     // (blocks of up to kCholLds entries take the secant correction inside the solve, on the matrix in LDS; k_secant above kept the
     // pairs and corrected the larger blocks itself)
     SecantPairs sp;
@@ -1574,21 +1580,47 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     gml_opts o;
     if (opts_in) o = *opts_in;
     else gml_default_opts(&o);
+    bool asked_auto = false;
     {
         // (auto: gml_internal.h -- the 38/31-bit limbs, the FP64-grade ones for tight tolerances and for small problems)
         const int asked = o.precision;
+        asked_auto = asked == GML_PREC_AUTO;
         o.precision = gml_resolve_precision(p, asked, o.tol > 0 ? o.tol : 1e-9);
         if (o.precision < 0) return fail(GML_EINVAL, "unknown precision %d", asked);
     }
     HIPCHK(hipSetDevice(p->device));
     const double t_start = gml_now_s();
-    Solver s(p, formulation, o, gml_lambda(regularizer_c, p->n, p->M));
-    int rc = s.init();
-    if (rc == GML_OK) rc = s.iterate(out, kkt_out);
-    s.stats.t_total = gml_now_s() - t_start;
-    s.stats.t_pack = p->t_ingest[3];
-    // everything that is neither a pass nor the direction phase: selection, trial points, bookkeeping
-    s.stats.t_host = std::max(0.0, s.stats.t_total - s.stats.t_pass - s.stats.t_hess);
-    if (stats_out && (rc == GML_OK || rc == GML_ENOTCONV)) *stats_out = s.stats;
+    int rc;
+    bool underflow = false;
+    {
+        Solver s(p, formulation, o, gml_lambda(regularizer_c, p->n, p->M));
+        rc = s.init();
+        if (rc == GML_OK) rc = s.iterate(out, kkt_out);
+        s.stats.t_total = gml_now_s() - t_start;
+        s.stats.t_pack = p->t_ingest[3];
+        // everything that is neither a pass nor the direction phase: selection, trial points, bookkeeping
+        s.stats.t_host = std::max(0.0, s.stats.t_total - s.stats.t_pass - s.stats.t_hess);
+        if (stats_out && (rc == GML_OK || rc == GML_ENOTCONV)) *stats_out = s.stats;
+        underflow = s.underflow;
+    }
+    if (rc == GML_EUNSUPPORTED && underflow && asked_auto) {
+        // `auto` is the reference's Float64 solve (:164-181) by other means: a histogram whose optimum lies where exp(-E) spreads over
+        // hundreds of units (c = 0 on near-separable data, |theta|_1 in the hundreds) cannot be held by the int8 limbs at an iterate;
+        // the reference returns a result there, so `auto` runs the solve again on the FP64-MFMA path.  A caller who named an
+        // int8-limb precision keeps the error.
+        const std::string first = gml_last_error();
+        gml_opts o64 = o;
+        o64.precision = GML_PREC_F64;
+        Solver s(p, formulation, o64, gml_lambda(regularizer_c, p->n, p->M));
+        rc = s.init();
+        if (rc == GML_OK) rc = s.iterate(out, kkt_out);
+        if (rc != GML_OK && rc != GML_ENOTCONV)
+            return fail(rc, "%s; the FP64 path, which precision auto falls back to, then failed: %s", first.c_str(), std::string(gml_last_error()).c_str());
+        s.stats.t_total = gml_now_s() - t_start;
+        s.stats.t_pack = p->t_ingest[3];
+        s.stats.t_host = std::max(0.0, s.stats.t_total - s.stats.t_pass - s.stats.t_hess);
+        s.stats.polished = 1; // (finished on the FP64 path)
+        if (stats_out) *stats_out = s.stats;
+    }
     return rc;
 }

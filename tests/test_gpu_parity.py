@@ -1104,3 +1104,25 @@ def test_coarse_early_passes_do_not_change_the_answer():
     assert sc["not_converged"] == 0 and np.abs(c - d).max() <= 1e-9
     assert se["not_converged"] == 0 and sg["not_converged"] == 0 and np.abs(e - g).max() <= 5e-9 and abs(se["iterations"] - sg["iterations"]) <= 1
     assert _kkt_from_oracle(spins, a, [0, 100, 511], lam) <= 1e-9 and _kkt_from_oracle(spins, e, [0, 100, 511], lam) <= 5e-9
+
+
+@pytest.mark.parametrize("form", ["RISE", "logRISE"])
+def test_auto_never_refuses_c0_near_separable(form):
+    # c = 0 on strongly coupled spins with few samples: the unregularised optimum lies where exp(-E) spans hundreds of units, or at
+    # infinity (then "not converged" is the answer, the reference's @assert).  `auto` is the reference's Float64 solve by other means:
+    # it must answer like precision f64 does -- never GML_EUNSUPPORTED -- and a named int8-limb precision that refuses says which one
+    rng = np.random.default_rng(3)
+    n = 10
+    m = np.triu(rng.uniform(1.0, 2.5, (n, n)) * rng.choice([-1, 1], (n, n)) * (rng.random((n, n)) < 0.5), 1)
+    hist = synthetic.enumerate_sample(m + m.T, 5000, seed=5)
+    with gml.Problem(hist) as p:
+        ref, kref, sref = p.learn(form, 0.0, tol=1e-9, precision="f64", raise_on_fail=False, max_iter=200)
+        out, kkt, st = p.learn(form, 0.0, tol=1e-9, precision="auto", raise_on_fail=False, max_iter=200)
+        conv = (kref <= 1e-9) & (kkt <= 1e-9)
+        if conv.any():
+            assert np.abs(out[conv] - ref[conv]).max() <= 1e-6 * max(1.0, np.abs(ref[conv]).max())
+        for prec in ("i8w", "i8x"):
+            try:
+                p.learn(form, 0.0, tol=1e-9, precision=prec, raise_on_fail=False, max_iter=200)
+            except gml.GMLError as e:
+                assert e.code == 5 and f"precision {prec}" in str(e)
