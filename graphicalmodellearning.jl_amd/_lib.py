@@ -93,6 +93,7 @@ def lib():
     L.gml_multi_keys.argtypes = [p, i64, p]
     L.gml_objgrad_batch.argtypes = [p, i32, i32, i64, p, p, i64, p, p]
     L.gml_hessvec_batch.argtypes = [p, i32, i64, p, p, p, i64, p]
+    L.gml_hessvec_batch_prec.argtypes = [p, i32, i32, i64, p, p, p, i64, p]
     L.gml_multi_create.argtypes = [p, i32, i64, i64, i64, i32, i32, p, i32, C.POINTER(p)]
     L.gml_multi_info.argtypes = [p] + [p] * 6
     L.gml_multi_learn.argtypes = [p, i32, dbl, C.POINTER(Opts), p, p, C.POINTER(Stats), p]
@@ -100,6 +101,7 @@ def lib():
     L.gml_multi_destroy.argtypes = [p]
     L.gml_multi_destroy.restype = None
     L.gml_learn.argtypes = [p, i32, dbl, C.POINTER(Opts), p, p, C.POINTER(Stats)]
+    L.gml_learn_warm.argtypes = [p, i32, dbl, C.POINTER(Opts), p, p, p, C.POINTER(Stats)]
     L.gml_terms_count.restype = i64
     L.gml_terms_count.argtypes = [i64, i32, i32]
     L.gml_terms_assemble.argtypes = [p, i64, i64, i32, i32, i32, p]
@@ -362,28 +364,29 @@ class Problem:
                                       C.c_void_p(int(theta_ptr)), int(ld), C.c_void_p(int(f_ptr)),
                                       C.c_void_p(int(g_ptr)) if g_ptr else None))
 
-    def hessvec_device(self, formulation, nodes, theta_ptr, vec_ptr, ld, hv_ptr):
-        """gml_hessvec_batch on rows resident in HBM (device addresses, as objgrad_device)"""
+    def hessvec_device(self, formulation, nodes, theta_ptr, vec_ptr, ld, hv_ptr, precision="i8x"):
+        """gml_hessvec_batch_prec on rows resident in HBM (device addresses, as objgrad_device)"""
         nodes = np.ascontiguousarray(nodes, dtype=np.int64)
-        check(lib().gml_hessvec_batch(self._h, FORMULATION_IDS[formulation], len(nodes), _ptr(nodes), C.c_void_p(int(theta_ptr)),
-                                      C.c_void_p(int(vec_ptr)), int(ld), C.c_void_p(int(hv_ptr))))
+        check(lib().gml_hessvec_batch_prec(self._h, FORMULATION_IDS[formulation], PRECISIONS[precision], len(nodes), _ptr(nodes),
+                                           C.c_void_p(int(theta_ptr)), C.c_void_p(int(vec_ptr)), int(ld), C.c_void_p(int(hv_ptr))))
 
-    def hessvec(self, formulation, nodes, theta, vec):
-        """Hess f_u(theta) @ vec for the listed nodes (gml_hessvec_batch; int8-limb passes)."""
+    def hessvec(self, formulation, nodes, theta, vec, precision="i8x"):
+        """Hess f_u(theta) @ vec for the listed nodes (gml_hessvec_batch_prec): "i8x" = int8-limb passes (~1e-8), "f64" = FP64 MFMA."""
         nodes = np.ascontiguousarray(nodes, dtype=np.int64)
         theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(len(nodes), -1)
         vec = np.ascontiguousarray(vec, dtype=np.float64).reshape(len(nodes), -1)
         out = np.zeros_like(theta)
-        check(lib().gml_hessvec_batch(self._h, FORMULATION_IDS[formulation], len(nodes), _ptr(nodes), _ptr(theta), _ptr(vec),
-                                      theta.shape[1], _ptr(out)))
+        check(lib().gml_hessvec_batch_prec(self._h, FORMULATION_IDS[formulation], PRECISIONS[precision], len(nodes), _ptr(nodes), _ptr(theta),
+                                           _ptr(vec), theta.shape[1], _ptr(out)))
         return out
 
     def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="auto", max_working=512, max_add=64,
               verbose=0, hess_samples=0, polish=True, max_cg=0, limbs_fwd=0, hv_limbs_fwd=0, hv_limbs_bwd=0, debug_row=0,
-              hv_subsample=0, cg_viol_frac=0.0, cg_eta=0.0, coarse=True, out_ptr=None, raise_on_fail=True, terms=None):
+              hv_subsample=0, cg_viol_frac=0.0, cg_eta=0.0, coarse=True, out_ptr=None, raise_on_fail=True, terms=None, x0=None):
         """gml_learn: (rows, kkt, stats).  terms = True / False (handles over all nodes): gml_learn_terms instead -- the solved
         rows stay on the device and the first result is the model's weight array in (length, key) order, symmetrised (True) or
-        not (False): the input of a FactorGraph (TermArray)."""
+        not (False): the input of a FactorGraph (TermArray).  x0: rows to start from ((node1-node0) x P, the layout of the result;
+        gml_learn_warm) -- a regularisation path solves each c from the previous solution."""
         L = lib()
         o = Opts()
         L.gml_default_opts(C.byref(o))
@@ -408,7 +411,13 @@ class Problem:
             if out_ptr is None:
                 out = np.zeros((R, self.P))
                 out_ptr = _ptr(out)
-            rc = L.gml_learn(self._h, FORMULATION_IDS[formulation], float(c), C.byref(o), out_ptr, _ptr(kkt), C.byref(st))
+            if x0 is not None:
+                x0 = np.ascontiguousarray(x0, dtype=np.float64)
+                if x0.shape != (R, self.P):
+                    raise GMLError(GML_EINVAL, f"x0 has shape {x0.shape}, the handle's rows are {(R, self.P)}")
+                rc = L.gml_learn_warm(self._h, FORMULATION_IDS[formulation], float(c), C.byref(o), _ptr(x0), out_ptr, _ptr(kkt), C.byref(st))
+            else:
+                rc = L.gml_learn(self._h, FORMULATION_IDS[formulation], float(c), C.byref(o), out_ptr, _ptr(kkt), C.byref(st))
         if rc == GML_ENOTCONV:
             if raise_on_fail:
                 err = GMLConvergenceError(L.gml_last_error().decode())

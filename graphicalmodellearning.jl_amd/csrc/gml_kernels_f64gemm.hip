@@ -111,6 +111,21 @@ __global__ __launch_bounds__(64 * F64_FWD_WAVES, 8 / F64_FWD_WAVES) void k_fwd_f
                     const double s = ((Sb[(int64_t)rc * wpr + (k >> 5)] >> (k & 31)) & 1u) ? -1.0 : 1.0; // the node's own spin
                     const double E = s * (acc[mi][ni][j] + tc);
                     double val;
+                    if (form >= 4) {
+                        // Hessian-vector forward (forms 4..6; Theta holds the direction p): U_k = h_k (acc + tc), acc + tc = sum_j p_j x_kj
+                        // over the raw columns -- the backward GEMM contracts U with the same raw columns, which gives H p since s^2 = 1.
+                        // The curvature weight h_k comes from the V the objective pass at theta left in this row: RISE / logRISE Z:
+                        // V = -w e^-E s, h = w e^-E = -V s; RPLE: V = -2 w sigma(-2E) s, h = 4 w sigma(-2E) sigma(2E).
+                        const double vold = V[(int64_t)r * Kp + k];
+                        double h = -vold * s;
+                        if (form == 6) {
+                            const double sg = wk > 0.0 ? h / (2.0 * wk) : 0.0; // sigma(-2E)
+                            h = 2.0 * h * (1.0 - sg);
+                        }
+                        val = h * (E * s); // (E s = acc + tc)
+                        V[(int64_t)r * Kp + k] = val;
+                        continue;
+                    }
                     if (form == 2) { // RPLE (:317)
                         const double t = -2.0 * E;
                         const double sp = t > 0 ? t + log1p(exp(-t)) : log1p(exp(t));

@@ -495,8 +495,9 @@ extern "C" int gml_objgrad_batch(gml_problem *p, int formulation, int precision,
 
 // gml_hessvec_batch for rows resident in HBM: the objective pass at theta leaves the curvature weights in the slots, the directions are
 // scattered into the internal layout, the Hessian-vector pass runs, a kernel writes hv (logRISE: with the rank-one correction)
-static int hessvec_dev(gml_problem *p, int form, int64_t nrows, const int64_t *nodes, const double *dtheta, const double *dvec, int64_t ld,
-                       double *dhv) {
+static int hv_second_pass(gml_problem *p, int64_t Rp, int ngroups, int npad, int formulation, int precision);
+static int hessvec_dev(gml_problem *p, int form, int precision, int64_t nrows, const int64_t *nodes, const double *dtheta, const double *dvec,
+                       int64_t ld, double *dhv) {
     const int64_t Qp = p->d.Qp, P = p->P, Rp = round_up(nrows, 32);
     const int32_t *dcols = nullptr;
     int rc = dev_cols(p, nrows, nodes, &dcols);
@@ -514,34 +515,18 @@ static int hessvec_dev(gml_problem *p, int form, int64_t nrows, const int64_t *n
         F2 = p->opG2 + (size_t)p->opG2rows * P;
     }
     std::vector<uint8_t> act((size_t)nrows, 1);
-    rc = pass_dev(p, nrows, nodes, act, dtheta, ld, form, GML_PREC_I8X, true, F2, G2, P, dcols, nullptr, 0, false, true);
+    rc = pass_dev(p, nrows, nodes, act, dtheta, ld, form, precision, true, F2, G2, P, dcols, nullptr, 0, false, true);
     if (rc) return rc;
     hipStream_t st = p->st;
     std::vector<int> groups;
     int npad = 0;
     rc = upload_ctl(p, nrows, nodes, act, groups, &npad);
     if (rc) return rc;
-    const int64_t W = p->ws_rows;
     HIPCHK(hipMemsetAsync(p->opFlag, 0, sizeof(int) * 4, st));
     HIPCHK(hipMemsetAsync(p->dTheta, 0, sizeof(double) * Rp * Qp, st));
     launch_ref_to_internal(dvec, ld, nrows, P, Qp, p->dRowcol, p->d.cconst, dcols, p->dTheta, p->opFlag, st);
-    gml::I8Pass a{};
-    a.theta = p->dTheta;
-    a.srow = p->dSrow;
-    a.rowcol = p->dRowcol;
-    a.groups = p->dGroups;
-    a.ngroups = (int)groups.size();
-    a.slot0 = 0;
-    a.slot1 = (int)Rp;
-    a.form = form;
-    a.want_grad = true;
-    a.F = nullptr;
-    a.G = p->dG;
-    a.hv = 1;
-    a.vmap = p->dSrow;
-    std::string err;
-    rc = gml::i8_pass(&p->i8ws, p->d, W, a, st, nullptr, &err);
-    if (rc) return fail(rc, "%s", err.c_str());
+    rc = hv_second_pass(p, Rp, (int)groups.size(), npad, form, precision);
+    if (rc) return rc;
     launch_hv_to_ref(p->dG, G2, F2, nrows, Qp, P, ld, p->dRowcol, p->d.cconst, dcols, form == GML_LOGRISE ? 1 : 0, dvec, dhv, st);
     HIPCHK(hipGetLastError());
     int bad[4] = {0, 0, 0, 0};
@@ -556,7 +541,56 @@ static int hessvec_dev(gml_problem *p, int form, int64_t nrows, const int64_t *n
 // ------------------------------------------------------------------------------------------
 extern "C" int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows, const int64_t *nodes, const double *theta,
                                  const double *vec, int64_t ld, double *hv) {
+    return gml_hessvec_batch_prec(p, formulation, GML_PREC_I8X, nrows, nodes, theta, vec, ld, hv);
+}
+
+// the second pass of a Hessian-vector call: the directions are in dTheta (internal layout), the control block lists all rows;
+// leaves H p (RISE, RPLE) / Hess Z p (logRISE) in dG
+static int hv_second_pass(gml_problem *p, int64_t Rp, int ngroups, int npad, int formulation, int precision) {
+    hipStream_t st = p->st;
+    if (precision == GML_PREC_F64) {
+        HIPCHK(hipMemsetAsync(p->dG, 0, sizeof(double) * Rp * p->d.Qp, st));
+        launch_fwd_f64(p->d, p->dTheta, p->dRowcol, p->dGroups, npad, formulation + 4, p->dV, p->dF, st); // V <- h (x . p), in place
+        launch_bwd_f64(p->d, p->dV, p->dGroups, ngroups, p->dG, st);
+        HIPCHK(hipGetLastError());
+        return GML_OK;
+    }
+    gml::I8Pass a{};
+    a.theta = p->dTheta;
+    a.srow = p->dSrow;
+    a.rowcol = p->dRowcol;
+    a.groups = p->dGroups;
+    a.ngroups = ngroups;
+    a.slot0 = 0;
+    a.slot1 = (int)Rp;
+    a.form = formulation;
+    a.want_grad = true;
+    a.F = nullptr;
+    a.G = p->dG;
+    a.hv = 1;
+    a.vmap = p->dSrow;
+    std::string err;
+    const int rc = gml::i8_pass(&p->i8ws, p->d, p->ws_rows, a, st, nullptr, &err);
+    if (rc) return fail(rc, "%s", err.c_str());
+    return GML_OK;
+}
+
+static int hv_precision(int precision) {
+    if (precision == GML_PREC_AUTO) return GML_PREC_I8X; // (an inexact Newton step needs no more; name f64 for the Float64-grade operator)
+    if (precision == GML_PREC_I8X || precision == GML_PREC_F64) return precision;
+    return -1;
+}
+
+extern "C" int gml_hessvec_batch_prec(gml_problem *p, int formulation, int precision, int64_t nrows, const int64_t *nodes, const double *theta,
+                                      const double *vec, int64_t ld, double *hv) {
     if (!p || !nodes || !theta || !vec || !hv) return fail(GML_EINVAL, "NULL argument");
+    {
+        const int asked = precision;
+        precision = hv_precision(asked);
+        if (precision < 0)
+            return fail(asked == GML_PREC_I8W ? GML_EUNSUPPORTED : GML_EINVAL,
+                        "Hessian-vector products run at precision i8x (31-bit curvature weights, ~1e-8) or f64 (FP64 MFMA, 1e-12); got %d", asked);
+    }
     if (formulation < 0 || formulation > 2) return fail(GML_EINVAL, "unknown formulation %d", formulation);
     if (nrows <= 0) return fail(GML_EINVAL, "nrows must be positive");
     if (ld < p->P) return fail(GML_EINVAL, "ld %lld smaller than the %lld parameters per node", (long long)ld, (long long)p->P);
@@ -567,7 +601,7 @@ extern "C" int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows,
     {
         const bool td = is_device_ptr(theta), vd = is_device_ptr(vec), hd = is_device_ptr(hv);
         if (td != vd || td != hd) return fail(GML_EINVAL, "theta, vec and hv must be all host or all device pointers");
-        if (td) return hessvec_dev(p, formulation, nrows, nodes, theta, vec, ld, hv);
+        if (td) return hessvec_dev(p, formulation, precision, nrows, nodes, theta, vec, ld, hv);
     }
     // 1. objective + gradient pass at theta: leaves the curvature weights (limb planes of V) in the slots 0..nrows-1
     RowSet rs;
@@ -589,7 +623,7 @@ extern "C" int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows,
         if (badrow[r]) return fail(GML_EINVAL, "row %lld contains a non-finite value", (long long)r);
     std::vector<uint8_t> act((size_t)nrows, 1);
     std::vector<double> fv((size_t)nrows);
-    int rc = device_pass(p, rs, act, Th.data(), formulation, GML_PREC_I8X, true, fv.data(), Gi.data(), nullptr);
+    int rc = device_pass(p, rs, act, Th.data(), formulation, precision, true, fv.data(), Gi.data(), nullptr);
     if (rc) return rc;
     // 2. Hessian-vector pass: the rows of the direction through the same slots (vmap = identity)
     hipStream_t st = p->st;
@@ -598,6 +632,7 @@ extern "C" int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows,
     HIPCHK(hipMemcpyAsync(p->dTheta, p->hTh, sizeof(double) * nrows * Qp, hipMemcpyHostToDevice, st));
     // control block of ALL rows: device_pass may have ended on a rescaled re-run of a subset (dense theta rows), which
     // leaves rowcol = -1 for the others and a shortened tile list
+    int hv_npad = 0;
     {
         const int ng = (int)(Rp / 32);
         int npad = 0;
@@ -607,24 +642,10 @@ extern "C" int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows,
         }
         for (int g = 0; g < ng || (npad % 4); ++g, ++npad) p->hCtl[2 * W + g] = g < ng ? g : -1;
         HIPCHK(hipMemcpyAsync(p->dSrow, p->hCtl, sizeof(int) * (2 * W + npad), hipMemcpyHostToDevice, st));
+        hv_npad = npad;
     }
-    gml::I8Pass a{};
-    a.theta = p->dTheta;
-    a.srow = p->dSrow;
-    a.rowcol = p->dRowcol;
-    a.groups = p->dGroups;
-    a.ngroups = (int)(Rp / 32);
-    a.slot0 = 0;
-    a.slot1 = (int)Rp;
-    a.form = formulation;
-    a.want_grad = true;
-    a.F = nullptr;
-    a.G = p->dG;
-    a.hv = 1;
-    a.vmap = p->dSrow;
-    std::string err;
-    rc = gml::i8_pass(&p->i8ws, p->d, W, a, st, nullptr, &err);
-    if (rc) return fail(rc, "%s", err.c_str());
+    rc = hv_second_pass(p, Rp, (int)(Rp / 32), hv_npad, formulation, precision);
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(p->hG, p->dG, sizeof(double) * nrows * Qp, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     parallel_for(nrows, [&](int64_t r) {

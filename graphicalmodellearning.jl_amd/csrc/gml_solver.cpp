@@ -175,6 +175,8 @@ struct Solver {
     hipStream_t st_pass = nullptr, st_own_hi = nullptr, st_own_lo = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bool dual = false;
+    const double *x0 = nullptr; // warm start (gml_learn_warm): the rows to start from, reference layout [R][P], host or device; NULL = zeros
+    int32_t *dColsRef = nullptr; // multi-body: column of every parameter slot of every local row (:94-104), built once (warm start, finish)
     bool underflow = false; // the solve ended because a row's weights left the fixed-point range at an iterate (gml_learn: auto -> FP64)
     bool at_zero = false; // the pass being queued evaluates X = 0 (the first pass of a solve; also its rescaled re-runs)
     ~Solver() { // (each handle by itself: init may have returned between two of the four creations)
@@ -327,6 +329,8 @@ struct Solver {
     int newton_cg_group(const std::vector<int> &cg_rows, bool subsample);
     int line_search();
     int finish(double *out, double *kkt_out, int iterations);
+    int ref_cols();
+    int load_x0();
     int iterate(double *out, double *kkt_out);
 };
 
@@ -1461,18 +1465,8 @@ int Solver::finish(double *out, double *kkt_out, int iterations) {
     // reference layout on the device (the direction array D is free now), then ONE copy: to the caller's host matrix, or --
     // `out` a device pointer (gml_multi_learn's dev_out blocks, device-side callers) -- device to device
     double *dres = D; // [R][P], P <= Qp
-    int32_t *dcols = nullptr;
-    if (p->order != 2) { // multi-body key order (:94-104): column of every parameter slot, from the host
-        std::vector<int32_t> cols((size_t)R * P);
-        gml_parallel_for(R, [&](int64_t r) {
-            NodeLayout L;
-            gml_build_layout(p, p->node0 + r, L);
-            std::memcpy(cols.data() + (size_t)r * P, L.cols.data(), sizeof(int32_t) * P);
-        });
-        HIPCHK(A.get(&dcols, (size_t)R * P));
-        HIPCHK(hipMemcpyAsync(dcols, cols.data(), sizeof(int32_t) * R * P, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st)); // cols is a local
-    }
+    RCCHK(ref_cols());
+    const int32_t *dcols = dColsRef;
     launch_rows_to_reference(Xt, R, Qp, P, p->node0, d.cconst, dcols, dres, st);
     HIPCHK(hipGetLastError());
     hipPointerAttribute_t attr;
@@ -1493,12 +1487,54 @@ int Solver::finish(double *out, double *kkt_out, int iterations) {
     return GML_OK;
 }
 
+// multi-body key order (:94-104): the column of every parameter slot of every local row, from the host, once per solve
+int Solver::ref_cols() {
+    if (p->order == 2 || dColsRef) return GML_OK;
+    std::vector<int32_t> cols((size_t)R * P);
+    gml_parallel_for(R, [&](int64_t r) {
+        NodeLayout L;
+        gml_build_layout(p, p->node0 + r, L);
+        std::memcpy(cols.data() + (size_t)r * P, L.cols.data(), sizeof(int32_t) * P);
+    });
+    HIPCHK(A.get(&dColsRef, (size_t)R * P));
+    HIPCHK(hipMemcpyAsync(dColsRef, cols.data(), sizeof(int32_t) * R * P, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st)); // cols is a local
+    return GML_OK;
+}
+
+// warm start: X <- the caller's rows (reference layout, host or device pointer)
+int Solver::load_x0() {
+    RCCHK(ref_cols());
+    hipPointerAttribute_t attr;
+    bool on_dev = false;
+    if (hipPointerGetAttributes(&attr, x0) == hipSuccess) on_dev = (attr.type == hipMemoryTypeDevice);
+    else (void)hipGetLastError();
+    const double *src = x0;
+    if (!on_dev) {
+        double *tmp = nullptr;
+        HIPCHK(A.get(&tmp, (size_t)R * P));
+        HIPCHK(hipMemcpyAsync(tmp, x0, sizeof(double) * R * P, hipMemcpyHostToDevice, st));
+        src = tmp;
+    }
+    int *dbad = nullptr;
+    HIPCHK(A.get(&dbad, 4));
+    HIPCHK(hipMemsetAsync(dbad, 0, sizeof(int) * 4, st));
+    launch_ref_to_internal(src, P, R, P, Qp, dNode, d.cconst, dColsRef, X, dbad, st);
+    HIPCHK(hipGetLastError());
+    int bad[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(bad, dbad, sizeof bad, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (bad[0]) return fail(GML_EINVAL, "the starting point contains a non-finite value");
+    return GML_OK;
+}
+
 int Solver::iterate(double *out, double *kkt_out) {
     // first pass at X = 0: every energy is 0, the forward kernel skips its sweeps over the columns (the same bits without the GEMM:
-    // 3.4 -> 1 ms of the headline solve's first pass)
+    // 3.4 -> 1 ms of the headline solve's first pass); a warm start (gml_learn_warm) begins at the caller's rows instead
     std::vector<int> rows_all((size_t)R);
     for (int64_t r = 0; r < R; ++r) rows_all[r] = (int)r;
-    at_zero = true;
+    if (x0) RCCHK(load_x0());
+    at_zero = x0 == nullptr;
     const int rc0 = run_pass(rows_all, X, G, true, false, f, Z, fn, nullptr, 0, prec);
     at_zero = false;
     RCCHK(rc0);
@@ -1572,6 +1608,11 @@ int Solver::iterate(double *out, double *kkt_out) {
 
 extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, const gml_opts *opts_in, double *out,
                          double *kkt_out, gml_stats *stats_out) {
+    return gml_learn_warm(p, formulation, regularizer_c, opts_in, nullptr, out, kkt_out, stats_out);
+}
+
+extern "C" int gml_learn_warm(gml_problem *p, int formulation, double regularizer_c, const gml_opts *opts_in, const double *x0, double *out,
+                              double *kkt_out, gml_stats *stats_out) {
     if (!p || !out) return fail(GML_EINVAL, "NULL argument");
     if (formulation < 0 || formulation > 2) return fail(GML_EINVAL, "unknown formulation %d", formulation);
     if (formulation != GML_RISE && p->order != 2)
@@ -1594,6 +1635,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
     bool underflow = false;
     {
         Solver s(p, formulation, o, gml_lambda(regularizer_c, p->n, p->M));
+        s.x0 = x0;
         rc = s.init();
         if (rc == GML_OK) rc = s.iterate(out, kkt_out);
         s.stats.t_total = gml_now_s() - t_start;
@@ -1612,6 +1654,7 @@ extern "C" int gml_learn(gml_problem *p, int formulation, double regularizer_c, 
         gml_opts o64 = o;
         o64.precision = GML_PREC_F64;
         Solver s(p, formulation, o64, gml_lambda(regularizer_c, p->n, p->M));
+        s.x0 = x0;
         rc = s.init();
         if (rc == GML_OK) rc = s.iterate(out, kkt_out);
         if (rc != GML_OK && rc != GML_ENOTCONV)

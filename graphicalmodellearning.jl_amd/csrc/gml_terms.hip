@@ -77,9 +77,9 @@ __host__ __device__ inline int64_t row_slot(const TermPlan &pl, const int32_t *c
     return pl.roff[s] + rank_lex(o, s - 1, pl.n - 1);
 }
 
-__global__ __launch_bounds__(256) void k_terms_sym(TermPlan pl, const double *__restrict__ rows, int64_t ld, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_terms_sym(TermPlan pl, const double *__restrict__ rows, int64_t ld, double *__restrict__ out, int64_t tmax) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= pl.off[pl.order + 1]) return;
+    if (t >= tmax) return;
     int s = 1;
     while (t >= pl.off[s + 1]) ++s;
     int32_t c[MAXORD];
@@ -87,6 +87,44 @@ __global__ __launch_bounds__(256) void k_terms_sym(TermPlan pl, const double *__
     double sum = 0.0;
     for (int a = 0; a < s; ++a) sum += rows[(int64_t)c[a] * ld + row_slot(pl, c, s, a)]; // ascending u
     out[t] = sum / (double)s; // `mean` (:147)
+}
+
+// The triples of an order-3 model (99 % of its terms; C5: 22.2 M of 22.4 M) without unranking and with every access coalesced.
+// A workgroup owns one smallest spin a and a 32 x 32 tile of (b, c), a < b < c.  Term (a, b, c) is the mean of
+//   row a, slot of (b, c)   consecutive in c   -- read along the tile's c
+//   row b, slot of (a, c)   consecutive in c   -- read along the tile's c
+//   row c, slot of (a, b)   consecutive in b, one ROW per c: a column walk of the rows matrix -- read along b (32 consecutive slots
+//                           of one row per wave half), transposed through LDS
+// and lands at off[3] + rank(a, b, c), consecutive in c.  HBM-bound: 3 x 8 B read + 8 B written per term (C5: 536 MB + 179 MB).
+constexpr int TT = 32;
+__device__ inline int64_t c2(int64_t x) { return x * (x - 1) / 2; }
+__device__ inline int64_t c3(int64_t x) { return x * (x - 1) * (x - 2) / 6; }
+__global__ __launch_bounds__(256) void k_terms_sym3(int64_t n, int64_t roff3, int64_t off3, const double *__restrict__ rows, int64_t ld,
+                                                    double *__restrict__ out) {
+    const int64_t a = blockIdx.z, b0 = (int64_t)blockIdx.y * TT, c0 = (int64_t)blockIdx.x * TT;
+    if (c0 + TT - 1 <= b0 || b0 + TT - 1 <= a) return; // no (b, c) of the tile has a < b < c
+    __shared__ double tile[TT][TT + 1];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t m = n - 1;
+    // pairs (x < y) of the m other spins of a row: slot roff3 + C(m,2) - C(m-x,2) + (y - x - 1)
+#pragma unroll
+    for (int i = 0; i < TT / 8; ++i) { // row c's entry for (a, b): a and b lie below c, so they keep their numbers among c's others
+        const int64_t c = c0 + ty + 8 * i, b = b0 + tx;
+        double v = 0.0;
+        if (c < n && b > a && b < c) v = rows[c * ld + roff3 + c2(m) - c2(m - a) + (b - a - 1)];
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TT / 8; ++i) {
+        const int64_t b = b0 + ty + 8 * i, c = c0 + tx;
+        if (b <= a || c <= b || c >= n) continue;
+        const double va = rows[a * ld + roff3 + c2(m) - c2(m - (b - 1)) + (c - b - 1)]; // (b, c) above a: renumbered b - 1, c - 1
+        const double vb = rows[b * ld + roff3 + c2(m) - c2(m - a) + (c - 1 - a - 1)];   // a below b, c above: a, c - 1
+        const double vc = tile[tx][ty + 8 * i];
+        const int64_t t = off3 + c3(n) - c3(n - a) + c2(n - a - 1) - c2(n - b) + (c - b - 1);
+        out[t] = ((va + vb) + vc) / 3.0; // ascending u, then `mean` (:147): the same operations as k_terms_sym
+    }
 }
 
 __global__ __launch_bounds__(256) void k_terms_unsym(TermPlan pl, const double *__restrict__ rows, int64_t ld, double *__restrict__ out) {
@@ -151,8 +189,17 @@ int gml_terms_assemble_dev(const double *drows, int64_t ld, int64_t n, int order
     if (rc != GML_OK) return rc;
     const int64_t T = symmetrize ? pl.off[order + 1] : pl.uoff[order + 1];
     const unsigned nb = (unsigned)((T + 255) / 256);
-    if (symmetrize) hipLaunchKernelGGL(k_terms_sym, dim3(nb), dim3(256), 0, st, pl, drows, ld, dout);
-    else hipLaunchKernelGGL(k_terms_unsym, dim3(nb), dim3(256), 0, st, pl, drows, ld, dout);
+    if (symmetrize && order == 3 && n >= 3 && n <= 65535) {
+        // fields and pairs by the generic kernel, the triples by the tiled one
+        const int64_t t2 = pl.off[3];
+        hipLaunchKernelGGL(k_terms_sym, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, st, pl, drows, ld, dout, t2);
+        const unsigned nt = (unsigned)((n + TT - 1) / TT);
+        hipLaunchKernelGGL(k_terms_sym3, dim3(nt, nt, (unsigned)n), dim3(256), 0, st, n, pl.roff[3], pl.off[3], drows, ld, dout);
+    } else if (symmetrize) {
+        hipLaunchKernelGGL(k_terms_sym, dim3(nb), dim3(256), 0, st, pl, drows, ld, dout, T);
+    } else {
+        hipLaunchKernelGGL(k_terms_unsym, dim3(nb), dim3(256), 0, st, pl, drows, ld, dout);
+    }
     HIPCHK(hipGetLastError());
     return GML_OK;
 }

@@ -4,6 +4,8 @@
 All arithmetic over the sample configurations runs in libgml_hip (HIP kernels on MI355X); this
 module only marshals arguments, gathers row blocks across ranks and applies the reference's
 result assembly (:181-188, :129-151)."""
+import warnings
+
 import numpy as np
 
 from . import _lib
@@ -140,6 +142,11 @@ def learn(samples, formulation=None, method=None):
     if not isinstance(method, GMLMethod):
         raise TypeError(f"no method matching learn(..., ::{type(method).__name__})")
     if isinstance(method, NLP):
+        if method.solver is not None:
+            # the reference would hand the per-node problems to this optimizer (:111, :164); there is no JuMP here to drive it
+            warnings.warn(f"NLP(solver={method.solver!r}): the configured optimizer is not used -- every node-wise problem is solved by the "
+                          "device solver of libgml_hip with its default options (pass HIP(...) to set them; to keep an external solver, "
+                          "register gml_objgrad_batch as its operator: INTEGRATION.md)", stacklevel=2)
         method = HIP()
     order = int(formulation.interaction_order) if isinstance(formulation, multiRISE) else 2
     world, rank = 1, 0

@@ -301,6 +301,14 @@ int gml_objgrad_batch(gml_problem *p, int formulation, int precision, int64_t nr
  */
 int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows, const int64_t *nodes, const double *theta,
                       const double *vec, int64_t ld, double *hv);
+/* The same with the arithmetic named: GML_PREC_I8X (what gml_hessvec_batch runs; GML_PREC_AUTO means this), or GML_PREC_F64 --
+ * both passes on the FP64 matrix cores (an objective pass at theta, then U_k = h_k (x_k . vec) formed in place of its weights and
+ * contracted by the same backward GEMM): the curvature operator at the accuracy of the reference's Float64 arithmetic (1e-12
+ * against a dense numpy Hessian, tests/test_gpu_operator_export.py), for external second-order solvers that want their Hessian
+ * as good as their gradient; ~10x the time of the int8 form.  GML_PREC_I8W: GML_EUNSUPPORTED (the Hessian-vector forms read
+ * 31-bit curvature weights whatever the objective pass wrote). */
+int gml_hessvec_batch_prec(gml_problem *p, int formulation, int precision, int64_t nrows, const int64_t *nodes, const double *theta,
+                           const double *vec, int64_t ld, double *hv);
 
 /*
  * gml_learn -- replaces learn(samples, formulation, method) for the handle's node range
@@ -319,6 +327,16 @@ int gml_hessvec_batch(gml_problem *p, int formulation, int64_t nrows, const int6
  */
 int gml_learn(gml_problem *p, int formulation, double regularizer_c, const gml_opts *opts,
               double *out, double *kkt, gml_stats *stats);
+
+/*
+ * gml_learn_warm -- gml_learn from a starting point instead of x = 0: x0 = (node1-node0) x P rows in the layout of `out` (host or
+ * device pointer; NULL = zeros = gml_learn).  The optimum does not depend on it (the problems are convex); the number of iterations
+ * does.  For regularisation paths -- the same samples solved at a sequence of c, each from the previous solution (the reference
+ * re-solves from scratch: JuMP start values are never set, :166-167) -- and for re-solves after more samples arrived.
+ * out may be x0 itself.
+ */
+int gml_learn_warm(gml_problem *p, int formulation, double regularizer_c, const gml_opts *opts, const double *x0, double *out,
+                   double *kkt, gml_stats *stats);
 
 /*
  * Result assembly of multiRISE on the device -- replaces the tail of learn(samples, ::multiRISE, ...): the per-node

@@ -126,3 +126,47 @@ def test_newton_resolve_with_fixed_entries_matches_numpy(logrise):
     for r, m in enumerate(sizes):
         scale = np.abs(want[r]).max()
         assert np.abs(out[r, :m] - want[r]).max() <= 1e-9 * scale, (m, np.abs(out[r, :m] - want[r]).max() / scale)
+
+
+# ---- gml_learn_warm: the same optimum from any starting point, in fewer iterations from a near one ----------------------------------
+@pytest.mark.parametrize("form,c", [("RISE", 0.4), ("logRISE", 0.8), ("RPLE", 0.2)])
+@pytest.mark.parametrize("prec", ["i8x", "i8w", "f64"])
+def test_warm_start_reaches_the_cold_optimum(form, c, prec):
+    import gml_amd as gml
+    synthetic = __import__("importlib").import_module("gml_amd.synthetic")
+    n, K = 96, 40000
+    J = synthetic.block_ising_model(n, block=16, seed=4)
+    with gml.Problem(model=J, num_samples=K, seed=1) as p:
+        cold, kc, sc = p.learn(form, c, tol=1e-10, precision=prec)
+        # from the optimum itself: the certifying pass, at most a polishing step
+        again, ka, sa = p.learn(form, c, tol=1e-10, precision=prec, x0=cold)
+        assert sa["iterations"] <= 2 and ka.max() <= 1e-10 and np.abs(again - cold).max() <= 2e-9
+        # a regularisation path: 2c -> c from the previous solution
+        far, _, sf = p.learn(form, 2 * c, tol=1e-10, precision=prec)
+        warm, kw, sw = p.learn(form, c, tol=1e-10, precision=prec, x0=far)
+        assert kw.max() <= 1e-10 and np.abs(warm - cold).max() <= 2e-9 and sw["iterations"] <= sc["iterations"]
+        assert ((warm != 0) == (cold != 0)).all()
+        # from a dense random point (every coordinate starts off its optimum, most of them off zero)
+        rnd = np.random.default_rng(0).normal(scale=0.05, size=cold.shape)
+        w2, k2, s2 = p.learn(form, c, tol=1e-10, precision=prec, x0=rnd)
+        assert k2.max() <= 1e-10 and np.abs(w2 - cold).max() <= 2e-9
+        bad = cold.copy()
+        bad[3, 7] = np.nan
+        with pytest.raises(gml.GMLError, match="non-finite"):
+            p.learn(form, c, tol=1e-10, precision=prec, x0=bad)
+        with pytest.raises(gml.GMLError, match="shape"):
+            p.learn(form, c, tol=1e-10, precision=prec, x0=cold[:5])
+
+
+def test_warm_start_multibody_and_node_shard():
+    import gml_amd as gml
+    synthetic = __import__("importlib").import_module("gml_amd.synthetic")
+    n, K = 24, 30000
+    terms = synthetic.block_multibody_terms(n, block=12, seed=7)
+    with gml.Problem(terms=terms, n=n, num_samples=K, seed=2, order=3, node_range=(5, 17)) as p:
+        cold, kc, sc = p.learn("RISE", 0.5, tol=1e-10)
+        far, _, _ = p.learn("RISE", 1.0, tol=1e-6)
+        warm, kw, sw = p.learn("RISE", 0.5, tol=1e-10, x0=far)
+        assert cold.shape == (12, p.P) and kw.max() <= 1e-10 and np.abs(warm - cold).max() <= 2e-9
+        again, ka, sa = p.learn("RISE", 0.5, tol=1e-10, x0=cold)
+        assert sa["iterations"] <= 2 and np.abs(again - cold).max() <= 2e-9

@@ -173,3 +173,54 @@ def test_device_pointer_operator_headline_pass_time():
           f"{res['device_ms_per_pass']:.2f} ms")
     assert np.array_equal(d_g.cpu().numpy(), g_h) and np.array_equal(d_f.cpu().numpy(), f_h)
     assert t_dev <= 1.03 * res["device_ms_per_pass"] + 0.2 and t_dev <= 10.8
+
+
+def _dense_hessian(form, counts, spins, u, theta):
+    """Hess f_u(theta) from the statistics matrix in numpy Float64 (GraphicalModelLearning.jl:162 statistics; :169-172, :278-281, :316-319)"""
+    s = spins.astype(np.float64)
+    stat = s * s[:, [u]]
+    stat[:, u] = s[:, u]
+    w = counts / counts.sum()
+    E = stat @ theta
+    if form == "RPLE":
+        sg = 1.0 / (1.0 + np.exp(2.0 * E))
+        return (stat * (4.0 * w * sg * (1.0 - sg))[:, None]).T @ stat
+    e = w * np.exp(-E)
+    H = (stat * e[:, None]).T @ stat
+    if form == "logRISE":
+        Z = e.sum()
+        g = -(stat * e[:, None]).sum(0) / Z
+        H = H / Z - np.outer(g, g)
+    return H
+
+
+@pytest.mark.parametrize("form", ["RISE", "logRISE", "RPLE"])
+def test_hessvec_precisions_against_a_dense_numpy_hessian(form):
+    # the curvature operator with its arithmetic named (gml_hessvec_batch_prec): "f64" = both passes on the FP64 matrix cores, held
+    # to the 1e-12 of the FP64 objective / gradient; "i8x" = the int8-limb form gml_learn's Newton-CG uses (31-bit weights)
+    import torch
+    n, K = 40, 6000
+    J = synthetic.block_ising_model(n, block=8, seed=6)
+    rng = np.random.default_rng(2)
+    spins, _ = synthetic.block_ising(n, K, block=8, seed=6)
+    counts = 1.0 + (np.arange(K) % 4)
+    nodes = np.array([0, 7, 13, 39, 22], dtype=np.int64)
+    theta = J[nodes] + rng.normal(scale=0.1, size=(len(nodes), n))
+    vec = rng.normal(size=(len(nodes), n))
+    want = np.stack([_dense_hessian(form, counts, spins, int(u), theta[a]) @ vec[a] for a, u in enumerate(nodes)])
+    scale = np.abs(want).max()
+    with gml.Problem(counts=counts, spins=spins) as p:
+        hv64 = p.hessvec(form, nodes, theta, vec, precision="f64")
+        hv8 = p.hessvec(form, nodes, theta, vec, precision="i8x")
+        assert np.abs(hv64 - want).max() <= 1e-12 * scale
+        assert np.abs(hv8 - want).max() <= 2e-7 * scale
+        assert np.array_equal(p.hessvec(form, nodes, theta, vec), hv8) and np.array_equal(p.hessvec(form, nodes, theta, vec, precision="auto"), hv8)
+        d_hv = torch.zeros((len(nodes), n), dtype=torch.float64, device="cuda")
+        p.hessvec_device(form, nodes, _dev(theta).data_ptr(), _dev(vec).data_ptr(), n, d_hv.data_ptr(), precision="f64")
+        assert np.abs(d_hv.cpu().numpy() - want).max() <= 1e-12 * scale
+        with pytest.raises(gml.GMLError, match="i8x .* or f64"):
+            p.hessvec(form, nodes, theta, vec, precision="i8w")
+        # the operator is linear in vec and symmetric: u . H v == v . H u
+        v2 = rng.normal(size=vec.shape)
+        h2 = p.hessvec(form, nodes, theta, v2, precision="f64")
+        assert np.abs((v2 * hv64).sum(1) - (vec * h2).sum(1)).max() <= 1e-11 * scale * n

@@ -1118,7 +1118,10 @@ def test_auto_never_refuses_c0_near_separable(form):
     with gml.Problem(hist) as p:
         ref, kref, sref = p.learn(form, 0.0, tol=1e-9, precision="f64", raise_on_fail=False, max_iter=200)
         out, kkt, st = p.learn(form, 0.0, tol=1e-9, precision="auto", raise_on_fail=False, max_iter=200)
-        conv = (kref <= 1e-9) & (kkt <= 1e-9)
+        # (rows with a separable direction "converge" wherever the gradient has decayed below tol, far out and not at a unique point:
+        #  the comparison is for the rows whose optimum is finite)
+        conv = (kref <= 1e-9) & (kkt <= 1e-9) & (np.abs(ref).max(1) < 8) & (np.abs(out).max(1) < 8)
+        assert conv.sum() >= 1
         if conv.any():
             assert np.abs(out[conv] - ref[conv]).max() <= 1e-6 * max(1.0, np.abs(ref[conv]).max())
         for prec in ("i8w", "i8x"):

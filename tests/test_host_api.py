@@ -104,6 +104,9 @@ def test_learn_default_arguments_are_rise():
     s = load_csv("a_samples.csv")
     R1 = oracle_learn(s)
     R2 = oracle_learn(s, gml.RISE(), gml.NLP())
+    with pytest.warns(UserWarning, match="configured optimizer is not used"):  # a configured Ipopt is not silently replaced
+        R3 = oracle_learn(s, gml.RISE(), gml.NLP(solver="Ipopt.Optimizer"))
+    assert np.array_equal(R2, R3)
     assert np.array_equal(R1, R2)
 
 
