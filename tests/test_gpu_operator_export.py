@@ -106,7 +106,8 @@ def test_device_pointer_operator_equals_host_pointer_operator(form, prec):
         vec[:, :n] = rng.normal(size=(len(nodes), n))
         hv_h = p.hessvec(form, nodes, theta, vec)
         d_hv = torch.full((len(nodes), ld), np.nan, dtype=torch.float64, device="cuda")
-        p.hessvec_device(form, nodes, d_th.data_ptr(), _dev(vec).data_ptr(), ld, d_hv.data_ptr())
+        d_vec = _dev(vec)
+        p.hessvec_device(form, nodes, d_th.data_ptr(), d_vec.data_ptr(), ld, d_hv.data_ptr())
         hv_d = d_hv.cpu().numpy()
         if form == "logRISE":  # (the rank-one correction is a device reduction there, a host loop here)
             assert np.abs(hv_d[:, :n] - hv_h[:, :n]).max() <= 1e-12 * max(1.0, np.abs(hv_h).max())
@@ -119,7 +120,8 @@ def test_device_pointer_operator_equals_host_pointer_operator(form, prec):
         bad = theta.copy()
         bad[3, 5] = np.inf
         with pytest.raises(gml.GMLError, match="non-finite"):
-            p.objgrad_device(form, nodes, _dev(bad).data_ptr(), ld, d_f.data_ptr(), d_g.data_ptr(), precision=prec)
+            d_bad = _dev(bad)
+            p.objgrad_device(form, nodes, d_bad.data_ptr(), ld, d_f.data_ptr(), d_g.data_ptr(), precision=prec)
 
 
 def test_device_pointer_operator_multibody_and_dynamic_range():
@@ -135,13 +137,15 @@ def test_device_pointer_operator_multibody_and_dynamic_range():
             for prec in ("i8w", "i8x"):
                 f_h, g_h = p.objgrad("RISE", nodes, theta, precision=prec)
                 d_f, d_g = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros((n, p.P), dtype=torch.float64, device="cuda")
-                p.objgrad_device("RISE", nodes, _dev(theta).data_ptr(), p.P, d_f.data_ptr(), d_g.data_ptr(), precision=prec)
+                d_th = _dev(theta)
+                p.objgrad_device("RISE", nodes, d_th.data_ptr(), p.P, d_f.data_ptr(), d_g.data_ptr(), precision=prec)
                 assert np.array_equal(d_f.cpu().numpy(), f_h) and np.array_equal(d_g.cpu().numpy(), g_h)
         sub = np.array([5, 2, 17], dtype=np.int64)  # another node list: the cached table is replaced
         th = rng.normal(scale=0.05, size=(3, p.P))
         f_h, g_h = p.objgrad("RISE", sub, th, precision="i8w")
         d_f, d_g = torch.zeros(3, dtype=torch.float64, device="cuda"), torch.zeros((3, p.P), dtype=torch.float64, device="cuda")
-        p.objgrad_device("RISE", sub, _dev(th).data_ptr(), p.P, d_f.data_ptr(), d_g.data_ptr(), precision="i8w")
+        d_th = _dev(th)
+        p.objgrad_device("RISE", sub, d_th.data_ptr(), p.P, d_f.data_ptr(), d_g.data_ptr(), precision="i8w")
         assert np.array_equal(d_f.cpu().numpy(), f_h) and np.array_equal(d_g.cpu().numpy(), g_h)
 
 
@@ -216,7 +220,8 @@ def test_hessvec_precisions_against_a_dense_numpy_hessian(form):
         assert np.abs(hv8 - want).max() <= 2e-7 * scale
         assert np.array_equal(p.hessvec(form, nodes, theta, vec), hv8) and np.array_equal(p.hessvec(form, nodes, theta, vec, precision="auto"), hv8)
         d_hv = torch.zeros((len(nodes), n), dtype=torch.float64, device="cuda")
-        p.hessvec_device(form, nodes, _dev(theta).data_ptr(), _dev(vec).data_ptr(), n, d_hv.data_ptr(), precision="f64")
+        d_th, d_vec = _dev(theta), _dev(vec)  # (held: a temporary's block returns to torch's allocator before the call runs)
+        p.hessvec_device(form, nodes, d_th.data_ptr(), d_vec.data_ptr(), n, d_hv.data_ptr(), precision="f64")
         assert np.abs(d_hv.cpu().numpy() - want).max() <= 1e-12 * scale
         with pytest.raises(gml.GMLError, match="i8x .* or f64"):
             p.hessvec(form, nodes, theta, vec, precision="i8w")
