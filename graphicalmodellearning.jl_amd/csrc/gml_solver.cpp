@@ -1664,6 +1664,49 @@ extern "C" int gml_learn_warm(gml_problem *p, int formulation, double regularize
         s.stats.t_host = std::max(0.0, s.stats.t_total - s.stats.t_pass - s.stats.t_hess);
         s.stats.polished = 1; // (finished on the FP64 path)
         if (stats_out) *stats_out = s.stats;
+    } else if (rc == GML_ENOTCONV && asked_auto && gml_is_i8(o.precision) && (double)p->K * (double)p->P * (double)p->n <= 268435456.0) {
+        // The other way an int8-limb solve can differ from the Float64 solve `auto` stands for: no row leaves the fixed-point range,
+        // but the iterates wander along a nearly flat direction on the noise of the limbs and never certify (RPLE at c = 0 on
+        // near-separable data: profiles/r6_robust_sweep.txt; the FP64 path converges there in 22 iterations).  On SMALL problems --
+        // every kernel launch-bound, the FP64 solve a few milliseconds -- `auto` therefore tries the FP64 path before it reports
+        // "not converged", and keeps whichever solve ended with fewer unconverged rows (then the smaller residual).  Host `out` only.
+        hipPointerAttribute_t attr;
+        bool dev_out = false;
+        if (hipPointerGetAttributes(&attr, out) == hipSuccess) dev_out = (attr.type == hipMemoryTypeDevice);
+        else (void)hipGetLastError();
+        if (!dev_out) {
+            const std::string first = gml_last_error();
+            const size_t R = (size_t)(p->node1 - p->node0);
+            std::vector<double> out1(out, out + R * (size_t)p->P), kkt1;
+            if (kkt_out) kkt1.assign(kkt_out, kkt_out + R);
+            gml_stats st1{};
+            if (stats_out) st1 = *stats_out;
+            gml_opts o64 = o;
+            o64.precision = GML_PREC_F64;
+            Solver s(p, formulation, o64, gml_lambda(regularizer_c, p->n, p->M));
+            s.x0 = x0;
+            int rc2 = s.init();
+            if (rc2 == GML_OK) rc2 = s.iterate(out, kkt_out);
+            const bool usable = rc2 == GML_OK || rc2 == GML_ENOTCONV;
+            const bool better = usable && (!stats_out || s.stats.not_converged < st1.not_converged ||
+                                           (s.stats.not_converged == st1.not_converged && s.stats.max_kkt < st1.max_kkt));
+            if (better) {
+                rc = rc2;
+                s.stats.t_total = gml_now_s() - t_start;
+                s.stats.t_pack = p->t_ingest[3];
+                s.stats.t_host = std::max(0.0, s.stats.t_total - s.stats.t_pass - s.stats.t_hess);
+                s.stats.polished = 1;
+                if (stats_out) *stats_out = s.stats;
+            } else { // the first solve stands
+                std::copy(out1.begin(), out1.end(), out);
+                if (kkt_out) std::copy(kkt1.begin(), kkt1.end(), kkt_out);
+                if (stats_out) {
+                    *stats_out = st1;
+                    stats_out->t_total = gml_now_s() - t_start;
+                }
+                (void)fail(GML_ENOTCONV, "%s", first.c_str());
+            }
+        }
     }
     return rc;
 }
