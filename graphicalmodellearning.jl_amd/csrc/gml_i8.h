@@ -77,6 +77,13 @@ struct I8Ws {
     // The consumers of V as a 31-bit number (Hessian weights, Hessian-vector forms) read 4 planes of the image from plane vpl0()
     // on: all of an i8x image, the top four of an i8w image (balanced digits: the top planes are V / (65536 tau) rounded to
     // nearest), whose unit is vscale() * tau.
+    // Column compaction of the forward GEMM (objective passes; gml_i8_pack.hip: k_col_union): per slot tile, the list of the
+    // statistics columns on which a row of the tile is non-zero, and the forward bit image of those columns alone
+    int *cnk = nullptr;    // [slots / 32] 64-column steps of the tile's compact image; -1: the tile runs on all columns
+    int *cmap = nullptr;   // [slots / 32][csteps * 64] the columns, ascending, -1 padded
+    int8_t *Xc = nullptr;  // [slots / 32][xc_tile bytes] compact forward images, Xb piece layout with the tile's own step count
+    int csteps = 0;        // capacity in steps per tile
+    int64_t xc_tile = 0;   // = Kp * csteps * 8
     int vpl0() const { return LBT - 4; }
     double vscale() const { return LBT == 6 ? 65536.0 : 1.0; }
 };
@@ -127,10 +134,20 @@ __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ t
         }                                                                                             \
     } while (0)
 
+// what a compacted forward pass hands its kernels (NULL: every tile runs on all columns)
+struct ColCompact {
+    const int *cnk, *cmap;
+    int cstride; // entries of cmap per tile
+    const int8_t *Xc;
+    int64_t xc_tile;
+};
+
 // ---- launchers across the kernel files ----------------------------------------------------------------------------------
 // gml_i8_pack.hip
 void launch_quant_theta(int LF, int ns, const I8Pass &a, const DevProblem &d, int hv, const double *tauV, int8_t *Tq, const SlotScalars &sc,
-                        double vdiv, double vsrc_scale, hipStream_t st);
+                        double vdiv, double vsrc_scale, hipStream_t st, const ColCompact *cc = nullptr);
+// the non-zero columns of every listed tile's rows -> cnk / cmap, then the compact forward images of the tiles that got one
+void launch_col_compact(const I8Pass &a, const DevProblem &d, I8Ws *w, hipStream_t st);
 // gml_i8_fwd.hip
 struct FwdLaunch {
     int chunk_tiles, part_tiles, ntk; // sample tiles: per backward chunk, of them taking part, compact count
@@ -144,6 +161,7 @@ struct FwdLaunch {
     hipStream_t st;
     bool coarse = false; // exp forms, LF = 4: V to multiples of 2^8 tau (planes 1..3)
     bool zero_theta = false; // every row of Theta is zero (the first pass of a solve): all energies are 0, the column sweep is skipped
+    const ColCompact *cc = nullptr; // objective passes: tiles with a compact column list sweep those columns only
 };
 void launch_fwd_i8(const FwdLaunch &a, int LF, int form, bool wantf, int hv);
 // gml_i8_bwd.hip
@@ -167,6 +185,7 @@ struct FwdWArgs {
     int8_t *Vq;
     hipStream_t st;
     bool zero_theta = false; // every row of Theta is zero: no column sweeps (the energies are 0)
+    const ColCompact *cc = nullptr; // tiles with a compact column list sweep those columns only
 };
 void launch_fwd_i8w(const FwdWArgs &a);
 void launch_finalize_i8w(const int32_t *Gacc, const SlotScalars &sc, const int *srow, const int *rowcol, int slot0, int ns, int64_t Qp,

@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const unsigned *__restrict__ Xb, const unsigned *__restrict__ Sb, const int8_t *__restrict__ Tq,
     const int *__restrict__ rowcol, const int *__restrict__ groups, int ngroups, const double *__restrict__ w,
     const double *__restrict__ sigma, const long long *__restrict__ qconst, const double *__restrict__ invtau,
-    int64_t Kp, int ntiles_k, int nk /* 64-column steps */, double wuni /* > 0: every real sample has this weight */,
+    int64_t Kp, int ntiles_k, int nk_all /* 64-column steps of a sweep over all columns (0: every row of Theta is zero) */,
+    double wuni /* > 0: every real sample has this weight */,
     int64_t Kreal, int8_t *__restrict__ Vq, long long *__restrict__ csum, long long *__restrict__ asum,
     double *__restrict__ fsum, unsigned *__restrict__ mmax,
     // Hessian-vector forms only: the limb planes of V written by the rows' last objective pass, the slot that holds
@@ -74,7 +75,10 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     // sub-sampled passes (Hessian-vector products over a part of the configurations): compact sample tile t stands for the
     // tile (t / part_tiles) * chunk_tiles + t % part_tiles -- the first part_tiles tiles of every split-K chunk of the
     // backward kernel.  chunk_tiles == part_tiles: every configuration.
-    int chunk_tiles, int part_tiles) {
+    int chunk_tiles, int part_tiles,
+    // column compaction of objective passes (gml_i8_pack.hip: k_col_union): steps of each tile's compact image (-1: all columns), the
+    // images, bytes per tile, and the steps between two tiles' Tq images (= Qfp / 64 whatever is swept)
+    const int *__restrict__ cnk, const int8_t *__restrict__ Xc, int64_t xc_tile, int nk_tq) {
     constexpr int WM = 2;                 // 32-sample MFMA tiles per wave
     constexpr bool HV = FORM >= 3;
     constexpr int BR = 32 * LF;           // rows of the Tq image
@@ -126,6 +130,16 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
     const int64_t k0 = (int64_t)st * 256;
     if (k0 >= Kp) return;
     const int mytile = groups[gi];
+    // the columns this tile sweeps: all of them, or its compact list (the image then has the tile's own step count in its strides)
+    int nk = nk_all;
+    const int8_t *xbase = reinterpret_cast<const int8_t *>(Xb);
+    if (cnk) {
+        const int ck = cnk[mytile];
+        if (ck >= 0) {
+            nk = ck;
+            xbase = Xc + (int64_t)mytile * xc_tile;
+        }
+    }
 
     // per-lane source of each 1-KB piece this wave loads, and its advance per 64-column step
     const int8_t *src[NP];
@@ -135,12 +149,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8(
         int pc = wave + 4 * j;
         if (pc >= NPIECE) pc = NPIECE - 1; // duplicate piece: keeps the per-wave vmcnt count uniform
         if (pc < 2) {
-            src[j] = reinterpret_cast<const int8_t *>(Xb) + ((int64_t)(2 * st + pc) * nk) * 1024 + lane * 16;
+            src[j] = xbase + ((int64_t)(2 * st + pc) * nk) * 1024 + lane * 16;
             adv[j] = 1024;
         } else {
             const int row = (pc - 2) * 16 + (lane >> 2);
             const int slot = (lane & 3) ^ ((row >> 2) & 3); // XOR swizzle applied to the source (LDS side is linear)
-            src[j] = Tq + ((int64_t)mytile * nk * BR + row) * 64 + slot * 16;
+            src[j] = Tq + ((int64_t)mytile * nk_tq * BR + row) * 64 + slot * 16;
             adv[j] = BR * 64;
         }
     }
@@ -585,7 +599,7 @@ static void launch_fwd5(const FwdLaunch &a) {
     hipLaunchKernelGGL((k_fwd_i8<LF, FORM, WANTF, WIDE, COARSE, UNIW>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.w->Tq, a.rowcol, a.groups,
                        a.ngroups, d.w, a.sc->sigma, a.sc->qconst, a.sc->invtau, d.Kp, ntk, a.zero_theta ? 0 : (int)(d.Qfp / 64), d.wuni, d.K, a.Vout,
                        a.sc->csum, a.sc->asum, a.F, a.sc->mmax, a.w->Vq, a.vmap, a.w->sc[0].tau, a.w->LBT, a.w->vpl0(), a.w->vscale(),
-                       a.chunk_tiles, a.part_tiles);
+                       a.chunk_tiles, a.part_tiles, a.cc ? a.cc->cnk : nullptr, a.cc ? a.cc->Xc : nullptr, a.cc ? a.cc->xc_tile : 0, (int)(d.Qfp / 64));
 }
 
 template <int LF, int FORM, bool WANTF, bool WIDE, bool UNIW>

@@ -140,6 +140,98 @@ void launch_expand_xt(const DevProblem &d, int8_t *Xt, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Column compaction of the forward GEMM.  The iterates of an l1-regularised solve are sparse -- a node's row holds a few dozen
+// non-zeros among thousands of columns -- and a column on which all 32 rows of a node tile are zero contributes exactly nothing to
+// the tile's integer sums.  k_col_union lists, per listed tile, the columns with a non-zero in one of the tile's active rows
+// (ascending; one workgroup per tile: flags by column, ordered append through wave ballots); k_build_xc builds the forward bit
+// image of those columns alone (k_build_xb through the list).  The quantisation kernel then writes the digits of those columns
+// into the first cnk[tile] steps of the tile's Tq image and the forward kernel sweeps cnk[tile] steps instead of Qfp / 64.
+// Tiles whose list exceeds the capacity (half of the columns, at most 32 steps) keep the sweep over all columns: cnk = -1.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_col_union(const double *__restrict__ Theta, const int *__restrict__ srow, const int *__restrict__ rowcol,
+                                                   const int *__restrict__ groups, int64_t Qp, int64_t Qfp, int csteps, int *__restrict__ cnk,
+                                                   int *__restrict__ cmap) {
+    const int tile = groups[blockIdx.x];
+    if (tile < 0) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    __shared__ const double *rows[32];
+    __shared__ int wcnt[4];
+    __shared__ int base;
+    if (tid < 32) {
+        const int slot = tile * 32 + tid;
+        rows[tid] = rowcol[slot] >= 0 ? Theta + (int64_t)srow[slot] * Qp : nullptr;
+    }
+    if (tid == 0) base = 0;
+    __syncthreads();
+    const int cap = csteps * 64;
+    int *cm = cmap + (int64_t)tile * cap;
+    for (int64_t c0 = 0; c0 < Qfp; c0 += 256) {
+        const int64_t c = c0 + tid;
+        bool nz = false;
+        if (c < Qfp) {
+#pragma unroll 8
+            for (int rl = 0; rl < 32; ++rl) {
+                const double *th = rows[rl];
+                if (th) nz |= th[c] != 0.0;
+            }
+        }
+        const unsigned long long m = __ballot(nz);
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int v = 0; v < wave; ++v) off += wcnt[v];
+        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (nz && pos < cap) cm[pos] = (int)c;
+        __syncthreads();
+        if (tid == 0) base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    const int cnt = base;
+    if (cnt > cap) {
+        if (tid == 0) cnk[tile] = -1;
+        return;
+    }
+    const int nkt = (cnt + 63) >> 6;
+    for (int j = cnt + tid; j < nkt * 64; j += 256) cm[j] = -1;
+    if (tid == 0) cnk[tile] = nkt;
+}
+
+// forward bit image of one tile's compact columns: k_build_xb with the column taken from the list (-1: a zero column)
+__global__ __launch_bounds__(256) void k_build_xc(const unsigned *__restrict__ Sb, int64_t wpr, const int32_t *__restrict__ keys, int ko,
+                                                  int64_t Qf, const int *__restrict__ groups, const int *__restrict__ cnk,
+                                                  const int *__restrict__ cmap, int csteps, int64_t xc_tile, unsigned *__restrict__ Xc) {
+    const int tile = groups[blockIdx.z];
+    if (tile < 0) return;
+    const int nk = cnk[tile], kt = blockIdx.y;
+    if (kt >= nk) return; // (also the tiles that run on all columns: nk = -1)
+    const int64_t w = (int64_t)blockIdx.x * 128 + (threadIdx.x >> 1);
+    const int h = threadIdx.x & 1;
+    if (w >= wpr) return;
+    const int *cm = cmap + (int64_t)tile * csteps * 64 + 64 * kt;
+    unsigned a[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int c = cm[xb_col(j, h)];
+        a[j] = c >= 0 ? stat_word(Sb, wpr, keys, ko, Qf, c, w) : 0u;
+    }
+    transpose32(a);
+    unsigned *img = Xc + (int64_t)tile * (xc_tile / 4);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int64_t k = w * 32 + s;
+        img[((((k >> 7) * nk + kt) * 128) + (k & 127)) * 2 + h] = a[s];
+    }
+}
+
+void launch_col_compact(const I8Pass &a, const DevProblem &d, I8Ws *w, hipStream_t st) {
+    hipLaunchKernelGGL(k_col_union, dim3((unsigned)a.ngroups), dim3(256), 0, st, a.theta, a.srow, a.rowcol, a.groups, d.Qp, d.Qfp, w->csteps, w->cnk,
+                       w->cmap);
+    const int64_t wpr = d.Kp / 32;
+    hipLaunchKernelGGL(k_build_xc, dim3((unsigned)((wpr + 127) / 128), (unsigned)w->csteps, (unsigned)a.ngroups), dim3(256), 0, st, d.Sb, wpr, d.keys,
+                       d.ko, d.Qf, a.groups, w->cnk, w->cmap, w->csteps, w->xc_tile, reinterpret_cast<unsigned *>(w->Xc));
+}
+
+// ------------------------------------------------------------------------------------------
 // quantise Theta rows into limb planes.  One workgroup per node row.
 // ------------------------------------------------------------------------------------------
 template <int LF>
@@ -152,7 +244,8 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
                                                      long long *__restrict__ qconst, long long *__restrict__ qconst2, const double *__restrict__ tauovr,
                                                      const double *__restrict__ tauovr_lnrow,
                                                      double vdiv /* largest |V| / tau the planes of this pass hold */,
-                                                     double vsrc_scale /* hv: unit of the V planes read, in multiples of tauV */) {
+                                                     double vsrc_scale /* hv: unit of the V planes read, in multiples of tauV */,
+                                                     const int *__restrict__ cnk, const int *__restrict__ cmap, int cstride) {
     const int r = slot0 + blockIdx.x; // slot
     if (rowcol[r] < 0) return;
     const double *th = Theta + (int64_t)srow[r] * Qp;
@@ -194,14 +287,22 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
     const double isg = ldexp(1.0, -sx);
     const int tile = r >> 5, rl = r & 31;
     const int64_t nk = Qfp >> 6;
-    double sabs = 0.0;
+    // sum_c |q_c| as an INTEGER (< 2^61 by the choice of sigma): the bound it feeds must not depend on the order of the additions --
+    // a compacted pass (below) visits other columns per thread than a pass over all of them, and both must give the same tau
+    long long sabs = 0;
     long long ssum = 0; // sum_c q_c: the energy of the all-(+1) configuration (the forward GEMM runs on b = [x = -1])
     long long shi = 0;  // (7 planes) the same sum for the number the top four planes alone spell: q_hi = q / 2^24 rounded to nearest
-    for (int64_t c = tid; c < Qfp; c += 256) {
-        long long q = (long long)rint(th[c] * isg);
-        sabs += fabs((double)q);
+    // compacted tile: the digits of the tile's non-zero columns (cmap: ascending, -1 padded) go to the first cnk[tile] steps of the
+    // tile's image; every other column of this row is zero and contributes nothing to any sum
+    const int ck = cnk ? cnk[tile] : -1;
+    const int64_t ncol = ck >= 0 ? (int64_t)ck * 64 : Qfp;
+    const int *cm = ck >= 0 ? cmap + (int64_t)tile * cstride : nullptr;
+    for (int64_t j = tid; j < ncol; j += 256) {
+        const int64_t c = cm ? cm[j] : j;
+        long long q = c >= 0 ? (long long)rint(th[c] * isg) : 0;
+        sabs += q < 0 ? -q : q;
         ssum += q;
-        int8_t *img = Tq + ((((int64_t)tile * nk + (c >> 6)) * LF) * 32 + rl) * 64 + (c & 63);
+        int8_t *img = Tq + ((((int64_t)tile * nk + (j >> 6)) * LF) * 32 + rl) * 64 + (j & 63);
 #pragma unroll
         for (int l = 0; l < LF; ++l) {
             if (LF > 5 && l == 3) shi += q; // what is left after three balanced digits
@@ -213,7 +314,7 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
     long long q0 = 0, q0hi = 0;
     if (tid == 0) {
         q0 = (long long)rint(th[cconst] * isg);
-        sabs += fabs((double)q0);
+        sabs += q0 < 0 ? -q0 : q0;
         if (LF > 5) {
             long long q = q0;
             for (int l = 0; l < 3; ++l) q = (q - (((q + 128) & 255) - 128)) >> 8;
@@ -222,13 +323,14 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
     }
     __shared__ long long redl[256];
     __shared__ long long redh[256];
-    red[tid] = sabs;
+    __shared__ long long reda[256];
+    reda[tid] = sabs;
     redl[tid] = ssum;
     redh[tid] = shi;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (tid < s) {
-            red[tid] += red[tid + s];
+            reda[tid] += reda[tid + s];
             redl[tid] += redl[tid + s];
             if (LF > 5) redh[tid] += redh[tid + s];
         }
@@ -238,7 +340,7 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
     q0hi += redh[0];
     if (tid == 0) {
         // |E| <= sigma * sum|q|  (|X| <= 1)
-        const double emax = red[0] * sg;
+        const double emax = (double)reda[0] * sg;
         double t, it;
         if (hv) {
             // Hessian-vector pass: the row is a direction p, the forward epilogue forms u_k = h_k (x_k . p) with
@@ -274,10 +376,13 @@ __global__ __launch_bounds__(256) void k_quant_theta(const double *__restrict__ 
 
 
 void launch_quant_theta(int LF, int ns, const I8Pass &a, const DevProblem &d, int hv, const double *tauV, int8_t *Tq, const SlotScalars &sc,
-                        double vdiv, double vsrc_scale, hipStream_t st) {
+                        double vdiv, double vsrc_scale, hipStream_t st, const ColCompact *cc) {
+    const int *cnk = cc ? cc->cnk : nullptr, *cmap = cc ? cc->cmap : nullptr;
+    const int cstride = cc ? cc->cstride : 0;
 #define QUANT(LFV)                                                                                                                    \
     hipLaunchKernelGGL((k_quant_theta<LFV>), dim3(ns), dim3(256), 0, st, a.theta, a.srow, a.rowcol, a.slot0, d.Qp, d.Qfp, d.cconst,   \
-                       d.wmax, a.form, hv, a.vmap, tauV, Tq, sc.sigma, sc.tau, sc.invtau, sc.qconst, sc.qconst2, a.tauovr, a.tauovr_lnrow, vdiv, vsrc_scale)
+                       d.wmax, a.form, hv, a.vmap, tauV, Tq, sc.sigma, sc.tau, sc.invtau, sc.qconst, sc.qconst2, a.tauovr, a.tauovr_lnrow, vdiv, vsrc_scale, \
+                       cnk, cmap, cstride)
     switch (LF) {
     case 2: QUANT(2); break;
     case 3: QUANT(3); break;

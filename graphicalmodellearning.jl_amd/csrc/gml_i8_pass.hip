@@ -23,7 +23,7 @@ void i8_free(void *p) {
     I8Ws *w = static_cast<I8Ws *>(p);
     if (!w) return;
     (void)hipDeviceSynchronize(); // once for all the blocks below (dev_free_synced)
-    void *ptrs[] = {w->Tq, w->Vq, w->Uq, w->Gacc, w->tauovr, w->Hq, w->hS, w->H64, w->Mb};
+    void *ptrs[] = {w->Tq, w->Vq, w->Uq, w->Gacc, w->tauovr, w->Hq, w->hS, w->H64, w->Mb, w->cnk, w->cmap, w->Xc};
     for (void *q : ptrs)
         if (q) (void)dev_free_synced(q);
     for (auto &sc : w->sc) {
@@ -125,6 +125,32 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
         I8CHK(dev_malloc(&w->Uq, (size_t)w->slots * LB * d.Kp));
         I8CHK(hipMemsetAsync(w->Uq, 0, (size_t)w->slots * LB * d.Kp, st));
     }
+    // column compaction of the forward GEMM (objective passes over sparse rows): buffers on first use; a workspace that cannot have
+    // them (no memory left) simply keeps sweeping all columns
+    const int nk_all = (int)(d.Qfp / 64);
+    const bool compact = a.compact && !hv && !a.zero_theta && nk_all >= 2;
+    ColCompact ccv{};
+    const ColCompact *cc = nullptr;
+    if (compact) {
+        if (!w->cnk && w->csteps == 0) {
+            const int csteps = std::min(32, nk_all / 2);
+            const int64_t ntile = w->slots / 32, xc_tile = d.Kp * (int64_t)csteps * 8;
+            size_t freeb = 0, totalb = 0;
+            if (dev_mem_info(&freeb, &totalb) == hipSuccess && (double)ntile * (double)xc_tile < 0.25 * (double)freeb &&
+                dev_malloc(&w->cnk, sizeof(int) * ntile) == hipSuccess && dev_malloc(&w->cmap, sizeof(int) * ntile * csteps * 64) == hipSuccess &&
+                dev_malloc(&w->Xc, (size_t)ntile * xc_tile) == hipSuccess) {
+                w->csteps = csteps;
+                w->xc_tile = xc_tile;
+            } else {
+                (void)hipGetLastError();
+                w->csteps = -1; // (tried: not again)
+            }
+        }
+        if (w->csteps > 0) {
+            ccv = ColCompact{w->cnk, w->cmap, w->csteps * 64, w->Xc, w->xc_tile};
+            cc = &ccv;
+        }
+    }
     const SlotScalars &sc = w->sc[hv ? 1 : 0];
     const int ns = a.slot1 - a.slot0;
     const bool grad = a.want_grad || hv;
@@ -133,7 +159,8 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     const int64_t gplane_stride = (int64_t)w->slots * lbg * d.Qfp;
     launch_zero_pass(sc, a.F, a.rowcol, a.slot0, ns, gacc0, grad ? (int64_t)ns * lbg * d.Qfp / 4 : 0, w->gplanes, gplane_stride / 4, st);
     if (LF < 3 && !hv) LF = 3; // 2 limbs exist for the directions of Hessian-vector passes only
-    launch_quant_theta(LF, ns, a, d, hv, w->sc[0].tau, w->Tq, sc, wide ? kVdiv6 : kVdiv4, w->vscale(), st);
+    if (cc) launch_col_compact(a, d, w, st); // cnk / cmap / Xc of the listed tiles, in front of the quantisation that follows them
+    launch_quant_theta(LF, ns, a, d, hv, w->sc[0].tau, w->Tq, sc, wide ? kVdiv6 : kVdiv4, w->vscale(), st, cc);
     // split-K plan of the backward GEMM (made here: a sub-sampled pass runs its forward kernel over the same parts)
     const int nNt = (int)((d.Qfp + 255) / 256);
     constexpr int TM = 1; // node tiles per backward workgroup (the 8-wave form with two, TM = 2, measured slower)
@@ -152,10 +179,12 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     if (wide) {
         FwdWArgs fw{&d, w->Tq, &sc, a.rowcol, a.groups, a.ngroups, a.form, !a.want_grad, coarse, a.F, w->Vq, st};
         fw.zero_theta = a.zero_theta && !hv;
+        fw.cc = cc;
         launch_fwd_i8w(fw);
     } else {
         FwdLaunch fl{(int)(kchunk / 256), (int)(kpart / 256), 0, w, &d, &sc, a.rowcol, a.groups, a.vmap, a.ngroups, a.F, hv ? w->Uq : w->Vq, st};
         fl.coarse = coarse;
+        fl.cc = cc;
         fl.zero_theta = a.zero_theta && !hv && kpart == kchunk;
         fl.ntk = ksub > 1 ? nsplit * fl.part_tiles : (int)(d.Kp / 256);
         if (ksub == 1) fl.chunk_tiles = fl.part_tiles = 1; // (every tile: no remapping)

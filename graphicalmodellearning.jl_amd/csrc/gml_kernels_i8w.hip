@@ -68,9 +68,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
     const unsigned *__restrict__ Xb, const unsigned *__restrict__ Sb, const int8_t *__restrict__ Tq, const int *__restrict__ rowcol,
     const int *__restrict__ groups, int ngroups, const double *__restrict__ w, const double *__restrict__ sigma,
     const long long *__restrict__ qconst, const long long *__restrict__ qconst2, const double *__restrict__ invtau, int64_t Kp, int ntiles_k,
-    int nk /* 64-column steps */,
+    int nk_all /* 64-column steps of a sweep over all columns (0: every row of Theta is zero) */,
     double wuni, int64_t Kreal, int8_t *__restrict__ Vq, long long *__restrict__ csum, long long *__restrict__ csum2,
-    long long *__restrict__ asum, long long *__restrict__ asum2, double *__restrict__ fsum, unsigned *__restrict__ mmax) {
+    long long *__restrict__ asum, long long *__restrict__ asum2, double *__restrict__ fsum, unsigned *__restrict__ mmax,
+    // column compaction (gml_i8_pack.hip: k_col_union): steps of each tile's compact image (-1: all columns), the images, bytes per tile,
+    // and the steps between two tiles' Tq images (= Qfp / 64 whatever is swept)
+    const int *__restrict__ cnk, const int8_t *__restrict__ Xc, int64_t xc_tile, int nk_tq) {
     constexpr int WM = 2; // 32-sample MFMA tiles per wave
     extern __shared__ __attribute__((aligned(16))) int8_t lds[]; // ring, then the exp (and log) tables
     double *etab = reinterpret_cast<double *>(lds + RINGW);
@@ -108,6 +111,16 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
     const int64_t k0 = (int64_t)st * 256;
     if (k0 >= Kp) return;
     const int mytile = groups[gi];
+    // the columns this tile sweeps: all of them, or its compact list (the image then has the tile's own step count in its strides)
+    int nk = nk_all;
+    const int8_t *xbase = reinterpret_cast<const int8_t *>(Xb);
+    if (cnk) {
+        const int ck = cnk[mytile];
+        if (ck >= 0) {
+            nk = ck;
+            xbase = Xc + (int64_t)mytile * xc_tile;
+        }
+    }
 
     // DMA plan: a ring stage holds DSW = 2 consecutive 64-column steps of ONE sweep; its 2 PA (2 PB) 1-KB pieces are dealt to the
     // four waves, 5 (4) each.  Piece pc of a step: pc < 2 the two 128-sample pieces of bits, else 16 rows of the sweep's digit
@@ -116,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd_i8w(
     // (lane >> 4) & 3).
     const int voffX = lane * 16;
     const int voffT = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
-    const int8_t *const gX = reinterpret_cast<const int8_t *>(Xb) + (int64_t)(2 * st) * nk * 1024;
-    const int8_t *const gT = Tq + (int64_t)mytile * nk * BRT * 64;
+    const int8_t *const gX = xbase + (int64_t)(2 * st) * nk * 1024;
+    const int8_t *const gT = Tq + (int64_t)mytile * nk_tq * BRT * 64;
     const int nst = (nk + DSW - 1) / DSW; // ring stages per sweep; global stage gs < nst: sweep A, else sweep B
     // per DMA instruction of this wave (wave-uniform, scalar registers): source of step 0, bytes per step, step within the
     // stage, destination within the stage
@@ -678,7 +691,8 @@ static void launch_fwd_w5(const FwdWArgs &a) {
     const int grid = ((ntk + 7) / 8) * 8 * a.ngroups; // one workgroup per (sample tile, node tile)
     hipLaunchKernelGGL((k_fwd_i8w<FORM, WANTF, WIDE, UNIW, COARSE>), dim3(grid), dim3(256), shmem, a.st, d.Xb, d.Sb, a.Tq, a.rowcol, a.groups,
                        a.ngroups, d.w, a.sc->sigma, a.sc->qconst, a.sc->qconst2, a.sc->invtau, d.Kp, ntk, a.zero_theta ? 0 : (int)(d.Qfp / 64), d.wuni, d.K, a.Vq,
-                       a.sc->csum, a.sc->csum2, a.sc->asum, a.sc->asum2, a.F, a.sc->mmax);
+                       a.sc->csum, a.sc->csum2, a.sc->asum, a.sc->asum2, a.F, a.sc->mmax, a.cc ? a.cc->cnk : nullptr, a.cc ? a.cc->Xc : nullptr,
+                       a.cc ? a.cc->xc_tile : 0, (int)(d.Qfp / 64));
 }
 
 template <int FORM, bool WANTF, bool WIDE, bool UNIW>

@@ -19,6 +19,9 @@
 using namespace gml;
 
 static double now_s() { return gml_now_s(); }
+// operator calls compact the forward GEMM (sparse rows are what an l1 solver evaluates); the timing hooks sweep all columns unless asked
+static bool op_compact() { return g_tune[GML_TUNE_NO_COMPACT] == 0; }
+static bool bench_compact() { return g_tune[GML_TUNE_NO_COMPACT] == 0 && g_tune[GML_TUNE_BENCH_COMPACT] > 0; }
 static void parallel_for(int64_t n, const std::function<void(int64_t)> &fn) { gml_parallel_for(n, fn); }
 static int64_t round_up(int64_t a, int64_t b) { return gml_round_up(a, b); }
 static void build_layout(const gml_problem *p, int64_t u, NodeLayout &L) { gml_build_layout(p, u, L); }
@@ -93,6 +96,7 @@ int gml_ensure_f64(gml_problem *p, int64_t vrows) {
     return GML_OK;
 }
 
+static thread_local bool t_bench_call = false; // device_pass on behalf of gml_bench_pass (its compaction follows the bench knob)
 struct RowSet {
     int64_t R = 0;
     std::vector<int64_t> node; // node id per row
@@ -144,6 +148,7 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     double *dOvr = nullptr;
     const bool wide = precision == GML_PREC_I8W;
+    const bool compact_ok = t_bench_call ? bench_compact() : op_compact();
     if (gml_is_i8(precision)) {
         if (tau_ovr) {
             HIPCHK(dev_malloc(&dOvr, sizeof(double) * Rp));
@@ -164,6 +169,7 @@ static int device_pass(gml_problem *p, const RowSet &rs, const std::vector<uint8
         a.G = p->dG;
         a.tauovr = dOvr;
         a.wide = wide;
+        a.compact = compact_ok;
         rc = gml::i8_pass(&p->i8ws, p->d, W, a, st, ms ? ev : nullptr, &err);
         if (rc) {
             if (dOvr) (void)dev_free(dOvr);
@@ -346,6 +352,7 @@ static int pass_dev(gml_problem *p, int64_t R, const int64_t *nodes, const std::
     }
     double *dOvr = nullptr;
     const bool wide = precision == GML_PREC_I8W;
+    const bool compact_ok = t_bench_call ? bench_compact() : op_compact();
     if (gml_is_i8(precision)) {
         if (tau_ovr) {
             HIPCHK(dev_malloc(&dOvr, sizeof(double) * Rp));
@@ -366,6 +373,7 @@ static int pass_dev(gml_problem *p, int64_t R, const int64_t *nodes, const std::
         a.G = p->dG;
         a.tauovr = dOvr;
         a.wide = wide;
+        a.compact = compact_ok;
         rc = gml::i8_pass(&p->i8ws, p->d, W, a, st, nullptr, &err);
         if (rc) {
             if (dOvr) (void)dev_free(dOvr);
@@ -794,6 +802,7 @@ extern "C" int gml_bench_pass_resident(gml_problem *p, int formulation, int prec
             a.F = p->dF;
             a.G = p->dG;
             a.wide = precision == GML_PREC_I8W;
+            a.compact = bench_compact();
             rc = gml::i8_pass(&p->i8ws, p->d, W, a, st, e3, &err);
             if (rc) return fail(rc, "%s", err.c_str());
         } else {
@@ -877,7 +886,9 @@ extern "C" int gml_bench_pass(gml_problem *p, int formulation, int precision, co
     double sum[2] = {0, 0};
     for (int s = 0; s < warmup + steps; ++s) {
         float ms[2] = {0, 0};
+        t_bench_call = true;
         int rc = device_pass(p, rs, act, Th.data(), formulation, precision, true, fv.data(), Gi.data(), nullptr, ms);
+        t_bench_call = false;
         if (rc) return rc;
         if (s >= warmup) {
             sum[0] += ms[0];

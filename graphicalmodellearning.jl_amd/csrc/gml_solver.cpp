@@ -667,6 +667,7 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         a.wide = wide;
         a.coarse = coarse_on;
         a.zero_theta = at_zero && tune[GML_TUNE_NO_ZERO_SHORTCUT] == 0; // the first pass of a solve: X = 0 for every row
+        a.compact = tune[GML_TUNE_NO_COMPACT] == 0; // iterates and trial points are sparse: the forward GEMM sweeps each tile's non-zero columns
         std::string err;
         if (dual) { // the pass behind what this handle has queued so far, on the low-priority stream
             HIPCHK(hipEventRecord(ev_a, st));
