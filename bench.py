@@ -322,6 +322,27 @@ def main():
                         "max_rel_f_diff_vs_headline": float(np.abs(f_res / f_o - 1).max())}
     f64 = others.get("f64")
 
+    # ---- the same pass with the forward GEMM COMPACTED to the columns on which a node tile's rows are non-zero (round 6; what
+    # gml_objgrad_batch does by default).  The evaluation point of this benchmark -- the rows of the generating model -- is sparse
+    # (15 couplings + a field per node), so a 32-row tile sweeps 32-48 of the 1024 columns; the integer sums and therefore all results
+    # are the same bits.  NOT the headline: `value` prices the contraction over all columns, which is what a dense Theta costs.
+    if args.precision in LIMBS:
+        import ctypes
+        Lb = gml._lib.lib()
+        Lb.gml_test_tune.restype = ctypes.c_double
+        Lb.gml_test_tune.argtypes = [ctypes.c_int, ctypes.c_double]
+        Lb.gml_test_tune(7, 1.0)  # (gml_solver.h: GML_TUNE_BENCH_COMPACT -- the timing hook compacts too)
+        try:
+            ns_c = max(3, min(50, args.steps // 4))
+            e_c, _, km_c, f_c, g_c = timed(args.precision, ns_c, 2)
+        finally:
+            Lb.gml_test_tune(7, 0.0)
+        extra["sparse_theta"] = {"what": "the timed pass with column compaction on (forward GEMM over each node tile's non-zero columns only); "
+                                         "the evaluation point is sparse: nnz per row = %d of %d" % (int((theta != 0).sum(1).max()), n),
+                                 "value": n * ns_c / e_c, "unit": "node-evals/s", "steps": ns_c, "ms_per_step": e_c / ns_c * 1e3,
+                                 "fwd_ms": km_c["fwd_ms"], "bwd_ms": km_c["bwd_ms"], "device_ms_per_pass": km_c["device_ms_per_pass"],
+                                 "same_bits_as_headline": bool(np.array_equal(g_c, g_res) and np.array_equal(f_c, f_res))}
+
     # ---- learn() wall-clock of this config ---------------------------------------------------------------------
     out = None
     STKEYS = ("iterations", "passes", "forward_passes", "node_evals", "max_kkt", "not_converged", "t_pass", "t_hess", "t_host", "polished")

@@ -127,6 +127,7 @@ inline double i8_vdiv(bool wide) { return wide ? 1.400e14 : 2130000000.0; }
 // unit of the values of a coarse pass, in multiples of SlotResult.tau (the noise of f and grad scales with it)
 inline double i8_coarse_unit(bool wide) { return wide ? 16777216.0 : 256.0; }
 void i8_free(void *ws);
+void i8_compact_table(void *ws, const int **cnk, int *csteps);
 // per-slot results of the last pass of the given kind (device pointers)
 void i8_slot_results(void *ws, int hv, const double **tau, const unsigned **mmax);
 // the limb planes of V of the workspace (device pointer, bytes): the kernel-timing experiments read per-workgroup timestamps from it

@@ -13,6 +13,13 @@ void i8_slot_results(void *p, int hv, const double **tau, const unsigned **mmax)
     *mmax = w ? w->sc[hv ? 1 : 0].mmax : nullptr;
 }
 
+// the compaction table of the last objective pass (device pointer; NULL: never compacted): steps per slot tile, -1 = all columns
+void i8_compact_table(void *p, const int **cnk, int *csteps) {
+    I8Ws *w = static_cast<I8Ws *>(p);
+    *cnk = w && w->csteps > 0 ? w->cnk : nullptr;
+    *csteps = w ? w->csteps : 0;
+}
+
 void i8_vq_buffer(void *p, const int8_t **vq, int64_t *bytes, const DevProblem &d) {
     I8Ws *w = static_cast<I8Ws *>(p);
     *vq = w ? w->Vq : nullptr;

@@ -667,7 +667,7 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         a.wide = wide;
         a.coarse = coarse_on;
         a.zero_theta = at_zero && tune[GML_TUNE_NO_ZERO_SHORTCUT] == 0; // the first pass of a solve: X = 0 for every row
-        a.compact = tune[GML_TUNE_NO_COMPACT] == 0; // iterates and trial points are sparse: the forward GEMM sweeps each tile's non-zero columns
+        a.compact = tune[GML_TUNE_NO_COMPACT] == 0 && tune[GML_TUNE_SOLVER_COMPACT] > 0; // (experiment knob: see gml_solver.h -- the solver's own iterates are not sparse enough per tile)
         std::string err;
         if (dual) { // the pass behind what this handle has queued so far, on the low-priority stream
             HIPCHK(hipEventRecord(ev_a, st));
@@ -678,6 +678,27 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         if (dual) { // ... and everything that follows behind the pass
             HIPCHK(hipEventRecord(ev_b, st_pass));
             HIPCHK(hipStreamWaitEvent(st, ev_b, 0));
+        }
+        if (o.verbose >= 2 && a.compact) { // what the compaction did to this pass: steps swept per tile (all = the tile ran on every column)
+            const int *dcnk = nullptr;
+            int cs = 0;
+            i8_compact_table(p->i8ws, &dcnk, &cs);
+            if (dcnk) {
+                std::vector<int> tl((size_t)(hi - lo) / 32);
+                HIPCHK(hipMemcpy(tl.data(), dcnk + lo / 32, sizeof(int) * tl.size(), hipMemcpyDeviceToHost));
+                int nall = 0, nc = 0, mx = 0;
+                long long sum = 0;
+                for (int v : tl) {
+                    if (v < 0) ++nall;
+                    else {
+                        ++nc;
+                        sum += v;
+                        mx = std::max(mx, v);
+                    }
+                }
+                fprintf(stderr, "[gml]   compaction: %d tiles on all %d steps, %d compacted (mean %.1f, max %d of cap %d steps)\n", nall, (int)(d.Qfp / 64),
+                        nc, nc ? (double)sum / nc : 0.0, mx, cs);
+            }
         }
         if (formulation == GML_LOGRISE && want_grad) // grad log Z = grad Z / Z (:279), Z from the pass results on the device
             launch_scale_slots_inv(a.srow, a.rowcol, (int)lo, (int)ns, kRes, Qp, dst, st);

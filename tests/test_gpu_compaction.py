@@ -10,7 +10,7 @@ import gml_amd as gml
 
 pytestmark = pytest.mark.gpu
 synthetic = __import__("importlib").import_module("gml_amd.synthetic")
-NO_COMPACT = 6  # gml_solver.h: GML_TUNE_NO_COMPACT
+NO_COMPACT, SOLVER_COMPACT = 6, 8  # gml_solver.h: GML_TUNE_NO_COMPACT (never), GML_TUNE_SOLVER_COMPACT (gml_learn's passes too: off by default)
 
 
 def tune(knob, value):
@@ -28,9 +28,14 @@ def both_ways():
             dense = fn()
         finally:
             tune(NO_COMPACT, 0)
-        return dense, fn()
+        tune(SOLVER_COMPACT, 1)
+        try:
+            return dense, fn()
+        finally:
+            tune(SOLVER_COMPACT, 0)
     yield run
     tune(NO_COMPACT, 0)
+    tune(SOLVER_COMPACT, 0)
 
 
 def sparse_rows(rng, nrows, P, nnz_lo, nnz_hi, pool=None, scale=0.3):
