@@ -192,6 +192,7 @@ def learn(samples, formulation=None, method=None):
         if method.devices is not None:
             out, kkt, st = _local_solve_multi(samples, formulation, method, order)
             node_range = (0, n)
+            device = int(list(method.devices)[0])  # (where a multiRISE result is assembled)
         elif fused:
             out, kkt, st = solve(samples, formulation, method, order, node_range, device, terms=bool(formulation.symmetrization))
         elif packed is not None:
