@@ -255,23 +255,39 @@ class Problem:
                                               C.byref(h)))
         elif terms is not None:
             # sample on the device from a model of any order given as {1-based key tuple: weight}: sampling.jl:60-88
-            if n is None:
-                n = max(max(k) for k in terms if len(k))
-            stride = max(1, max(len(k) for k in terms))
-            keys = np.full((len(terms), stride), -1, dtype=np.int32)
-            wts = np.zeros(len(terms), dtype=np.float64)
-            for t, (k, v) in enumerate(terms.items()):
-                keys[t, :len(k)] = np.asarray(k, dtype=np.int64) - 1
-                wts[t] = v
+            if hasattr(terms, "keys_array"):
+                # an array-backed learned model (factor_graph.TermArray: millions of terms): its non-zero terms, without a Python loop
+                nz = np.flatnonzero(terms.weights != 0.0)
+                if n is None:
+                    n = terms.varible_count
+                stride = terms.order
+                wts = np.ascontiguousarray(terms.weights[nz])
+                keys = np.empty((len(nz), stride), dtype=np.int32)
+                chunk = 1 << 22
+                for a in range(0, len(terms), chunk):  # (the key table is generated window by window: it is never held whole)
+                    lo, hi = np.searchsorted(nz, (a, min(len(terms), a + chunk)))
+                    if hi > lo:
+                        keys[lo:hi] = terms.keys_array(a, min(chunk, len(terms) - a))[nz[lo:hi] - a] - 1
+                if len(nz) == 0:
+                    keys, wts = np.array([[0] + [-1] * (stride - 1)], dtype=np.int32), np.zeros(1)
+            else:
+                if n is None:
+                    n = max(max(k) for k in terms if len(k))
+                stride = max(1, max(len(k) for k in terms))
+                keys = np.full((len(terms), stride), -1, dtype=np.int32)
+                wts = np.zeros(len(terms), dtype=np.float64)
+                for t, (k, v) in enumerate(terms.items()):
+                    keys[t, :len(k)] = np.asarray(k, dtype=np.int64) - 1
+                    wts[t] = v
             n0, n1 = node_range if node_range is not None else (0, int(n))
             if histogram:
-                check(L.gml_problem_create_sampled_hist(_ptr(keys), stride, _ptr(wts), len(terms), int(n), int(num_samples), int(seed),
+                check(L.gml_problem_create_sampled_hist(_ptr(keys), stride, _ptr(wts), len(wts), int(n), int(num_samples), int(seed),
                                                         int(mcmc_sweeps or 0), int(order), n0, n1, int(device), C.byref(h)))
             elif mcmc_sweeps:  # Glauber chains instead of exact enumeration (components above 22 spins)
-                check(L.gml_problem_create_mcmc_terms(_ptr(keys), stride, _ptr(wts), len(terms), int(n), int(num_samples),
+                check(L.gml_problem_create_mcmc_terms(_ptr(keys), stride, _ptr(wts), len(wts), int(n), int(num_samples),
                                                       int(seed), int(mcmc_sweeps), int(order), n0, n1, int(device), C.byref(h)))
             else:
-                check(L.gml_problem_create_sampled_terms(_ptr(keys), stride, _ptr(wts), len(terms), int(n), int(num_samples),
+                check(L.gml_problem_create_sampled_terms(_ptr(keys), stride, _ptr(wts), len(wts), int(n), int(num_samples),
                                                          int(seed), int(order), n0, n1, int(device), C.byref(h)))
         elif model is not None:
             # sample on the device from a pairwise model (n x n, diagonal = fields): sampling.jl:34-57
@@ -403,6 +419,8 @@ class Problem:
         out = None
         kkt = np.zeros(R)
         st = Stats()
+        if terms is not None and x0 is not None:
+            raise GMLError(GML_EINVAL, "x0 (gml_learn_warm) and terms (gml_learn_terms) cannot be combined: solve with x0, then terms_assemble")
         if terms is not None:
             out = np.empty(terms_count(self.n, self.order, terms))
             rc = L.gml_learn_terms(self._h, FORMULATION_IDS[formulation], float(c), int(bool(terms)), C.byref(o), _ptr(out), _ptr(kkt),

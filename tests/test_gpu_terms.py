@@ -203,3 +203,21 @@ def test_c5_front_door_full_size():
     nz = np.count_nonzero(fg.terms.weights)
     assert len(terms) <= nz < len(fg)
     assert t_front < 75.0  # measured 21.9 s (solve 21.8 s)
+
+
+def test_sampling_from_an_array_backed_learned_model(monkeypatch):
+    # runtests.jl:161-181 in spirit: learn a multi-body model, sample from the learned model.  The array-backed FactorGraph feeds the
+    # device sampler its non-zero terms without a Python loop over the term list; the same draws as from the dict of those terms
+    n, K = 24, 40000
+    terms = synthetic.block_multibody_terms(n, block=12, seed=3)
+    with gml.Problem(terms=terms, n=n, num_samples=K, seed=4, order=3) as p:
+        spins = p.spins()
+    hist = np.concatenate([np.ones((K, 1), dtype=np.int8), spins], axis=1)
+    monkeypatch.setattr(__import__("importlib").import_module("gml_amd.learn"), "DICT_TERMS_MAX", 0)
+    fa = gml.learn(hist, gml.multiRISE(1.5, True, 3), gml.HIP(tol=1e-9))
+    assert isinstance(fa.terms, TermArray)
+    nz = {k: v for k, v in fa.terms.items() if v != 0.0}
+    assert 0 < len(nz) < len(fa)
+    s_arr = gml.sample(fa, 20000, seed=7)
+    s_dict = gml.sample(gml.FactorGraph(3, n, "spin", nz), 20000, seed=7)
+    assert np.array_equal(s_arr, s_dict) and s_arr[:, 0].sum() == 20000
