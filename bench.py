@@ -72,6 +72,8 @@ def parse_args():
     ap.add_argument("--no-f64", action="store_true", help="skip the FP64-path leg")
     ap.add_argument("--no-i8x", action="store_true", help="skip the i8x (accelerated mode) leg")
     ap.add_argument("--no-weighted", action="store_true", help="skip the weighted-histogram pass")
+    ap.add_argument("--no-sparse-theta", action="store_true", help="skip the leg that times the pass with column compaction on (its launches carry the "
+                                                                   "forward kernel's name: a rocprofv3 --stats average of the timed passes must not mix them in)")
     ap.add_argument("--no-shards", action="store_true", help="skip the one-GPU measurement of every rank's workload of an 8-GPU run")
     ap.add_argument("--cpu-learn-max-s", type=float, default=100.0, help="run the CPU learn() of THIS config in full when the "
                                                                            "measured CPU rate predicts at most this many seconds")
@@ -326,7 +328,7 @@ def main():
     # gml_objgrad_batch does by default).  The evaluation point of this benchmark -- the rows of the generating model -- is sparse
     # (15 couplings + a field per node), so a 32-row tile sweeps 32-48 of the 1024 columns; the integer sums and therefore all results
     # are the same bits.  NOT the headline: `value` prices the contraction over all columns, which is what a dense Theta costs.
-    if args.precision in LIMBS:
+    if args.precision in LIMBS and not args.no_sparse_theta:
         import ctypes
         Lb = gml._lib.lib()
         Lb.gml_test_tune.restype = ctypes.c_double

@@ -5,7 +5,7 @@ o=gpurun_out/prof_util
 rm -rf $o; mkdir -p $o
 for c in MfmaUtil "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   d=$o/$(echo $c | tr ' ' '_')
-  rocprofv3 --pmc $c --output-format csv -d $d -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-learn --no-host-learn --no-weighted > $d.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $d -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-learn --no-host-learn --no-weighted --no-sparse-theta > $d.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, json, collections
