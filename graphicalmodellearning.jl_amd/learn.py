@@ -148,6 +148,13 @@ def learn(samples, formulation=None, method=None):
                           "device solver of libgml_hip with its default options (pass HIP(...) to set them; to keep an external solver, "
                           "register gml_objgrad_batch as its operator: INTEGRATION.md)", stacklevel=2)
         method = HIP()
+    # (argument errors before any collective: every rank raises the same thing at the same point)
+    if method.devices is not None and (method.distributed or method.node_range is not None or method.device is not None):
+        raise ValueError("HIP: devices (all nodes over several GPUs from this process) excludes distributed, node_range and device")
+    if method.distributed and method.node_range is not None:
+        raise ValueError("HIP: distributed=True derives the node range from the rank; node_range must not be given")
+    if method.precision not in _lib.PRECISIONS:
+        raise ValueError(f"HIP: unknown precision {method.precision!r} (use 'auto', 'i8x', 'i8w' or 'f64')")
     order = int(formulation.interaction_order) if isinstance(formulation, multiRISE) else 2
     world, rank = 1, 0
     if method.distributed:
@@ -167,12 +174,6 @@ def learn(samples, formulation=None, method=None):
             raise ValueError("samples must be a K x (1+n) histogram matrix")
         n = samples.shape[1] - 1
 
-    if method.devices is not None and (method.distributed or method.node_range is not None or method.device is not None):
-        raise ValueError("HIP: devices (all nodes over several GPUs from this process) excludes distributed, node_range and device")
-    if method.distributed and method.node_range is not None:
-        raise ValueError("HIP: distributed=True derives the node range from the rank; node_range must not be given")
-    if method.precision not in _lib.PRECISIONS:
-        raise ValueError(f"HIP: unknown precision {method.precision!r} (use 'auto', 'i8x', 'i8w' or 'f64')")
     node_range = method.node_range or _node_partition(n, world, rank)
     device = method.device
     if device is None:
