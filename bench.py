@@ -451,18 +451,17 @@ def main():
                 t0 = time.perf_counter()
                 with gml.Problem(hist, device=device) as ph:
                     t1 = time.perf_counter()
-                    oh, kh, sh = ph.learn("RISE", 0.4, tol=1e-9, precision=args.precision, raise_on_fail=False)
-                    Rh = 0.5 * (oh + oh.T)  # :184-186
+                    Rh, kh, sh = ph.learn("RISE", 0.4, tol=1e-9, precision=args.precision, raise_on_fail=False, matrix=True)  # solve + :184-186 on the device
                     t2 = time.perf_counter()
                     it = ph.ingest_times()
                 runs.append({"pack_s": it["pack_s"], "upload_s": it["upload_s"], "images_s": it["images_s"], "alloc_s": it["alloc_s"],
-                             "weights_s": it["weights_s"], "create_s": t1 - t0,
+                             "weights_s": it["weights_s"], "create_s": t1 - t0, "symmetrise_s": sh["t_assemble"],
                              "solve_s": t2 - t1, "total_s": t2 - t0})
             med = sorted(runs, key=lambda r: r["total_s"])[1]
             extra["learn_from_host"] = dict(med, input="column-major Int64 K x (1+n) histogram (Matrix{Int64} of sample())",
                                             host_bytes=int(hist.nbytes), pcie_bytes=int(K * n / 8 + 8 * K),
                                             runs_total_s=[r["total_s"] for r in runs],
-                                            same_result_as_device_samples=bool(out is not None and np.array_equal(oh, out)),
+                                            same_result_as_device_samples=bool(out is not None and np.array_equal(Rh, 0.5 * (out + out.T))),
                                             max_err_vs_true_model=float(np.abs(Rh - J).max()))
             del hist
         else:

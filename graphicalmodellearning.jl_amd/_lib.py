@@ -109,6 +109,8 @@ def lib():
     L.gml_terms_rank.restype = i64
     L.gml_terms_rank.argtypes = [i64, i32, i32, p, i32]
     L.gml_learn_terms.argtypes = [p, i32, dbl, i32, C.POINTER(Opts), p, p, C.POINTER(Stats)]
+    L.gml_learn_matrix.argtypes = [p, i32, dbl, i32, C.POINTER(Opts), p, p, C.POINTER(Stats)]
+    L.gml_matrix_symmetrize.argtypes = [p, i64, i64, i32, p]
     L.gml_bench_pass.argtypes = [p, i32, i32, p, i32, i32, p]
     L.gml_bench_pass_resident.argtypes = [p, i32, i32, p, i32, i32, p, p, p, p]
     _lib = L
@@ -200,6 +202,16 @@ def terms_assemble(rows, n, order, symmetrize, device=0, ld=None):
             raise GMLError(GML_EINVAL, f"terms_assemble needs the rows of all {n} nodes, got {rows.shape}")
         ptr, ld = _ptr(rows), rows.shape[1]
     check(lib().gml_terms_assemble(ptr, ld, int(n), int(order), int(bool(symmetrize)), int(device), _ptr(out)))
+    return out
+
+
+def matrix_symmetrize(rows, device=0):
+    """gml_matrix_symmetrize: 0.5 (R + R') of the gathered n x n rows, on the device (:184-186); same bits as the host expression"""
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    if rows.ndim != 2 or rows.shape[0] != rows.shape[1]:
+        raise GMLError(GML_EINVAL, f"matrix_symmetrize needs the rows of all nodes (a square matrix), got {rows.shape}")
+    out = np.empty_like(rows)
+    check(lib().gml_matrix_symmetrize(_ptr(rows), rows.shape[1], rows.shape[0], int(device), _ptr(out)))
     return out
 
 
@@ -398,11 +410,12 @@ class Problem:
 
     def learn(self, formulation, c, *, tol=1e-9, max_iter=100, precision="auto", max_working=512, max_add=64,
               verbose=0, hess_samples=0, polish=True, max_cg=0, limbs_fwd=0, hv_limbs_fwd=0, hv_limbs_bwd=0, debug_row=0,
-              hv_subsample=0, cg_viol_frac=0.0, cg_eta=0.0, coarse=True, out_ptr=None, raise_on_fail=True, terms=None, x0=None):
+              hv_subsample=0, cg_viol_frac=0.0, cg_eta=0.0, coarse=True, out_ptr=None, raise_on_fail=True, terms=None, x0=None, matrix=None):
         """gml_learn: (rows, kkt, stats).  terms = True / False (handles over all nodes): gml_learn_terms instead -- the solved
         rows stay on the device and the first result is the model's weight array in (length, key) order, symmetrised (True) or
         not (False): the input of a FactorGraph (TermArray).  x0: rows to start from ((node1-node0) x P, the layout of the result;
-        gml_learn_warm) -- a regularisation path solves each c from the previous solution."""
+        gml_learn_warm) -- a regularisation path solves each c from the previous solution.  matrix = True / False (pairwise handles
+        over all nodes): gml_learn_matrix -- the n x n result, symmetrised on the device (True) or as it is (False)."""
         L = lib()
         o = Opts()
         L.gml_default_opts(C.byref(o))
@@ -419,9 +432,15 @@ class Problem:
         out = None
         kkt = np.zeros(R)
         st = Stats()
+        if matrix is not None and (terms is not None or x0 is not None or out_ptr is not None):
+            raise GMLError(GML_EINVAL, "matrix (gml_learn_matrix) cannot be combined with terms, x0 or out_ptr")
         if terms is not None and x0 is not None:
             raise GMLError(GML_EINVAL, "x0 (gml_learn_warm) and terms (gml_learn_terms) cannot be combined: solve with x0, then terms_assemble")
-        if terms is not None:
+        if matrix is not None:
+            out = np.zeros((R, self.P))
+            rc = L.gml_learn_matrix(self._h, FORMULATION_IDS[formulation], float(c), int(bool(matrix)), C.byref(o), _ptr(out), _ptr(kkt),
+                                    C.byref(st))
+        elif terms is not None:
             out = np.empty(terms_count(self.n, self.order, terms))
             rc = L.gml_learn_terms(self._h, FORMULATION_IDS[formulation], float(c), int(bool(terms)), C.byref(o), _ptr(out), _ptr(kkt),
                                    C.byref(st))

@@ -15,7 +15,6 @@ module GraphicalModelLearningHIP
 
 using GraphicalModelLearning
 import GraphicalModelLearning: learn, GMLMethod, GMLFormulation, RISE, RISEA, logRISE, RPLE, multiRISE, FactorGraph
-import LinearAlgebra
 
 export HIP, trim_cache
 
@@ -174,10 +173,39 @@ function solve_rows_multi(s, dtype, formulation, method::HIP, order::Int)
 end
 
 # RISE / logRISE / RPLE / RISEA: n x n matrix, diagonal = fields  (:154-189, :263-298, :301-336, :210-260)
+# One GPU, all nodes: gml_learn_matrix -- the solve and `0.5 * (reconstruction + transpose(reconstruction))` (:184-186) in one call,
+# the rows never leaving the device (on the host that line walks the transposed operand with a stride of n doubles: 0.2 s at n = 4096).
+# Node shards and several GPUs: the gathered rows through gml_matrix_symmetrize.
 function learn(samples::Array{T,2}, formulation::Union{RISE,RISEA,logRISE,RPLE}, method::HIP) where T <: Real
+    n = size(samples, 2) - 1
+    if method.devices === nothing && method.node_range === nothing && formulation.symmetrization
+        s = T <: AbstractFloat ? convert(Array{Float64,2}, samples) : convert(Array{Int64,2}, samples)
+        K = size(s, 1)
+        handle = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:gml_problem_create, libgml), Cint,
+                   (Ptr{Cvoid}, Cint, Int64, Int64, Int64, Cint, Cint, Int64, Int64, Cint, Ref{Ptr{Cvoid}}),
+                   s, eltype(s) == Float64 ? GML_F64 : GML_I64, K, n, K, 1, 2, 0, n, method.device, handle)
+        rc == GML_OK || error("gml_problem_create: $(lasterr())")
+        try
+            out = Array{Float64}(undef, n, n)             # symmetric: row-major and column-major coincide
+            stats = Ref{GmlStats}()
+            rc = ccall((:gml_learn_matrix, libgml), Cint,
+                       (Ptr{Cvoid}, Cint, Cdouble, Cint, Ref{GmlOpts}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{GmlStats}),
+                       handle[], formulation_id(formulation), Float64(formulation.regularizer), Cint(1), gmlopts(method), out, C_NULL, stats)
+            rc == GML_ENOTCONV && throw(AssertionError(lasterr()))              # @assert ... LOCALLY_SOLVED (:180)
+            rc == GML_OK || error("gml_learn_matrix: $(lasterr())")
+            return out
+        finally
+            ccall((:gml_problem_destroy, libgml), Cvoid, (Ptr{Cvoid},), handle[])
+        end
+    end
     reconstruction, _, _ = solve_rows(samples, formulation, method, 2)
     if formulation.symmetrization && size(reconstruction, 1) == size(reconstruction, 2)
-        reconstruction = 0.5 * (reconstruction + transpose(reconstruction))      # :184-186
+        rt = permutedims(reconstruction)                                          # C row-major n x n
+        rc = ccall((:gml_matrix_symmetrize, libgml), Cint, (Ptr{Cdouble}, Int64, Int64, Cint, Ptr{Cdouble}),
+                   rt, n, n, method.devices === nothing ? method.device : method.devices[1], rt)   # :184-186, in place
+        rc == GML_OK || error("gml_matrix_symmetrize: $(lasterr())")
+        reconstruction = rt                                                       # symmetric: no transpose back needed
     end
     return reconstruction
 end

@@ -28,18 +28,24 @@ def _node_partition(n, world, rank):
 DICT_TERMS_MAX = 1 << 17
 
 
-def _local_solve_hip(samples, formulation, method, order, node_range, device, terms=None, packed=None):
+def _local_solve_hip(samples, formulation, method, order, node_range, device, terms=None, packed=None, matrix=None):
     """rows of the local node range through libgml_hip: (out, kkt, stats).  terms = True / False (all nodes, multiRISE): the
     model's weight array instead of the rows -- solve and assembly in one library call, the rows never leave the device.
     packed = (sign_bits, counts or None, K): the handle is built from the packed form (gml_problem_create_packed) and `samples`
-    is not looked at -- the ranks of a distributed run, which receive the bits from rank 0."""
+    is not looked at -- the ranks of a distributed run, which receive the bits from rank 0.  matrix = True / False (all nodes,
+    pairwise): the n x n result of gml_learn_matrix, symmetrised on the device (True)."""
     src = {"packed": packed} if packed is not None else {"samples": samples}
     with _lib.Problem(order=order, node_range=node_range, device=device, **src) as prob:
         out, kkt, st = prob.learn(_form_name(formulation), formulation.regularizer, tol=method.tol,
                                   max_iter=method.max_iter, precision=method.precision,
                                   max_working=method.max_working, max_add=method.max_add, verbose=method.verbose,
-                                  hess_samples=method.hess_samples, polish=method.polish, terms=terms)
+                                  hess_samples=method.hess_samples, polish=method.polish, terms=terms, matrix=matrix)
     return out, kkt, st
+
+
+def _symmetrize_hip(R, device):
+    """0.5 (R + R') of the gathered rows on the device (gml_matrix_symmetrize; :184-186)"""
+    return _lib.matrix_symmetrize(R, device=device)
 
 
 _PRODUCT_SOLVE = _local_solve_hip  # (what `solve` is unless a test substituted the module attribute)
@@ -182,13 +188,15 @@ def learn(samples, formulation=None, method=None):
             import torch
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
     # (module attributes, looked up per call: the CPU-only tests of this layer substitute the oracle for both steps)
-    solve, assemble = _local_solve_hip, _assemble_terms_hip
+    solve, assemble, symmetrize = _local_solve_hip, _assemble_terms_hip, _symmetrize_hip
     multi = isinstance(formulation, multiRISE)
     if multi and not (method.distributed and world > 1) and method.devices is None and tuple(node_range) != (0, n):
         raise ValueError("multiRISE assembles a FactorGraph from the rows of ALL nodes (:129-151): solve node shards with "
                          "Problem.learn and hand the gathered rows to _lib.terms_assemble")
     # one process, one GPU, all nodes: solve + assembly in one library call (gml_learn_terms)
-    fused = multi and solve is _PRODUCT_SOLVE and method.devices is None and not (method.distributed and world > 1)
+    one_call = solve is _PRODUCT_SOLVE and method.devices is None and not (method.distributed and world > 1)
+    fused = multi and one_call
+    fused_sym = (not multi) and one_call and bool(formulation.symmetrization) and tuple(node_range) == (0, n)  # (gml_learn_matrix)
     try:
         if method.devices is not None:
             out, kkt, st = _local_solve_multi(samples, formulation, method, order)
@@ -196,6 +204,8 @@ def learn(samples, formulation=None, method=None):
             device = int(list(method.devices)[0])  # (where a multiRISE result is assembled)
         elif fused:
             out, kkt, st = solve(samples, formulation, method, order, node_range, device, terms=bool(formulation.symmetrization))
+        elif fused_sym:
+            out, kkt, st = solve(samples, formulation, method, order, node_range, device, matrix=True)
         elif packed is not None:
             out, kkt, st = solve(None, formulation, method, order, node_range, device, packed=packed)[:3]
         else:
@@ -227,7 +237,7 @@ def learn(samples, formulation=None, method=None):
         terms = TermArray(n, order, bool(formulation.symmetrization), weights)
         return FactorGraph(order, n, "spin", terms.to_dict() if len(terms) <= DICT_TERMS_MAX else terms)  # :151
 
-    R = np.array(out)  # rows node_range; out[u, :] = reconstruction[u, 1:n] (:181)
-    if formulation.symmetrization and R.shape[0] == R.shape[1]:
-        R = 0.5 * (R + R.T)  # :184-186
+    R = np.asarray(out)  # rows node_range; out[u, :] = reconstruction[u, 1:n] (:181)
+    if formulation.symmetrization and R.shape[0] == R.shape[1] and not fused_sym:
+        R = symmetrize(R, device)  # :184-186, on the device (the host expression walks R' with a stride of n doubles: 0.22 s at n = 4096)
     return R

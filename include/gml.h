@@ -372,6 +372,20 @@ int gml_learn_terms(gml_problem *p, int formulation, double regularizer_c, int s
                     double *kkt, gml_stats *stats);
 
 /*
+ * The pairwise counterpart: `reconstruction = 0.5 * (reconstruction + transpose(reconstruction))` (:184-186) on the device.
+ * On the host that one line walks the transposed operand with a stride of n doubles: 16 ms at n = 1024 (a sixth of the headline
+ * solve), 0.22 s at n = 4096 (as much as a whole config-4 solve on eight GPUs).  (a + b) * 0.5 in FP64: the same bits.
+ *   gml_learn_matrix        gml_learn over ALL nodes of a pairwise handle + the symmetrisation (symmetrize != 0), the rows never
+ *                           leaving the device: out = the n x n matrix the reference's learn returns (host or device pointer);
+ *                           stats->t_assemble = the symmetrisation + the copy.  symmetrize == 0: plain gml_learn.
+ *   gml_matrix_symmetrize   the same for rows gathered from node shards: rows n x n (leading dimension ld), out n x n, host or
+ *                           device pointers, in place allowed
+ */
+int gml_learn_matrix(gml_problem *p, int formulation, double regularizer_c, int symmetrize, const gml_opts *opts, double *out,
+                     double *kkt, gml_stats *stats);
+int gml_matrix_symmetrize(const double *rows, int64_t ld, int64_t n, int device, double *out);
+
+/*
  * gml_multi_* -- the node loop of `learn` (:161: `for current_spin = 1:num_spins`, rows stored at :181) over several
  * GPUs of one node from a single caller (the reference's host language has no process group: Julia's
  * `learn(samples, RISE(), HIP(devices = 0:7))` binds these).  GPU g owns the nodes [g n / G, (g+1) n / G): one handle and

@@ -123,13 +123,15 @@ static int run(const char *samples_csv, const char *learned_csv, double c, int s
     o.cg_viol_frac = o.cg_eta = 0.0;
     gml_stats st;
     memset(&st, 0xEE, sizeof st); /* Ref{GmlStats}() is uninitialised memory */
-    rc = gml_learn(h, GML_RISE, c, &o, out, NULL /* C_NULL */, &st);
+    /* learn(samples, ::RISE, ::HIP): symmetrization -> gml_learn_matrix (solve + 0.5 (R + R') on the device, :184-186), else gml_learn */
+    if (symmetrize) rc = gml_learn_matrix(h, GML_RISE, c, 1, &o, out, NULL /* C_NULL */, &st);
+    else rc = gml_learn(h, GML_RISE, c, &o, out, NULL /* C_NULL */, &st);
     if (rc != GML_OK) {
         fprintf(stderr, "gml_learn: %s\n", gml_last_error());
         return 5;
     }
     gml_problem_destroy(h);
-    const double e1 = compare(out, n, symmetrize, W);
+    const double e1 = compare(out, n, 0 /* already symmetrised by the library */, W);
     printf("single max_abs_diff %.3e iterations %d passes %d max_kkt %.3e lambda %.6e not_converged %d\n", e1, st.iterations, st.passes,
            st.max_kkt, st.lambda, st.not_converged);
     const double lam = c * sqrt(log((double)n * n / 0.05) / 1e6); /* the fixtures hold 1e6 samples (:157) */
@@ -155,7 +157,14 @@ static int run(const char *samples_csv, const char *learned_csv, double c, int s
         return 9;
     }
     gml_multi_destroy(m);
-    const double e2 = compare(out2, n, symmetrize, W);
+    if (symmetrize) { /* the gathered rows through gml_matrix_symmetrize, in place (as the .jl does on `rt`) */
+        rc = gml_matrix_symmetrize(out2, n, n, devs[0], out2);
+        if (rc != GML_OK) {
+            fprintf(stderr, "gml_matrix_symmetrize: %s\n", gml_last_error());
+            return 12;
+        }
+    }
+    const double e2 = compare(out2, n, 0, W);
     printf("multi max_abs_diff %.3e iterations %d not_converged %d\n", e2, st.iterations, st.not_converged);
     if (st.not_converged != 0) return 10;
     return (e1 <= 5e-8 && e2 <= 5e-8) ? 0 : 11;

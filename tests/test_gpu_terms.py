@@ -221,3 +221,43 @@ def test_sampling_from_an_array_backed_learned_model(monkeypatch):
     s_arr = gml.sample(fa, 20000, seed=7)
     s_dict = gml.sample(gml.FactorGraph(3, n, "spin", nz), 20000, seed=7)
     assert np.array_equal(s_arr, s_dict) and s_arr[:, 0].sum() == 20000
+
+
+# ---- the pairwise counterpart: 0.5 (R + R') on the device (gml_learn_matrix / gml_matrix_symmetrize, :184-186) ---------------------------
+@pytest.mark.parametrize("n", [1, 3, 31, 32, 33, 100, 257])
+def test_matrix_symmetrize_equals_the_host_expression(n):
+    import torch
+    R = np.random.default_rng(n).normal(size=(n, n))
+    want = 0.5 * (R + R.T)
+    assert np.array_equal(_lib.matrix_symmetrize(R), want)
+    pad = np.full((n, n + 3), np.nan)
+    pad[:, :n] = R
+    out = np.empty((n, n))
+    _lib.check(_lib.lib().gml_matrix_symmetrize(pad.ctypes.data, n + 3, n, 0, out.ctypes.data))  # a padded leading dimension
+    assert np.array_equal(out, want)
+    d = torch.from_numpy(R).cuda()
+    _lib.check(_lib.lib().gml_matrix_symmetrize(d.data_ptr(), n, n, 0, d.data_ptr()))             # device pointers, in place
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("form,F", [("RISE", gml.RISE), ("logRISE", gml.logRISE), ("RPLE", gml.RPLE)])
+def test_pairwise_front_door_symmetrises_on_the_device(form, F):
+    n, K = 160, 30000
+    J = synthetic.block_ising_model(n, block=16, seed=5)
+    with gml.Problem(model=J, num_samples=K, seed=6) as p:
+        spins = p.spins()
+        rows, _, _ = p.learn(form, F().regularizer, tol=1e-9, precision="i8w")
+        sym, _, st = p.learn(form, F().regularizer, tol=1e-9, precision="i8w", matrix=True)
+        raw, _, _ = p.learn(form, F().regularizer, tol=1e-9, precision="i8w", matrix=False)
+    if form != "RPLE":  # (RPLE's line search compares objective values that carry atomics' rounding: two solves agree to the tolerance)
+        assert np.array_equal(raw, rows) and np.array_equal(sym, 0.5 * (rows + rows.T))
+    assert st["t_assemble"] > 0
+    hist = np.concatenate([np.ones((K, 1), dtype=np.int8), spins], axis=1)
+    got = gml.learn(hist, F(), gml.HIP(tol=1e-9, precision="i8w"))
+    assert np.array_equal(got, got.T) and np.abs(got - 0.5 * (rows + rows.T)).max() <= (0 if form != "RPLE" else 2e-9)
+    two = gml.learn(hist, F(), gml.HIP(tol=1e-9, precision="i8w", devices=[0, 0]))  # gathered rows -> gml_matrix_symmetrize
+    assert np.array_equal(two, two.T) and np.abs(two - got).max() <= 2e-9
+    with gml.Problem(hist, node_range=(0, 64)) as q:
+        with pytest.raises(gml.GMLError, match="ALL nodes"):
+            q.learn(form, 0.4, matrix=True)

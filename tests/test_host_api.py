@@ -20,9 +20,9 @@ def unpack_histogram(packed):
     return np.concatenate([(np.ones(K) if counts is None else counts)[:, None], 1.0 - 2.0 * sp], axis=1)
 
 
-def oracle_local_solve(samples, formulation, method, order, node_range, device, terms=None, packed=None):
+def oracle_local_solve(samples, formulation, method, order, node_range, device, terms=None, packed=None, matrix=None):
     name = type(formulation).__name__
-    assert terms is None  # (the fused solve + assembly call is the product solver's own)
+    assert terms is None and matrix is None  # (the fused solve + assembly calls are the product solver's own)
     if packed is not None:  # a rank of a distributed run: the bits rank 0 broadcast, no sample matrix
         assert samples is None
         samples = unpack_histogram(packed)
@@ -47,20 +47,25 @@ def oracle_assemble_terms(rows, n, order, symmetrize, device):
     return np.array([rec[k] for k in O.listing_order(rec)])
 
 
+def host_symmetrize(R, device):
+    return 0.5 * (R + R.T)  # GraphicalModelLearning.jl:184-186 as the reference writes it
+
+
 def inject_oracle():
     learn_module._local_solve_hip = oracle_local_solve
     learn_module._assemble_terms_hip = oracle_assemble_terms
+    learn_module._symmetrize_hip = host_symmetrize
 
 
 def oracle_learn(*args):
     """gml.learn with the CPU oracle standing in for the per-rank device solver and the device assembly (host-layer tests
     without a GPU)"""
-    old = learn_module._local_solve_hip, learn_module._assemble_terms_hip
+    old = learn_module._local_solve_hip, learn_module._assemble_terms_hip, learn_module._symmetrize_hip
     inject_oracle()
     try:
         return gml.learn(*args)
     finally:
-        learn_module._local_solve_hip, learn_module._assemble_terms_hip = old
+        learn_module._local_solve_hip, learn_module._assemble_terms_hip, learn_module._symmetrize_hip = old
 
 
 def test_type_defaults_match_reference():
