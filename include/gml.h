@@ -326,8 +326,8 @@ int gml_hessvec_batch_prec(gml_problem *p, int formulation, int precision, int64
  *         layout (pairwise: reconstruction[u, 1:n] of :181, diagonal slot = field).
  *         May be a host pointer or a device pointer (detected).
  *   kkt   optional (node1-node0) host array: final max|pseudo-gradient| per node.
- * Symmetrisation (:184-186, :135-149) needs all rows and is done by the caller after the
- * gather (see the Python / Julia host layer).
+ * Symmetrisation (:184-186, :135-149) needs all rows: handles over all nodes take gml_learn_matrix / gml_learn_terms (solve and
+ * result assembly in one call, on the device), node shards gather their rows and call gml_matrix_symmetrize / gml_terms_assemble.
  * Returns GML_ENOTCONV if some node stayed above opts->tol (out is still filled).
  */
 int gml_learn(gml_problem *p, int formulation, double regularizer_c, const gml_opts *opts,
