@@ -7,6 +7,7 @@
  *   - the same for gml_multi_* with devices {0, 0} (HIP(devices = [0, 0])).
  * Modes:  layout                       print sizeof / offsetof of the two structs (no device needed)
  *         run <samples.csv> <learned.csv> <c> <symmetrize>   learn RISE(c, symmetrize) and compare (needs a GPU)
+ *         terms <samples.csv> <c> <symmetrize> <order>       learn multiRISE(c, symmetrize, order) and print its terms (needs a GPU)
  */
 #include "gml.h"
 
@@ -170,8 +171,56 @@ static int run(const char *samples_csv, const char *learned_csv, double c, int s
     return (e1 <= 5e-8 && e2 <= 5e-8) ? 0 : 11;
 }
 
+/* learn(samples, ::multiRISE, ::HIP) as the .jl file calls it: gml_terms_count -> gml_problem_create(order) -> gml_learn_terms ->
+ * gml_terms_keys; prints every term as "term k1 k2 ... weight" (1-based keys, like the Dict the .jl builds) */
+static int terms(const char *samples_csv, double c, int symmetrize, int order) {
+    double *S;
+    int K, cols;
+    if (read_csv(samples_csv, &S, &K, &cols)) return 2;
+    const int n = cols - 1;
+    int64_t *s = malloc(sizeof(int64_t) * (size_t)K * cols);
+    for (int k = 0; k < K; ++k)
+        for (int j = 0; j < cols; ++j) s[k + (size_t)j * K] = (int64_t)llround(S[(size_t)k * cols + j]);
+    const int64_t nterms = gml_terms_count(n, order, symmetrize);
+    if (nterms < 0) return 3;
+    double *weights = malloc(sizeof(double) * (size_t)nterms); /* Vector{Float64}(undef, nterms) */
+    gml_problem *h = NULL;
+    int rc = gml_problem_create(s, GML_I64, K, n, K, 1, order, 0, n, 0, &h);
+    if (rc != GML_OK) {
+        fprintf(stderr, "gml_problem_create: %s\n", gml_last_error());
+        return 4;
+    }
+    gml_opts o;
+    memset(&o, 0, sizeof o);
+    o.tol = 1e-10;
+    o.max_iter = 100;
+    o.precision = GML_PREC_AUTO;
+    o.max_working = 512;
+    o.max_add = 64;
+    gml_stats st;
+    memset(&st, 0xEE, sizeof st);
+    rc = gml_learn_terms(h, GML_RISE, c, symmetrize, &o, weights, NULL, &st);
+    gml_problem_destroy(h);
+    if (rc != GML_OK) {
+        fprintf(stderr, "gml_learn_terms: %s\n", gml_last_error());
+        return 5;
+    }
+    int32_t *keys = malloc(sizeof(int32_t) * (size_t)order * (size_t)nterms); /* Array{Int32}(undef, order, nterms) */
+    rc = gml_terms_keys(n, order, symmetrize, 0, nterms, keys);
+    if (rc != GML_OK) return 6;
+    printf("nterms %lld not_converged %d t_assemble_positive %d\n", (long long)nterms, st.not_converged, st.t_assemble > 0.0);
+    for (int64_t t = 0; t < nterms; ++t) {
+        printf("term");
+        for (int j = 0; j < order; ++j)
+            if (keys[t * order + j] >= 0) printf(" %d", keys[t * order + j] + 1);
+        printf(" %.17g\n", weights[t]);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "layout")) return layout();
+    if (argc >= 6 && !strcmp(argv[1], "terms")) return terms(argv[2], atof(argv[3]), atoi(argv[4]), atoi(argv[5]));
     if (argc >= 6 && !strcmp(argv[1], "run")) return run(argv[2], argv[3], atof(argv[4]), atoi(argv[5]));
     fprintf(stderr, "usage: %s layout | run samples.csv learned.csv c symmetrize\n", argv[0]);
     return 64;

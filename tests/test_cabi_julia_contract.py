@@ -82,3 +82,22 @@ def test_ccall_sequence_reproduces_the_goldens(exe, name, c, sym):
         assert r.returncode in (0, 11)
     else:
         assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sym", [1, 0])
+def test_ccall_sequence_of_the_multirise_method(exe, sym):
+    # learn(samples, multiRISE(0.2, sym, 3), HIP()) as the .jl calls the ABI -- gml_terms_count, gml_problem_create(order 3),
+    # gml_learn_terms, gml_terms_keys on a column-major Int64 matrix -- against the Python front door on the same fixture
+    import numpy as np
+
+    import gml_amd as gml
+    r = subprocess.run([exe, "terms", os.path.join(GOLDEN, "c_samples.csv"), "0.2", str(sym), "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr
+    head = re.search(r"nterms (\d+) not_converged (\d+) t_assemble_positive (\d)", r.stdout)
+    got = {tuple(int(v) for v in ln.split()[1:-1]): float(ln.split()[-1]) for ln in r.stdout.splitlines() if ln.startswith("term")}
+    s = np.loadtxt(os.path.join(GOLDEN, "c_samples.csv"), delimiter=",")
+    fg = gml.learn(s, gml.multiRISE(0.2, bool(sym), 3), gml.HIP(tol=1e-10))
+    assert int(head.group(1)) == len(got) == len(fg) and int(head.group(2)) == 0 and int(head.group(3)) == 1
+    assert got.keys() == fg.terms.keys() and all(got[k] == v for k, v in fg.terms.items())  # the same library call: the same bits
+    assert list(got) == sorted(got, key=lambda k: (len(k), k))                                 # in the reference's listing order
