@@ -177,6 +177,7 @@ struct Solver {
     bool dual = false;
     const double *x0 = nullptr; // warm start (gml_learn_warm): the rows to start from, reference layout [R][P], host or device; NULL = zeros
     int32_t *dColsRef = nullptr; // multi-body: column of every parameter slot of every local row (:94-104), built once (warm start, finish)
+    int compact_skip = 0, compact_backoff = 0; // passes that do not try the column compaction after one that came out dense (run_pass)
     bool underflow = false; // the solve ended because a row's weights left the fixed-point range at an iterate (gml_learn: auto -> FP64)
     bool at_zero = false; // the pass being queued evaluates X = 0 (the first pass of a solve; also its rescaled re-runs)
     ~Solver() { // (each handle by itself: init may have returned between two of the four creations)
@@ -667,7 +668,14 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
         a.wide = wide;
         a.coarse = coarse_on;
         a.zero_theta = at_zero && tune[GML_TUNE_NO_ZERO_SHORTCUT] == 0; // the first pass of a solve: X = 0 for every row
-        a.compact = tune[GML_TUNE_NO_COMPACT] == 0 && tune[GML_TUNE_SOLVER_COMPACT] > 0; // (experiment knob: see gml_solver.h -- the solver's own iterates are not sparse enough per tile)
+        // Column compaction of the forward GEMM.  It pays where the rows are sparse RELATIVE TO THE COLUMN COUNT: multi-body
+        // statistics, thousands of spins (config 5 at c = 1.2: 25 non-zeros of 130 817 per node, learn() 3.5 -> 2.2 s).  With the
+        // 1 024 columns of the headline problem a tile's 32 rows cover every column after the third pass and the two extra launches
+        // cost a 128-node shard 5 %: problems below 4 096 columns do not try.  A pass whose tiles came out (mostly) dense makes the
+        // next 2, 4, ... 16 passes skip the attempt.
+        const bool may_compact = tune[GML_TUNE_NO_COMPACT] == 0 && (tune[GML_TUNE_SOLVER_COMPACT] > 0 || d.Qfp >= 4096);
+        if (may_compact && compact_skip > 0) --compact_skip;
+        else a.compact = may_compact;
         std::string err;
         if (dual) { // the pass behind what this handle has queued so far, on the low-priority stream
             HIPCHK(hipEventRecord(ev_a, st));
@@ -679,33 +687,36 @@ int Solver::run_pass(const std::vector<int> &rows, const double *src, double *ds
             HIPCHK(hipEventRecord(ev_b, st_pass));
             HIPCHK(hipStreamWaitEvent(st, ev_b, 0));
         }
-        if (o.verbose >= 2 && a.compact) { // what the compaction did to this pass: steps swept per tile (all = the tile ran on every column)
-            const int *dcnk = nullptr;
-            int cs = 0;
-            i8_compact_table(p->i8ws, &dcnk, &cs);
-            if (dcnk) {
-                std::vector<int> tl((size_t)(hi - lo) / 32);
-                HIPCHK(hipMemcpy(tl.data(), dcnk + lo / 32, sizeof(int) * tl.size(), hipMemcpyDeviceToHost));
-                int nall = 0, nc = 0, mx = 0;
-                long long sum = 0;
-                for (int v : tl) {
-                    if (v < 0) ++nall;
-                    else {
-                        ++nc;
-                        sum += v;
-                        mx = std::max(mx, v);
-                    }
-                }
-                fprintf(stderr, "[gml]   compaction: %d tiles on all %d steps, %d compacted (mean %.1f, max %d of cap %d steps)\n", nall, (int)(d.Qfp / 64),
-                        nc, nc ? (double)sum / nc : 0.0, mx, cs);
-            }
-        }
         if (formulation == GML_LOGRISE && want_grad) // grad log Z = grad Z / Z (:279), Z from the pass results on the device
             launch_scale_slots_inv(a.srow, a.rowcol, (int)lo, (int)ns, kRes, Qp, dst, st);
         RCCHK(fetch(res + lo, dRes + lo, sizeof(SlotResult) * ns));
         if (after) RCCHK((*after)());
         HIPCHK(hipGetLastError());
+        std::vector<int> ctab;
+        if (a.compact) { // what the compaction made of this pass comes down with its results
+            const int *dcnk = nullptr;
+            int cs = 0;
+            i8_compact_table(p->i8ws, &dcnk, &cs);
+            if (dcnk) {
+                ctab.assign((size_t)(hi - lo) / 32, 0);
+                HIPCHK(stg.d2h(ctab.data(), dcnk + lo / 32, sizeof(int) * ctab.size()));
+            }
+        }
         HIPCHK(stg.sync());
+        if (!ctab.empty()) {
+            const int nk_all = (int)(d.Qfp / 64);
+            long long swept = 0;
+            for (int v : ctab) swept += v < 0 ? nk_all : v;
+            if ((double)swept > 0.6 * (double)nk_all * (double)ctab.size()) {
+                compact_backoff = std::min(16, std::max(2, 2 * compact_backoff));
+                compact_skip = compact_backoff;
+            } else {
+                compact_backoff = 0;
+            }
+            if (o.verbose >= 2)
+                fprintf(stderr, "[gml]   compaction: %lld of %lld column steps swept over %zu tiles%s\n", swept, (long long)nk_all * (long long)ctab.size(),
+                        ctab.size(), compact_skip ? " (the next passes do not try)" : "");
+        }
         if (step_on_device) // (the trial's scalars came down with the pass)
             for (int64_t a2 = 0; a2 < n; ++a2) stepn[rows[a2]] = trial[rows[a2]].stepn;
         fh.resize((size_t)n);

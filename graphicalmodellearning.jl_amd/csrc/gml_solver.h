@@ -19,7 +19,7 @@ struct SelectOut {
 extern double g_hv_sparse_ratio;
 extern std::atomic<long long> g_hv_sparse_calls; // products taken entry by entry so far (all solves of the process)
 // experiment knobs (gml_test_tune; 0 = the built-in rule): what scripts/gpu_tune_*.py sweep, not an interface
-enum { GML_TUNE_KH_BASE = 0, GML_TUNE_FACE_ROUNDS = 1 /* value - 1 = rounds */, GML_TUNE_HESS_WGS = 2, GML_TUNE_DUAL_STREAMS = 3 /* 1: passes on a low-priority stream, the rest on a high-priority one; 2: two streams of equal priority */, GML_TUNE_NO_ZERO_SHORTCUT = 4 /* 1: the first pass runs its GEMM like any other */, GML_TUNE_NO_ZEROCOPY = 5 /* 1: results and row lists through device arrays and copies, as on handles too large for the pinned arena */, GML_TUNE_NO_COMPACT = 6 /* 1: the forward GEMMs of objective passes sweep all columns, always (A/B of the column compaction) */, GML_TUNE_BENCH_COMPACT = 7 /* 1: the timing hooks gml_bench_pass* compact too (they sweep all columns by default: the bench headline prices the dense contraction) */, GML_TUNE_SOLVER_COMPACT = 8 /* 1: gml_learn's own passes compact too.  Off by default: measured (profiles/r6_compact_ab.txt) -- at the regularisers of the reference the optimum of a node keeps ~100 noise-level coefficients, a tile's 32 rows cover every column, and only the first three passes of a solve compact: no gain, 1 % overhead */, GML_NTUNE = 16 };
+enum { GML_TUNE_KH_BASE = 0, GML_TUNE_FACE_ROUNDS = 1 /* value - 1 = rounds */, GML_TUNE_HESS_WGS = 2, GML_TUNE_DUAL_STREAMS = 3 /* 1: passes on a low-priority stream, the rest on a high-priority one; 2: two streams of equal priority */, GML_TUNE_NO_ZERO_SHORTCUT = 4 /* 1: the first pass runs its GEMM like any other */, GML_TUNE_NO_ZEROCOPY = 5 /* 1: results and row lists through device arrays and copies, as on handles too large for the pinned arena */, GML_TUNE_NO_COMPACT = 6 /* 1: the forward GEMMs of objective passes sweep all columns, always (A/B of the column compaction) */, GML_TUNE_BENCH_COMPACT = 7 /* 1: the timing hooks gml_bench_pass* compact too (they sweep all columns by default: the bench headline prices the dense contraction) */, GML_TUNE_SOLVER_COMPACT = 8 /* 1: gml_learn's own passes try the compaction whatever the column count.  By default they do from 4 096 statistics columns on (multi-body problems, thousands of spins: config 5 at c = 1.2 3.5 -> 2.2 s): measured (profiles/r6_compact_ab.txt) -- with the 1 024 columns of the headline problem a node's optimum keeps ~100 noise-level coefficients, a tile's 32 rows cover every column after the third pass: no gain, 1 - 5 % overhead */, GML_NTUNE = 16 };
 extern double g_tune[GML_NTUNE];
 
 // the rows' lists of working-set columns (k_cg_tiles): row r's |W| = nw[r] columns, in column order, at FV + t0[r] * T

@@ -1,5 +1,5 @@
 """Column compaction of the forward GEMM (round 6): learn() wall-clock and pass time with the compaction off / on, interleaved on one
-box (gml_test_tune knob 8 = gml_learn's passes compact; knob 7 = the timing hook compacts too; operator calls compact by default).  Solutions are compared bit for bit."""
+box (gml_test_tune knob 6 = never compact; knob 7 = the timing hook compacts too; by default operator calls compact, and gml_learn's passes do from 4 096 statistics columns on).  Solutions are compared bit for bit."""
 import ctypes as C
 import sys
 import time
@@ -19,11 +19,12 @@ def learn_ab(tag, p, form, c, prec, tol=1e-9, reps=3, **kw):
     res = {}
     for rep in range(reps):
         for mode in ("dense", "compact"):
-            L.gml_test_tune(8, 0.0 if mode == "dense" else 1.0)  # (the solver's passes compact only when asked: knob 8)
+            L.gml_test_tune(6, 1.0 if mode == "dense" else 0.0)  # dense: never compact; compact: the library's default rule (gml_learn
+            # tries from 4 096 statistics columns on, with a back-off after passes that came out dense)
             t0 = time.perf_counter()
             out, kkt, st = p.learn(form, c, tol=tol, precision=prec, raise_on_fail=False, **kw)
             res.setdefault(mode, []).append((time.perf_counter() - t0, out, st))
-    L.gml_test_tune(8, 0.0)
+    L.gml_test_tune(6, 0.0)
     td, tc = sorted(t for t, _, _ in res["dense"])[reps // 2], sorted(t for t, _, _ in res["compact"])[reps // 2]
     same = np.array_equal(res["dense"][-1][1], res["compact"][-1][1])
     sd, sc = res["dense"][-1][2], res["compact"][-1][2]
