@@ -110,7 +110,7 @@ struct I8Pass {
     bool compact;         // objective passes: the forward GEMM of a node tile sweeps only the columns on which one of the tile's rows is
                           // non-zero (l1-sparse iterates: a few dozen of thousands of columns) -- the compact column list and the bit
                           // image of those columns are built on the device in front of the pass; the integer sums, hence every result
-                          // bit, are those of the sweep over all columns.  Tiles whose union exceeds half of the columns run dense
+                          // bit, are those of the sweep over all columns.  Tiles whose union exceeds a quarter of the columns run dense
     bool coarse;          // the cheap form of an objective pass (exp forms) for iterates far from the optimum.  wide: the top four
                           // planes of theta (30 bits), V in three planes (dithered 23 bits): one forward sweep and one backward launch
                           // instead of two; SlotResult.tau stays the unit of the 47-bit planes, the values are multiples of 2^24 tau.

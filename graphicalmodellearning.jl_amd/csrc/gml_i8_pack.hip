@@ -146,7 +146,7 @@ void launch_expand_xt(const DevProblem &d, int8_t *Xt, hipStream_t st) {
 // (ascending; one workgroup per tile: flags by column, ordered append through wave ballots); k_build_xc builds the forward bit
 // image of those columns alone (k_build_xb through the list).  The quantisation kernel then writes the digits of those columns
 // into the first cnk[tile] steps of the tile's Tq image and the forward kernel sweeps cnk[tile] steps instead of Qfp / 64.
-// Tiles whose list exceeds the capacity (half of the columns, at most 32 steps) keep the sweep over all columns: cnk = -1.
+// Tiles whose list exceeds the capacity (a quarter of the columns, at most 32 steps) keep the sweep over all columns: cnk = -1.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_col_union(const double *__restrict__ Theta, const int *__restrict__ srow, const int *__restrict__ rowcol,
                                                    const int *__restrict__ groups, int64_t Qp, int64_t Qfp, int csteps, int *__restrict__ cnk,

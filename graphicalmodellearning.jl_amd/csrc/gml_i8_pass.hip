@@ -140,7 +140,10 @@ int i8_pass(void **wsp, const DevProblem &d, int64_t slot_capacity, const I8Pass
     const ColCompact *cc = nullptr;
     if (compact) {
         if (!w->cnk && w->csteps == 0) {
-            const int csteps = std::min(32, nk_all / 2);
+            // capacity: a quarter of the columns, 32 steps at most.  Building a tile's compact image costs K * 8 B of HBM writes per
+            // step; above a quarter of the columns that eats what the shorter sweep saves (config 4's first passes: 32 of 64 steps,
+            // 4 GB of images per pass, 2 % slower than sweeping everything)
+            const int csteps = std::min(32, std::max(1, nk_all / 4));
             const int64_t ntile = w->slots / 32, xc_tile = d.Kp * (int64_t)csteps * 8;
             size_t freeb = 0, totalb = 0;
             if (dev_mem_info(&freeb, &totalb) == hipSuccess && (double)ntile * (double)xc_tile < 0.25 * (double)freeb &&

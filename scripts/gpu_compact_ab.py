@@ -28,7 +28,7 @@ def learn_ab(tag, p, form, c, prec, tol=1e-9, reps=3, **kw):
     td, tc = sorted(t for t, _, _ in res["dense"])[reps // 2], sorted(t for t, _, _ in res["compact"])[reps // 2]
     same = np.array_equal(res["dense"][-1][1], res["compact"][-1][1])
     sd, sc = res["dense"][-1][2], res["compact"][-1][2]
-    print(f"{tag:<44s} {prec}: learn() all columns {td * 1e3:9.2f} ms (t_pass {sd['t_pass'] * 1e3:8.2f})   compacted {tc * 1e3:9.2f} ms "
+    print(f"{tag:<44s} {prec}: learn() all columns {td * 1e3:9.2f} ms (t_pass {sd['t_pass'] * 1e3:8.2f})   default rule {tc * 1e3:9.2f} ms "
           f"(t_pass {sc['t_pass'] * 1e3:8.2f})   x{td / tc:.2f}   iterations {sd['iterations']}/{sc['iterations']}  same bits: {same}", flush=True)
 
 

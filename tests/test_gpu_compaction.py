@@ -50,16 +50,16 @@ def sparse_rows(rng, nrows, P, nnz_lo, nnz_hi, pool=None, scale=0.3):
 @pytest.mark.parametrize("form", ["RISE", "logRISE", "RPLE"])
 @pytest.mark.parametrize("prec", ["i8x", "i8w"])
 def test_objgrad_bits_do_not_depend_on_the_compaction(form, prec, both_ways):
-    n, K = 512, 30000  # 8 column steps: lists of up to 4 steps (256 columns) are compacted, longer ones sweep everything
+    n, K = 1024, 30000  # 16 column steps: lists of up to 4 steps (256 columns) are compacted, longer ones sweep everything
     rng = np.random.default_rng(11)
     spins, _ = synthetic.block_ising(n, K, block=16, seed=3)
     counts = 1.0 + (np.arange(K) % 3)
     nodes = rng.permutation(n)[:150].astype(np.int64)  # 4 full tiles + a partial one, rows not in node order
     th = sparse_rows(rng, len(nodes), n, 3, 12, pool=np.arange(40))          # tiles 0..: a union of <= 40 columns: one step
-    th[32:64] = sparse_rows(rng, 32, n, 3, 12, pool=np.arange(0, 512, 3))   # tile 1: a union of ~150 columns: three steps
+    th[32:64] = sparse_rows(rng, 32, n, 3, 12, pool=np.arange(0, 1024, 6))  # tile 1: a union of ~150 columns: three steps
     th[64:96] = sparse_rows(rng, 32, n, 20, 60)                              # tile 2: > 256 columns in the union: not compacted
     th[96:128] = 0.0                                                        # tile 3: all rows zero: no column at all
-    th[100, 511] = 0.7                                                      # ... but one entry, in the last column
+    th[100, 1023] = 0.7                                                      # ... but one entry, in the last column
     with gml.Problem(counts=counts, spins=spins) as p:
         (f0, g0), (f1, g1) = both_ways(lambda: p.objgrad(form, nodes, th, precision=prec))
     assert np.array_equal(g0, g1)
