@@ -38,3 +38,23 @@ for sym in (1, 0):
 t0 = time.perf_counter()
 w = _lib.terms_assemble(rows.data_ptr(), n, order, True, ld=P)
 print(f"device rows -> host weight array: {(time.perf_counter() - t0) * 1e3:.1f} ms ({w.nbytes / 1e6:.0f} MB to pageable host memory)")
+# the pairwise counterpart (k_pair_sym): 0.5 (R + R') at config-4 size, in HBM
+for npair in (1024, 4096):
+    R = torch.randn((npair, npair), dtype=torch.float64, device="cuda")
+    S = torch.empty_like(R)
+    for _ in range(3):
+        _lib.check(L.gml_matrix_symmetrize(R.data_ptr(), npair, npair, 0, S.data_ptr()))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(20):
+        _lib.check(L.gml_matrix_symmetrize(R.data_ptr(), npair, npair, 0, S.data_ptr()))
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / 20
+    nb = 3 * 8.0 * npair * npair  # R read twice (once transposed), S written
+    Rh = R.cpu().numpy()
+    t0 = time.perf_counter()
+    Sh = 0.5 * (Rh + Rh.T)
+    t_host = time.perf_counter() - t0
+    print(f"pairwise symmetrisation n={npair}: {ms:.3f} ms per call on the device ({nb / ms / 1e6:.0f} GB/s on {nb / 1e6:.0f} MB), "
+          f"{t_host * 1e3:.1f} ms for the host expression; same bits: {bool(np.array_equal(S.cpu().numpy(), Sh))}", flush=True)
