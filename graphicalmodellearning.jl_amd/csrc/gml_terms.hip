@@ -127,15 +127,20 @@ __global__ __launch_bounds__(256) void k_terms_sym3(int64_t n, int64_t roff3, in
     }
 }
 
-__global__ __launch_bounds__(256) void k_terms_unsym(TermPlan pl, const double *__restrict__ rows, int64_t ld, double *__restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= pl.uoff[pl.order + 1]) return;
-    int s = 1;
-    while (t >= pl.uoff[s + 1]) ++s;
-    const int64_t r = t - pl.uoff[s], u = r / pl.rcnt[s], j = r % pl.rcnt[s];
-    int64_t slot;
-    if (pl.pairwise) slot = s == 1 ? u : j + (j >= u);
-    else slot = pl.roff[s] + j;
+// unsymmetrised: a strided copy -- row u's slots of size s go to uoff[s] + u rcnt[s] + (slot - roff[s]).  One grid row per node, the
+// slots along x: no division per element, both sides coalesced
+__global__ __launch_bounds__(256) void k_terms_unsym(TermPlan pl, const double *__restrict__ rows, int64_t ld, double *__restrict__ out, int64_t u0) {
+    const int64_t u = u0 + blockIdx.y, slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t P = pl.pairwise ? pl.n : pl.roff[pl.order + 1];
+    if (slot >= P) return;
+    int64_t t;
+    if (pl.pairwise) {
+        t = slot == u ? u : pl.uoff[2] + u * pl.rcnt[2] + (slot - (slot > u)); // slot i <-> spin i, slot u = the field (:162)
+    } else {
+        int s = 1;
+        while (slot >= pl.roff[s + 1]) ++s;
+        t = pl.uoff[s] + u * pl.rcnt[s] + (slot - pl.roff[s]);
+    }
     out[t] = rows[u * ld + slot];
 }
 
@@ -198,7 +203,10 @@ int gml_terms_assemble_dev(const double *drows, int64_t ld, int64_t n, int order
     } else if (symmetrize) {
         hipLaunchKernelGGL(k_terms_sym, dim3(nb), dim3(256), 0, st, pl, drows, ld, dout, T);
     } else {
-        hipLaunchKernelGGL(k_terms_unsym, dim3(nb), dim3(256), 0, st, pl, drows, ld, dout);
+        const int64_t P = pl.pairwise ? n : pl.roff[order + 1];
+        for (int64_t u0 = 0; u0 < n; u0 += 65535) // (grid rows: at most 65 535 per launch)
+            hipLaunchKernelGGL(k_terms_unsym, dim3((unsigned)((P + 255) / 256), (unsigned)std::min<int64_t>(65535, n - u0)), dim3(256), 0, st, pl,
+                               drows, ld, dout, u0);
     }
     HIPCHK(hipGetLastError());
     return GML_OK;
